@@ -1,0 +1,236 @@
+"""ctypes front end of oracle/liboracle.so — the CPU restatement of the reference hot path.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (cubesat-apds_amd/) never imports this module. See oracle/oracle.h for what is
+restated, which reference lines it follows and the parity status (AKAZE/match: "parity unpinned").
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH_DTYPE = np.dtype([("query_idx", "<i4"), ("train_idx", "<i4"), ("img_idx", "<i4"), ("distance", "<f4")])
+
+PLANE_LT, PLANE_LSMOOTH, PLANE_LX, PLANE_LY, PLANE_LDET, PLANE_LFLOW, PLANE_MASK0, PLANE_MASK1 = range(8)
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in ("akaze_oracle.cpp", "match_oracle.cpp", "homography_oracle.cpp", "oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            so = build()
+        L = C.CDLL(so)
+        u8p, f32p, i32p, f64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double))
+        L.oracle_akaze_run.restype = C.c_void_p
+        L.oracle_akaze_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int, C.c_int]
+        for name, rt in (("oracle_akaze_num_keypoints", C.c_int), ("oracle_akaze_keypoints", C.c_void_p),
+                         ("oracle_akaze_descriptors", C.c_void_p), ("oracle_akaze_desc_bytes", C.c_int),
+                         ("oracle_akaze_num_levels", C.c_int), ("oracle_akaze_kcontrast", C.c_float),
+                         ("oracle_akaze_gray", C.c_void_p)):
+            getattr(L, name).restype = rt
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.oracle_akaze_level_info.restype = None
+        L.oracle_akaze_level_info.argtypes = [C.c_void_p, C.c_int, i32p, f32p]
+        L.oracle_akaze_level_tau.restype = C.c_int
+        L.oracle_akaze_level_tau.argtypes = [C.c_void_p, C.c_int, f32p, C.c_int]
+        L.oracle_akaze_plane.restype = C.c_void_p
+        L.oracle_akaze_plane.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.oracle_akaze_free.restype = None
+        L.oracle_akaze_free.argtypes = [C.c_void_p]
+        L.oracle_knn_hamming.restype = None
+        L.oracle_knn_hamming.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_int,
+                                         C.c_void_p, C.c_void_p]
+        L.oracle_get_knn_matches.restype = C.c_int
+        L.oracle_get_knn_matches.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t, C.c_int,
+                                             C.c_int, C.c_float, C.c_void_p]
+        L.oracle_get_bruteforce_matches.restype = C.c_int
+        L.oracle_get_bruteforce_matches.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_size_t,
+                                                    C.c_int, C.c_void_p]
+        L.oracle_get_points_from_matches.restype = C.c_int
+        L.oracle_get_points_from_matches.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                     C.c_void_p, C.c_void_p]
+        L.oracle_find_homography.restype = C.c_int
+        L.oracle_find_homography.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
+                                             C.c_void_p, C.c_void_p]
+        L.oracle_homography_4pt.restype = C.c_int
+        L.oracle_homography_4pt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_ransac_samples.restype = C.c_int
+        L.oracle_ransac_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_raster_to_mat.restype = C.c_int
+        L.oracle_raster_to_mat.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_get_threads.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class AkazeResult:
+    """Keypoints, descriptors and (optionally) every intermediate plane of one oracle AKAZE run."""
+
+    def __init__(self, handle, keep):
+        L = lib()
+        self._h = handle
+        n = L.oracle_akaze_num_keypoints(handle)
+        self.desc_bytes = L.oracle_akaze_desc_bytes(handle)
+        kp = np.zeros(n, KEYPOINT_DTYPE)
+        desc = np.zeros((n, self.desc_bytes), np.uint8)
+        if n:
+            C.memmove(_ptr(kp), L.oracle_akaze_keypoints(handle), kp.nbytes)
+            C.memmove(_ptr(desc), L.oracle_akaze_descriptors(handle), desc.nbytes)
+        self.keypoints, self.descriptors = kp, desc
+        self.kcontrast = L.oracle_akaze_kcontrast(handle)
+        self.levels = []
+        for i in range(L.oracle_akaze_num_levels(handle)):
+            info = (C.c_int32 * 8)()
+            finfo = (C.c_float * 4)()
+            L.oracle_akaze_level_info(handle, i, info, finfo)
+            tau = (C.c_float * 64)()
+            nt = L.oracle_akaze_level_tau(handle, i, tau, 64)
+            self.levels.append(dict(w=info[0], h=info[1], octave=info[2], sublevel=info[3], sigma_size=info[4],
+                                    border=info[5], nsteps=info[6], esigma=finfo[0], etime=finfo[1], ratio=finfo[2],
+                                    kcontrast=finfo[3], tau=np.array(tau[:nt], np.float32)))
+        self._keep = keep
+
+    def plane(self, level, which):
+        L = lib()
+        lv = self.levels[level]
+        p = L.oracle_akaze_plane(self._h, level, which)
+        if not p:
+            return None
+        dt = np.uint8 if which >= PLANE_MASK0 else np.float32
+        out = np.zeros((lv["h"], lv["w"]), dt)
+        C.memmove(_ptr(out), p, out.nbytes)
+        return out
+
+    def gray(self):
+        L = lib()
+        p = L.oracle_akaze_gray(self._h)
+        if not p:
+            return None
+        lv = self.levels[0]
+        out = np.zeros((lv["h"], lv["w"]), np.float32)
+        C.memmove(_ptr(out), p, out.nbytes)
+        return out
+
+    def close(self):
+        if self._h:
+            lib().oracle_akaze_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+def akaze(img, max_points=(1 << 18) - 1, keep_planes=False):
+    """img: HxW (gray) or HxWx{3,4} uint8 (BGR / BGRA). Mirrors feature_extraction/src/lib.rs:61-92."""
+    img = np.ascontiguousarray(img, np.uint8)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    h = lib().oracle_akaze_run(_ptr(img), img.shape[0], img.shape[1], ch, img.strides[0], int(max_points), int(keep_planes))
+    if not h:
+        raise ValueError("oracle_akaze_run rejected the arguments")
+    return AkazeResult(h, keep_planes)
+
+
+def knn_hamming(q, t, k):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    idx = np.zeros((q.shape[0], k), np.int32)
+    dist = np.zeros((q.shape[0], k), np.int32)
+    lib().oracle_knn_hamming(_ptr(q), q.shape[0], q.strides[0], _ptr(t), t.shape[0], t.strides[0] if t.shape[0] else q.shape[1],
+                             q.shape[1], k, _ptr(idx), _ptr(dist))
+    return idx, dist
+
+
+def get_knn_matches(q, t, k, filter_strength):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    out = np.zeros(max(q.shape[0], 1), DMATCH_DTYPE)
+    n = lib().oracle_get_knn_matches(_ptr(q), q.shape[0], q.strides[0] if q.shape[0] else 0, _ptr(t), t.shape[0],
+                                     t.strides[0] if t.shape[0] else 0, q.shape[1], k, filter_strength, _ptr(out))
+    if n < 0:
+        raise RuntimeError(f"oracle error {n}")
+    return out[:n].copy()
+
+
+def get_bruteforce_matches(q, t):
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    out = np.zeros(max(q.shape[0], 1), DMATCH_DTYPE)
+    n = lib().oracle_get_bruteforce_matches(_ptr(q), q.shape[0], q.strides[0] if q.shape[0] else 0, _ptr(t), t.shape[0],
+                                            t.strides[0] if t.shape[0] else 0, q.shape[1], _ptr(out))
+    if n < 0:
+        raise RuntimeError(f"oracle error {n}")
+    return out[:n].copy()
+
+
+def get_points_from_matches(kp1, kp2, matches, bug_compatible=False):
+    kp1 = np.ascontiguousarray(kp1, KEYPOINT_DTYPE)
+    kp2 = np.ascontiguousarray(kp2, KEYPOINT_DTYPE)
+    matches = np.ascontiguousarray(matches, DMATCH_DTYPE)
+    p1 = np.zeros((len(matches), 2), np.float32)
+    p2 = np.zeros((len(matches), 2), np.float32)
+    rc = lib().oracle_get_points_from_matches(_ptr(kp1), len(kp1), _ptr(kp2), len(kp2), _ptr(matches), len(matches),
+                                              int(bug_compatible), _ptr(p1), _ptr(p2))
+    if rc < 0:
+        raise RuntimeError(f"oracle error {rc}")
+    return p1, p2
+
+
+def find_homography(src, dst, method=0, thr=3.0, max_iters=2000, confidence=0.995):
+    """Returns (found, H 3x3 f64, mask n u8)."""
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+    dst = np.ascontiguousarray(dst, np.float32).reshape(-1, 2)
+    H = np.zeros(9, np.float64)
+    mask = np.zeros(len(src), np.uint8)
+    rc = lib().oracle_find_homography(_ptr(src), _ptr(dst), len(src), method, thr, max_iters, confidence, _ptr(H), _ptr(mask))
+    if rc < 0:
+        raise RuntimeError(f"oracle error {rc}")
+    return rc == 1, H.reshape(3, 3), mask
+
+
+def homography_4pt(src, dst):
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+    dst = np.ascontiguousarray(dst, np.float32).reshape(-1, 2)
+    H = np.zeros(9, np.float64)
+    rc = lib().oracle_homography_4pt(_ptr(src), _ptr(dst), len(src), _ptr(H))
+    return rc, H.reshape(3, 3)
+
+
+def ransac_samples(src, dst, iters):
+    src = np.ascontiguousarray(src, np.float32).reshape(-1, 2)
+    dst = np.ascontiguousarray(dst, np.float32).reshape(-1, 2)
+    idx = np.zeros((iters, 4), np.int32)
+    n = lib().oracle_ransac_samples(_ptr(src), _ptr(dst), len(src), iters, _ptr(idx))
+    return idx[:n]
+
+
+def raster_to_mat(rgba, w, h):
+    rgba = np.ascontiguousarray(rgba, np.uint8).reshape(-1, 4)
+    out = np.zeros((max(h, 0), max(w, 0), 4), np.uint8)
+    rc = lib().oracle_raster_to_mat(_ptr(rgba), rgba.shape[0], w, h, _ptr(out))
+    if rc < 0:
+        raise ValueError("MatError::Unknown (len != w*h)")
+    return out

@@ -1,0 +1,768 @@
+// oracle/akaze_oracle.cpp — scalar CPU restatement of AKAZE (M-LDB, 486 bit). TEST INFRASTRUCTURE ONLY.
+//
+// Follows the reference call site feature_extraction/src/lib.rs:61-92
+//   AKAZE::create(DESCRIPTOR_MLDB, 0, 3, 0.001, 4, 4, DIFF_PM_G2, max_points); detect_and_compute(img, empty mask)
+// whose arithmetic lives in third-party OpenCV (opencv crate 0.88.8 -> OpenCV 4.8/4.9, not in /root/reference):
+// features2d/src/akaze.cpp, kaze/AKAZEFeatures.cpp, kaze/nldiffusion_functions.cpp, kaze/fed.cpp.
+// Restated from the published algorithm; PARITY UNPINNED (see oracle.h).
+//
+// Floating point contract (this file DEFINES it for the repo; the HIP kernels mirror it):
+//   * every product/sum is a separate IEEE-754 binary32 operation, no FMA contraction
+//     (build with -ffp-contract=off), evaluation order exactly as written;
+//   * symmetric separable kernels:  acc = k0*c; acc += k1*(lo1+hi1); acc += k2*(lo2+hi2); ...
+//   * antisymmetric [-1,0,1] kernels: hi - lo;
+//   * sin/cos of the keypoint angle: double libm rounded to float.
+#include "oracle.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+int g_threads = 1;
+
+inline int cv_round_f(float v) { return (int)lrintf(v); }   // round-half-even, like cvRound
+inline int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+inline int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+struct Level {
+    int w = 0, h = 0, octave = 0, sublevel = 0, sigma_size = 0, border = 0;
+    float esigma = 0, etime = 0, ratio = 1, kcontrast = 0;
+    std::vector<float> tau;
+    std::vector<float> Lt, Lsmooth, Lx, Ly, Ldet, Lflow;
+    std::vector<uint8_t> mask0, mask1;
+};
+
+// ---- fed.cpp -------------------------------------------------------------------------------
+bool fed_is_prime(int n) {
+    if (n <= 1) return false;
+    if (n == 2 || n == 3 || n == 5 || n == 7) return true;
+    if (n % 2 == 0 || n % 3 == 0 || n % 5 == 0 || n % 7 == 0) return false;
+    int upper = (int)std::sqrt((double)n + 1.0);
+    for (int d = 11; d <= upper; d += 2)
+        if (n % d == 0) return false;
+    return true;
+}
+
+std::vector<float> fed_tau(float T, float tau_max) {
+    // fed_tau_by_process_time(T, 1, tau_max, reordering=true)
+    int n = (int)std::ceil(sqrtf(3.0f * T / tau_max + 0.25f) - 0.5f - 1.0e-8f);
+    std::vector<float> tau;
+    if (n <= 0) return tau;
+    float scale = 3.0f * T / (tau_max * (float)(n * (n + 1)));
+    std::vector<float> tauh(n);
+    tau.resize(n);
+    float c = 1.0f / (4.0f * (float)n + 2.0f);
+    float d = scale * tau_max / 2.0f;
+    for (int k = 0; k < n; ++k) {
+        float hc = cosf((float)M_PI * (2.0f * (float)k + 1.0f) * c);
+        tauh[k] = d / (hc * hc);
+    }
+    int kappa = n / 2;
+    int prime = n + 1;
+    while (!fed_is_prime(prime)) prime++;
+    for (int k = 0, l = 0; l < n; ++k, ++l) {
+        int index = 0;
+        while ((index = ((k + 1) * kappa) % prime - 1) >= n) k++;
+        tau[l] = tauh[index];
+    }
+    return tau;
+}
+
+// ---- separable filters ---------------------------------------------------------------------
+std::vector<float> gauss_kernel(int n, double sigma) {
+    std::vector<double> k(n);
+    double sum = 0, s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        k[i] = std::exp(s2 * x * x);
+        sum += k[i];
+    }
+    std::vector<float> out(n);
+    for (int i = 0; i < n; i++) out[i] = (float)(k[i] / sum);
+    return out;
+}
+
+// GaussianBlur(BORDER_REPLICATE), symmetric odd kernel, row pass then column pass.
+void gauss_blur(const std::vector<float>& src, std::vector<float>& dst, int w, int h, const std::vector<float>& k) {
+    const int r = (int)k.size() / 2;
+    std::vector<float> tmp((size_t)w * h);
+    dst.resize((size_t)w * h);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < h; y++) {
+        const float* s = &src[(size_t)y * w];
+        float* t = &tmp[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            float acc = k[r] * s[x];
+            for (int j = 1; j <= r; j++) acc += k[r + j] * (s[clampi(x - j, w)] + s[clampi(x + j, w)]);
+            t[x] = acc;
+        }
+    }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < h; y++) {
+        float* d = &dst[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            float acc = k[r] * tmp[(size_t)y * w + x];
+            for (int j = 1; j <= r; j++)
+                acc += k[r + j] * (tmp[(size_t)clampi(y - j, h) * w + x] + tmp[(size_t)clampi(y + j, h) * w + x]);
+            d[x] = acc;
+        }
+    }
+}
+
+// Dilated 3x3 derivative pair, BORDER_REFLECT_101 (sepFilter2D default):
+//   Lx = colsmooth( row: hi - lo ),  Ly = coldiff( row: smooth ),  taps at -s, 0, +s;
+//   smooth = {kside, kmid, kside}.  s=1, kside=3, kmid=10 is cv::Scharr(scale=1).
+void deriv_pair(const std::vector<float>& src, std::vector<float>& Lx, std::vector<float>& Ly, int w, int h, int s,
+                float kside, float kmid) {
+    std::vector<float> rd((size_t)w * h), rs((size_t)w * h);
+    Lx.resize((size_t)w * h);
+    Ly.resize((size_t)w * h);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < h; y++) {
+        const float* p = &src[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            float lo = p[reflect101(x - s, w)], hi = p[reflect101(x + s, w)];
+            rd[(size_t)y * w + x] = hi - lo;
+            float acc = kmid * p[x];
+            acc += kside * (lo + hi);
+            rs[(size_t)y * w + x] = acc;
+        }
+    }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < h; y++) {
+        int ym = reflect101(y - s, h), yp = reflect101(y + s, h);
+        for (int x = 0; x < w; x++) {
+            float acc = kmid * rd[(size_t)y * w + x];
+            acc += kside * (rd[(size_t)ym * w + x] + rd[(size_t)yp * w + x]);
+            Lx[(size_t)y * w + x] = acc;
+            Ly[(size_t)y * w + x] = rs[(size_t)yp * w + x] - rs[(size_t)ym * w + x];
+        }
+    }
+}
+
+// ---- nldiffusion_functions.cpp -------------------------------------------------------------
+void pm_g2(const std::vector<float>& Lx, const std::vector<float>& Ly, std::vector<float>& dst, float k) {
+    const size_t n = Lx.size();
+    dst.resize(n);
+    const float k2inv = 1.0f / (k * k);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (long long i = 0; i < (long long)n; i++) dst[i] = 1.0f / (1.0f + ((Lx[i] * Lx[i] + Ly[i] * Ly[i]) * k2inv));
+}
+
+float compute_kcontrast(const std::vector<float>& Lx, const std::vector<float>& Ly, int w, int h, float perc, int nbins) {
+    const int cw = w - 2, ch = h - 2;
+    if (cw <= 0 || ch <= 0) return 0.03f;
+    std::vector<float> modg((size_t)cw * ch);
+    float hmax = 0.0f;
+    for (int y = 1; y < h - 1; y++)
+        for (int x = 1; x < w - 1; x++) {
+            float lx = Lx[(size_t)y * w + x], ly = Ly[(size_t)y * w + x];
+            float dist = sqrtf(lx * lx + ly * ly);
+            modg[(size_t)(y - 1) * cw + (x - 1)] = dist;
+            hmax = std::max(hmax, dist);
+        }
+    if (hmax == 0.0f) return 0.03f;
+    const float scale = (float)(nbins - 1) / hmax;
+    std::vector<int> hist(nbins, 0);
+    for (size_t i = 0; i < modg.size(); i++) hist[(int)(modg[i] * scale)]++;
+    const int total = cw * ch;
+    const int nthreshold = (int)((total - hist[0]) * perc);
+    int nelements = 0;
+    for (int k = 1; k < nbins; k++) {
+        if (nelements >= nthreshold) return hmax * k / nbins;
+        nelements += hist[k];
+    }
+    return 0.03f;
+}
+
+// one explicit diffusion step: Lnew = Lt + step_size * div(c grad Lt); corners get +0
+void nld_step(const std::vector<float>& Lt, const std::vector<float>& Lf, std::vector<float>& Lnew, int w, int h,
+              float step_size) {
+    Lnew.resize((size_t)w * h);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < h; y++) {
+        const float* lt_c = &Lt[(size_t)y * w];
+        const float* lf_c = &Lf[(size_t)y * w];
+        const float* lt_a = y > 0 ? lt_c - w : nullptr;
+        const float* lf_a = y > 0 ? lf_c - w : nullptr;
+        const float* lt_b = y < h - 1 ? lt_c + w : nullptr;
+        const float* lf_b = y < h - 1 ? lf_c + w : nullptr;
+        float* out = &Lnew[(size_t)y * w];
+        for (int x = 0; x < w; x++) {
+            float step_r;
+            const bool top = y == 0, bot = y == h - 1, left = x == 0, right = x == w - 1;
+            if ((top || bot) && (left || right)) {
+                step_r = 0.0f;
+            } else if (top) {
+                step_r = (lf_c[x] + lf_c[x + 1]) * (lt_c[x + 1] - lt_c[x]) + (lf_c[x] + lf_c[x - 1]) * (lt_c[x - 1] - lt_c[x]) +
+                         (lf_c[x] + lf_b[x]) * (lt_b[x] - lt_c[x]);
+            } else if (bot) {
+                step_r = (lf_c[x] + lf_c[x + 1]) * (lt_c[x + 1] - lt_c[x]) + (lf_c[x] + lf_c[x - 1]) * (lt_c[x - 1] - lt_c[x]) +
+                         (lf_c[x] + lf_a[x]) * (lt_a[x] - lt_c[x]);
+            } else if (left) {
+                step_r = (lf_c[0] + lf_c[1]) * (lt_c[1] - lt_c[0]) + (lf_c[0] + lf_b[0]) * (lt_b[0] - lt_c[0]) +
+                         (lf_c[0] + lf_a[0]) * (lt_a[0] - lt_c[0]);
+            } else if (right) {
+                step_r = (lf_c[x] + lf_c[x - 1]) * (lt_c[x - 1] - lt_c[x]) + (lf_c[x] + lf_b[x]) * (lt_b[x] - lt_c[x]) +
+                         (lf_c[x] + lf_a[x]) * (lt_a[x] - lt_c[x]);
+            } else {
+                step_r = (lf_c[x] + lf_c[x + 1]) * (lt_c[x + 1] - lt_c[x]) + (lf_c[x] + lf_c[x - 1]) * (lt_c[x - 1] - lt_c[x]) +
+                         (lf_c[x] + lf_b[x]) * (lt_b[x] - lt_c[x]) + (lf_c[x] + lf_a[x]) * (lt_a[x] - lt_c[x]);
+            }
+            out[x] = lt_c[x] + step_r * step_size;
+        }
+    }
+}
+
+// resize(INTER_AREA) to (dw,dh) = (sw>>1, sh>>1). Even source: 2x2 mean. Odd source: general area weights.
+void half_sample(const std::vector<float>& src, int sw, int sh, std::vector<float>& dst, int dw, int dh) {
+    dst.resize((size_t)dw * dh);
+    if (sw == 2 * dw && sh == 2 * dh) {
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (int y = 0; y < dh; y++) {
+            const float* s0 = &src[(size_t)(2 * y) * sw];
+            const float* s1 = s0 + sw;
+            for (int x = 0; x < dw; x++)
+                dst[(size_t)y * dw + x] = ((s0[2 * x] + s0[2 * x + 1]) + (s1[2 * x] + s1[2 * x + 1])) * 0.25f;
+        }
+        return;
+    }
+    // general INTER_AREA: each destination pixel integrates the source box [x*sx,(x+1)*sx) with fractional end weights
+    const double sx = (double)sw / dw, sy = (double)sh / dh;
+    auto build = [](int ssize, int dsize, double scale, std::vector<int>& si, std::vector<int>& di, std::vector<float>& al) {
+        for (int d = 0; d < dsize; d++) {
+            double f1 = d * scale, f2 = f1 + scale;
+            double cell = std::min(scale, ssize - f1);
+            int s1 = (int)std::ceil(f1), s2 = (int)std::floor(f2);
+            s2 = std::min(s2, ssize);
+            s1 = std::min(s1, s2);
+            if (s1 - f1 > 1e-3) { si.push_back(s1 - 1); di.push_back(d); al.push_back((float)((s1 - f1) / cell)); }
+            for (int s = s1; s < s2; s++) { si.push_back(s); di.push_back(d); al.push_back((float)(1.0 / cell)); }
+            if (f2 - s2 > 1e-3) {
+                si.push_back(s2); di.push_back(d);
+                al.push_back((float)(std::min(std::min(f2 - s2, 1.0), cell) / cell));
+            }
+        }
+    };
+    std::vector<int> xs, xd, ys, yd;
+    std::vector<float> xa, ya;
+    build(sw, dw, sx, xs, xd, xa);
+    build(sh, dh, sy, ys, yd, ya);
+    std::vector<float> rowbuf(dw), sum(dw);
+    int prev_dy = ys.empty() ? 0 : yd[0];
+    std::fill(sum.begin(), sum.end(), 0.0f);
+    for (size_t j = 0; j < ys.size(); j++) {
+        const float* s = &src[(size_t)ys[j] * sw];
+        std::fill(rowbuf.begin(), rowbuf.end(), 0.0f);
+        for (size_t k = 0; k < xs.size(); k++) rowbuf[xd[k]] += s[xs[k]] * xa[k];
+        if (yd[j] != prev_dy) {
+            for (int x = 0; x < dw; x++) dst[(size_t)prev_dy * dw + x] = sum[x];
+            prev_dy = yd[j];
+            for (int x = 0; x < dw; x++) sum[x] = ya[j] * rowbuf[x];
+        } else {
+            for (int x = 0; x < dw; x++) sum[x] += ya[j] * rowbuf[x];
+        }
+    }
+    for (int x = 0; x < dw; x++) dst[(size_t)prev_dy * dw + x] = sum[x];
+}
+
+// ---- orientation + descriptor helpers --------------------------------------------------------
+const float atan2_p1 = 0.9997878412794807f * (float)(180 / M_PI);
+const float atan2_p3 = -0.3258083974640975f * (float)(180 / M_PI);
+const float atan2_p5 = 0.1555786518463281f * (float)(180 / M_PI);
+const float atan2_p7 = -0.04432655554792128f * (float)(180 / M_PI);
+
+float fast_atan2_deg(float y, float x) {
+    float ax = std::fabs(x), ay = std::fabs(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((atan2_p7 * c2 + atan2_p5) * c2 + atan2_p3) * c2 + atan2_p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((atan2_p7 * c2 + atan2_p5) * c2 + atan2_p3) * c2 + atan2_p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+const float gauss25[7][7] = {
+    {0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f},
+    {0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f},
+    {0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f},
+    {0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f},
+    {0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f},
+    {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
+    {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f}};
+
+float main_orientation(const oracle_keypoint& kpt, const Level& e) {
+    const int scale = cv_round_f(0.5f * kpt.size / e.ratio);
+    const int x0 = cv_round_f(kpt.x / e.ratio);
+    const int y0 = cv_round_f(kpt.y / e.ratio);
+    const int ang_size = 109;
+    float resX[ang_size], resY[ang_size], Ang[ang_size];
+    int n = 0;
+    for (int i = -6; i <= 6; ++i)
+        for (int j = -6; j <= 6; ++j)
+            if (i * i + j * j < 36) {
+                const float wgt = gauss25[std::abs(i)][std::abs(j)];
+                const int y = clampi(y0 + i * scale, e.h), x = clampi(x0 + j * scale, e.w);
+                resX[n] = wgt * e.Lx[(size_t)y * e.w + x];
+                resY[n] = wgt * e.Ly[(size_t)y * e.w + x];
+                ++n;
+            }
+    const float rad = (float)(M_PI / 180);
+    for (int i = 0; i < ang_size; i++) Ang[i] = fast_atan2_deg(resY[i], resX[i]) * rad;
+
+    const int slices = 42;
+    const float ang_step = (float)(2.0 * M_PI / slices);
+    const int nkeys = (int)((float)(2.0 * M_PI) / ang_step);
+    uint8_t cum[slices + 1];
+    uint8_t sorted_idx[ang_size];
+    std::memset(cum, 0, sizeof(cum));
+    for (int i = 0; i < ang_size; i++) {
+        int b = (int)(Ang[i] / ang_step);
+        if (b < 0 || b >= nkeys) b = 0;
+        cum[b]++;
+    }
+    for (int i = 1; i <= slices; i++) cum[i] = (uint8_t)(cum[i] + cum[i - 1]);
+    for (int i = 0; i < ang_size; i++) {
+        int b = (int)(Ang[i] / ang_step);
+        if (b < 0 || b >= nkeys) b = 0;
+        sorted_idx[--cum[b]] = (uint8_t)i;
+    }
+    const uint8_t* slice = cum;   // now exclusive starts; slice[slices] is the total
+    const int win = 7;
+    float maxX = 0.0f, maxY = 0.0f;
+    for (int i = slice[0]; i < slice[win]; i++) {
+        maxX += resX[sorted_idx[i]];
+        maxY += resY[sorted_idx[i]];
+    }
+    float maxNorm = maxX * maxX + maxY * maxY;
+    for (int sn = 1; sn <= slices - win; sn++) {
+        if (slice[sn] == slice[sn - 1] && slice[sn + win] == slice[sn + win - 1]) continue;
+        float sumX = 0.0f, sumY = 0.0f;
+        for (int i = slice[sn]; i < slice[sn + win]; i++) {
+            sumX += resX[sorted_idx[i]];
+            sumY += resY[sorted_idx[i]];
+        }
+        float norm = sumX * sumX + sumY * sumY;
+        if (norm > maxNorm) maxNorm = norm, maxX = sumX, maxY = sumY;
+    }
+    for (int sn = slices - win + 1; sn < slices; sn++) {
+        int remain = sn + win - slices;
+        if (slice[sn] == slice[sn - 1] && slice[remain] == slice[remain - 1]) continue;
+        float sumX = 0.0f, sumY = 0.0f;
+        for (int i = slice[sn]; i < slice[slices]; i++) {
+            sumX += resX[sorted_idx[i]];
+            sumY += resY[sorted_idx[i]];
+        }
+        for (int i = slice[0]; i < slice[remain]; i++) {
+            sumX += resX[sorted_idx[i]];
+            sumY += resY[sorted_idx[i]];
+        }
+        float norm = sumX * sumX + sumY * sumY;
+        if (norm > maxNorm) maxNorm = norm, maxX = sumX, maxY = sumY;
+    }
+    return fast_atan2_deg(maxY, maxX);
+}
+
+inline int32_t toggle_flt(float f) {
+    int32_t i;
+    std::memcpy(&i, &f, 4);
+    return i ^ (i < 0 ? 0x7fffffff : 0);
+}
+
+void mldb_descriptor(const oracle_keypoint& kpt, const Level& e, uint8_t* desc, int desc_size) {
+    const int pattern_size = 10, chan = 3;
+    float values[16 * 3];
+    const float ratio = (float)(1 << kpt.octave);
+    const float scale = (float)cv_round_f(0.5f * kpt.size / ratio);
+    const float xf = kpt.x / ratio, yf = kpt.y / ratio;
+    const float angle = kpt.angle * (float)(M_PI / 180.f);
+    const float co = (float)std::cos((double)angle), si = (float)std::sin((double)angle);
+    std::memset(desc, 0, desc_size);
+    int dpos = 0;
+    const int steps[3] = {10, 7, 5};   // ceil(10*{1, 2/3, 1/2})
+    for (int lvl = 0; lvl < 3; lvl++) {
+        const int val_count = (lvl + 2) * (lvl + 2);
+        const int sample_step = steps[lvl];
+        int valpos = 0;
+        for (int i = -pattern_size; i < pattern_size; i += sample_step)
+            for (int j = -pattern_size; j < pattern_size; j += sample_step) {
+                float di = 0.0f, dx = 0.0f, dy = 0.0f;
+                int nsamples = 0;
+                for (int k = i; k < i + sample_step; k++)
+                    for (int l = j; l < j + sample_step; l++) {
+                        float sample_y = yf + (l * co * scale + k * si * scale);
+                        float sample_x = xf + (-l * si * scale + k * co * scale);
+                        int y1 = cv_round_f(sample_y), x1 = cv_round_f(sample_x);
+                        if (y1 < 0 || y1 >= e.h || x1 < 0 || x1 >= e.w) continue;
+                        float ri = e.Lt[(size_t)y1 * e.w + x1];
+                        di += ri;
+                        float rx = e.Lx[(size_t)y1 * e.w + x1], ry = e.Ly[(size_t)y1 * e.w + x1];
+                        float rry = rx * co + ry * si;
+                        float rrx = -rx * si + ry * co;
+                        dx += rrx;
+                        dy += rry;
+                        nsamples++;
+                    }
+                if (nsamples > 0) {
+                    const float inv = 1.0f / nsamples;
+                    di *= inv;
+                    dx *= inv;
+                    dy *= inv;
+                }
+                values[valpos] = di;
+                values[valpos + 1] = dx;
+                values[valpos + 2] = dy;
+                valpos += chan;
+            }
+        int32_t iv[16 * 3];
+        for (int i = 0; i < val_count * chan; i++) iv[i] = toggle_flt(values[i]);
+        for (int pos = 0; pos < chan; pos++)
+            for (int i = 0; i < val_count; i++) {
+                const int32_t ival = iv[chan * i + pos];
+                for (int j = i + 1; j < val_count; j++) {
+                    if (ival > iv[chan * j + pos]) desc[dpos >> 3] |= (uint8_t)(1 << (dpos & 7));
+                    dpos++;
+                }
+            }
+    }
+}
+
+bool find_neighbor_point(int x, int y, const std::vector<uint8_t>& mask, int w, int h, int radius, int& idx) {
+    for (int i = y - radius; i < y + radius; ++i) {
+        if (i < 0 || i >= h) continue;
+        for (int j = x - radius; j < x + radius; ++j) {
+            if (j < 0 || j >= w) continue;
+            if (mask[(size_t)i * w + j] == 0) continue;
+            int dx = j - x, dy = i - y;
+            if (dx * dx + dy * dy <= radius * radius) {
+                idx = i * w + j;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+}  // namespace
+
+struct oracle_akaze {
+    std::vector<Level> ev;
+    std::vector<float> gray;
+    std::vector<oracle_keypoint> kps;
+    std::vector<uint8_t> desc;
+    float kcontrast = 0;
+    int desc_bytes = 61;
+};
+
+extern "C" {
+
+void oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int oracle_get_threads(void) { return g_threads; }
+
+oracle_akaze* oracle_akaze_run(const uint8_t* img, int rows, int cols, int channels, size_t stride, int max_points,
+                               int keep_planes) {
+    if (!img || rows <= 2 || cols <= 2 || (channels != 1 && channels != 3 && channels != 4)) return nullptr;
+    if (stride < (size_t)cols * channels) return nullptr;
+    oracle_akaze* A = new oracle_akaze();
+    const int W = cols, H = rows;
+    const float soffset = 1.6f, derivative_factor = 1.5f, dthreshold = 0.001f;
+    int omax = 4;
+    const int nsublevels = 4;
+
+    // --- Allocate_Memory_Evolution
+    const float smax = 10.0f * sqrtf(2.0f);
+    {
+        int lw = W, lh = H, power = 1;
+        for (int i = 0; i < omax; i++) {
+            for (int j = 0; j < nsublevels; j++) {
+                Level s;
+                s.w = lw;
+                s.h = lh;
+                s.esigma = soffset * powf(2.f, (float)j / (float)nsublevels + i);
+                s.sigma_size = cv_round_f(s.esigma * derivative_factor / power);
+                s.etime = 0.5f * (s.esigma * s.esigma);
+                s.octave = i;
+                s.sublevel = j;
+                s.ratio = (float)power;
+                s.border = cv_round_f(smax * s.sigma_size) + 1;
+                A->ev.push_back(std::move(s));
+            }
+            power <<= 1;
+            lh >>= 1;
+            lw >>= 1;
+            if (lw < 80 || lh < 40) {
+                omax = i + 1;
+                break;
+            }
+        }
+        for (size_t i = 1; i < A->ev.size(); i++) A->ev[i].tau = fed_tau(A->ev[i].etime - A->ev[i - 1].etime, 0.25f);
+    }
+    std::vector<Level>& ev = A->ev;
+
+    // --- prepareInputImage: BGR(A)->gray (15 bit fixed point), then * (1/255)
+    std::vector<float>& gray = A->gray;
+    gray.resize((size_t)W * H);
+    const float inv255 = (float)(1.0 / 255.0);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (int y = 0; y < H; y++) {
+        const uint8_t* p = img + (size_t)y * stride;
+        for (int x = 0; x < W; x++) {
+            int g;
+            if (channels == 1)
+                g = p[x];
+            else {
+                const uint8_t* q = p + (size_t)x * channels;
+                g = (q[0] * 3735 + q[1] * 19235 + q[2] * 9798 + (1 << 14)) >> 15;
+            }
+            gray[(size_t)y * W + x] = (float)g * inv255;
+        }
+    }
+
+    // --- Create_Nonlinear_Scale_Space
+    const std::vector<float> g16 = gauss_kernel(9, (double)soffset);   // ceil(2*(1+(1.6-0.8)/0.3)) = 8 -> 9
+    const std::vector<float> g10 = gauss_kernel(5, 1.0);
+    gauss_blur(gray, ev[0].Lsmooth, W, H, g16);
+    ev[0].Lt = ev[0].Lsmooth;
+    float kcontrast = 0.03f;
+    if (ev.size() > 1) {
+        std::vector<float> sm, lx, ly;
+        gauss_blur(gray, sm, W, H, g10);
+        deriv_pair(sm, lx, ly, W, H, 1, 3.0f, 10.0f);
+        kcontrast = compute_kcontrast(lx, ly, W, H, 0.7f, 300);
+    }
+    A->kcontrast = kcontrast;
+    ev[0].kcontrast = kcontrast;
+    {
+        std::vector<float> lx, ly, nxt;
+        for (size_t i = 1; i < ev.size(); i++) {
+            Level& e = ev[i];
+            if (e.octave > ev[i - 1].octave) {
+                half_sample(ev[i - 1].Lt, ev[i - 1].w, ev[i - 1].h, e.Lt, e.w, e.h);
+                kcontrast *= 0.75f;
+            } else {
+                e.Lt = ev[i - 1].Lt;
+            }
+            e.kcontrast = kcontrast;
+            gauss_blur(e.Lt, e.Lsmooth, e.w, e.h, g10);
+            deriv_pair(e.Lsmooth, lx, ly, e.w, e.h, 1, 3.0f, 10.0f);
+            pm_g2(lx, ly, e.Lflow, kcontrast);
+            for (size_t j = 0; j < e.tau.size(); j++) {
+                nld_step(e.Lt, e.Lflow, nxt, e.w, e.h, e.tau[j] * 0.5f);
+                e.Lt.swap(nxt);
+            }
+            if (!keep_planes) std::vector<float>().swap(e.Lflow);
+        }
+    }
+
+    // --- Compute_Determinant_Hessian_Response
+    for (size_t i = 0; i < ev.size(); i++) {
+        Level& e = ev[i];
+        const int s = e.sigma_size;
+        float kside, kmid;
+        if (s == 1) {
+            kside = 3.0f;   // getDerivKernels(ksize 0 = Scharr, normalize=true): {3,10,3}/32
+            kmid = 10.0f;
+            kside = kside / 32.0f;
+            kmid = kmid / 32.0f;
+        } else {
+            const float wgt = 10.0f / 3.0f;
+            const float norm = 1.0f / (2.0f * s * (wgt + 2.0f));
+            kside = norm;
+            kmid = wgt * norm;
+        }
+        std::vector<float> Lxx, Lxy, Lyy, dummy;
+        deriv_pair(e.Lsmooth, e.Lx, e.Ly, e.w, e.h, s, kside, kmid);
+        deriv_pair(e.Lx, Lxx, Lxy, e.w, e.h, s, kside, kmid);
+        deriv_pair(e.Ly, dummy, Lyy, e.w, e.h, s, kside, kmid);
+        const float sq = (float)(s * s * s * s);
+        e.Ldet.resize((size_t)e.w * e.h);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (long long j = 0; j < (long long)e.Ldet.size(); j++) e.Ldet[j] = (Lxx[j] * Lyy[j] - Lxy[j] * Lxy[j]) * sq;
+        if (!keep_planes) std::vector<float>().swap(e.Lsmooth);
+    }
+
+    // --- Find_Scale_Space_Extrema
+    for (size_t i = 0; i < ev.size(); i++) {
+        Level& e = ev[i];
+        e.mask1.assign((size_t)e.w * e.h, 0);
+        if (e.border + 1 >= e.h) continue;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (int y = e.border; y < e.h - e.border; y++) {
+            const float* prev = &e.Ldet[(size_t)(y - 1) * e.w];
+            const float* curr = prev + e.w;
+            const float* next = curr + e.w;
+            for (int x = e.border; x < e.w - e.border; x++) {
+                const float value = curr[x];
+                if (value <= dthreshold) continue;
+                if (value <= curr[x - 1] || value <= curr[x + 1]) continue;
+                if (value <= prev[x - 1] || value <= prev[x] || value <= prev[x + 1]) continue;
+                if (value <= next[x - 1] || value <= next[x] || value <= next[x + 1]) continue;
+                e.mask1[(size_t)y * e.w + x] = 1;
+            }
+        }
+        if (keep_planes) e.mask0 = e.mask1;
+    }
+    // lower-level suppression
+    for (size_t i = 1; i < ev.size(); i++) {
+        Level& e = ev[i];
+        Level& p = ev[i - 1];
+        const int diff_ratio = (int)e.ratio / (int)p.ratio;
+        const int search_radius = e.sigma_size * diff_ratio;
+        for (int y = 0; y < e.h; y++)
+            for (int x = 0; x < e.w; x++) {
+                const size_t j = (size_t)y * e.w + x;
+                if (!e.mask1[j]) continue;
+                int idx_prev = 0;
+                const int p_x = x * diff_ratio, p_y = y * diff_ratio;
+                if (find_neighbor_point(p_x, p_y, p.mask1, p.w, p.h, search_radius, idx_prev)) {
+                    if (e.Ldet[j] > p.Ldet[idx_prev]) p.mask1[idx_prev] = 0;
+                }
+            }
+    }
+    // upper-level suppression
+    for (int i = (int)ev.size() - 2; i >= 0; i--) {
+        Level& e = ev[i];
+        Level& nx = ev[i + 1];
+        const int diff_ratio = (int)nx.ratio / (int)e.ratio;
+        const int search_radius = nx.sigma_size;
+        for (int y = 0; y < e.h; y++)
+            for (int x = 0; x < e.w; x++) {
+                const size_t j = (size_t)y * e.w + x;
+                if (!e.mask1[j]) continue;
+                int idx_next = 0;
+                const int p_x = x / diff_ratio, p_y = y / diff_ratio;
+                if (find_neighbor_point(p_x, p_y, nx.mask1, nx.w, nx.h, search_radius, idx_next)) {
+                    if (e.Ldet[j] > nx.Ldet[idx_next]) nx.mask1[idx_next] = 0;
+                }
+            }
+    }
+
+    // --- Do_Subpixel_Refinement
+    std::vector<oracle_keypoint>& kps = A->kps;
+    for (size_t i = 0; i < ev.size(); i++) {
+        const Level& e = ev[i];
+        const float* ldet = e.Ldet.data();
+        const float ratio = e.ratio;
+        const int cols_l = e.w;
+        for (int y = 0; y < e.h; y++)
+            for (int x = 0; x < e.w; x++) {
+                if (!e.mask1[(size_t)y * e.w + x]) continue;
+                oracle_keypoint kp;
+                kp.x = x * e.ratio;
+                kp.y = y * e.ratio;
+                kp.size = e.esigma * derivative_factor;
+                kp.angle = -1;
+                kp.response = ldet[(size_t)y * cols_l + x];
+                kp.octave = e.octave;
+                kp.class_id = (int)i;
+                const size_t c = (size_t)y * cols_l + x;
+                float Dx = 0.5f * (ldet[c + 1] - ldet[c - 1]);
+                float Dy = 0.5f * (ldet[c + cols_l] - ldet[c - cols_l]);
+                float Dxx = ldet[c + 1] + ldet[c - 1] - 2.0f * ldet[c];
+                float Dyy = ldet[c + cols_l] + ldet[c - cols_l] - 2.0f * ldet[c];
+                float Dxy = 0.25f * (ldet[c + cols_l + 1] + ldet[c - cols_l - 1] - ldet[c - cols_l + 1] - ldet[c + cols_l - 1]);
+                // solve [[Dxx,Dxy],[Dxy,Dyy]] * d = [-Dx,-Dy]  (Matx 2x2 fast solve)
+                float dx = 0.0f, dy = 0.0f;
+                float det = Dxx * Dyy - Dxy * Dxy;
+                if (det != 0) {
+                    det = 1 / det;
+                    const float b0 = -Dx, b1 = -Dy;
+                    dx = (b0 * Dyy - b1 * Dxy) * det;
+                    dy = (b1 * Dxx - b0 * Dxy) * det;
+                }
+                if (std::fabs(dx) > 1.0f || std::fabs(dy) > 1.0f) continue;
+                kp.x += dx * ratio + .5f * (ratio - 1.f);
+                kp.y += dy * ratio + .5f * (ratio - 1.f);
+                kp.angle = 0.0f;
+                kp.size *= 2.0f;
+                kps.push_back(kp);
+            }
+    }
+    // --- max_points: keep strongest (response desc; ties by detection order)
+    if (max_points > 0 && (int)kps.size() > max_points) {
+        std::vector<int> order(kps.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return kps[a].response > kps[b].response; });
+        std::vector<oracle_keypoint> kept(max_points);
+        for (int i = 0; i < max_points; i++) kept[i] = kps[order[i]];
+        kps.swap(kept);
+    }
+
+    // --- Compute_Descriptors: orientation then M-LDB
+    const int K = (int)kps.size();
+    A->desc.assign((size_t)K * A->desc_bytes, 0);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 64)
+    for (int i = 0; i < K; i++) {
+        const Level& e = ev[kps[i].class_id];
+        kps[i].angle = main_orientation(kps[i], e);
+        mldb_descriptor(kps[i], e, &A->desc[(size_t)i * A->desc_bytes], A->desc_bytes);
+    }
+    if (!keep_planes) {
+        for (auto& e : ev) {
+            std::vector<float>().swap(e.Lt);
+            std::vector<float>().swap(e.Lx);
+            std::vector<float>().swap(e.Ly);
+            std::vector<float>().swap(e.Ldet);
+            std::vector<uint8_t>().swap(e.mask1);
+        }
+        std::vector<float>().swap(A->gray);
+    }
+    return A;
+}
+
+int oracle_akaze_num_keypoints(const oracle_akaze* a) { return (int)a->kps.size(); }
+const oracle_keypoint* oracle_akaze_keypoints(const oracle_akaze* a) { return a->kps.data(); }
+const uint8_t* oracle_akaze_descriptors(const oracle_akaze* a) { return a->desc.data(); }
+int oracle_akaze_desc_bytes(const oracle_akaze* a) { return a->desc_bytes; }
+int oracle_akaze_num_levels(const oracle_akaze* a) { return (int)a->ev.size(); }
+float oracle_akaze_kcontrast(const oracle_akaze* a) { return a->kcontrast; }
+void oracle_akaze_level_info(const oracle_akaze* a, int level, int* info, float* finfo) {
+    const Level& e = a->ev[level];
+    info[0] = e.w; info[1] = e.h; info[2] = e.octave; info[3] = e.sublevel;
+    info[4] = e.sigma_size; info[5] = e.border; info[6] = (int)e.tau.size(); info[7] = 0;
+    finfo[0] = e.esigma; finfo[1] = e.etime; finfo[2] = e.ratio; finfo[3] = e.kcontrast;
+}
+int oracle_akaze_level_tau(const oracle_akaze* a, int level, float* tau_out, int cap) {
+    const Level& e = a->ev[level];
+    int n = std::min(cap, (int)e.tau.size());
+    for (int i = 0; i < n; i++) tau_out[i] = e.tau[i];
+    return (int)e.tau.size();
+}
+const void* oracle_akaze_plane(const oracle_akaze* a, int level, int which) {
+    const Level& e = a->ev[level];
+    switch (which) {
+        case ORACLE_PLANE_LT: return e.Lt.empty() ? nullptr : e.Lt.data();
+        case ORACLE_PLANE_LSMOOTH: return e.Lsmooth.empty() ? nullptr : e.Lsmooth.data();
+        case ORACLE_PLANE_LX: return e.Lx.empty() ? nullptr : e.Lx.data();
+        case ORACLE_PLANE_LY: return e.Ly.empty() ? nullptr : e.Ly.data();
+        case ORACLE_PLANE_LDET: return e.Ldet.empty() ? nullptr : e.Ldet.data();
+        case ORACLE_PLANE_LFLOW: return e.Lflow.empty() ? nullptr : e.Lflow.data();
+        case ORACLE_PLANE_MASK0: return e.mask0.empty() ? nullptr : e.mask0.data();
+        case ORACLE_PLANE_MASK1: return e.mask1.empty() ? nullptr : e.mask1.data();
+    }
+    return nullptr;
+}
+const float* oracle_akaze_gray(const oracle_akaze* a) { return a->gray.empty() ? nullptr : a->gray.data(); }
+void oracle_akaze_free(oracle_akaze* a) { delete a; }
+
+}  // extern "C"

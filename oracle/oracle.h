@@ -1,0 +1,107 @@
+/*
+ * oracle/oracle.h — CPU restatement of the cubesat-APDS hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This library is the parity checker and the timed "port" CPU baseline. Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it. The product
+ * (cubesat-apds_amd/, libapds_hip.so) never includes, links or calls anything here.
+ *
+ * What it restates (reference file:line -> third-party algorithm behind it):
+ *   feature_extraction/src/lib.rs:61-92   AKAZE::create(MLDB,0,3,0.001,4,4,PM_G2,max_points)+detectAndCompute
+ *                                          -> OpenCV 4.8/4.9 features2d AKAZE (kaze/AKAZEFeatures.cpp,
+ *                                             kaze/nldiffusion_functions.cpp, kaze/fed.cpp)
+ *   feature_extraction/src/lib.rs:94-114  BFMatcher(NORM_HAMMING,false).knnMatch + Lowe ratio test
+ *   feature_extraction/src/lib.rs:116-126 BFMatcher(NORM_HAMMING,true).match (batchDistance cross-check)
+ *   feature_extraction/src/lib.rs:161-180 get_points_from_matches
+ *   homographier/src/homographier/mod.rs:231-259 calib3d findHomography (0 / RANSAC / LMEDS)
+ *   homographier/src/homographier/mod.rs:183-220 raster_to_mat (RGBA -> BGRA)
+ *
+ * OpenCV (crate opencv = "0.88.8", system OpenCV 4.8.x/4.9.0, unpinned: the reference has no
+ * Cargo.lock) is NOT in /root/reference and not installed here, so the arithmetic is restated
+ * from the published algorithm.
+ *
+ * PARITY STATUS
+ *   pinned   : homography (reference test homography_success, mod.rs:437-472), raster_to_mat
+ *              (mod.rs:556-603), Cmat layout/at_2d (mod.rs:515-553, 606-625).
+ *   UNPINNED : AKAZE keypoints/descriptors and Hamming match values. The reference holds only
+ *              count assertions (9079/9357 keypoints, 27 and 3228 matches; lib.rs:273,295,314)
+ *              on two GeoTIFFs that are git-ignored and absent. "parity unpinned".
+ */
+#ifndef APDS_ORACLE_H
+#define APDS_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* cv::KeyPoint layout (28 bytes) */
+typedef struct {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} oracle_keypoint;
+
+/* cv::DMatch layout (16 bytes) */
+typedef struct {
+    int32_t query_idx, train_idx, img_idx;
+    float distance;
+} oracle_dmatch;
+
+typedef struct oracle_akaze oracle_akaze;
+
+enum { ORACLE_PLANE_LT = 0, ORACLE_PLANE_LSMOOTH = 1, ORACLE_PLANE_LX = 2, ORACLE_PLANE_LY = 3,
+       ORACLE_PLANE_LDET = 4, ORACLE_PLANE_LFLOW = 5, ORACLE_PLANE_MASK0 = 6 /* u8 extrema before cross-level */,
+       ORACLE_PLANE_MASK1 = 7 /* u8 after cross-level */ };
+
+void oracle_set_threads(int n);
+int  oracle_get_threads(void);
+
+/* feature_extraction/src/lib.rs:61-92. channels in {1,3,4}; stride in bytes. max_points<=0 -> no cap.
+ * keep_planes!=0 keeps every intermediate plane for per-stage tests. Returns NULL on bad arguments. */
+oracle_akaze* oracle_akaze_run(const uint8_t* img, int rows, int cols, int channels, size_t stride,
+                               int max_points, int keep_planes);
+int   oracle_akaze_num_keypoints(const oracle_akaze*);
+const oracle_keypoint* oracle_akaze_keypoints(const oracle_akaze*);
+const uint8_t* oracle_akaze_descriptors(const oracle_akaze*);   /* K x 61 */
+int   oracle_akaze_desc_bytes(const oracle_akaze*);
+int   oracle_akaze_num_levels(const oracle_akaze*);
+float oracle_akaze_kcontrast(const oracle_akaze*);
+/* info[8] = {w, h, octave, sublevel, sigma_size, border, nsteps, 0}; finfo[4] = {esigma, etime, ratio, kcontrast_at_level} */
+void  oracle_akaze_level_info(const oracle_akaze*, int level, int* info, float* finfo);
+int   oracle_akaze_level_tau(const oracle_akaze*, int level, float* tau_out, int cap);
+const void* oracle_akaze_plane(const oracle_akaze*, int level, int which);
+const float* oracle_akaze_gray(const oracle_akaze*);
+void  oracle_akaze_free(oracle_akaze*);
+
+/* Hamming brute force. Rows are desc_bytes long with the given byte strides. idx/dist are nq*k,
+ * filled with -1 / INT_MAX where the train set has fewer than k rows. Ties: lower train index first. */
+void oracle_knn_hamming(const uint8_t* q, int nq, size_t q_stride, const uint8_t* t, int nt, size_t t_stride,
+                        int desc_bytes, int k, int32_t* idx, int32_t* dist);
+/* lib.rs:94-114. Returns match count >= 0, or a negative OpenCV-style code (-211 when a query has < 2 neighbours). */
+int oracle_get_knn_matches(const uint8_t* q, int nq, size_t q_stride, const uint8_t* t, int nt, size_t t_stride,
+                           int desc_bytes, int k, float filter_strength, oracle_dmatch* out /* nq */);
+/* lib.rs:116-126 (crossCheck=true). out holds up to nq entries. */
+int oracle_get_bruteforce_matches(const uint8_t* q, int nq, size_t q_stride, const uint8_t* t, int nt, size_t t_stride,
+                                  int desc_bytes, oracle_dmatch* out /* nq */);
+/* lib.rs:161-180. bug_compatible!=0 reproduces the reference's img_idx / img1-twice behaviour.
+ * Returns 0, or -211 on an out-of-range index. pts are 2*nm floats each. */
+int oracle_get_points_from_matches(const oracle_keypoint* kp1, int n1, const oracle_keypoint* kp2, int n2,
+                                   const oracle_dmatch* m, int nm, int bug_compatible, float* pts1, float* pts2);
+
+/* mod.rs:231-259. method: 0 least squares, 4 LMEDS, 8 RANSAC. thr<=0 -> 3. max_iters/confidence: OpenCV
+ * defaults are 2000 / 0.995. Returns 1 if a model was found (H filled, H[8]==1), 0 if none, <0 on error
+ * (-215 bad args, -2 RHO unsupported). mask (n bytes) may be NULL. */
+int oracle_find_homography(const float* src_xy, const float* dst_xy, int n, int method, double thr,
+                           int max_iters, double confidence, double* H, uint8_t* mask);
+/* helpers exposed for GPU per-stage parity */
+int  oracle_homography_4pt(const float* src_xy, const float* dst_xy, int count, double* H);   /* runKernel */
+int  oracle_ransac_samples(const float* src_xy, const float* dst_xy, int n, int iters, int32_t* idx4 /* iters*4 */);
+
+/* mod.rs:183-220: RGBA8 slice -> BGRA rows. Returns 0 or -1 (MatError::Unknown) if len != w*h. */
+int oracle_raster_to_mat(const uint8_t* rgba, size_t n_pixels, int w, int h, uint8_t* bgra);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
