@@ -1,0 +1,112 @@
+"""ctypes binding of libapds_hip.so (C ABI: include/apds.h). Fails loudly when the library is missing."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libapds_hip.so")
+_LIB = None
+
+KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
+                           ("octave", "<i4"), ("class_id", "<i4")])
+DMATCH_DTYPE = np.dtype([("query_idx", "<i4"), ("train_idx", "<i4"), ("img_idx", "<i4"), ("distance", "<f4")])
+assert KEYPOINT_DTYPE.itemsize == 28 and DMATCH_DTYPE.itemsize == 16
+
+ERR_INTERNAL, ERR_NOMEM, ERR_BAD_ARG, ERR_NO_DEVICE, ERR_OUT_OF_RANGE, ERR_ASSERT, ERR_EMPTY = -2, -4, -5, -216, -211, -215, -1000
+
+# every symbol include/apds.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "apds_last_error", "apds_free", "apds_device_count", "apds_set_device", "apds_build_info",
+    "apds_akaze_extract", "apds_get_knn_matches", "apds_get_bruteforce_matches", "apds_knn_match",
+    "apds_get_points_from_matches", "apds_find_homography", "apds_find_homography_ex", "apds_raster_to_mat",
+    "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_ratio_filter",
+    "apds_dev_cross_check", "apds_dev_akaze_extract", "apds_dev_points_from_matches", "apds_dev_find_homography",
+    "apds_dev_valu_popcount_peak", "apds_dev_last_kernel_ms", "apds_dev_timing_enable",
+]
+
+
+class ApdsError(RuntimeError):
+    """Mirror of opencv::Error{code, message} as surfaced by the reference crates."""
+
+    def __init__(self, code, message):
+        super().__init__(f"apds error {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+def build_library(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/ into libapds_hip.so (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", csrc, "-j8"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ApdsError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp, i, f, d, sz, i64, u32 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_int64, C.c_uint32
+        pp, ip = C.POINTER(C.c_void_p), C.POINTER(C.c_int)
+        sig = {
+            "apds_last_error": (C.c_char_p, []),
+            "apds_free": (None, [vp]),
+            "apds_device_count": (i, []),
+            "apds_set_device": (i, [i]),
+            "apds_build_info": (C.c_char_p, []),
+            "apds_akaze_extract": (i, [vp, i, i, i, sz, i, pp, pp, ip, ip]),
+            "apds_get_knn_matches": (i, [vp, i, vp, i, i, i, f, pp, ip]),
+            "apds_get_bruteforce_matches": (i, [vp, i, vp, i, i, pp, ip]),
+            "apds_knn_match": (i, [vp, i, vp, i, i, i, vp, vp]),
+            "apds_get_points_from_matches": (i, [vp, i, vp, i, vp, i, i, vp, vp]),
+            "apds_find_homography": (i, [vp, vp, i, i, d, vp, vp]),
+            "apds_find_homography_ex": (i, [vp, vp, i, i, d, i, d, vp, vp]),
+            "apds_raster_to_mat": (i, [vp, sz, i, i, vp]),
+            "apds_dev_pack_descriptors": (i, [vp, i64, i, i64, vp, vp]),
+            "apds_dev_hamming_topk": (i, [vp, i, vp, i64, u32, i, vp, vp]),
+            "apds_dev_merge_topk": (i, [vp, i, i, i, vp, vp]),
+            "apds_dev_ratio_filter": (i, [vp, i, i, f, vp, ip, vp]),
+            "apds_dev_cross_check": (i, [vp, i64, i, vp, ip, vp]),
+            "apds_dev_akaze_extract": (i, [vp, i, i, i, sz, i, vp, vp, i, ip, vp]),
+            "apds_dev_points_from_matches": (i, [vp, i, vp, i, vp, i, i, vp, vp, vp]),
+            "apds_dev_find_homography": (i, [vp, vp, i, i, d, i, d, vp, vp, vp]),
+            "apds_dev_valu_popcount_peak": (i, [C.POINTER(d)]),
+            "apds_dev_last_kernel_ms": (i, [C.c_char_p, C.POINTER(f), ip]),
+            "apds_dev_timing_enable": (i, [i]),
+        }
+        for name, (rt, at) in sig.items():
+            fn = getattr(L, name)
+            fn.restype = rt
+            fn.argtypes = at
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise ApdsError(rc, lib().apds_last_error().decode("utf-8", "replace"))
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def take(pointer, count, dtype, shape=None):
+    """Copy `count` items from a library-allocated host buffer into numpy and apds_free() it."""
+    out = np.zeros(count if shape is None else shape, dtype)
+    if pointer.value:
+        if out.nbytes:
+            C.memmove(ptr(out), pointer, out.nbytes)
+        lib().apds_free(pointer)
+    return out
+
+
+def kernel_ms(name):
+    ms, n = C.c_float(0), C.c_int(0)
+    check(lib().apds_dev_last_kernel_ms(name.encode(), C.byref(ms), C.byref(n)))
+    return ms.value, n.value

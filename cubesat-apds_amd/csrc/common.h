@@ -1,0 +1,109 @@
+// csrc/common.h — host-side plumbing shared by the entry points: error mapping, the per-thread HIP
+// stream + grow-only device workspace, and hipEvent kernel timing for bench.py.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/apds.h"
+
+namespace apds {
+
+struct Error {
+    int code;
+    std::string msg;
+};
+
+void set_last_error(const std::string& m);
+
+[[noreturn]] inline void fail(int code, const std::string& m) { throw Error{code, m}; }
+
+inline void hip_check(hipError_t e, const char* what, const char* file, int line) {
+    if (e == hipSuccess) return;
+    int code = APDS_ERR_INTERNAL;
+    if (e == hipErrorNoDevice || e == hipErrorInvalidDevice || e == hipErrorNoBinaryForGpu || e == hipErrorInsufficientDriver ||
+        e == hipErrorNotInitialized)
+        code = APDS_ERR_NO_DEVICE;
+    if (e == hipErrorOutOfMemory) code = APDS_ERR_NOMEM;
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    (void)hipGetLastError();
+    throw Error{code, buf};
+}
+#define HIP_CHECK(x) ::apds::hip_check((x), #x, __FILE__, __LINE__)
+#define APDS_REQUIRE(cond, code, msg) \
+    do {                               \
+        if (!(cond)) ::apds::fail((code), (msg)); \
+    } while (0)
+
+// Per host thread: device ordinal, a private stream, a bump-allocated workspace that only grows.
+struct ThreadCtx {
+    int device = 0;
+    bool ready = false;
+    hipStream_t stream = nullptr;
+    std::vector<std::pair<char*, size_t>> slabs;
+    size_t slab_used = 0;   // in slabs.back()
+    bool timing = false;
+    struct Ev {
+        hipEvent_t a, b;
+        hipStream_t s;
+    };
+    std::map<std::string, std::vector<Ev>> events;
+
+    void ensure();
+    void* alloc(size_t bytes);   // valid until the next ws_reset()
+    void ws_reset();             // frees all but one slab sized to the high-water mark
+    template <class T>
+    T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
+};
+ThreadCtx& ctx();
+
+inline hipStream_t pick_stream(void* s) { return s ? static_cast<hipStream_t>(s) : ctx().stream; }
+
+// RAII: time one named kernel with hipEvents on the stream it is launched on (only when enabled).
+struct KernelTimer {
+    ThreadCtx::Ev ev{};
+    bool on;
+    const char* name;
+    KernelTimer(const char* nm, hipStream_t s) : on(ctx().timing), name(nm) {
+        if (!on) return;
+        ev.s = s;
+        HIP_CHECK(hipEventCreate(&ev.a));
+        HIP_CHECK(hipEventCreate(&ev.b));
+        HIP_CHECK(hipEventRecord(ev.a, s));
+    }
+    ~KernelTimer() {
+        if (!on) return;
+        (void)hipEventRecord(ev.b, ev.s);
+        ctx().events[name].push_back(ev);
+    }
+};
+
+// Wrap an entry-point body: map exceptions to status codes + last_error text.
+template <class F>
+int guarded(F&& f) {
+    try {
+        f();
+        return APDS_OK;
+    } catch (const Error& e) {
+        set_last_error(e.msg);
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        set_last_error("host allocation failed");
+        return APDS_ERR_NOMEM;
+    } catch (const std::exception& e) {
+        set_last_error(e.what());
+        return APDS_ERR_INTERNAL;
+    } catch (...) {
+        set_last_error("unknown failure");
+        return APDS_ERR_INTERNAL;
+    }
+}
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace apds

@@ -1,0 +1,27 @@
+// csrc/kernels.h — host-callable launchers implemented in the .hip files.
+#pragma once
+#include "common.h"
+
+namespace apds {
+
+// match_hamming.hip
+void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s);
+void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_t* out, hipStream_t s);
+void pack_rows_device(const void* src, long long n, int desc_bytes, long long src_stride, void* dst, hipStream_t s);
+int* scan_flags_device(const uint8_t* flags, int n, int** total_dev, hipStream_t s);
+int ratio_filter_device(const uint64_t* keys, int nq, int k, float fs, apds_dmatch* out, hipStream_t s);
+int cross_check_device(const uint64_t* train_best, long long n_train, int nq, apds_dmatch* out, hipStream_t s);
+double valu_popcount_peak_device();
+
+// akaze.hip
+int akaze_extract_device(const void* img, int rows, int cols, int channels, size_t stride, int max_points, apds_keypoint* kps,
+                         uint8_t* desc64, int capacity, hipStream_t s);
+void points_from_matches_device(const apds_keypoint* kp1, int n1, const apds_keypoint* kp2, int n2, const apds_dmatch* m, int nm,
+                                int bug_compatible, float* pts1, float* pts2, int* err_flag, hipStream_t s);
+void rgba_to_bgra_device(const uint8_t* rgba, size_t n_pixels, uint8_t* bgra, hipStream_t s);
+
+// homography.hip
+int find_homography_device(const float* src, const float* dst, int n, int method, double thr, int max_iters, double confidence,
+                           double* H_host, uint8_t* mask_dev, hipStream_t s);
+
+}  // namespace apds

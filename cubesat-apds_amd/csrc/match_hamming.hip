@@ -1,0 +1,498 @@
+// csrc/match_hamming.hip — Hamming brute-force top-k on gfx950 (integer VALU + scalar broadcast).
+//
+// Replaces BFMatcher(NORM_HAMMING).knnMatch / match(crossCheck) behind
+// /root/reference/feature_extraction/src/lib.rs:94-126.
+//
+// Mapping (CDNA4): one LANE owns T query descriptors (16 dwords each, in VGPRs for the whole kernel);
+// one WAVE walks a contiguous chunk of train rows. A train row is wave-uniform, so it is fetched with
+// scalar loads (s_load_dwordx16: one 64-byte line per row) and fed to the VALU as an SGPR operand:
+//     v_xor_b32  t, s_row[j], v_q[j]      v_bcnt_u32_b32  acc, t, acc
+// = 32 VALU lane-ops per (query,row) pair, no LDS and no cross-lane traffic on the hot path. The running
+// top-k lives per lane; the popcount chain starts at -threshold so "distance < current k-th best" is the
+// sign bit, a whole group of pairs is screened with one v_min3/v_cmp, and the insertion code runs only for
+// the rare groups that contain a hit. Train rows are split into chunks over blockIdx.y so the grid fills
+// 256 CUs; per-chunk candidates are merged by a second tiny kernel. Keys are (distance << 32 | index):
+// unsigned 64-bit min reproduces BFMatcher's order (distance, then lower train index).
+#include "common.h"
+
+namespace apds {
+
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr uint64_t EMPTY_KEY = ~0ull;
+static constexpr int INF_THR = 1 << 20;          // > any Hamming distance of a 512-bit row
+static constexpr uint32_t NO_INDEX = 0xFFFFFFFFu;
+
+// acc + popcount(x) in ONE VALU op. hipcc otherwise splits the accumulate into v_bcnt(x,0) + v_add3 (5 ops per
+// two dwords instead of 4), so the accumulate form is spelled out.
+__device__ __forceinline__ int bcnt_acc(uint32_t x, int acc) {
+    int r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+template <int T>
+__device__ __forceinline__ void row_distances(const u32x16 row, const uint32_t (&q)[T][16], const int (&start)[T], int (&acc)[T]) {
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        int a = start[t];
+#pragma unroll
+        for (int j = 0; j < 16; j++) a = bcnt_acc(q[t][j] ^ row[j], a);
+        acc[t] = a;
+    }
+}
+
+template <int T, int K>
+__device__ __forceinline__ void insert_hits(const int (&acc)[T], const int (&nthr_old)[T], uint32_t r, int (&bd)[T][K],
+                                            uint32_t (&bi)[T][K]) {
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        const int d = acc[t] - nthr_old[t];
+        if (d < bd[t][K - 1]) {
+            if (K == 2) {
+                if (d < bd[t][0]) {
+                    bd[t][1] = bd[t][0];
+                    bi[t][1] = bi[t][0];
+                    bd[t][0] = d;
+                    bi[t][0] = r;
+                } else {
+                    bd[t][1] = d;
+                    bi[t][1] = r;
+                }
+            } else {
+                bd[t][0] = d;
+                bi[t][0] = r;
+            }
+        }
+    }
+}
+
+// grid: x = ceil(nq / (256*T)), y = chunks. block = 256 threads = 4 waves, each wave its own 64*T queries.
+template <int T, int K>
+__global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restrict__ train, int n_train,
+                                                           const u32x4* __restrict__ queries, int nq, int rows_per_chunk,
+                                                           const int* __restrict__ init_thr, uint64_t* __restrict__ out,
+                                                           uint32_t index_base) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int qbase = (blockIdx.x * 4 + wave) * (64 * T);
+    if (qbase >= nq) return;   // wave-uniform
+    const int chunk = blockIdx.y;
+    const int row0 = chunk * rows_per_chunk;
+    const int row1 = min(n_train, row0 + rows_per_chunk);
+
+    uint32_t q[T][16];
+    int bd[T][K];
+    uint32_t bi[T][K];
+    int nthr[T];
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        const int qi = min(qbase + t * 64 + lane, nq - 1);
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const u32x4 x = queries[(size_t)qi * 4 + v];
+            q[t][4 * v + 0] = x.x;
+            q[t][4 * v + 1] = x.y;
+            q[t][4 * v + 2] = x.z;
+            q[t][4 * v + 3] = x.w;
+        }
+        const int thr0 = init_thr ? init_thr[qi] : INF_THR;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            bd[t][k] = thr0;
+            bi[t][k] = NO_INDEX;
+        }
+        nthr[t] = -thr0;
+    }
+
+    // Screen two rows against the lane's T queries; run the insertion code only if some lane has a hit.
+    auto pair_step = [&](const u32x16& a0, const u32x16& a1, int r) {
+        int acc0[T], acc1[T];
+        row_distances<T>(a0, q, nthr, acc0);
+        row_distances<T>(a1, q, nthr, acc1);
+        int m = acc0[0];
+#pragma unroll
+        for (int t = 1; t < T; t++) m = min(m, acc0[t]);
+#pragma unroll
+        for (int t = 0; t < T; t++) m = min(m, acc1[t]);
+        if (__any(m < 0)) {
+            int nthr_old[T];
+#pragma unroll
+            for (int t = 0; t < T; t++) nthr_old[t] = nthr[t];
+            insert_hits<T, K>(acc0, nthr_old, (uint32_t)r, bd, bi);
+            insert_hits<T, K>(acc1, nthr_old, (uint32_t)(r + 1), bd, bi);
+#pragma unroll
+            for (int t = 0; t < T; t++) nthr[t] = -bd[t][K - 1];
+        }
+    };
+
+    int r = row0;
+    // Main loop: four rows per trip as two ping-pong pairs (A, B). The scalar loads of one pair are issued
+    // before the 2*T*32 VALU ops of the other pair, so their latency sits under compute; SMEM returns out
+    // of order, hence the only wait is lgkmcnt(0) and it always lands after a full compute phase.
+    if (r + 3 < row1) {
+        u32x16 a0 = train[r], a1 = train[r + 1];
+        __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+        for (; r + 3 < row1; r += 4) {
+            const u32x16 b0 = train[r + 2], b1 = train[r + 3];
+            __builtin_amdgcn_sched_barrier(0);
+            pair_step(a0, a1, r);
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // pair B has landed (issued one compute phase ago)
+            const int rn = min(r + 4, row1 - 1), rm = min(r + 5, row1 - 1);
+            a0 = train[rn];
+            a1 = train[rm];
+            __builtin_amdgcn_sched_barrier(0);
+            pair_step(b0, b1, r + 2);
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // pair A has landed
+        }
+    }
+    for (; r < row1; r++) {   // tail: at most three rows
+        const u32x16 a0 = train[r];
+        int acc0[T];
+        row_distances<T>(a0, q, nthr, acc0);
+        insert_hits<T, K>(acc0, nthr, (uint32_t)r, bd, bi);
+#pragma unroll
+        for (int t = 0; t < T; t++) nthr[t] = -bd[t][K - 1];
+    }
+
+#pragma unroll
+    for (int t = 0; t < T; t++) {
+        const int qi = qbase + t * 64 + lane;
+        if (qi < nq) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint64_t key = bi[t][k] == NO_INDEX ? EMPTY_KEY : ((uint64_t)(uint32_t)bd[t][k] << 32) | (uint64_t)(bi[t][k] + index_base);
+                out[((size_t)chunk * nq + qi) * K + k] = key;
+            }
+        }
+    }
+}
+
+// merge `parts` sorted candidate lists per query into the k smallest keys
+template <int K>
+__global__ void merge_topk_kernel(const uint64_t* __restrict__ parts_keys, int parts, int nq, uint64_t* __restrict__ out) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    uint64_t b0 = EMPTY_KEY, b1 = EMPTY_KEY;
+    for (int p = 0; p < parts; p++) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const uint64_t key = parts_keys[((size_t)p * nq + qi) * K + k];
+            if (key < b0) {
+                b1 = b0;
+                b0 = key;
+            } else if (key < b1) {
+                b1 = key;
+            }
+        }
+    }
+    out[(size_t)qi * K] = b0;
+    if (K == 2) out[(size_t)qi * K + 1] = b1;
+}
+
+// second-best distance of a sample of train rows -> initial thresholds for the full scan
+__global__ void thr_from_keys_kernel(const uint64_t* __restrict__ keys, int nq, int K, int* __restrict__ thr) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    const uint64_t key = keys[(size_t)qi * K + (K - 1)];
+    thr[qi] = key == EMPTY_KEY ? INF_THR : (int)(key >> 32);
+}
+
+__global__ void pack_rows_kernel(const uint8_t* __restrict__ src, long long n, int desc_bytes, long long src_stride,
+                                 uint32_t* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one dword of one row
+    if (i >= n * 16) return;
+    const long long row = i >> 4;
+    const int w = (int)(i & 15);
+    const uint8_t* p = src + row * src_stride + w * 4;
+    uint32_t v = 0;
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+        if (w * 4 + b < desc_bytes) v |= (uint32_t)p[b] << (8 * b);
+    dst[i] = v;
+}
+
+__global__ void ratio_flag_kernel(const uint64_t* __restrict__ keys, int nq, int K, float fs, uint8_t* __restrict__ flags) {
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    const uint64_t k0 = keys[(size_t)qi * K], k1 = keys[(size_t)qi * K + 1];
+    const float d0 = (float)(uint32_t)(k0 >> 32), d1 = (float)(uint32_t)(k1 >> 32);
+    flags[qi] = (k0 != EMPTY_KEY && k1 != EMPTY_KEY && d0 < d1 * fs) ? 1 : 0;
+}
+
+__global__ void crosscheck_scatter_kernel(const uint64_t* __restrict__ train_best, long long n_train, unsigned long long* __restrict__ best_per_query) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_train) return;
+    const uint64_t key = train_best[i];
+    if (key == EMPTY_KEY) return;
+    const uint32_t qidx = (uint32_t)key;
+    const uint64_t cand = (key & 0xFFFFFFFF00000000ull) | (uint64_t)(uint32_t)i;
+    atomicMin(&best_per_query[qidx], (unsigned long long)cand);
+}
+
+__global__ void nonempty_flag_kernel(const uint64_t* __restrict__ keys, int n, uint8_t* __restrict__ flags) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flags[i] = keys[i] != EMPTY_KEY;
+}
+
+// ---- ordered compaction: flags -> exclusive positions (3 small kernels, no host round trip) -------------
+static constexpr int SCAN_BLOCK = 1024;
+
+__global__ __launch_bounds__(SCAN_BLOCK) void scan_block_counts_kernel(const uint8_t* __restrict__ flags, int n, int* __restrict__ block_counts) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const int f = i < n ? (flags[i] != 0) : 0;
+    const unsigned long long b = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; w++) s += wsum[w];
+        block_counts[blockIdx.x] = s;
+    }
+}
+
+// single block: exclusive scan of block_counts in place, total to *total
+__global__ __launch_bounds__(1024) void scan_offsets_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ total) {
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblocks ? block_counts[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int incl = buf[threadIdx.x];
+        if (i < nblocks) block_counts[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__device__ __forceinline__ int block_exclusive_pos(int f, int block_offset) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    const unsigned long long b = __ballot(f);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wsum[w] = __popcll(b);
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < w; k++) before += wsum[k];
+    return block_offset + before + __popcll(b & ((1ull << lane) - 1ull));
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void emit_ratio_matches_kernel(const uint64_t* __restrict__ keys, int nq, int K, const uint8_t* __restrict__ flags,
+                                                                        const int* __restrict__ block_offsets, apds_dmatch* __restrict__ out) {
+    const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const int f = i < nq ? (flags[i] != 0) : 0;
+    const int pos = block_exclusive_pos(f, block_offsets[blockIdx.x]);
+    if (f) {
+        const uint64_t k0 = keys[(size_t)i * K];
+        apds_dmatch m;
+        m.query_idx = i;
+        m.train_idx = (int32_t)(uint32_t)k0;
+        m.img_idx = 0;
+        m.distance = (float)(uint32_t)(k0 >> 32);
+        out[pos] = m;
+    }
+}
+
+// ---- register-only VALU microbenchmark (denominator of the popcount roofline) ---------------------------
+__global__ __launch_bounds__(256) void valu_popcount_peak_kernel(uint32_t* __restrict__ sink, int iters) {
+    uint32_t q[16];
+#pragma unroll
+    for (int j = 0; j < 16; j++) q[j] = threadIdx.x * 2654435761u + j * 40503u;
+    int acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    uint32_t s = blockIdx.x * 97u + 1u;
+    for (int it = 0; it < iters; it++) {
+        // s is wave-uniform (SGPR operand), like a train row dword
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            acc0 += __popc(q[j] ^ s);
+            acc1 += __popc(q[j] ^ (s + 1));
+            acc2 += __popc(q[j] ^ (s + 2));
+            acc3 += __popc(q[j] ^ (s + 3));
+        }
+        s = s * 1664525u + 1013904223u;
+    }
+    if ((acc0 + acc1 + acc2 + acc3) == 0x7fffffff) sink[0] = 1;
+}
+
+// ---- host launchers -------------------------------------------------------------------------------------
+struct ChunkPlan {
+    int T, chunks, rows_per_chunk, qtiles_blocks;
+};
+
+static ChunkPlan plan_chunks(int nq, long long n_train) {
+    ChunkPlan p;
+    p.T = nq >= 64 * 4 * 64 ? 4 : (nq >= 64 * 2 * 64 ? 2 : 1);
+    const int waves_q = ceil_div(nq, 64 * p.T);
+    p.qtiles_blocks = ceil_div(waves_q, 4);
+    const int target_waves = 256 * 4 * 6;
+    long long chunks = ceil_div(target_waves, waves_q);
+    const long long max_chunks = std::max<long long>(1, n_train / 4096);
+    chunks = std::min<long long>(std::max<long long>(chunks, 1), std::min<long long>(max_chunks, 65535));
+    long long rpc = (n_train + chunks - 1) / chunks;
+    rpc = (rpc + 1) & ~1ll;
+    p.rows_per_chunk = (int)rpc;
+    p.chunks = (int)((n_train + rpc - 1) / rpc);
+    return p;
+}
+
+template <int K>
+static void launch_topk(const void* q, int nq, const void* t, long long nt, uint32_t index_base, const int* init_thr,
+                        uint64_t* parts, const ChunkPlan& p, hipStream_t s) {
+    dim3 grid(p.qtiles_blocks, p.chunks), block(256);
+    const u32x16* tr = static_cast<const u32x16*>(t);
+    const u32x4* qq = static_cast<const u32x4*>(q);
+    KernelTimer timer("hamming_topk", s);
+    switch (p.T) {
+        case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base); break;
+        case 2: hipLaunchKernelGGL((hamming_topk_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base); break;
+        default: hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base); break;
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+// Full top-k of nq queries over nt train rows (device, 64-byte rows). out: nq*k keys.
+void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out,
+                         hipStream_t s) {
+    APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "device top-k supports k in {1,2}");
+    APDS_REQUIRE(nt < (1ll << 31), APDS_ERR_ASSERT, "train set too large for one call; shard it");
+    if (nq <= 0) return;
+    if (nt <= 0) {
+        HIP_CHECK(hipMemsetAsync(out, 0xFF, (size_t)nq * k * 8, s));
+        return;
+    }
+    ThreadCtx& c = ctx();
+    // Phase 0 (only for large scans): exact top-k over the first `sample` rows gives per-query thresholds that
+    // every chunk starts from, so the rare-hit fast path is reached immediately. The sample rows have the
+    // lowest indices, hence a later row at equal distance never outranks them: strict '<' stays exact.
+    const long long sample = nt >= 8 * 16384 ? 16384 : 0;
+    const int* thr = nullptr;
+    uint64_t* sample_keys = nullptr;
+    if (sample) {
+        ChunkPlan sp = plan_chunks(nq, sample);
+        uint64_t* sparts = c.alloc_n<uint64_t>((size_t)sp.chunks * nq * k);
+        sample_keys = c.alloc_n<uint64_t>((size_t)nq * k);
+        if (k == 2) launch_topk<2>(q, nq, t, sample, index_base, nullptr, sparts, sp, s);
+        else launch_topk<1>(q, nq, t, sample, index_base, nullptr, sparts, sp, s);
+        if (k == 2) hipLaunchKernelGGL((merge_topk_kernel<2>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, sparts, sp.chunks, nq, sample_keys);
+        else hipLaunchKernelGGL((merge_topk_kernel<1>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, sparts, sp.chunks, nq, sample_keys);
+        int* thr_buf = c.alloc_n<int>(nq);
+        hipLaunchKernelGGL(thr_from_keys_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, sample_keys, nq, k, thr_buf);
+        thr = thr_buf;
+    }
+    const char* rest = static_cast<const char*>(t) + (size_t)sample * 64;
+    const long long nrest = nt - sample;
+    ChunkPlan p = plan_chunks(nq, nrest);
+    // parts: [chunks (+1 for the sample result)][nq][k]
+    uint64_t* parts = c.alloc_n<uint64_t>((size_t)(p.chunks + 1) * nq * k);
+    if (k == 2) launch_topk<2>(q, nq, rest, nrest, index_base + (uint32_t)sample, thr, parts, p, s);
+    else launch_topk<1>(q, nq, rest, nrest, index_base + (uint32_t)sample, thr, parts, p, s);
+    int nparts = p.chunks;
+    if (sample) {
+        HIP_CHECK(hipMemcpyAsync(parts + (size_t)p.chunks * nq * k, sample_keys, (size_t)nq * k * 8, hipMemcpyDeviceToDevice, s));
+        nparts++;
+    }
+    if (k == 2) hipLaunchKernelGGL((merge_topk_kernel<2>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, nq, out);
+    else hipLaunchKernelGGL((merge_topk_kernel<1>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, nq, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_t* out, hipStream_t s) {
+    APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "k in {1,2}");
+    if (nq <= 0) return;
+    if (k == 2) hipLaunchKernelGGL((merge_topk_kernel<2>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, nq, out);
+    else hipLaunchKernelGGL((merge_topk_kernel<1>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, nq, out);
+    HIP_CHECK(hipGetLastError());
+}
+
+void pack_rows_device(const void* src, long long n, int desc_bytes, long long src_stride, void* dst, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(ceil_div(n * 16, 256)), dim3(256), 0, s, static_cast<const uint8_t*>(src), n, desc_bytes, src_stride,
+                       static_cast<uint32_t*>(dst));
+    HIP_CHECK(hipGetLastError());
+}
+
+// flags (n bytes) -> block offsets; returns device pointers for the emit kernel; *total_dev holds the count
+int* scan_flags_device(const uint8_t* flags, int n, int** total_dev, hipStream_t s) {
+    ThreadCtx& c = ctx();
+    const int nblocks = std::max(1, ceil_div(n, SCAN_BLOCK));
+    int* block_counts = c.alloc_n<int>(nblocks + 1);
+    int* total = block_counts + nblocks;
+    hipLaunchKernelGGL(scan_block_counts_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, flags, n, block_counts);
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total);
+    HIP_CHECK(hipGetLastError());
+    *total_dev = total;
+    return block_counts;
+}
+
+int ratio_filter_device(const uint64_t* keys, int nq, int k, float fs, apds_dmatch* out, hipStream_t s) {
+    if (nq <= 0) return 0;
+    ThreadCtx& c = ctx();
+    uint8_t* flags = c.alloc_n<uint8_t>(nq);
+    hipLaunchKernelGGL(ratio_flag_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, keys, nq, k, fs, flags);
+    int* total_dev = nullptr;
+    int* offs = scan_flags_device(flags, nq, &total_dev, s);
+    hipLaunchKernelGGL(emit_ratio_matches_kernel, dim3(ceil_div(nq, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, s, keys, nq, k, flags, offs, out);
+    HIP_CHECK(hipGetLastError());
+    int total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, total_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return total;
+}
+
+int cross_check_device(const uint64_t* train_best, long long n_train, int nq, apds_dmatch* out, hipStream_t s) {
+    if (nq <= 0 || n_train <= 0) return 0;
+    ThreadCtx& c = ctx();
+    uint64_t* best = c.alloc_n<uint64_t>(nq);
+    HIP_CHECK(hipMemsetAsync(best, 0xFF, (size_t)nq * 8, s));
+    hipLaunchKernelGGL(crosscheck_scatter_kernel, dim3(ceil_div(n_train, 256)), dim3(256), 0, s, train_best, n_train,
+                       reinterpret_cast<unsigned long long*>(best));
+    uint8_t* flags = c.alloc_n<uint8_t>(nq);
+    hipLaunchKernelGGL(nonempty_flag_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, best, nq, flags);
+    int* total_dev = nullptr;
+    int* offs = scan_flags_device(flags, nq, &total_dev, s);
+    hipLaunchKernelGGL(emit_ratio_matches_kernel, dim3(ceil_div(nq, SCAN_BLOCK)), dim3(SCAN_BLOCK), 0, s, best, nq, 1, flags, offs, out);
+    HIP_CHECK(hipGetLastError());
+    int total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, total_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return total;
+}
+
+double valu_popcount_peak_device() {
+    ThreadCtx& c = ctx();
+    uint32_t* sink = c.alloc_n<uint32_t>(64);
+    const int iters = 4096, blocks = 256 * 8;
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    hipLaunchKernelGGL(valu_popcount_peak_kernel, dim3(blocks), dim3(256), 0, c.stream, sink, 64);
+    double best = 0;
+    for (int rep = 0; rep < 5; rep++) {
+        HIP_CHECK(hipEventRecord(a, c.stream));
+        hipLaunchKernelGGL(valu_popcount_peak_kernel, dim3(blocks), dim3(256), 0, c.stream, sink, iters);
+        HIP_CHECK(hipEventRecord(b, c.stream));
+        HIP_CHECK(hipEventSynchronize(b));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, a, b));
+        const double ops = (double)blocks * 256 * (double)iters * 16 * 4 * 2;
+        best = std::max(best, ops / (ms * 1e-3));
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return best;
+}
+
+}  // namespace apds

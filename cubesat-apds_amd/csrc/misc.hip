@@ -1,0 +1,50 @@
+// csrc/misc.hip — small byte/gather kernels on the edges of the path.
+#include "kernels.h"
+
+namespace apds {
+
+// feature_extraction/src/lib.rs:161-180. bug_compatible reproduces :169 (img_idx) and :176-177 (img1 twice).
+__global__ void points_from_matches_kernel(const apds_keypoint* __restrict__ kp1, int n1, const apds_keypoint* __restrict__ kp2, int n2,
+                                           const apds_dmatch* __restrict__ m, int nm, int bug, float2* __restrict__ p1,
+                                           float2* __restrict__ p2, int* __restrict__ err) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nm) return;
+    const apds_dmatch mm = m[i];
+    const int i1 = bug ? mm.img_idx : mm.query_idx;
+    const int i2 = mm.train_idx;
+    if (i1 < 0 || i1 >= n1 || i2 < 0 || i2 >= n2) {
+        atomicExch(err, 1);
+        return;
+    }
+    const float2 a = make_float2(kp1[i1].x, kp1[i1].y);
+    p1[i] = a;
+    p2[i] = bug ? a : make_float2(kp2[i2].x, kp2[i2].y);
+}
+
+// homographier/src/homographier/mod.rs:183-220: RGBA8 -> BGRA (Vec4b), one dword per pixel
+__global__ void rgba_to_bgra_kernel(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t v = in[i];   // bytes R,G,B,A = bits 0-7, 8-15, 16-23, 24-31
+        out[i] = (v & 0xFF00FF00u) | ((v & 0xFFu) << 16) | ((v >> 16) & 0xFFu);
+    }
+}
+
+void points_from_matches_device(const apds_keypoint* kp1, int n1, const apds_keypoint* kp2, int n2, const apds_dmatch* m, int nm,
+                                int bug_compatible, float* pts1, float* pts2, int* err_flag, hipStream_t s) {
+    if (nm <= 0) return;
+    hipLaunchKernelGGL(points_from_matches_kernel, dim3(ceil_div(nm, 256)), dim3(256), 0, s, kp1, n1, kp2, n2, m, nm, bug_compatible,
+                       reinterpret_cast<float2*>(pts1), reinterpret_cast<float2*>(pts2), err_flag);
+    HIP_CHECK(hipGetLastError());
+}
+
+void rgba_to_bgra_device(const uint8_t* rgba, size_t n_pixels, uint8_t* bgra, hipStream_t s) {
+    if (!n_pixels) return;
+    const int blocks = (int)std::min<size_t>((n_pixels + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(rgba_to_bgra_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(rgba), n_pixels,
+                       reinterpret_cast<uint32_t*>(bgra));
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace apds

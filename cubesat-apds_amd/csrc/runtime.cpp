@@ -1,0 +1,131 @@
+// csrc/runtime.cpp — library-level entry points and the per-thread runtime (stream, workspace, timing).
+#include <cstdlib>
+#include <cstring>
+
+#include "common.h"
+
+namespace apds {
+
+static thread_local std::string g_last_error;
+static thread_local ThreadCtx g_ctx;
+
+void set_last_error(const std::string& m) { g_last_error = m; }
+ThreadCtx& ctx() {
+    g_ctx.ensure();
+    return g_ctx;
+}
+
+void ThreadCtx::ensure() {
+    if (ready) return;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        fail(APDS_ERR_NO_DEVICE, "no HIP device available: libapds_hip has no CPU fallback");
+    }
+    if (device >= n) fail(APDS_ERR_NO_DEVICE, "device ordinal out of range");
+    HIP_CHECK(hipSetDevice(device));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    ready = true;
+}
+
+void* ThreadCtx::alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~size_t(255);
+    if (bytes == 0) bytes = 256;
+    if (slabs.empty() || slab_used + bytes > slabs.back().second) {
+        size_t want = bytes;
+        if (!slabs.empty()) want = std::max(want, slabs.back().second * 2);
+        want = std::max(want, size_t(1) << 22);
+        char* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, want));
+        slabs.emplace_back(p, want);
+        slab_used = 0;
+    }
+    void* r = slabs.back().first + slab_used;
+    slab_used += bytes;
+    return r;
+}
+
+void ThreadCtx::ws_reset() {
+    if (slabs.size() > 1) {
+        size_t total = 0;
+        for (auto& s : slabs) total += s.second;
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipDeviceSynchronize());
+        for (auto& s : slabs) (void)hipFree(s.first);
+        slabs.clear();
+        char* p = nullptr;
+        HIP_CHECK(hipMalloc(&p, total));
+        slabs.emplace_back(p, total);
+    }
+    slab_used = 0;
+}
+
+}  // namespace apds
+
+using namespace apds;
+
+extern "C" {
+
+const char* apds_last_error(void) { return g_last_error.c_str(); }
+
+void apds_free(void* p) { std::free(p); }
+
+int apds_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int apds_set_device(int ordinal) {
+    return guarded([&] {
+        APDS_REQUIRE(ordinal >= 0, APDS_ERR_BAD_ARG, "negative device ordinal");
+        if (g_ctx.ready && g_ctx.device != ordinal) {
+            // drop this thread's stream/workspace on the old device
+            HIP_CHECK(hipSetDevice(g_ctx.device));
+            (void)hipStreamSynchronize(g_ctx.stream);
+            for (auto& s : g_ctx.slabs) (void)hipFree(s.first);
+            g_ctx.slabs.clear();
+            g_ctx.slab_used = 0;
+            (void)hipStreamDestroy(g_ctx.stream);
+            g_ctx.ready = false;
+        }
+        g_ctx.device = ordinal;
+        g_ctx.ensure();
+    });
+}
+
+const char* apds_build_info(void) { return "libapds_hip gfx950 (CDNA4) hand-written HIP kernels; -ffp-contract=off"; }
+
+int apds_dev_timing_enable(int on) {
+    return guarded([&] { ctx().timing = on != 0; });
+}
+
+int apds_dev_last_kernel_ms(const char* which, float* ms, int* launches) {
+    return guarded([&] {
+        APDS_REQUIRE(which && ms, APDS_ERR_BAD_ARG, "null argument");
+        ThreadCtx& c = ctx();
+        auto it = c.events.find(which);
+        float total = 0;
+        int n = 0;
+        if (it != c.events.end()) {
+            for (auto& ev : it->second) {
+                HIP_CHECK(hipEventSynchronize(ev.b));
+                float t = 0;
+                HIP_CHECK(hipEventElapsedTime(&t, ev.a, ev.b));
+                total += t;
+                n++;
+                (void)hipEventDestroy(ev.a);
+                (void)hipEventDestroy(ev.b);
+            }
+            c.events.erase(it);
+        }
+        *ms = total;
+        if (launches) *launches = n;
+    });
+}
+
+}  // extern "C"

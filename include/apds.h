@@ -1,0 +1,160 @@
+/*
+ * include/apds.h — C ABI of libapds_hip.so, the MI355X (gfx950) implementation of the cubesat-APDS
+ * hot path: AKAZE feature extraction -> Hamming brute-force match -> RANSAC homography.
+ *
+ * Every entry point replaces one public item of the reference's Rust crates `feature_extraction`
+ * and `homographier` (cited per function as /root/reference/<file>:<line>). The Rust shim that keeps
+ * the crates' signatures and forwards here is in INTEGRATION.md / rust_shim/.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ / torch types cross this boundary;
+ *   - return 0 on success, a negative OpenCV-style status otherwise (the reference surfaces
+ *     opencv::Error{code,..}): APDS_ERR_* below; text via apds_last_error() (thread local);
+ *   - inputs are borrowed for the duration of the call; variable-length outputs are allocated by
+ *     the library and released with apds_free(); fixed-size outputs are caller allocated;
+ *   - every function is re-entrant and may be called concurrently from many host threads (the
+ *     reference calls extraction from a rayon pool with no lock: preprocessor/src/main.rs:227-245,277);
+ *     each host thread gets its own HIP stream and device workspace;
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
+ *     APDS_ERR_NO_DEVICE.
+ *
+ * The "_dev" functions are the same operations on buffers already resident in HBM (device
+ * pointers + an optional hipStream_t passed as void*); they are what bench.py times and what the
+ * multi-GPU sharded matcher is built from.
+ */
+#ifndef APDS_H
+#define APDS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define APDS_OK 0
+#define APDS_ERR_INTERNAL (-2)      /* cv::Error::StsError  (HIP runtime failure, unsupported method) */
+#define APDS_ERR_NOMEM (-4)         /* cv::Error::StsNoMem */
+#define APDS_ERR_BAD_ARG (-5)       /* cv::Error::StsBadArg */
+#define APDS_ERR_NO_DEVICE (-216)   /* cv::Error::GpuNotSupported: no HIP device / kernels not loadable */
+#define APDS_ERR_OUT_OF_RANGE (-211)/* cv::Error::StsOutOfRange */
+#define APDS_ERR_ASSERT (-215)      /* cv::Error::StsAssert (bad shapes, k < 1, too few points) */
+#define APDS_ERR_EMPTY (-1000)      /* no model found: the shim maps it to MatError::Empty (mod.rs:114-119,258) */
+
+/* feature_extraction/src/lib.rs:12-13  MAX_POINTS_SHIFT / MAX_POINTS (twin: feature_database/src/keypointdb.rs:12) */
+#define APDS_MAX_POINTS_SHIFT 18
+#define APDS_MAX_POINTS ((1 << APDS_MAX_POINTS_SHIFT) - 1)
+#define APDS_DESC_BYTES 61          /* 486-bit M-LDB */
+#define APDS_DESC_STRIDE 64         /* device row pitch (one 64-byte line per descriptor) */
+
+/* cv::KeyPoint, 28 bytes (fields read back by to_db_type, lib.rs:34-58) */
+typedef struct apds_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} apds_keypoint;
+
+/* cv::DMatch, 16 bytes */
+typedef struct apds_dmatch {
+    int32_t query_idx, train_idx, img_idx;
+    float distance;
+} apds_dmatch;
+
+/* homographier/src/homographier/mod.rs:25-31  enum HomographyMethod */
+enum { APDS_HOMOGRAPHY_DEFAULT = 0, APDS_HOMOGRAPHY_LMEDS = 4, APDS_HOMOGRAPHY_RANSAC = 8, APDS_HOMOGRAPHY_RHO = 16 };
+
+/* ---- library ------------------------------------------------------------------------------ */
+const char* apds_last_error(void);
+void apds_free(void* p);
+int apds_device_count(void);
+int apds_set_device(int ordinal);             /* device used by the calling thread (default 0) */
+const char* apds_build_info(void);            /* "gfx950 ..." */
+
+/* ---- feature_extraction ------------------------------------------------------------------- */
+
+/* lib.rs:61-92  akaze_keypoint_descriptor_extraction_def(img:&Mat, max_points:Option<i32>) -> ExtractedKeyPoint
+ * img: rows x cols x channels u8 (channels 1 gray, 3 BGR, 4 BGRA), row pitch stride_bytes.
+ * max_points <= 0 means None (-> APDS_MAX_POINTS). Outputs: *kps (n x 28 B), *desc (n x 61 B, rows packed),
+ * both owned by the caller afterwards (apds_free). */
+int apds_akaze_extract(const uint8_t* img, int rows, int cols, int channels, size_t stride_bytes, int max_points,
+                       apds_keypoint** kps, uint8_t** desc, int* n, int* desc_bytes);
+
+/* lib.rs:94-114  get_knn_matches(origin_desc, target_desc, k, filter_strength) -> Vector<DMatch>
+ * Hamming k-NN of each origin (query) row over the target (train) rows, then keep m[0] iff
+ * m[0].distance < m[1].distance * filter_strength. Returns APDS_ERR_OUT_OF_RANGE when a query has fewer
+ * than two neighbours (k < 2 or n_target < 2), like the reference's `i.get(1)?`. Rows are desc_bytes long, packed. */
+int apds_get_knn_matches(const uint8_t* origin_desc, int n_origin, const uint8_t* target_desc, int n_target,
+                         int desc_bytes, int k, float filter_strength, apds_dmatch** matches, int* n_matches);
+
+/* lib.rs:116-126  get_bruteforce_matches(origin_desc, target_desc) -> Vector<DMatch>  (crossCheck = true) */
+int apds_get_bruteforce_matches(const uint8_t* origin_desc, int n_origin, const uint8_t* target_desc, int n_target,
+                                int desc_bytes, apds_dmatch** matches, int* n_matches);
+
+/* BFMatcher::knnMatch itself (lib.rs:103): idx/dist are n_query*k, -1 / INT32_MAX where fewer than k exist. */
+int apds_knn_match(const uint8_t* query_desc, int n_query, const uint8_t* train_desc, int n_train, int desc_bytes,
+                   int k, int32_t* idx, int32_t* dist);
+
+/* lib.rs:161-180  get_points_from_matches. bug_compatible = 1 reproduces the reference exactly (img1 index taken
+ * from img_idx, both outputs from img1); 0 is the intended gather (query_idx -> img1, train_idx -> img2).
+ * pts1/pts2: n_matches x 2 floats, caller allocated. */
+int apds_get_points_from_matches(const apds_keypoint* img1_kp, int n1, const apds_keypoint* img2_kp, int n2,
+                                 const apds_dmatch* matches, int n_matches, int bug_compatible, float* pts1, float* pts2);
+
+/* ---- homographier -------------------------------------------------------------------------- */
+
+/* mod.rs:231-259  find_homography_mat(input, reference, method, reproj_threshold) -> (Cmat<f64>, Option<Cmat<u8>>)
+ * method: APDS_HOMOGRAPHY_*; reproj_threshold <= 0 -> 3.0. H: 9 doubles row major (H[8] == 1). mask: n bytes or
+ * NULL (the shim passes it for RANSAC / LMEDS only, mod.rs:253-257). APDS_ERR_EMPTY when no model is found. */
+int apds_find_homography(const float* input_xy, const float* reference_xy, int n, int method, double reproj_threshold,
+                         double* H, uint8_t* mask);
+/* same with OpenCV's two defaulted arguments exposed (maxIters 2000, confidence 0.995) */
+int apds_find_homography_ex(const float* input_xy, const float* reference_xy, int n, int method, double reproj_threshold,
+                            int max_iters, double confidence, double* H, uint8_t* mask);
+
+/* mod.rs:183-220  raster_to_mat(pixels:&[RGBA8], w, h) -> Cmat<Vec4b>: RGBA -> BGRA rows.
+ * APDS_ERR_BAD_ARG (MatError::Unknown) when n_pixels != w*h. bgra: w*h*4 bytes, caller allocated. */
+int apds_raster_to_mat(const uint8_t* rgba, size_t n_pixels, int w, int h, uint8_t* bgra);
+
+/* ---- device-resident API ------------------------------------------------------------------- */
+/* All pointers below are HIP device pointers. stream: hipStream_t or NULL (the thread's own stream).
+ * Calls are asynchronous on that stream unless they return a count to the host. */
+
+/* Pack n rows of desc_bytes (<= 64) bytes into 64-byte rows (zero padded). */
+int apds_dev_pack_descriptors(const void* src_rows, int64_t n, int desc_bytes, int64_t src_stride, void* dst_rows64, void* stream);
+
+/* Hamming top-k (k in {1,2}) of n_query rows against n_train rows, both 64-byte pitch.
+ * out_keys: n_query*k uint64 = (distance << 32) | (train_index + index_base), ascending; 0xFFFF... when absent.
+ * Ordering equals BFMatcher's: by distance, ties to the lower train index. */
+int apds_dev_hamming_topk(const void* query_rows64, int n_query, const void* train_rows64, int64_t n_train,
+                          uint32_t index_base, int k, void* out_keys, void* stream);
+/* Merge `parts` candidate lists (each n_query*k keys, e.g. gathered from DB shards) into the global top-k. */
+int apds_dev_merge_topk(const void* keys_parts, int parts, int n_query, int k, void* out_keys, void* stream);
+/* Lowe ratio filter on merged keys (k >= 2): writes compacted matches in query order, count to *n_matches (host). */
+int apds_dev_ratio_filter(const void* keys, int n_query, int k, float filter_strength, void* out_matches, int* n_matches, void* stream);
+/* Cross-check: given for every train row its best query key (from apds_dev_hamming_topk with roles swapped, k=1),
+ * produce matches in query order. */
+int apds_dev_cross_check(const void* train_best_keys, int64_t n_train, int n_query, void* out_matches, int* n_matches, void* stream);
+
+/* AKAZE on a device image. Results stay on the device: kps (capacity x 28 B), desc64 (capacity x 64 B).
+ * Returns the keypoint count in *n (host). capacity >= min(max_points, APDS_MAX_POINTS). */
+int apds_dev_akaze_extract(const void* img, int rows, int cols, int channels, size_t stride_bytes, int max_points,
+                           void* kps, void* desc64, int capacity, int* n, void* stream);
+
+/* gather matched coordinates on the device: pts1/pts2 n_matches x 2 float */
+int apds_dev_points_from_matches(const void* kp1, int n1, const void* kp2, int n2, const void* matches, int n_matches,
+                                 int bug_compatible, void* pts1, void* pts2, void* stream);
+
+/* RANSAC / LMEDS / least-squares homography on device point lists. H (9 doubles) and found flag go to the host. */
+int apds_dev_find_homography(const void* input_xy, const void* reference_xy, int n, int method, double reproj_threshold,
+                             int max_iters, double confidence, double* H, void* mask_dev, void* stream);
+
+/* Measurement helpers used by bench.py (not part of the reference surface). */
+/* Register-only xor+popcount loop: returns measured lane-ops/s (32-bit xor + bcnt counted as 2 ops). */
+int apds_dev_valu_popcount_peak(double* lane_ops_per_s);
+/* Time of the last hamming_topk main kernel launched by this thread, measured with hipEvents on its stream (ms). */
+int apds_dev_last_kernel_ms(const char* which, float* ms, int* launches);
+int apds_dev_timing_enable(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* APDS_H */

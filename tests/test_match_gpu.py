@@ -1,0 +1,106 @@
+"""GPU: Hamming match parity, HIP path (through the C ABI) vs the oracle. Bit-exact: indices, distances, order."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a, b):
+    return np.unpackbits(a[:, None, :] ^ b[None, :, :], axis=2).sum(2)
+
+
+@pytest.mark.parametrize("nq,nt,k", [(1, 2, 2), (3, 5, 2), (64, 64, 2), (65, 4097, 2), (1000, 10000, 2), (257, 33333, 1),
+                                     (5000, 20000, 2), (20000, 3001, 2)])
+def test_knn_match_equals_oracle(gpu_pkg, oracle_mod, nq, nt, k):
+    db = gpu_pkg.synth.make_descriptor_db(nt, seed=0x44420001 + nt)
+    q, _ = gpu_pkg.synth.make_queries(db, nq, seed=0x51550001 + nq)
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q, db, k)
+    oi, od = oracle_mod.knn_hamming(q, db, k)
+    assert np.array_equal(dist, od)
+    assert np.array_equal(idx, oi)
+
+
+def test_ties_prefer_lower_train_index(gpu_pkg, oracle_mod):
+    rng = np.random.default_rng(5)
+    # few distinct rows repeated many times: every query has massive ties, across chunk borders too
+    base = rng.integers(0, 256, (7, 61), dtype=np.uint8)
+    base[:, 60] &= 0x3F
+    db = base[rng.integers(0, 7, 150000)]
+    q = base[rng.integers(0, 7, 300)].copy()
+    q[::3, 5] ^= 1
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q, db, 2)
+    oi, od = oracle_mod.knn_hamming(q, db, 2)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi)
+
+
+def test_large_db_uses_sample_thresholds(gpu_pkg, oracle_mod):
+    # >= 131072 rows switches on the threshold pre-pass; planted neighbours sit inside and outside the sample
+    db = gpu_pkg.synth.make_descriptor_db(200000)
+    q, src = gpu_pkg.synth.make_queries(db, 3000)
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q, db, 2)
+    oracle_mod.set_threads(8)
+    oi, od = oracle_mod.knn_hamming(q, db, 2)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi)
+    assert ((src >= 0) & (src < 16384)).any() and (src >= 16384).any()
+
+
+def test_get_knn_matches(gpu_pkg, oracle_mod):
+    db = gpu_pkg.synth.make_descriptor_db(10000)
+    q, src = gpu_pkg.synth.make_queries(db, 3000)
+    got = gpu_pkg.feature_extraction.get_knn_matches(q, db, 2, 0.3)
+    want = oracle_mod.get_knn_matches(q, db, 2, 0.3)
+    assert np.array_equal(got, want)
+    assert len(got) == (src >= 0).sum()
+    # k > 2 gives the same result: only the two nearest are consumed (lib.rs:107-111)
+    assert np.array_equal(gpu_pkg.feature_extraction.get_knn_matches(q, db, 5, 0.3), want)
+    for fs in (0.0, 0.5, 0.8, 1.0, 1.5):
+        assert np.array_equal(gpu_pkg.feature_extraction.get_knn_matches(q, db, 2, fs), oracle_mod.get_knn_matches(q, db, 2, fs))
+
+
+@pytest.mark.parametrize("nq,nt", [(50, 80), (1000, 1000), (3000, 10000), (9000, 2500)])
+def test_get_bruteforce_matches(gpu_pkg, oracle_mod, nq, nt):
+    db = gpu_pkg.synth.make_descriptor_db(nt)
+    q, _ = gpu_pkg.synth.make_queries(db, nq, planted=0.5)
+    got = gpu_pkg.feature_extraction.get_bruteforce_matches(q, db)
+    want = oracle_mod.get_bruteforce_matches(q, db)
+    assert np.array_equal(got, want)
+
+
+def test_other_descriptor_lengths(gpu_pkg, oracle_mod):
+    rng = np.random.default_rng(3)
+    for nb in (1, 4, 32, 61, 64):
+        q = rng.integers(0, 256, (100, nb), dtype=np.uint8)
+        t = rng.integers(0, 256, (999, nb), dtype=np.uint8)
+        idx, dist = gpu_pkg.feature_extraction.knn_match(q, t, 2)
+        oi, od = oracle_mod.knn_hamming(q, t, 2)
+        assert np.array_equal(dist, od) and np.array_equal(idx, oi), nb
+
+
+def test_points_from_matches(gpu_pkg, oracle_mod):
+    rng = np.random.default_rng(11)
+    K, M = gpu_pkg._lib.KEYPOINT_DTYPE, gpu_pkg._lib.DMATCH_DTYPE
+    k1, k2 = np.zeros(500, K), np.zeros(700, K)
+    for k in (k1, k2):
+        k["x"], k["y"] = rng.random(len(k)) * 4096, rng.random(len(k)) * 4096
+    m = np.zeros(300, M)
+    m["query_idx"], m["train_idx"] = rng.integers(0, 500, 300), rng.integers(0, 700, 300)
+    for bug in (False, True):
+        g1, g2 = gpu_pkg.feature_extraction.get_points_from_matches(k1, k2, m, bug)
+        o1, o2 = oracle_mod.get_points_from_matches(k1, k2, m, bug)
+        assert np.array_equal(g1, o1) and np.array_equal(g2, o2)
+    m["train_idx"][7] = 700
+    with pytest.raises(gpu_pkg.ApdsError) as e:
+        gpu_pkg.feature_extraction.get_points_from_matches(k1, k2, m)
+    assert e.value.code == -211
+
+
+def test_raster_to_mat(gpu_pkg, oracle_mod):
+    # reference KAT mod.rs:556-603 plus a random image against the oracle
+    n = 4
+    px = np.array([[1, (i % n) + 1, (i // n) + 1, 1] for i in range(n * n)], np.uint8)
+    m = gpu_pkg.homographier.raster_to_mat(px, n, n).mat
+    assert tuple(m[0, 0]) == (1, 1, 1, 1) and tuple(m[3, 3]) == (4, 4, 1, 1)
+    assert tuple(m[0, 3]) == (1, 4, 1, 1) and tuple(m[3, 0]) == (4, 1, 1, 1)
+    rng = np.random.default_rng(2)
+    big = rng.integers(0, 256, (333 * 517, 4), dtype=np.uint8)
+    assert np.array_equal(gpu_pkg.homographier.raster_to_mat(big, 517, 333).mat, oracle_mod.raster_to_mat(big, 517, 333))

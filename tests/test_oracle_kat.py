@@ -1,0 +1,145 @@
+"""CPU: pin the oracle against every runnable known-answer test the reference holds on this path
+ and check its internal consistency. No GPU."""
+import numpy as np
+import pytest
+
+
+def test_homography_success_kat(oracle_mod):
+    # /root/reference/homographier/src/homographier/mod.rs:437-472: 10x10 grid mapped to itself, RANSAC thr 1.0
+    pts = np.array([(i, j) for i in range(1, 11) for j in range(1, 11)], np.float32)
+    found, H, mask = oracle_mod.find_homography(pts, pts, 8, 1.0)
+    assert found
+    assert np.array_equal(np.round(H), np.eye(3))
+    assert mask.sum() == 100
+
+
+def test_raster_to_mat_kat(oracle_mod):
+    # mod.rs:556-603: 4x4 RGBA(1, col, row, 1) -> BGRA
+    n = 4
+    px = np.array([[1, (i % n) + 1, (i // n) + 1, 1] for i in range(n * n)], np.uint8)
+    m = oracle_mod.raster_to_mat(px, n, n)
+    assert tuple(m[0, 0]) == (1, 1, 1, 1)
+    assert tuple(m[3, 3]) == (4, 4, 1, 1)
+    assert tuple(m[0, 3]) == (1, 4, 1, 1)
+    assert tuple(m[3, 0]) == (4, 1, 1, 1)
+    with pytest.raises(ValueError):      # mod.rs:185-187
+        oracle_mod.raster_to_mat(px, 5, 4)
+
+
+def test_homography_methods_agree_on_clean_data(oracle_mod, pkg):
+    src, dst, H_true, inl = pkg.synth.make_ransac_set(4000, inlier_frac=1.0, noise=0.0)
+    for method in (0, 4, 8):
+        found, H, mask = oracle_mod.find_homography(src, dst, method, 3.0)
+        assert found
+        assert np.allclose(H, H_true, rtol=1e-4, atol=1e-3), method
+        # LMEDS derives its own threshold from the median error (~1e-3 px on clean data), so it may drop a few points
+        assert mask.all() if method != 4 else mask.mean() > 0.5
+
+
+def test_ransac_recovers_planted_model(oracle_mod, pkg):
+    src, dst, H_true, inl = pkg.synth.make_ransac_set(5000)
+    found, H, mask = oracle_mod.find_homography(src, dst, 8, 3.0)
+    assert found
+    got = mask.astype(bool)
+    assert (got & inl).sum() >= 0.99 * inl.sum()
+    assert (got & ~inl).sum() <= 0.01 * len(src)
+    assert np.allclose(H, H_true, rtol=5e-3, atol=0.5)
+
+
+def test_too_few_points_is_an_error(oracle_mod):
+    pts = np.zeros((3, 2), np.float32)
+    with pytest.raises(RuntimeError):
+        oracle_mod.find_homography(pts, pts, 8, 3.0)
+
+
+def test_hamming_knn_definition(oracle_mod):
+    rng = np.random.default_rng(1)
+    q = rng.integers(0, 256, (37, 61), dtype=np.uint8)
+    t = rng.integers(0, 256, (211, 61), dtype=np.uint8)
+    t[17] = q[3]            # exact duplicate pair -> distance 0
+    t[90] = q[3]            # tie: the lower index must come first
+    idx, dist = oracle_mod.knn_hamming(q, t, 2)
+    d = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)
+    order = np.lexsort((np.arange(t.shape[0])[None, :].repeat(len(q), 0), d), axis=1)[:, :2]
+    assert np.array_equal(idx, order)
+    assert np.array_equal(dist, np.take_along_axis(d, order, 1))
+    assert tuple(idx[3]) == (17, 90) and tuple(dist[3]) == (0, 0)
+
+
+def test_knn_ratio_and_errors(oracle_mod, pkg):
+    db = pkg.synth.make_descriptor_db(3000)
+    q, src = pkg.synth.make_queries(db, 400)
+    m = oracle_mod.get_knn_matches(q, db, 2, 0.3)
+    planted = np.nonzero(src >= 0)[0]
+    assert np.array_equal(m["query_idx"], planted)
+    assert np.array_equal(m["train_idx"], src[planted])
+    assert (m["img_idx"] == 0).all()
+    with pytest.raises(RuntimeError):          # lib.rs:108: i.get(1)? with k == 1
+        oracle_mod.get_knn_matches(q, db, 1, 0.3)
+    with pytest.raises(RuntimeError):          # one train row -> one neighbour
+        oracle_mod.get_knn_matches(q, db[:1], 2, 0.3)
+    assert len(oracle_mod.get_knn_matches(q[:0], db, 2, 0.3)) == 0
+    assert len(oracle_mod.get_knn_matches(q, db[:0], 2, 0.3)) == 0
+
+
+def test_cross_check_definition(oracle_mod):
+    rng = np.random.default_rng(7)
+    q = rng.integers(0, 256, (50, 61), dtype=np.uint8)
+    t = rng.integers(0, 256, (80, 61), dtype=np.uint8)
+    m = oracle_mod.get_bruteforce_matches(q, t)
+    d = np.unpackbits(q[:, None, :] ^ t[None, :, :], axis=2).sum(2)     # [q, t]
+    nn_q_of_t = d.argmin(0)                                              # first minimum = lower query index
+    want = {}
+    for ti in range(t.shape[0]):
+        qi = nn_q_of_t[ti]
+        if qi not in want or d[qi, ti] < want[qi][1]:
+            want[qi] = (ti, d[qi, ti])
+    assert list(m["query_idx"]) == sorted(want)
+    for row in m:
+        assert want[row["query_idx"]] == (row["train_idx"], int(row["distance"]))
+
+
+def test_points_from_matches_modes(oracle_mod):
+    K = oracle_mod.KEYPOINT_DTYPE
+    k1 = np.zeros(3, K)
+    k2 = np.zeros(4, K)
+    k1["x"], k1["y"] = [1, 2, 3], [10, 20, 30]
+    k2["x"], k2["y"] = [5, 6, 7, 8], [50, 60, 70, 80]
+    m = np.zeros(2, oracle_mod.DMATCH_DTYPE)
+    m["query_idx"], m["train_idx"] = [2, 1], [0, 3]
+    p1, p2 = oracle_mod.get_points_from_matches(k1, k2, m)
+    assert p1.tolist() == [[3, 30], [2, 20]] and p2.tolist() == [[5, 50], [8, 80]]
+    b1, b2 = oracle_mod.get_points_from_matches(k1, k2, m, bug_compatible=True)   # lib.rs:169,176-177
+    assert b1.tolist() == [[1, 10], [1, 10]] and np.array_equal(b1, b2)
+
+
+def test_akaze_structure(oracle_mod, pkg):
+    tile = pkg.synth.make_tile(256, 320, frame_index=3)
+    r = oracle_mod.akaze(tile, keep_planes=True)
+    # evolution: octaves halve, a new octave is dropped when width < 80 or height < 40
+    assert [(lv["w"], lv["h"]) for lv in r.levels[::4]] == [(320, 256), (160, 128), (80, 64)]
+    assert [lv["sigma_size"] for lv in r.levels[:4]] == [2, 3, 3, 4]
+    assert [lv["nsteps"] for lv in r.levels[:5]] == [0, 3, 3, 4, 4]
+    assert len(r.keypoints) > 20
+    kp = r.keypoints
+    assert r.descriptors.shape == (len(kp), 61)
+    assert (r.descriptors[:, 60] & 0xC0 == 0).all()          # bits 486,487 never set
+    assert ((kp["angle"] >= 0) & (kp["angle"] < 360)).all()
+    assert (kp["response"] > 0.001).all()
+    assert np.array_equal(kp["octave"], np.array([r.levels[c]["octave"] for c in kp["class_id"]]))
+    # level-major, then row-major output order
+    order = np.lexsort((np.arange(len(kp)), kp["class_id"]))
+    assert np.array_equal(order, np.arange(len(kp)))
+    # grey replicated into BGR(A) and a single-channel image give the same result
+    r1 = oracle_mod.akaze(tile[..., 0].copy())
+    assert np.array_equal(r1.descriptors, r.descriptors) and np.array_equal(r1.keypoints, kp)
+    # max_points keeps the strongest
+    r2 = oracle_mod.akaze(tile, max_points=10)
+    assert len(r2.keypoints) == 10
+    assert np.array_equal(np.sort(r2.keypoints["response"])[::-1], np.sort(kp["response"])[::-1][:10])
+
+
+def test_akaze_blank_image(oracle_mod):
+    r = oracle_mod.akaze(np.full((128, 128, 3), 77, np.uint8))
+    assert len(r.keypoints) == 0 and r.descriptors.shape == (0, 61)
+    assert abs(r.kcontrast - 0.03) < 1e-9
