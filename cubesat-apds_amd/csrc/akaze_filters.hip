@@ -1,0 +1,351 @@
+// csrc/akaze_filters.hip — AKAZE nonlinear scale space and determinant-of-Hessian planes on gfx950.
+//
+// Replaces the OpenCV work behind /root/reference/feature_extraction/src/lib.rs:64-79 (AKAZE::create(...)
+// .detect_and_compute): gray conversion, Gaussian smoothing, Scharr derivatives, Perona-Malik g2 conductivity,
+// FED diffusion steps, 2x2 half-sampling and the scaled second derivatives.
+//
+// All planes are f32, row-major, pitch == width, resident in HBM. These kernels are HBM-bandwidth bound:
+// every stencil stages its input tile (+halo, border already applied) in LDS once, so each plane is read
+// from HBM once per pass and written once; rows are read as contiguous 256-byte wave accesses.
+//
+// Float contract (identical to oracle/akaze_oracle.cpp, and what makes keypoint sets bit-equal): one IEEE
+// binary32 operation per source operation, no FMA contraction (-ffp-contract=off), correctly rounded
+// division; symmetric taps as  acc = k0*c; acc += k1*(lo1+hi1); ...  antisymmetric taps as  hi - lo.
+#include "akaze.h"
+
+namespace apds {
+
+__device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+__device__ __forceinline__ int reflect101(int i, int n) {
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
+
+// ---- a1.1: BGR(A)/gray u8 -> f32 in [0,1] ----------------------------------------------------------
+__global__ void gray_kernel(const uint8_t* __restrict__ img, int rows, int cols, int channels, size_t stride, float* __restrict__ out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= cols) return;
+    const uint8_t* p = img + (size_t)y * stride;
+    int g;
+    if (channels == 1) {
+        g = p[x];
+    } else if (channels == 4) {
+        const uint32_t v = reinterpret_cast<const uint32_t*>(p)[x];   // B,G,R,A little endian (rows are 4-byte aligned)
+        g = (int)((v & 0xFF) * 3735u + ((v >> 8) & 0xFF) * 19235u + ((v >> 16) & 0xFF) * 9798u + (1u << 14)) >> 15;
+    } else {
+        const uint8_t* q = p + (size_t)x * 3;
+        g = (q[0] * 3735 + q[1] * 19235 + q[2] * 9798 + (1 << 14)) >> 15;
+    }
+    out[(size_t)y * cols + x] = (float)g * (float)(1.0 / 255.0);
+}
+
+// ---- separable symmetric blur, BORDER_REPLICATE (GaussianBlur) --------------------------------------
+static constexpr int TW = 64, TH = 16;   // output tile, 256 threads
+
+template <int R>
+__global__ __launch_bounds__(256) void gauss_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, GaussTaps taps) {
+    __shared__ float s_src[(TH + 2 * R) * (TW + 2 * R)];
+    __shared__ float s_tmp[(TH + 2 * R) * TW];
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    constexpr int SW = TW + 2 * R, SH = TH + 2 * R;
+    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int gx = clampi(x0 - R + lx, w), gy = clampi(y0 - R + ly, h);
+        s_src[i] = src[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SH * TW; i += 256) {
+        const int ly = i / TW, lx = i - ly * TW;
+        const float* p = &s_src[ly * SW + lx + R];
+        float acc = taps.k[0] * p[0];
+#pragma unroll
+        for (int j = 1; j <= R; j++) acc += taps.k[j] * (p[-j] + p[j]);
+        s_tmp[i] = acc;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            const float* p = &s_tmp[(ly + R) * TW + lx];
+            float acc = taps.k[0] * p[0];
+#pragma unroll
+            for (int j = 1; j <= R; j++) acc += taps.k[j] * (p[-j * TW] + p[j * TW]);
+            dst[(size_t)gy * w + gx] = acc;
+        }
+    }
+}
+
+// ---- dilated 3x3 derivative pair, BORDER_REFLECT_101 ------------------------------------------------
+// Lx = colsmooth(row: hi - lo), Ly = coldiff(row: smooth); taps at -s, 0, +s; smooth = {kside, kmid, kside}.
+// MODE 0: write Lx, Ly.  MODE 1: write flow = 1/(1 + (Lx^2+Ly^2)/k^2)  (k read from device memory).
+// MODE 2: write |grad| and atomically track its maximum over interior pixels (contrast factor pass).
+template <int MODE>
+__global__ __launch_bounds__(256) void deriv_pair_kernel(const float* __restrict__ src, float* __restrict__ outA, float* __restrict__ outB,
+                                                         int w, int h, int s, float kside, float kmid, const float* __restrict__ kptr,
+                                                         unsigned int* __restrict__ hmax_bits) {
+    extern __shared__ float smem[];
+    const int SW = TW + 2 * s, SH = TH + 2 * s;
+    float* s_src = smem;                 // SH x SW
+    float* s_rd = s_src + SH * SW;       // SH x TW   row pass, derivative
+    float* s_rs = s_rd + SH * TW;        // SH x TW   row pass, smooth
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int gx = reflect101(x0 - s + lx, w), gy = reflect101(y0 - s + ly, h);
+        s_src[i] = src[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SH * TW; i += 256) {
+        const int ly = i / TW, lx = i - ly * TW;
+        const float* p = &s_src[ly * SW + lx + s];
+        const float lo = p[-s], hi = p[s];
+        s_rd[i] = hi - lo;
+        float acc = kmid * p[0];
+        acc += kside * (lo + hi);
+        s_rs[i] = acc;
+    }
+    __syncthreads();
+    float k2inv = 0.f;
+    if (MODE == 1) {
+        const float k = *kptr;
+        k2inv = 1.0f / (k * k);
+    }
+    float local_max = 0.f;
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            const int c = (ly + s) * TW + lx;
+            float ax = kmid * s_rd[c];
+            ax += kside * (s_rd[c - s * TW] + s_rd[c + s * TW]);
+            const float ay = s_rs[c + s * TW] - s_rs[c - s * TW];
+            const size_t o = (size_t)gy * w + gx;
+            if (MODE == 0) {
+                outA[o] = ax;
+                outB[o] = ay;
+            } else if (MODE == 1) {
+                outA[o] = 1.0f / (1.0f + ((ax * ax + ay * ay) * k2inv));
+            } else {
+                const float m = sqrtf(ax * ax + ay * ay);
+                outA[o] = m;
+                if (gx >= 1 && gx < w - 1 && gy >= 1 && gy < h - 1) local_max = fmaxf(local_max, m);
+            }
+        }
+    }
+    if (MODE == 2) {
+        // non-negative floats order like their bit patterns
+        unsigned int bits = __float_as_uint(local_max);
+        for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned int)__shfl_xor((int)bits, off));
+        if ((threadIdx.x & 63) == 0 && bits) atomicMax(hmax_bits, bits);
+    }
+}
+
+// ---- contrast factor: 300-bin histogram of |grad|/hmax over interior pixels, 70th percentile -----------
+__global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __restrict__ modg, int w, int h, const unsigned int* __restrict__ hmax_bits,
+                                                              int* __restrict__ hist) {
+    __shared__ int s_hist[300];
+    for (int i = threadIdx.x; i < 300; i += 256) s_hist[i] = 0;
+    __syncthreads();
+    const float hmax = __uint_as_float(*hmax_bits);
+    if (hmax != 0.0f) {
+        const float scale = 299.0f / hmax;
+        const int cw = w - 2, ch = h - 2;
+        const long long total = (long long)cw * ch;
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+            const int y = (int)(i / cw), x = (int)(i - (long long)y * cw);
+            const float v = modg[(size_t)(y + 1) * w + (x + 1)];
+            atomicAdd(&s_hist[(int)(v * scale)], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 300; i += 256)
+        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+}
+
+// single thread: kcontrast and its per-octave values k, k*0.75, (k*0.75)*0.75, ...
+__global__ void kcontrast_finish_kernel(const int* __restrict__ hist, const unsigned int* __restrict__ hmax_bits, int w, int h,
+                                        float* __restrict__ k_oct, int n_oct) {
+    if (threadIdx.x || blockIdx.x) return;
+    const float hmax = __uint_as_float(*hmax_bits);
+    float k = 0.03f;
+    if (hmax != 0.0f && w > 2 && h > 2) {
+        const int nbins = 300;
+        const int total = (w - 2) * (h - 2);
+        const int nthreshold = (int)((total - hist[0]) * 0.7f);
+        int nelements = 0;
+        for (int b = 1; b < nbins; b++) {
+            if (nelements >= nthreshold) {
+                k = hmax * b / nbins;
+                break;
+            }
+            nelements += hist[b];
+        }
+    }
+    for (int o = 0; o < n_oct; o++) {
+        k_oct[o] = k;
+        k *= 0.75f;
+    }
+}
+
+// ---- one explicit FED diffusion step: Lnew = Lt + step_size * div(c grad Lt) -----------------------------
+__global__ __launch_bounds__(256) void nld_step_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w,
+                                                       int h, float step_size) {
+    __shared__ float s_t[(TH + 2) * (TW + 2)];
+    __shared__ float s_f[(TH + 2) * (TW + 2)];
+    constexpr int SW = TW + 2, SH = TH + 2;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int gx = clampi(x0 - 1 + lx, w), gy = clampi(y0 - 1 + ly, h);   // clamped values are never used by a border case
+        const size_t o = (size_t)gy * w + gx;
+        s_t[i] = Lt[o];
+        s_f[i] = Lf[o];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
+        const int x = x0 + lx, y = y0 + ly;
+        if (x >= w || y >= h) continue;
+        const int c = (ly + 1) * SW + lx + 1;
+        const float tc = s_t[c], fc = s_f[c];
+        const bool top = y == 0, bot = y == h - 1, left = x == 0, right = x == w - 1;
+        const float xp = (fc + s_f[c + 1]) * (s_t[c + 1] - tc);
+        const float xm = (fc + s_f[c - 1]) * (s_t[c - 1] - tc);
+        const float yp = (fc + s_f[c + SW]) * (s_t[c + SW] - tc);   // row below
+        const float ym = (fc + s_f[c - SW]) * (s_t[c - SW] - tc);   // row above
+        float step_r;
+        if ((top || bot) && (left || right)) step_r = 0.0f;
+        else if (top) step_r = xp + xm + yp;
+        else if (bot) step_r = xp + xm + ym;
+        else if (left) step_r = xp + yp + ym;
+        else if (right) step_r = xm + yp + ym;
+        else step_r = xp + xm + yp + ym;
+        Lnew[(size_t)y * w + x] = tc + step_r * step_size;
+    }
+}
+
+// ---- resize(INTER_AREA) by exactly 2: mean of 2x2 ---------------------------------------------------------
+__global__ void half_sample_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    const float2 a = *reinterpret_cast<const float2*>(&src[(size_t)(2 * y) * sw + 2 * x]);
+    const float2 b = *reinterpret_cast<const float2*>(&src[(size_t)(2 * y + 1) * sw + 2 * x]);
+    dst[(size_t)y * dw + x] = ((a.x + a.y) + (b.x + b.y)) * 0.25f;
+}
+
+// general INTER_AREA (odd source sizes): per destination pixel, up to 4 taps per axis from host-built tables
+__global__ void area_resize_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh, const int* __restrict__ xofs,
+                                   const float* __restrict__ xw, const int* __restrict__ xcnt, const int* __restrict__ yofs,
+                                   const float* __restrict__ yw, const int* __restrict__ ycnt) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dw || y >= dh) return;
+    float sum = 0.0f;
+    const int ny = ycnt[y], nx = xcnt[x];
+    for (int j = 0; j < ny; j++) {
+        const float* s = &src[(size_t)yofs[y * 4 + j] * sw];
+        float row = 0.0f;
+        for (int k = 0; k < nx; k++) row += s[xofs[x * 4 + k]] * xw[x * 4 + k];
+        if (j == 0) sum = yw[y * 4 + j] * row;
+        else sum += yw[y * 4 + j] * row;
+    }
+    dst[(size_t)y * dw + x] = sum;
+}
+
+// ---- Ldet = (Lxx*Lyy - Lxy^2) * sigma_size^4 from Lx, Ly (second application of the dilated pair) -----------
+__global__ __launch_bounds__(256) void hessian_det_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, float* __restrict__ Ldet, int w,
+                                                          int h, int s, float kside, float kmid, float sq) {
+    extern __shared__ float smem[];
+    const int SW = TW + 2 * s, SH = TH + 2 * s;
+    float* s_x = smem;                 // SH x SW  (Lx)
+    float* s_y = s_x + SH * SW;        // SH x SW  (Ly)
+    float* r_xd = s_y + SH * SW;       // SH x TW  row-diff of Lx   -> Lxx
+    float* r_xs = r_xd + SH * TW;      // SH x TW  row-smooth of Lx -> Lxy
+    float* r_ys = r_xs + SH * TW;      // SH x TW  row-smooth of Ly -> Lyy
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int gx = reflect101(x0 - s + lx, w), gy = reflect101(y0 - s + ly, h);
+        const size_t o = (size_t)gy * w + gx;
+        s_x[i] = Lx[o];
+        s_y[i] = Ly[o];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SH * TW; i += 256) {
+        const int ly = i / TW, lx = i - ly * TW;
+        const float* p = &s_x[ly * SW + lx + s];
+        const float lo = p[-s], hi = p[s];
+        r_xd[i] = hi - lo;
+        float acc = kmid * p[0];
+        acc += kside * (lo + hi);
+        r_xs[i] = acc;
+        const float* q = &s_y[ly * SW + lx + s];
+        float acy = kmid * q[0];
+        acy += kside * (q[-s] + q[s]);
+        r_ys[i] = acy;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) {
+            const int c = (ly + s) * TW + lx;
+            float lxx = kmid * r_xd[c];
+            lxx += kside * (r_xd[c - s * TW] + r_xd[c + s * TW]);
+            const float lxy = r_xs[c + s * TW] - r_xs[c - s * TW];
+            const float lyy = r_ys[c + s * TW] - r_ys[c - s * TW];
+            Ldet[(size_t)gy * w + gx] = (lxx * lyy - lxy * lxy) * sq;
+        }
+    }
+}
+
+// ---- host launchers -------------------------------------------------------------------------------------
+void launch_gray(const void* img, int rows, int cols, int channels, size_t stride, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(gray_kernel, dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, static_cast<const uint8_t*>(img), rows, cols, channels, stride, out);
+}
+
+void launch_gauss(const float* src, float* dst, int w, int h, const GaussTaps& taps, int radius, hipStream_t s) {
+    dim3 grid(ceil_div(w, TW), ceil_div(h, TH));
+    if (radius == 4) hipLaunchKernelGGL((gauss_kernel<4>), grid, dim3(256), 0, s, src, dst, w, h, taps);
+    else hipLaunchKernelGGL((gauss_kernel<2>), grid, dim3(256), 0, s, src, dst, w, h, taps);
+}
+
+static size_t deriv_lds_bytes(int s) { return (size_t)((TH + 2 * s) * (TW + 2 * s) + 2 * (TH + 2 * s) * TW) * sizeof(float); }
+
+void launch_deriv_pair(const float* src, float* outA, float* outB, int w, int h, int sc, float kside, float kmid, hipStream_t s) {
+    hipLaunchKernelGGL((deriv_pair_kernel<0>), dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), deriv_lds_bytes(sc), s, src, outA, outB, w, h, sc, kside,
+                       kmid, (const float*)nullptr, (unsigned int*)nullptr);
+}
+void launch_flow(const float* src, float* flow, int w, int h, const float* kptr, hipStream_t s) {
+    hipLaunchKernelGGL((deriv_pair_kernel<1>), dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), deriv_lds_bytes(1), s, src, flow, (float*)nullptr, w, h, 1,
+                       3.0f, 10.0f, kptr, (unsigned int*)nullptr);
+}
+void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s) {
+    HIP_CHECK(hipMemsetAsync(hmax_bits, 0, sizeof(unsigned int), s));
+    HIP_CHECK(hipMemsetAsync(hist, 0, 300 * sizeof(int), s));
+    hipLaunchKernelGGL((deriv_pair_kernel<2>), dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), deriv_lds_bytes(1), s, smooth, modg_tmp, (float*)nullptr, w,
+                       h, 1, 3.0f, 10.0f, (const float*)nullptr, hmax_bits);
+    hipLaunchKernelGGL(kcontrast_hist_kernel, dim3(1024), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist);
+    hipLaunchKernelGGL(kcontrast_finish_kernel, dim3(1), dim3(64), 0, s, hist, hmax_bits, w, h, k_oct, n_oct);
+}
+void launch_nld_step(const float* Lt, const float* Lf, float* Lnew, int w, int h, float step_size, hipStream_t s) {
+    hipLaunchKernelGGL(nld_step_kernel, dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), 0, s, Lt, Lf, Lnew, w, h, step_size);
+}
+void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s) {
+    hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, src, sw, dst, dw, dh);
+}
+void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, const int* xofs, const float* xw, const int* xcnt, const int* yofs,
+                        const float* yw, const int* ycnt, hipStream_t s) {
+    hipLaunchKernelGGL(area_resize_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, src, sw, dst, dw, dh, xofs, xw, xcnt, yofs, yw, ycnt);
+}
+void launch_hessian_det(const float* Lx, const float* Ly, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s) {
+    const size_t lds = (size_t)(2 * (TH + 2 * sc) * (TW + 2 * sc) + 3 * (TH + 2 * sc) * TW) * sizeof(float);
+    hipLaunchKernelGGL(hessian_det_kernel, dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), lds, s, Lx, Ly, Ldet, w, h, sc, kside, kmid,
+                       (float)(sc * sc * sc * sc));
+}
+
+}  // namespace apds

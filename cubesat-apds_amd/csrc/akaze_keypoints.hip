@@ -1,0 +1,871 @@
+// csrc/akaze_keypoints.hip — AKAZE keypoint side on gfx950: scale-space extrema, cross-level suppression,
+// sub-pixel refinement with ordered compaction, main orientation and the 486-bit M-LDB descriptor.
+//
+// Replaces OpenCV AKAZEFeatures::Find_Scale_Space_Extrema / Do_Subpixel_Refinement / Compute_Main_Orientation /
+// MLDB_Full_Descriptor_Invoker behind /root/reference/feature_extraction/src/lib.rs:79.
+//
+// Output order is the reference's: level-major, then row-major (ordered compaction by prefix sums, no atomics
+// in anything that decides an index). The cross-level suppression is sequential in OpenCV (each keypoint may
+// delete a keypoint of the neighbouring level, which changes what later keypoints find); it is reproduced
+// exactly by dependency rounds: a keypoint is processed in the first round in which no EARLIER (row-major)
+// keypoint of its own level with an overlapping search window is still pending. All levels run in the same
+// rounds because the passes of one phase only read snapshots of the level they iterate over.
+#include "akaze.h"
+
+namespace apds {
+
+__device__ __forceinline__ int clampi2(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+// ---- a1.6 extrema: 3x3 strict maxima above the threshold, inside the level's border ----------------------
+__global__ void extrema_kernel(const float* __restrict__ Ldet, int w, int h, int border, float thr, uint8_t* __restrict__ mask,
+                               uint32_t* __restrict__ list, int* __restrict__ list_count) {
+    const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = border + blockIdx.y;
+    if (x >= w - border || y >= h - border) return;
+    const float* curr = Ldet + (size_t)y * w;
+    const float* prev = curr - w;
+    const float* next = curr + w;
+    const float v = curr[x];
+    if (v <= thr) return;
+    if (v <= curr[x - 1] || v <= curr[x + 1]) return;
+    if (v <= prev[x - 1] || v <= prev[x] || v <= prev[x + 1]) return;
+    if (v <= next[x - 1] || v <= next[x] || v <= next[x + 1]) return;
+    mask[(size_t)y * w + x] = 1;
+    const int slot = atomicAdd(list_count, 1);   // list order is irrelevant (only used to enumerate candidates)
+    list[slot] = (uint32_t)x | ((uint32_t)y << 16);
+}
+
+// ---- cross-level suppression -------------------------------------------------------------------------------
+static constexpr uint8_t ST_PENDING = 255, ST_DONE_OLD = 254;
+
+struct SuppressArgs {
+    int n_levels;
+    int phase;   // 0: compare with the previous level (ascending passes), 1: with the next level
+    int w[AKAZE_MAX_LEVELS], h[AKAZE_MAX_LEVELS], sigma_size[AKAZE_MAX_LEVELS], iratio[AKAZE_MAX_LEVELS];
+    const float* Ldet[AKAZE_MAX_LEVELS];
+    uint8_t* mask[AKAZE_MAX_LEVELS];     // live keypoint masks (searched and cleared)
+    uint8_t* status[AKAZE_MAX_LEVELS];   // snapshot of the iterated level: 0 none, 255 pending, else done stamp
+    const uint32_t* list[AKAZE_MAX_LEVELS];
+    const int* list_count;               // [n_levels]
+    int list_base[AKAZE_MAX_LEVELS + 1]; // prefix of per-level list capacities in the flattened thread space
+};
+
+__global__ void suppress_init_status_kernel(SuppressArgs A) {
+    const int lvl = blockIdx.y;
+    const int cnt = A.list_count[lvl];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const uint32_t e = A.list[lvl][i];
+        const size_t p = (size_t)(e >> 16) * A.w[lvl] + (e & 0xFFFF);
+        A.status[lvl][p] = A.mask[lvl][p] ? ST_PENDING : 0;
+    }
+}
+
+__global__ void suppress_canon_kernel(SuppressArgs A) {
+    const int lvl = blockIdx.y;
+    const int cnt = A.list_count[lvl];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const uint32_t e = A.list[lvl][i];
+        const size_t p = (size_t)(e >> 16) * A.w[lvl] + (e & 0xFFFF);
+        const uint8_t s = A.status[lvl][p];
+        if (s >= 1 && s <= 253) A.status[lvl][p] = ST_DONE_OLD;
+    }
+}
+
+// first set mask pixel in [x-r,x+r) x [y-r,y+r) (row-major scan) that lies within radius r
+__device__ __forceinline__ bool find_neighbor(const uint8_t* __restrict__ mask, int w, int h, int x, int y, int r, int& idx) {
+    for (int i = y - r; i < y + r; ++i) {
+        if (i < 0 || i >= h) continue;
+        for (int j = x - r; j < x + r; ++j) {
+            if (j < 0 || j >= w) continue;
+            if (!mask[(size_t)i * w + j]) continue;
+            const int dx = j - x, dy = i - y;
+            if (dx * dx + dy * dy <= r * r) {
+                idx = i * w + j;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+__global__ void suppress_round_kernel(SuppressArgs A, uint8_t stamp, int* __restrict__ pending_out) {
+    const int lvl = blockIdx.y;
+    const int other = A.phase == 0 ? lvl - 1 : lvl + 1;
+    if (other < 0 || other >= A.n_levels) return;
+    const int cnt = A.list_count[lvl];
+    const int w = A.w[lvl];
+    uint8_t* status = A.status[lvl];
+    int local_pending = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const uint32_t e = A.list[lvl][i];
+        const int x = e & 0xFFFF, y = e >> 16;
+        const size_t p = (size_t)y * w + x;
+        if (status[p] != ST_PENDING) continue;
+        // interaction distance in this level's pixels (conservative superset of "search windows overlap")
+        int D, diff, radius;
+        if (A.phase == 0) {
+            diff = A.iratio[lvl] / A.iratio[other];
+            radius = A.sigma_size[lvl] * diff;
+            D = 2 * A.sigma_size[lvl];
+        } else {
+            diff = A.iratio[other] / A.iratio[lvl];
+            radius = A.sigma_size[other];
+            D = (2 * radius + 1) * diff;
+        }
+        bool ready = true;
+        for (int yy = max(y - D, 0); yy <= y && ready; yy++) {
+            const int xe = yy == y ? x - 1 : min(x + D, w - 1);
+            for (int xx = max(x - D, 0); xx <= xe; xx++) {
+                const uint8_t s = status[(size_t)yy * w + xx];
+                if (s == ST_PENDING || s == stamp) {   // still pending, or finished only in this very round
+                    ready = false;
+                    break;
+                }
+            }
+        }
+        if (!ready) {
+            local_pending++;
+            continue;
+        }
+        int idx = 0;
+        const int px = A.phase == 0 ? x * diff : x / diff, py = A.phase == 0 ? y * diff : y / diff;
+        if (find_neighbor(A.mask[other], A.w[other], A.h[other], px, py, radius, idx)) {
+            if (A.Ldet[lvl][p] > A.Ldet[other][idx]) A.mask[other][idx] = 0;
+        }
+        status[p] = stamp;
+    }
+    if (local_pending) atomicAdd(pending_out, local_pending);
+}
+
+// ---- a1.7 sub-pixel refinement ---------------------------------------------------------------------------------
+struct Refined {
+    float x, y, response;
+    bool ok;
+};
+
+__device__ __forceinline__ Refined refine(const float* __restrict__ ldet, int cols, int x, int y, float ratio) {
+    const size_t c = (size_t)y * cols + x;
+    const float Dx = 0.5f * (ldet[c + 1] - ldet[c - 1]);
+    const float Dy = 0.5f * (ldet[c + cols] - ldet[c - cols]);
+    const float Dxx = ldet[c + 1] + ldet[c - 1] - 2.0f * ldet[c];
+    const float Dyy = ldet[c + cols] + ldet[c - cols] - 2.0f * ldet[c];
+    const float Dxy = 0.25f * (ldet[c + cols + 1] + ldet[c - cols - 1] - ldet[c - cols + 1] - ldet[c + cols - 1]);
+    float dx = 0.0f, dy = 0.0f;
+    float det = Dxx * Dyy - Dxy * Dxy;
+    if (det != 0) {
+        det = 1 / det;
+        const float b0 = -Dx, b1 = -Dy;
+        dx = (b0 * Dyy - b1 * Dxy) * det;
+        dy = (b1 * Dxx - b0 * Dxy) * det;
+    }
+    Refined r;
+    r.ok = !(fabsf(dx) > 1.0f || fabsf(dy) > 1.0f);
+    r.x = x * ratio + (dx * ratio + .5f * (ratio - 1.f));
+    r.y = y * ratio + (dy * ratio + .5f * (ratio - 1.f));
+    r.response = ldet[c];
+    return r;
+}
+
+// drop candidates whose refinement is unstable, so the concatenated masks become the final keypoint flags
+__global__ void subpixel_filter_kernel(LevelTable T, const uint32_t* const* __restrict__ lists, const int* __restrict__ list_count) {
+    const int lvl = blockIdx.y;
+    const int cnt = list_count[lvl];
+    const uint32_t* list = lists[lvl];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const uint32_t e = list[i];
+        const int x = e & 0xFFFF, y = e >> 16;
+        const size_t p = (size_t)y * T.w[lvl] + x;
+        if (!T.mask[lvl][p]) continue;
+        const Refined r = refine(T.Ldet[lvl], T.w[lvl], x, y, T.ratio[lvl]);
+        if (!r.ok) T.mask[lvl][p] = 0;
+    }
+}
+
+static constexpr int SCAN_BLOCK = 1024;
+
+__global__ __launch_bounds__(SCAN_BLOCK) void emit_keypoints_kernel(LevelTable T, const uint8_t* __restrict__ flags, long long total,
+                                                                    const int* __restrict__ block_offsets, apds_keypoint* __restrict__ kps,
+                                                                    int capacity) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    const long long e = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const int f = e < total ? (flags[e] != 0) : 0;
+    const unsigned long long b = __ballot(f);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) wsum[wv] = __popcll(b);
+    __syncthreads();
+    if (!f) return;
+    int before = 0;
+    for (int k = 0; k < wv; k++) before += wsum[k];
+    const int pos = block_offsets[blockIdx.x] + before + __popcll(b & ((1ull << lane) - 1ull));
+    if (pos >= capacity) return;
+    int lvl = 0;
+    while (lvl + 1 < T.n && e >= T.pix_offset[lvl + 1]) lvl++;
+    const long long pix = e - T.pix_offset[lvl];
+    const int y = (int)(pix / T.w[lvl]), x = (int)(pix - (long long)y * T.w[lvl]);
+    const Refined r = refine(T.Ldet[lvl], T.w[lvl], x, y, T.ratio[lvl]);
+    apds_keypoint kp;
+    kp.x = r.x;
+    kp.y = r.y;
+    kp.size = (T.esigma[lvl] * 1.5f) * 2.0f;
+    kp.angle = 0.0f;
+    kp.response = r.response;
+    kp.octave = T.octave[lvl];
+    kp.class_id = lvl;
+    kps[pos] = kp;
+}
+
+// ---- max_points: keep the `keep` strongest (response desc, ties by detection order), in that order -------------
+__global__ __launch_bounds__(256) void rank_select_kernel(const apds_keypoint* __restrict__ in, int n, int keep, apds_keypoint* __restrict__ out) {
+    __shared__ float s_resp[256];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float mine = i < n ? in[i].response : 0.f;
+    int rank = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int j = base + threadIdx.x;
+        s_resp[threadIdx.x] = j < n ? in[j].response : -1.f;
+        __syncthreads();
+        const int lim = min(256, n - base);
+        for (int k = 0; k < lim; k++) {
+            const float r = s_resp[k];
+            rank += (r > mine) || (r == mine && base + k < i);
+        }
+        __syncthreads();
+    }
+    if (i < n && rank < keep) out[rank] = in[i];
+}
+
+// ---- a1.8 main orientation: one wave per keypoint ---------------------------------------------------------------
+__constant__ float c_gauss25[7][7] = {
+    {0.02546481f, 0.02350698f, 0.01849125f, 0.01239505f, 0.00708017f, 0.00344629f, 0.00142946f},
+    {0.02350698f, 0.02169968f, 0.01706957f, 0.01144208f, 0.00653582f, 0.00318132f, 0.00131956f},
+    {0.01849125f, 0.01706957f, 0.01342740f, 0.00900066f, 0.00514126f, 0.00250252f, 0.00103800f},
+    {0.01239505f, 0.01144208f, 0.00900066f, 0.00603332f, 0.00344629f, 0.00167749f, 0.00069579f},
+    {0.00708017f, 0.00653582f, 0.00514126f, 0.00344629f, 0.00196855f, 0.00095820f, 0.00039744f},
+    {0.00344629f, 0.00318132f, 0.00250252f, 0.00167749f, 0.00095820f, 0.00046640f, 0.00019346f},
+    {0.00142946f, 0.00131956f, 0.00103800f, 0.00069579f, 0.00039744f, 0.00019346f, 0.00008024f}};
+
+struct OrientTable {
+    int8_t dx[109], dy[109];
+};
+constexpr OrientTable make_orient_table() {
+    OrientTable t{};
+    int k = 0;
+    for (int i = -6; i <= 6; ++i)
+        for (int j = -6; j <= 6; ++j)
+            if (i * i + j * j < 36) {
+                t.dy[k] = (int8_t)i;
+                t.dx[k] = (int8_t)j;
+                ++k;
+            }
+    return t;
+}
+__constant__ OrientTable c_orient = make_orient_table();
+
+__device__ __forceinline__ float fast_atan2_deg(float y, float x) {
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.14159265358979323846);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.14159265358979323846);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.14159265358979323846);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.14159265358979323846);
+    const float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)2.2204460492503131e-16);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+__global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_keypoint* __restrict__ kps, int n, float ang_step, int nkeys) {
+    __shared__ float s_x[4][112], s_y[4][112];
+    __shared__ uint8_t s_bin[4][112], s_sorted[4][112];
+    __shared__ int s_start[4][44];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ki = blockIdx.x * 4 + wv;
+    const bool live = ki < n;
+    const apds_keypoint kp = kps[live ? ki : 0];
+    const int lvl = kp.class_id;
+    const int w = T.w[lvl], h = T.h[lvl];
+    const float ratio = T.ratio[lvl];
+    const int scale = __float2int_rn(0.5f * kp.size / ratio);
+    const int x0 = __float2int_rn(kp.x / ratio), y0 = __float2int_rn(kp.y / ratio);
+    const float* __restrict__ Lx = T.Lx[lvl];
+    const float* __restrict__ Ly = T.Ly[lvl];
+    const float rad = (float)(3.14159265358979323846 / 180);
+    for (int k = lane; k < 109; k += 64) {
+        const int i = c_orient.dy[k], j = c_orient.dx[k];
+        const float wgt = c_gauss25[i < 0 ? -i : i][j < 0 ? -j : j];
+        const int y = clampi2(y0 + i * scale, h), x = clampi2(x0 + j * scale, w);
+        const float rx = wgt * Lx[(size_t)y * w + x], ry = wgt * Ly[(size_t)y * w + x];
+        const float ang = fast_atan2_deg(ry, rx) * rad;
+        int b = (int)(ang / ang_step);
+        if (b < 0 || b >= nkeys) b = 0;
+        s_x[wv][k] = rx;
+        s_y[wv][k] = ry;
+        s_bin[wv][k] = (uint8_t)b;
+    }
+    __syncthreads();
+    // counting sort, identical to idx[--cum[b]] = i for ascending i: within a bin the larger sample index comes first
+    if (lane < 43) {
+        int cnt = 0;   // samples in bins < lane  -> start of bin `lane` (lane == 42 gives the total)
+        for (int k = 0; k < 109; k++) cnt += s_bin[wv][k] < lane;
+        s_start[wv][lane] = cnt;
+    }
+    __syncthreads();
+    for (int k = lane; k < 109; k += 64) {
+        const int b = s_bin[wv][k];
+        int later = 0;   // samples of the same bin with a larger index precede this one
+        for (int k2 = k + 1; k2 < 109; k2++) later += s_bin[wv][k2] == b;
+        s_sorted[wv][s_start[wv][b] + later] = (uint8_t)k;
+    }
+    __syncthreads();
+    float sumX = 0.0f, sumY = 0.0f, norm = -1.0f;
+    if (lane < 42) {
+        const int sn = lane, win = 7, slices = 42;
+        const int* st = s_start[wv];
+        if (sn <= slices - win) {
+            for (int i = st[sn]; i < st[sn + win]; i++) {
+                const int idx = s_sorted[wv][i];
+                sumX += s_x[wv][idx];
+                sumY += s_y[wv][idx];
+            }
+        } else {
+            const int remain = sn + win - slices;
+            for (int i = st[sn]; i < st[slices]; i++) {
+                const int idx = s_sorted[wv][i];
+                sumX += s_x[wv][idx];
+                sumY += s_y[wv][idx];
+            }
+            for (int i = st[0]; i < st[remain]; i++) {
+                const int idx = s_sorted[wv][i];
+                sumX += s_x[wv][idx];
+                sumY += s_y[wv][idx];
+            }
+        }
+        norm = sumX * sumX + sumY * sumY;
+    }
+    // arg max over windows, the first window wins ties (the reference only replaces on strictly greater)
+    int best = lane;
+    for (int off = 32; off > 0; off >>= 1) {
+        const float on = __shfl_xor(norm, off);
+        const int ob = __shfl_xor(best, off);
+        const float ox = __shfl_xor(sumX, off), oy = __shfl_xor(sumY, off);
+        if (on > norm || (on == norm && ob < best)) {
+            norm = on;
+            best = ob;
+            sumX = ox;
+            sumY = oy;
+        }
+    }
+    if (live && lane == 0) kps[ki].angle = fast_atan2_deg(sumY, sumX);
+}
+
+// ---- a1.9 M-LDB 486-bit descriptor: one wave per keypoint ----------------------------------------------------------
+// deterministic double sin/cos on [0, 2pi] (Cody-Waite reduction + Taylor/Horner; same arithmetic as the oracle)
+__device__ __forceinline__ void det_sincos(double a, double& s, double& c) {
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;
+    const int k = (int)(a * two_over_pi + 0.5);
+    const double r = (a - k * pio2_hi) - k * pio2_lo;
+    const double r2 = r * r;
+    double ps = -7.6471637318198164759e-13;          // -1/15!
+    ps = ps * r2 + 1.6059043836821614599e-10;        //  1/13!
+    ps = ps * r2 + -2.5052108385441718775e-08;       // -1/11!
+    ps = ps * r2 + 2.7557319223985890653e-06;        //  1/9!
+    ps = ps * r2 + -1.9841269841269841270e-04;       // -1/7!
+    ps = ps * r2 + 8.3333333333333333333e-03;        //  1/5!
+    ps = ps * r2 + -1.6666666666666666667e-01;       // -1/3!
+    const double sr = r + r * (r2 * ps);
+    double pc = 4.7794773323873852974e-14;           //  1/16!
+    pc = pc * r2 + -1.1470745597729724714e-11;       // -1/14!
+    pc = pc * r2 + 2.0876756987868098979e-09;        //  1/12!
+    pc = pc * r2 + -2.7557319223985890653e-07;       // -1/10!
+    pc = pc * r2 + 2.4801587301587301587e-05;        //  1/8!
+    pc = pc * r2 + -1.3888888888888888889e-03;       // -1/6!
+    pc = pc * r2 + 4.1666666666666666667e-02;        //  1/4!
+    pc = pc * r2 + -0.5;
+    const double cr = 1.0 + r2 * pc;
+    switch (k & 3) {
+        case 0: s = sr; c = cr; break;
+        case 1: s = cr; c = -sr; break;
+        case 2: s = -sr; c = -cr; break;
+        default: s = -cr; c = sr; break;
+    }
+}
+
+struct MldbLut {
+    uint8_t a[488], b[488];
+};
+constexpr MldbLut make_mldb_lut() {
+    MldbLut L{};
+    int dpos = 0, base = 0;
+    for (int g = 0; g < 3; g++) {
+        const int cnt = (g + 2) * (g + 2);
+        for (int pos = 0; pos < 3; pos++)
+            for (int i = 0; i < cnt; i++)
+                for (int j = i + 1; j < cnt; j++) {
+                    L.a[dpos] = (uint8_t)(base + 3 * i + pos);
+                    L.b[dpos] = (uint8_t)(base + 3 * j + pos);
+                    dpos++;
+                }
+        base += 3 * cnt;
+    }
+    return L;
+}
+__constant__ MldbLut c_mldb = make_mldb_lut();
+
+__global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, int n, uint32_t* __restrict__ desc64) {
+    __shared__ int s_val[4][88];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int ki = blockIdx.x * 4 + wv;
+    const bool live = ki < n;
+    const apds_keypoint kp = kps[live ? ki : 0];
+    const int lvl = kp.class_id;
+    const int w = T.w[lvl], h = T.h[lvl];
+    const float* __restrict__ Lt = T.Lt[lvl];
+    const float* __restrict__ Lx = T.Lx[lvl];
+    const float* __restrict__ Ly = T.Ly[lvl];
+    const float ratio = (float)(1 << kp.octave);
+    const float scale = (float)__float2int_rn(0.5f * kp.size / ratio);
+    const float xf = kp.x / ratio, yf = kp.y / ratio;
+    const float angle = kp.angle * (float)(3.14159265358979323846 / 180.f);
+    double sd, cd;
+    det_sincos((double)angle, sd, cd);
+    const float co = (float)cd, si = (float)sd;
+    if (lane < 29) {
+        // lane -> (grid, cell)
+        int g, cell, side, step, base;
+        if (lane < 4) g = 0, cell = lane, side = 2, step = 10, base = 0;
+        else if (lane < 13) g = 1, cell = lane - 4, side = 3, step = 7, base = 12;
+        else g = 2, cell = lane - 13, side = 4, step = 5, base = 39;
+        (void)g;
+        const int i0 = -10 + (cell / side) * step, j0 = -10 + (cell % side) * step;
+        float di = 0.0f, dx = 0.0f, dy = 0.0f;
+        int nsamples = 0;
+        for (int k = i0; k < i0 + step; k++)
+            for (int l = j0; l < j0 + step; l++) {
+                const float sample_y = yf + (l * co * scale + k * si * scale);
+                const float sample_x = xf + (-l * si * scale + k * co * scale);
+                const int y1 = __float2int_rn(sample_y), x1 = __float2int_rn(sample_x);
+                if (y1 < 0 || y1 >= h || x1 < 0 || x1 >= w) continue;
+                const size_t o = (size_t)y1 * w + x1;
+                const float ri = Lt[o];
+                di += ri;
+                const float rx = Lx[o], ry = Ly[o];
+                const float rry = rx * co + ry * si;
+                const float rrx = -rx * si + ry * co;
+                dx += rrx;
+                dy += rry;
+                nsamples++;
+            }
+        if (nsamples > 0) {
+            const float inv = 1.0f / nsamples;
+            di *= inv;
+            dx *= inv;
+            dy *= inv;
+        }
+        const int v0 = __float_as_int(di), v1 = __float_as_int(dx), v2 = __float_as_int(dy);
+        s_val[wv][base + 3 * cell + 0] = v0 ^ (v0 < 0 ? 0x7fffffff : 0);   // CV_TOGGLE_FLT: int order == float order
+        s_val[wv][base + 3 * cell + 1] = v1 ^ (v1 < 0 ? 0x7fffffff : 0);
+        s_val[wv][base + 3 * cell + 2] = v2 ^ (v2 < 0 ? 0x7fffffff : 0);
+    }
+    __syncthreads();
+    if (live && lane < 16) {
+        uint32_t word = 0;
+#pragma unroll 4
+        for (int b = 0; b < 32; b++) {
+            const int pos = lane * 32 + b;
+            if (pos < 486 && s_val[wv][c_mldb.a[pos]] > s_val[wv][c_mldb.b[pos]]) word |= 1u << b;
+        }
+        desc64[(size_t)ki * 16 + lane] = word;   // 61 payload bytes + 3 zero bytes per 64-byte row
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------
+static void launch_extrema_level(const float* Ldet, int w, int h, int border, float thr, uint8_t* mask, uint32_t* list, int* list_count, hipStream_t s) {
+    if (border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0) return;
+    hipLaunchKernelGGL(extrema_kernel, dim3(ceil_div(w - 2 * border, 256), h - 2 * border), dim3(256), 0, s, Ldet, w, h, border, thr, mask, list, list_count);
+}
+
+namespace {
+
+bool fed_is_prime(int n) {
+    if (n <= 1) return false;
+    if (n == 2 || n == 3 || n == 5 || n == 7) return true;
+    if (n % 2 == 0 || n % 3 == 0 || n % 5 == 0 || n % 7 == 0) return false;
+    const int upper = (int)std::sqrt((double)n + 1.0);
+    for (int d = 11; d <= upper; d += 2)
+        if (n % d == 0) return false;
+    return true;
+}
+
+// fed_tau_by_process_time(T, 1, 0.25, reordering = true): FED step sizes for one evolution level
+int fed_tau(float T, float tau_max, float* tau) {
+    const int n = (int)std::ceil(sqrtf(3.0f * T / tau_max + 0.25f) - 0.5f - 1.0e-8f);
+    if (n <= 0) return 0;
+    APDS_REQUIRE(n <= 64, APDS_ERR_INTERNAL, "FED cycle longer than expected");
+    const float scale = 3.0f * T / (tau_max * (float)(n * (n + 1)));
+    float tauh[64];
+    const float c = 1.0f / (4.0f * (float)n + 2.0f);
+    const float d = scale * tau_max / 2.0f;
+    for (int k = 0; k < n; ++k) {
+        const float hc = cosf((float)M_PI * (2.0f * (float)k + 1.0f) * c);
+        tauh[k] = d / (hc * hc);
+    }
+    const int kappa = n / 2;
+    int prime = n + 1;
+    while (!fed_is_prime(prime)) prime++;
+    for (int k = 0, l = 0; l < n; ++k, ++l) {
+        int index = 0;
+        while ((index = ((k + 1) * kappa) % prime - 1) >= n) k++;
+        tau[l] = tauh[index];
+    }
+    return n;
+}
+
+GaussTaps gauss_taps(int n, double sigma) {
+    double k[9], sum = 0;
+    const double s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < n; i++) {
+        const double x = i - (n - 1) * 0.5;
+        k[i] = std::exp(s2 * x * x);
+        sum += k[i];
+    }
+    GaussTaps t{};
+    const int r = n / 2;
+    for (int j = 0; j <= r; j++) t.k[j] = (float)(k[r + j] / sum);
+    return t;
+}
+
+// INTER_AREA tap tables for one axis (<= 4 taps per destination pixel)
+void area_tables(int ssize, int dsize, std::vector<int>& ofs, std::vector<float>& wgt, std::vector<int>& cnt) {
+    const double scale = (double)ssize / dsize;
+    ofs.assign((size_t)dsize * 4, 0);
+    wgt.assign((size_t)dsize * 4, 0.f);
+    cnt.assign(dsize, 0);
+    for (int d = 0; d < dsize; d++) {
+        const double f1 = d * scale, f2 = f1 + scale;
+        const double cell = std::min(scale, ssize - f1);
+        int s1 = (int)std::ceil(f1), s2 = (int)std::floor(f2);
+        s2 = std::min(s2, ssize);
+        s1 = std::min(s1, s2);
+        auto push = [&](int sidx, double a) {
+            APDS_REQUIRE(cnt[d] < 4, APDS_ERR_INTERNAL, "area resize tap overflow");
+            ofs[(size_t)d * 4 + cnt[d]] = sidx;
+            wgt[(size_t)d * 4 + cnt[d]] = (float)a;
+            cnt[d]++;
+        };
+        if (s1 - f1 > 1e-3) push(s1 - 1, (s1 - f1) / cell);
+        for (int sx = s1; sx < s2; sx++) push(sx, 1.0 / cell);
+        if (f2 - s2 > 1e-3) push(s2, std::min(std::min(f2 - s2, 1.0), cell) / cell);
+    }
+}
+
+template <class T>
+T* upload(const std::vector<T>& v, hipStream_t s) {
+    T* d = ctx().alloc_n<T>(v.size());
+    HIP_CHECK(hipMemcpyAsync(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return d;
+}
+
+}  // namespace
+
+// kernels from match_hamming.hip's compaction utility, re-declared for the 64-bit flag space used here
+__global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8_t* __restrict__ flags, long long n, int* __restrict__ block_counts) {
+    __shared__ int wsum[SCAN_BLOCK / 64];
+    const long long i = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
+    const int f = i < n ? (flags[i] != 0) : 0;
+    const unsigned long long b = __ballot(f);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int w = 0; w < SCAN_BLOCK / 64; w++) sum += wsum[w];
+        block_counts[blockIdx.x] = sum;
+    }
+}
+
+__global__ __launch_bounds__(1024) void kp_scan_offsets_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ total) {
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nblocks; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nblocks ? block_counts[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            const int add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += add;
+            __syncthreads();
+        }
+        const int incl = buf[threadIdx.x];
+        if (i < nblocks) block_counts[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void pack_desc61_kernel(const uint8_t* __restrict__ d64, int n, uint8_t* __restrict__ d61) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * 61) return;
+    const long long r = i / 61;
+    d61[i] = d64[r * 64 + (i - r * 61)];
+}
+
+void pack_desc61_device(const uint8_t* d64, int n, uint8_t* d61, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(pack_desc61_kernel, dim3(ceil_div((long long)n * 61, 256)), dim3(256), 0, s, d64, n, d61);
+}
+
+AkazeDebugRequest& akaze_debug_request() {
+    static thread_local AkazeDebugRequest r;
+    return r;
+}
+
+// feature_extraction/src/lib.rs:61-92 on a device image. Returns the keypoint count; kps/desc64 must hold `capacity` rows.
+int akaze_extract_device(const void* img, int rows, int cols, int channels, size_t stride, int max_points, apds_keypoint* kps_out,
+                         uint8_t* desc64_out, int capacity, hipStream_t s) {
+    APDS_REQUIRE(img != nullptr, APDS_ERR_BAD_ARG, "null image");
+    APDS_REQUIRE(channels == 1 || channels == 3 || channels == 4, APDS_ERR_ASSERT, "image must have 1, 3 or 4 channels");
+    APDS_REQUIRE(rows > 2 && cols > 2, APDS_ERR_ASSERT, "image must be larger than 2x2");   // AKAZE CV_Assert(img_height > 2 && img_width > 2)
+    APDS_REQUIRE(rows < 65536 && cols < 65536, APDS_ERR_ASSERT, "image side must be < 65536");
+    APDS_REQUIRE(stride >= (size_t)cols * channels, APDS_ERR_ASSERT, "row stride smaller than a row");
+    if (max_points <= 0) max_points = APDS_MAX_POINTS;
+    ThreadCtx& c = ctx();
+    const int W = cols, H = rows;
+    const float soffset = 1.6f, derivative_factor = 1.5f, dthreshold = 0.001f;
+
+    // ---- evolution (Allocate_Memory_Evolution)
+    std::vector<LevelDesc> ev;
+    {
+        int omax = 4;
+        const int nsub = 4;
+        const float smax = 10.0f * sqrtf(2.0f);
+        int lw = W, lh = H, power = 1;
+        for (int i = 0; i < omax; i++) {
+            for (int j = 0; j < nsub; j++) {
+                LevelDesc d{};
+                d.w = lw;
+                d.h = lh;
+                d.esigma = soffset * powf(2.f, (float)j / (float)nsub + i);
+                d.sigma_size = (int)lrintf(d.esigma * derivative_factor / power);
+                d.etime = 0.5f * (d.esigma * d.esigma);
+                d.octave = i;
+                d.sublevel = j;
+                d.ratio = (float)power;
+                d.border = (int)lrintf(smax * d.sigma_size) + 1;
+                ev.push_back(d);
+            }
+            power <<= 1;
+            lh >>= 1;
+            lw >>= 1;
+            if (lw < 80 || lh < 40) break;
+        }
+        for (size_t i = 1; i < ev.size(); i++) ev[i].nsteps = fed_tau(ev[i].etime - ev[i - 1].etime, 0.25f, ev[i].tau);
+    }
+    const int L = (int)ev.size();
+    const int n_oct = ev.back().octave + 1;
+
+    // ---- device planes
+    const size_t n0 = (size_t)W * H;
+    float* gray = c.alloc_n<float>(n0);
+    float* tmpS = c.alloc_n<float>(n0);
+    float* tmpF = c.alloc_n<float>(n0);
+    float* tmpP = c.alloc_n<float>(n0);
+    long long total_pix = 0;
+    for (auto& e : ev) {
+        const size_t n = (size_t)e.w * e.h;
+        e.Lt = c.alloc_n<float>(n);
+        e.Lx = c.alloc_n<float>(n);
+        e.Ly = c.alloc_n<float>(n);
+        e.Ldet = c.alloc_n<float>(n);
+        e.pix_offset = total_pix;
+        total_pix += (long long)n;
+    }
+    uint8_t* mask_all = c.alloc_n<uint8_t>((size_t)total_pix);
+    uint8_t* status_all = c.alloc_n<uint8_t>((size_t)total_pix);
+    unsigned int* hmax_bits = c.alloc_n<unsigned int>(1);
+    int* hist = c.alloc_n<int>(300);
+    float* k_oct = c.alloc_n<float>(8);
+    int* list_count = c.alloc_n<int>(AKAZE_MAX_LEVELS);
+    int* pending_dev = c.alloc_n<int>(1);
+
+    // ---- a1.1 / a1.2 / a1.3
+    launch_gray(img, H, W, channels, stride, gray, s);
+    const GaussTaps g16 = gauss_taps(9, (double)soffset), g10 = gauss_taps(5, 1.0);
+    launch_gauss(gray, ev[0].Lt, W, H, g16, 4, s);   // Lt[0] == Lsmooth[0]
+    if (L > 1) {
+        launch_gauss(gray, tmpS, W, H, g10, 2, s);
+        launch_kcontrast(tmpS, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s);
+    }
+    auto deriv_weights = [](int sc, float& kside, float& kmid) {
+        if (sc == 1) {
+            kside = 3.0f / 32.0f;
+            kmid = 10.0f / 32.0f;
+        } else {
+            const float wgt = 10.0f / 3.0f;
+            const float norm = 1.0f / (2.0f * sc * (wgt + 2.0f));
+            kside = norm;
+            kmid = wgt * norm;
+        }
+    };
+    // ---- a1.4 / a1.5 per level: Lsmooth -> (Lx, Ly, Ldet) and flow; FED steps ping-pong into Lt[i]
+    for (int i = 0; i < L; i++) {
+        LevelDesc& e = ev[i];
+        const float* smooth;
+        if (i == 0) {
+            smooth = e.Lt;
+        } else {
+            const LevelDesc& p = ev[i - 1];
+            const float* P;   // the level's starting image
+            if (e.octave > p.octave) {
+                float* dstP = (e.nsteps % 2 == 0) ? e.Lt : tmpP;   // so that the last FED step lands in e.Lt
+                if (p.w == 2 * e.w && p.h == 2 * e.h) {
+                    launch_half_sample(p.Lt, p.w, dstP, e.w, e.h, s);
+                } else {
+                    std::vector<int> xo, yo, xc, yc;
+                    std::vector<float> xw, yw;
+                    area_tables(p.w, e.w, xo, xw, xc);
+                    area_tables(p.h, e.h, yo, yw, yc);
+                    HIP_CHECK(hipStreamSynchronize(s));   // host tables must outlive the async copies
+                    launch_area_resize(p.Lt, p.w, dstP, e.w, e.h, upload(xo, s), upload(xw, s), upload(xc, s), upload(yo, s), upload(yw, s), upload(yc, s), s);
+                    HIP_CHECK(hipStreamSynchronize(s));
+                }
+                P = dstP;
+            } else {
+                P = p.Lt;
+            }
+            launch_gauss(P, tmpS, e.w, e.h, g10, 2, s);
+            smooth = tmpS;
+            launch_flow(tmpS, tmpF, e.w, e.h, k_oct + e.octave, s);
+            const float* in = P;
+            for (int k = 1; k <= e.nsteps; k++) {
+                float* out = ((e.nsteps - k) % 2 == 0) ? e.Lt : tmpP;
+                launch_nld_step(in, tmpF, out, e.w, e.h, e.tau[k - 1] * 0.5f, s);
+                in = out;
+            }
+            if (e.nsteps == 0 && P != e.Lt) HIP_CHECK(hipMemcpyAsync(e.Lt, P, (size_t)e.w * e.h * 4, hipMemcpyDeviceToDevice, s));
+        }
+        float kside, kmid;
+        deriv_weights(e.sigma_size, kside, kmid);
+        launch_deriv_pair(smooth, e.Lx, e.Ly, e.w, e.h, e.sigma_size, kside, kmid, s);
+        launch_hessian_det(e.Lx, e.Ly, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, s);
+    }
+    HIP_CHECK(hipGetLastError());
+
+    // ---- a1.6 extrema + candidate lists
+    LevelTable T{};
+    SuppressArgs A{};
+    T.n = A.n_levels = L;
+    std::vector<uint32_t*> lists(L);
+    for (int i = 0; i < L; i++) {
+        const LevelDesc& e = ev[i];
+        T.w[i] = A.w[i] = e.w;
+        T.h[i] = A.h[i] = e.h;
+        T.octave[i] = e.octave;
+        T.sigma_size[i] = A.sigma_size[i] = e.sigma_size;
+        T.border[i] = e.border;
+        T.esigma[i] = e.esigma;
+        T.ratio[i] = e.ratio;
+        A.iratio[i] = (int)e.ratio;
+        T.pix_offset[i] = e.pix_offset;
+        T.Lt[i] = e.Lt;
+        T.Lx[i] = e.Lx;
+        T.Ly[i] = e.Ly;
+        T.Ldet[i] = A.Ldet[i] = e.Ldet;
+        T.mask[i] = A.mask[i] = mask_all + e.pix_offset;
+        A.status[i] = status_all + e.pix_offset;
+        lists[i] = c.alloc_n<uint32_t>((size_t)((e.w + 1) / 2) * ((e.h + 1) / 2));   // strict 3x3 maxima are never adjacent
+        A.list[i] = lists[i];
+    }
+    T.pix_offset[L] = total_pix;
+    A.list_count = list_count;
+    HIP_CHECK(hipMemsetAsync(mask_all, 0, (size_t)total_pix, s));
+    HIP_CHECK(hipMemsetAsync(status_all, 0, (size_t)total_pix, s));
+    HIP_CHECK(hipMemsetAsync(list_count, 0, AKAZE_MAX_LEVELS * sizeof(int), s));
+    for (int i = 0; i < L; i++)
+        launch_extrema_level(ev[i].Ldet, ev[i].w, ev[i].h, ev[i].border, dthreshold, T.mask[i], lists[i], list_count + i, s);
+
+    // ---- cross-level suppression: phase 0 (vs previous level), then phase 1 (vs next level)
+    if (L > 1) {
+        const dim3 lgrid(64, L), lblock(256);
+        for (int phase = 0; phase < 2; phase++) {
+            A.phase = phase;
+            hipLaunchKernelGGL(suppress_init_status_kernel, lgrid, lblock, 0, s, A);
+            int round = 0;
+            for (;;) {
+                for (int b = 0; b < 4; b++) {
+                    if (b == 3) HIP_CHECK(hipMemsetAsync(pending_dev, 0, sizeof(int), s));
+                    const uint8_t stamp = (uint8_t)(round % 253 + 1);
+                    hipLaunchKernelGGL(suppress_round_kernel, lgrid, lblock, 0, s, A, stamp, pending_dev);
+                    round++;
+                    if (round % 253 == 0) hipLaunchKernelGGL(suppress_canon_kernel, lgrid, lblock, 0, s, A);
+                }
+                int pending = 0;
+                HIP_CHECK(hipMemcpyAsync(&pending, pending_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                if (pending == 0) break;
+                APDS_REQUIRE(round < 1000000, APDS_ERR_INTERNAL, "cross-level suppression did not converge");
+            }
+        }
+    }
+
+    AkazeDebugRequest& dbg = akaze_debug_request();
+    if (dbg.armed && dbg.level >= 0 && dbg.level < L) {
+        const LevelDesc& e = ev[dbg.level];
+        const size_t n = (size_t)e.w * e.h;
+        const void* src = nullptr;
+        size_t bytes = n * 4;
+        switch (dbg.which) {
+            case 0: src = e.Lt; break;
+            case 2: src = e.Lx; break;
+            case 3: src = e.Ly; break;
+            case 4: src = e.Ldet; break;
+            case 7: src = T.mask[dbg.level]; bytes = n; break;
+            case 8: src = k_oct; bytes = 4; break;
+        }
+        if (src) HIP_CHECK(hipMemcpyAsync(dbg.host_out, src, bytes, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        dbg.armed = false;
+    }
+
+    // ---- a1.7 sub-pixel filter, ordered compaction (level-major, row-major)
+    uint32_t** lists_dev = c.alloc_n<uint32_t*>(L);
+    HIP_CHECK(hipMemcpyAsync(lists_dev, lists.data(), L * sizeof(uint32_t*), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(subpixel_filter_kernel, dim3(64, L), dim3(256), 0, s, T, (const uint32_t* const*)lists_dev, (const int*)list_count);
+    const int nblocks = ceil_div(total_pix, SCAN_BLOCK);
+    int* block_counts = c.alloc_n<int>(nblocks + 1);
+    int* total_dev = block_counts + nblocks;
+    hipLaunchKernelGGL(kp_block_counts_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, mask_all, total_pix, block_counts);
+    hipLaunchKernelGGL(kp_scan_offsets_kernel, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total_dev);
+    int K = 0;
+    HIP_CHECK(hipMemcpyAsync(&K, total_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));   // lists (host vector) were also consumed by now
+    if (K == 0) return 0;
+    const int keep = std::min(K, max_points);
+    APDS_REQUIRE(keep <= capacity, APDS_ERR_ASSERT, "output capacity smaller than the keypoint count");
+    apds_keypoint* kps_all = (K == keep) ? kps_out : c.alloc_n<apds_keypoint>(K);
+    hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, T, (const uint8_t*)mask_all, total_pix, (const int*)block_counts, kps_all, K);
+    if (K > keep) hipLaunchKernelGGL(rank_select_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, s, (const apds_keypoint*)kps_all, K, keep, kps_out);
+
+    // ---- a1.8 / a1.9
+    const float ang_step = (float)(2.0 * M_PI / 42);
+    const int nkeys = (int)((float)(2.0 * M_PI) / ang_step);
+    hipLaunchKernelGGL(orientation_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, T, kps_out, keep, ang_step, nkeys);
+    hipLaunchKernelGGL(mldb_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, T, (const apds_keypoint*)kps_out, keep, reinterpret_cast<uint32_t*>(desc64_out));
+    HIP_CHECK(hipGetLastError());
+    return keep;
+}
+
+}  // namespace apds

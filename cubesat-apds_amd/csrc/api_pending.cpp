@@ -2,12 +2,6 @@
 #include "kernels.h"
 using namespace apds;
 extern "C" {
-int apds_akaze_extract(const uint8_t*, int, int, int, size_t, int, apds_keypoint**, uint8_t**, int*, int*) {
-    return guarded([&] { fail(APDS_ERR_INTERNAL, "apds_akaze_extract: kernels not built into this library yet"); });
-}
-int apds_dev_akaze_extract(const void*, int, int, int, size_t, int, void*, void*, int, int*, void*) {
-    return guarded([&] { fail(APDS_ERR_INTERNAL, "apds_dev_akaze_extract: kernels not built into this library yet"); });
-}
 int apds_find_homography(const float*, const float*, int, int, double, double*, uint8_t*) {
     return guarded([&] { fail(APDS_ERR_INTERNAL, "apds_find_homography: kernels not built into this library yet"); });
 }

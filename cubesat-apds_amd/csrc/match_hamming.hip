@@ -13,6 +13,8 @@
 // the rare groups that contain a hit. Train rows are split into chunks over blockIdx.y so the grid fills
 // 256 CUs; per-chunk candidates are merged by a second tiny kernel. Keys are (distance << 32 | index):
 // unsigned 64-bit min reproduces BFMatcher's order (distance, then lower train index).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace apds {
@@ -307,24 +309,29 @@ __global__ __launch_bounds__(SCAN_BLOCK) void emit_ratio_matches_kernel(const ui
 }
 
 // ---- register-only VALU microbenchmark (denominator of the popcount roofline) ---------------------------
-__global__ __launch_bounds__(256) void valu_popcount_peak_kernel(uint32_t* __restrict__ sink, int iters) {
+// MODE 0: the match kernel's inner pair (v_xor with an SGPR operand + accumulating v_bcnt); 1: v_xor only;
+// 2: v_bcnt only; 3: v_add_u32 only. All count one lane-op per instruction per lane.
+template <int MODE>
+__global__ __launch_bounds__(256) void valu_peak_kernel(uint32_t* __restrict__ sink, int iters) {
     uint32_t q[16];
 #pragma unroll
     for (int j = 0; j < 16; j++) q[j] = threadIdx.x * 2654435761u + j * 40503u;
-    int acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+    int acc[4] = {0, 1, 2, 3};
     uint32_t s = blockIdx.x * 97u + 1u;
     for (int it = 0; it < iters; it++) {
-        // s is wave-uniform (SGPR operand), like a train row dword
 #pragma unroll
         for (int j = 0; j < 16; j++) {
-            acc0 += __popc(q[j] ^ s);
-            acc1 += __popc(q[j] ^ (s + 1));
-            acc2 += __popc(q[j] ^ (s + 2));
-            acc3 += __popc(q[j] ^ (s + 3));
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                if (MODE == 0) acc[c] = bcnt_acc(q[j] ^ (s + c), acc[c]);
+                else if (MODE == 1) { uint32_t r; asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "s"(s + c), "v"((uint32_t)acc[c])); acc[c] = (int)r; }
+                else if (MODE == 2) acc[c] = bcnt_acc(q[j], acc[c]);
+                else { uint32_t r; asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(s + c), "v"((uint32_t)acc[c])); acc[c] = (int)r; }
+            }
         }
         s = s * 1664525u + 1013904223u;
     }
-    if ((acc0 + acc1 + acc2 + acc3) == 0x7fffffff) sink[0] = 1;
+    if ((acc[0] + acc[1] + acc[2] + acc[3]) == 0x7fffffff) sink[0] = 1;
 }
 
 // ---- host launchers -------------------------------------------------------------------------------------
@@ -332,17 +339,28 @@ struct ChunkPlan {
     int T, chunks, rows_per_chunk, qtiles_blocks;
 };
 
+static int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+
+// Work items are (64*T queries) x (rows_per_chunk train rows) per wave. Items are kept small enough that the
+// grid is many dispatch rounds deep (the block scheduler then balances the tail), but not so small that the
+// per-chunk candidate lists dominate the merge.
 static ChunkPlan plan_chunks(int nq, long long n_train) {
     ChunkPlan p;
+    static const int forced_t = env_int("APDS_MATCH_T", 0);
+    static const int target_waves = env_int("APDS_MATCH_TARGET_WAVES", 256 * 4 * 4 * 12);
+    static const int min_rows = env_int("APDS_MATCH_MIN_ROWS", 1024);
     p.T = nq >= 64 * 4 * 64 ? 4 : (nq >= 64 * 2 * 64 ? 2 : 1);
+    if (forced_t == 1 || forced_t == 2 || forced_t == 4) p.T = forced_t;
     const int waves_q = ceil_div(nq, 64 * p.T);
     p.qtiles_blocks = ceil_div(waves_q, 4);
-    const int target_waves = 256 * 4 * 6;
     long long chunks = ceil_div(target_waves, waves_q);
-    const long long max_chunks = std::max<long long>(1, n_train / 4096);
+    const long long max_chunks = std::max<long long>(1, n_train / min_rows);
     chunks = std::min<long long>(std::max<long long>(chunks, 1), std::min<long long>(max_chunks, 65535));
     long long rpc = (n_train + chunks - 1) / chunks;
-    rpc = (rpc + 1) & ~1ll;
+    rpc = (rpc + 3) & ~3ll;
     p.rows_per_chunk = (int)rpc;
     p.chunks = (int)((n_train + rpc - 1) / rpc);
     return p;
@@ -471,28 +489,39 @@ int cross_check_device(const uint64_t* train_best, long long n_train, int nq, ap
     return total;
 }
 
-double valu_popcount_peak_device() {
-    ThreadCtx& c = ctx();
-    uint32_t* sink = c.alloc_n<uint32_t>(64);
+template <int MODE>
+static double run_valu_peak(uint32_t* sink, hipStream_t st) {
     const int iters = 4096, blocks = 256 * 8;
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a));
     HIP_CHECK(hipEventCreate(&b));
-    hipLaunchKernelGGL(valu_popcount_peak_kernel, dim3(blocks), dim3(256), 0, c.stream, sink, 64);
+    hipLaunchKernelGGL((valu_peak_kernel<MODE>), dim3(blocks), dim3(256), 0, st, sink, 64);
     double best = 0;
     for (int rep = 0; rep < 5; rep++) {
-        HIP_CHECK(hipEventRecord(a, c.stream));
-        hipLaunchKernelGGL(valu_popcount_peak_kernel, dim3(blocks), dim3(256), 0, c.stream, sink, iters);
-        HIP_CHECK(hipEventRecord(b, c.stream));
+        HIP_CHECK(hipEventRecord(a, st));
+        hipLaunchKernelGGL((valu_peak_kernel<MODE>), dim3(blocks), dim3(256), 0, st, sink, iters);
+        HIP_CHECK(hipEventRecord(b, st));
         HIP_CHECK(hipEventSynchronize(b));
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-        const double ops = (double)blocks * 256 * (double)iters * 16 * 4 * 2;
+        const double ops = (double)blocks * 256 * (double)iters * 16 * 4 * (MODE == 0 ? 2 : 1);
         best = std::max(best, ops / (ms * 1e-3));
     }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     return best;
+}
+
+// lane-ops/s of the xor+bcnt pair; if APDS_VALU_PROBE is set also prints the single-instruction rates
+double valu_popcount_peak_device() {
+    ThreadCtx& c = ctx();
+    uint32_t* sink = c.alloc_n<uint32_t>(64);
+    const double pair = run_valu_peak<0>(sink, c.stream);
+    if (getenv("APDS_VALU_PROBE")) {
+        fprintf(stderr, "[apds] VALU lane-ops/s: xor+bcnt %.3e  xor %.3e  bcnt %.3e  add_u32 %.3e\n", pair, run_valu_peak<1>(sink, c.stream),
+                run_valu_peak<2>(sink, c.stream), run_valu_peak<3>(sink, c.stream));
+    }
+    return pair;
 }
 
 }  // namespace apds

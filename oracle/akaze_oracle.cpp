@@ -11,7 +11,7 @@
 //     (build with -ffp-contract=off), evaluation order exactly as written;
 //   * symmetric separable kernels:  acc = k0*c; acc += k1*(lo1+hi1); acc += k2*(lo2+hi2); ...
 //   * antisymmetric [-1,0,1] kernels: hi - lo;
-//   * sin/cos of the keypoint angle: double libm rounded to float.
+//   * sin/cos of the keypoint angle: det_sincos() below (fixed double arithmetic), rounded to float.
 #include "oracle.h"
 
 #include <algorithm>
@@ -383,6 +383,40 @@ float main_orientation(const oracle_keypoint& kpt, const Level& e) {
     return fast_atan2_deg(maxY, maxX);
 }
 
+// Deterministic double sin/cos on [0, 2pi]: Cody-Waite reduction by pi/2 + Taylor series in Horner form.
+// libm's cosf/sinf differ in the last ulp between hosts and GPUs; this fixed arithmetic (|error| < 2e-16,
+// then rounded to float) is the repo's definition of cos(angle)/sin(angle) for the M-LDB sampling grid.
+void det_sincos(double a, double& s, double& c) {
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;
+    const int k = (int)(a * two_over_pi + 0.5);
+    const double r = (a - k * pio2_hi) - k * pio2_lo;
+    const double r2 = r * r;
+    double ps = -7.6471637318198164759e-13;
+    ps = ps * r2 + 1.6059043836821614599e-10;
+    ps = ps * r2 + -2.5052108385441718775e-08;
+    ps = ps * r2 + 2.7557319223985890653e-06;
+    ps = ps * r2 + -1.9841269841269841270e-04;
+    ps = ps * r2 + 8.3333333333333333333e-03;
+    ps = ps * r2 + -1.6666666666666666667e-01;
+    const double sr = r + r * (r2 * ps);
+    double pc = 4.7794773323873852974e-14;
+    pc = pc * r2 + -1.1470745597729724714e-11;
+    pc = pc * r2 + 2.0876756987868098979e-09;
+    pc = pc * r2 + -2.7557319223985890653e-07;
+    pc = pc * r2 + 2.4801587301587301587e-05;
+    pc = pc * r2 + -1.3888888888888888889e-03;
+    pc = pc * r2 + 4.1666666666666666667e-02;
+    pc = pc * r2 + -0.5;
+    const double cr = 1.0 + r2 * pc;
+    switch (k & 3) {
+        case 0: s = sr; c = cr; break;
+        case 1: s = cr; c = -sr; break;
+        case 2: s = -sr; c = -cr; break;
+        default: s = -cr; c = sr; break;
+    }
+}
+
 inline int32_t toggle_flt(float f) {
     int32_t i;
     std::memcpy(&i, &f, 4);
@@ -396,7 +430,9 @@ void mldb_descriptor(const oracle_keypoint& kpt, const Level& e, uint8_t* desc, 
     const float scale = (float)cv_round_f(0.5f * kpt.size / ratio);
     const float xf = kpt.x / ratio, yf = kpt.y / ratio;
     const float angle = kpt.angle * (float)(M_PI / 180.f);
-    const float co = (float)std::cos((double)angle), si = (float)std::sin((double)angle);
+    double sd, cd;
+    det_sincos((double)angle, sd, cd);
+    const float co = (float)cd, si = (float)sd;
     std::memset(desc, 0, desc_size);
     int dpos = 0;
     const int steps[3] = {10, 7, 5};   // ceil(10*{1, 2/3, 1/2})
