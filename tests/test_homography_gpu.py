@@ -1,0 +1,102 @@
+"""GPU: findHomography parity, HIP path (through the C ABI) vs the oracle.
+Bar: inlier masks bit-exact (the 4-point models are bit-identical and scored in f32 with the same operations);
+H within rtol 1e-6 / atol 1e-8 after H[2][2] = 1 (the refit's per-point sums are parallel reductions in f64)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-6, 1e-8
+
+
+def _check(pkg, oracle_mod, src, dst, method, thr, max_iters=2000, conf=0.995):
+    hg = pkg.homographier
+    H = np.zeros(9)
+    mask = np.zeros(len(src), np.uint8)
+    rc = pkg.lib().apds_find_homography_ex(pkg._lib.ptr(src), pkg._lib.ptr(dst), len(src), int(method), float(thr), max_iters, conf,
+                                           pkg._lib.ptr(H), pkg._lib.ptr(mask))
+    found, Ho, mo = oracle_mod.find_homography(src, dst, int(method), thr, max_iters, conf)
+    assert (rc == 0) == found, (rc, found)
+    if found:
+        assert np.array_equal(mask, mo), (mask.sum(), mo.sum())
+        assert np.allclose(H.reshape(3, 3), Ho, rtol=RTOL, atol=ATOL), np.abs(H.reshape(3, 3) - Ho).max()
+    else:
+        assert rc == -1000
+    return found, H.reshape(3, 3), mask
+
+
+def test_reference_kat_homography_success(gpu_pkg):
+    # /root/reference/homographier/src/homographier/mod.rs:437-472
+    hg = gpu_pkg.homographier
+    pts = np.array([(i, j) for i in range(1, 11) for j in range(1, 11)], np.float32)
+    H, mask = hg.find_homography_mat(pts, pts, hg.HomographyMethod.RANSAC, 1.0)
+    for r in range(3):
+        for c in range(3):
+            assert round(float(H.at_2d(r, c))) == (1 if r == c else 0)
+    assert mask is not None and mask.mat.shape == (100, 1) and mask.mat.all()
+    H2, mask2 = hg.find_homography_mat(pts, pts, None, None)       # Default method: no mask (mod.rs:253-257)
+    assert mask2 is None and np.allclose(H2.mat, np.eye(3), atol=1e-9)
+
+
+@pytest.mark.parametrize("n,inl,noise", [(5, 1.0, 0.0), (50, 0.8, 0.3), (2000, 0.4, 0.5), (50000, 0.4, 0.5), (10000, 0.15, 1.0)])
+def test_ransac_equals_oracle(gpu_pkg, oracle_mod, n, inl, noise):
+    src, dst, H_true, flag = gpu_pkg.synth.make_ransac_set(n, seed=0x52410001 + n, inlier_frac=inl, noise=noise)
+    found, H, mask = _check(gpu_pkg, oracle_mod, src, dst, 8, 3.0)
+    assert found
+    if n >= 2000:
+        assert (mask.astype(bool) & flag).sum() >= 0.98 * flag.sum()
+
+
+def test_ransac_4096_iterations_config4(gpu_pkg, oracle_mod):
+    # BASELINE config 4: 50k tentative matches, 4096 hypotheses budget
+    src, dst, H_true, flag = gpu_pkg.synth.make_ransac_set(50000)
+    found, H, mask = _check(gpu_pkg, oracle_mod, src, dst, 8, 3.0, max_iters=4096)
+    assert found and np.allclose(H, H_true, rtol=5e-3, atol=0.5)
+
+
+@pytest.mark.parametrize("thr", [0.5, 1.0, 3.0, 10.0])
+def test_ransac_thresholds(gpu_pkg, oracle_mod, thr):
+    src, dst, _, _ = gpu_pkg.synth.make_ransac_set(3000, seed=77)
+    _check(gpu_pkg, oracle_mod, src, dst, 8, thr)
+
+
+def test_least_squares_and_lmeds(gpu_pkg, oracle_mod):
+    src, dst, H_true, _ = gpu_pkg.synth.make_ransac_set(4000, seed=5, inlier_frac=1.0, noise=0.2)
+    _check(gpu_pkg, oracle_mod, src, dst, 0, 3.0)
+    src, dst, H_true, flag = gpu_pkg.synth.make_ransac_set(4001, seed=6, inlier_frac=0.75, noise=0.3)
+    found, H, mask = _check(gpu_pkg, oracle_mod, src, dst, 4, 3.0)
+    assert found and np.allclose(H, H_true, rtol=5e-3, atol=0.5)
+
+
+def test_all_outliers_and_degenerate(gpu_pkg, oracle_mod):
+    rng = np.random.default_rng(8)
+    src = (rng.random((500, 2)) * 1000).astype(np.float32)
+    dst = (rng.random((500, 2)) * 1000).astype(np.float32)
+    _check(gpu_pkg, oracle_mod, src, dst, 8, 0.5)      # may or may not find a model; must agree with the oracle
+    line = np.stack([np.arange(50, dtype=np.float32), np.arange(50, dtype=np.float32) * 2], 1)
+    _check(gpu_pkg, oracle_mod, line, line, 8, 3.0)    # collinear: getSubset never succeeds -> no model
+    hg = gpu_pkg.homographier
+    with pytest.raises(hg.MatError) as e:
+        hg.find_homography_mat(line, line, hg.HomographyMethod.RANSAC, 3.0)
+    assert e.value.kind == "Empty"
+    with pytest.raises(hg.MatError) as e:              # fewer than 4 points is an OpenCV error
+        hg.find_homography_mat(line[:3], line[:3], hg.HomographyMethod.RANSAC, 3.0)
+    assert e.value.kind == "Opencv"
+    with pytest.raises(hg.MatError):                   # RHO is not implemented: loud failure, not a silent substitute
+        hg.find_homography_mat(src, dst, hg.HomographyMethod.RHO, 3.0)
+
+
+def test_pipeline_extract_match_homography(gpu_pkg, oracle_mod):
+    """The composition the reference only has in its tests (lib.rs:197-249) plus find_homography_mat: a tile and a
+    shifted crop of it must give a translation."""
+    fe, hg = gpu_pkg.feature_extraction, gpu_pkg.homographier
+    big = gpu_pkg.synth.make_tile(640, 640, frame_index=11, channels=1)
+    a, b = big[:512, :512], big[37:37 + 512, 52:52 + 512]
+    ea, eb = fe.akaze_keypoint_descriptor_extraction_def(a, None), fe.akaze_keypoint_descriptor_extraction_def(b, None)
+    m = fe.get_knn_matches(ea.descriptors, eb.descriptors, 2, 0.8)
+    assert np.array_equal(m, oracle_mod.get_knn_matches(ea.descriptors, eb.descriptors, 2, 0.8))
+    assert len(m) >= 20
+    p1, p2 = fe.get_points_from_matches(ea.keypoints, eb.keypoints, m)
+    H, mask = hg.find_homography_mat(p1, p2, hg.HomographyMethod.RANSAC, 3.0)
+    assert mask.mat.sum() >= 0.6 * len(m)
+    assert np.allclose(H.mat, [[1, 0, -52], [0, 1, -37], [0, 0, 1]], atol=0.35)
