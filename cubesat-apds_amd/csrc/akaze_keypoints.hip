@@ -643,6 +643,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     APDS_REQUIRE(stride >= (size_t)cols * channels, APDS_ERR_ASSERT, "row stride smaller than a row");
     if (max_points <= 0) max_points = APDS_MAX_POINTS;
     ThreadCtx& c = ctx();
+    KernelTimer whole("akaze_extract", s);   // whole extraction (all kernels + the two count read-backs), for bench.py
     const int W = cols, H = rows;
     const float soffset = 1.6f, derivative_factor = 1.5f, dthreshold = 0.001f;
 

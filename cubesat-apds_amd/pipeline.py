@@ -1,0 +1,145 @@
+"""Device-resident composition of the hot path and its multi-GPU form.
+
+frame (u8, HBM) -> AKAZE -> descriptors -> Hamming top-2 against a resident descriptor DB -> ratio test ->
+matched points -> RANSAC homography.  The reference only chains these steps inside unit tests
+(/root/reference/feature_extraction/src/lib.rs:197-249) and never calls find_homography_mat on the result; this
+module is the composed pipeline the north-star metric (frames/s) is measured on.
+
+Multi-GPU (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm):
+  * the descriptor DB is row-sharded: rank r holds rows [base_r, base_r + n_r) resident in its HBM;
+  * frames are data-parallel: every rank extracts its own frame;
+  * the only exchange is in the match step: all-gather of the ranks' query descriptors (padded to a fixed row
+    count), local top-k of ALL queries against the local shard, all-gather of the per-shard top-k keys
+    (packed u64 = distance << 32 | global row), then each rank merges the candidates of its own queries.
+    u64 min-merge reproduces the single-GPU result exactly, including the lowest-index tie break.
+torch is used for device buffers, streams and the collectives only; every compute step is a libapds_hip kernel.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+
+EMPTY_KEY = -1  # 0xFFFF_FFFF_FFFF_FFFF as int64
+
+
+def torch_stream():
+    """torch's current HIP stream as the void* the C ABI takes: kernels and collectives then share one stream."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class HipBackend:
+    """Local compute through the C ABI (device pointers of torch tensors, launched on torch's current stream)."""
+
+    def topk(self, q_rows64, train_rows64, index_base, k):
+        nq, nt = q_rows64.shape[0], train_rows64.shape[0]
+        out = torch.empty((nq, k), dtype=torch.int64, device=q_rows64.device)
+        check(lib().apds_dev_hamming_topk(q_rows64.data_ptr(), nq, train_rows64.data_ptr(), nt, int(index_base), k, out.data_ptr(), torch_stream()))
+        return out
+
+    def merge(self, parts, k):
+        """parts: [P, Q, k] int64 -> [Q, k]"""
+        p, q = parts.shape[0], parts.shape[1]
+        out = torch.empty((q, k), dtype=torch.int64, device=parts.device)
+        check(lib().apds_dev_merge_topk(parts.data_ptr(), p, q, k, out.data_ptr(), torch_stream()))
+        return out
+
+
+class ShardedMatcher:
+    """Hamming k-NN of per-rank query sets against a row-sharded resident DB."""
+
+    def __init__(self, local_rows64, index_base, group=None, backend=None, pad_rows=32768):
+        self.rows = local_rows64
+        self.index_base = int(index_base)
+        self.group = group
+        self.backend = backend or HipBackend()
+        self.pad_rows = pad_rows
+        if group is not None:
+            import torch.distributed as dist
+            self.dist = dist
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+        else:
+            self.dist, self.world, self.rank = None, 1, 0
+
+    def knn(self, q_rows64, k=2):
+        """q_rows64: this rank's queries [Q_r, 64] u8. Returns [Q_r, k] int64 keys over the WHOLE DB."""
+        be = self.backend
+        if self.world == 1:
+            return be.topk(q_rows64, self.rows, self.index_base, k)
+        dist, dev = self.dist, q_rows64.device
+        nq = q_rows64.shape[0]
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        dist.all_gather(counts, torch.tensor([nq], dtype=torch.int64, device=dev), group=self.group)
+        counts = [int(c.item()) for c in counts]
+        pad = max(self.pad_rows, max(counts))
+        mine = torch.zeros((pad, 64), dtype=torch.uint8, device=dev)
+        mine[:nq] = q_rows64
+        gathered = torch.empty((self.world, pad, 64), dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=self.group)
+        all_q = torch.cat([gathered[r, :counts[r]] for r in range(self.world)], 0).contiguous()
+        local = be.topk(all_q, self.rows, self.index_base, k)            # [sum Q, k] against the local shard
+        total = all_q.shape[0]
+        parts = torch.empty((self.world, total, k), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(parts.view(-1), local.view(-1), group=self.group)   # per-shard top-k of every query
+        off = sum(counts[:self.rank])
+        own = parts[:, off:off + nq, :].contiguous()
+        return be.merge(own, k)
+
+
+class FramePipeline:
+    """One rank's resident state: frames, DB shard (+ the DB rows' keypoint coordinates), output buffers."""
+
+    def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0"):
+        self.dev = torch.device(device)
+        self.matcher = ShardedMatcher(db_rows64, index_base, group)
+        self.db_xy_all = db_xy                      # [N_total, 2] f32 on device (replicated: 8 B/row)
+        self.cap = max_points
+        self.kps = torch.empty((self.cap, 7), dtype=torch.float32, device=self.dev)       # 28-byte cv::KeyPoint rows
+        self.desc = torch.empty((self.cap, 64), dtype=torch.uint8, device=self.dev)
+        self.matches = torch.empty((self.cap, 4), dtype=torch.int32, device=self.dev)     # 16-byte cv::DMatch rows
+        self.p1 = torch.empty((self.cap, 2), dtype=torch.float32, device=self.dev)
+        self.p2 = torch.empty((self.cap, 2), dtype=torch.float32, device=self.dev)
+        self.mask = torch.empty(self.cap, dtype=torch.uint8, device=self.dev)
+
+    def step(self, frame, filter_strength=0.8, reproj_thr=3.0, max_iters=2000, confidence=0.995):
+        """frame: [H, W, C] u8 device tensor. Returns dict(n_keypoints, n_matches, H (3x3 numpy) or None, n_inliers)."""
+        L = lib()
+        h, w = frame.shape[0], frame.shape[1]
+        ch = 1 if frame.dim() == 2 else frame.shape[2]
+        n = C.c_int(0)
+        check(L.apds_dev_akaze_extract(frame.data_ptr(), h, w, ch, frame.stride(0), self.cap, self.kps.data_ptr(), self.desc.data_ptr(), self.cap,
+                                       C.byref(n), torch_stream()))
+        K = n.value
+        out = dict(n_keypoints=K, n_matches=0, H=None, n_inliers=0)
+        keys = self.matcher.knn(self.desc[:K], 2)
+        if K == 0:
+            return out
+        nm = C.c_int(0)
+        check(L.apds_dev_ratio_filter(keys.data_ptr(), K, 2, float(filter_strength), self.matches.data_ptr(), C.byref(nm), torch_stream()))
+        M = nm.value
+        out["n_matches"] = M
+        if M < 4:
+            return out
+        # query_idx -> this frame's keypoints, train_idx -> DB row coordinates (28-byte rows with x,y first are not needed:
+        # the DB side keeps only xy, so the gather is done on packed float2 rows)
+        check(L.apds_dev_points_from_matches(self.kps.data_ptr(), K, self._db_kp_view().data_ptr(), self.db_xy_all.shape[0], self.matches.data_ptr(), M, 0,
+                                             self.p1.data_ptr(), self.p2.data_ptr(), torch_stream()))
+        H = np.zeros(9, np.float64)
+        rc = L.apds_dev_find_homography(self.p1.data_ptr(), self.p2.data_ptr(), M, 8, float(reproj_thr), int(max_iters), float(confidence),
+                                        _lib.ptr(H), self.mask.data_ptr(), torch_stream())
+        if rc == 0:
+            out["H"] = H.reshape(3, 3)
+            out["n_inliers"] = int(self.mask[:M].sum().item())
+        elif rc != _lib.ERR_EMPTY:
+            check(rc)
+        return out
+
+    def _db_kp_view(self):
+        if not hasattr(self, "_db_kp"):
+            kp = torch.zeros((self.db_xy_all.shape[0], 7), dtype=torch.float32, device=self.dev)
+            kp[:, 0:2] = self.db_xy_all
+            self._db_kp = kp
+        return self._db_kp
