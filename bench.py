@@ -92,6 +92,9 @@ def main():
     kps = torch.empty((cap, 7), dtype=torch.float32, device=dev)
     desc = torch.empty((cap, 64), dtype=torch.uint8, device=dev)
     planted_rows, planted_xy = [], []
+    setup_stream = torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(setup_stream)      # everything below (kernels, torch ops, collectives) is ordered on this stream
     for f in frames_np:
         rolled = torch.from_numpy(np.roll(f, shift, axis=(0, 1)).copy()).to(dev)
         n = C.c_int(0)
@@ -131,6 +134,7 @@ def main():
     db_local = torch.cat(parts).contiguous()
     db_xy = torch.zeros((NDB, 2), dtype=torch.float32, device=dev)
     db_xy[:P] = all_xy[:P]
+    torch.cuda.synchronize()
     pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
 
     def run_step(i):

@@ -26,8 +26,13 @@ EMPTY_KEY = -1  # 0xFFFF_FFFF_FFFF_FFFF as int64
 
 
 def torch_stream():
-    """torch's current HIP stream as the void* the C ABI takes: kernels and collectives then share one stream."""
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """torch's current HIP stream as the void* the C ABI takes, so kernels, torch ops and collectives are ordered on ONE
+    stream. torch's default stream has handle 0, which the C ABI reads as "the calling thread's own stream" (a different,
+    non-blocking stream): callers must therefore work inside `with torch.cuda.stream(torch.cuda.Stream())`."""
+    h = torch.cuda.current_stream().cuda_stream
+    if h == 0:
+        raise RuntimeError("run the pipeline under an explicit torch.cuda.Stream (the default stream's handle is NULL)")
+    return C.c_void_p(h)
 
 
 class HipBackend:
@@ -94,6 +99,7 @@ class FramePipeline:
 
     def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0"):
         self.dev = torch.device(device)
+        self.stream = torch.cuda.Stream(self.dev)
         self.matcher = ShardedMatcher(db_rows64, index_base, group)
         self.db_xy_all = db_xy                      # [N_total, 2] f32 on device (replicated: 8 B/row)
         self.cap = max_points
@@ -106,6 +112,10 @@ class FramePipeline:
 
     def step(self, frame, filter_strength=0.8, reproj_thr=3.0, max_iters=2000, confidence=0.995):
         """frame: [H, W, C] u8 device tensor. Returns dict(n_keypoints, n_matches, H (3x3 numpy) or None, n_inliers)."""
+        with torch.cuda.stream(self.stream):
+            return self._step(frame, filter_strength, reproj_thr, max_iters, confidence)
+
+    def _step(self, frame, filter_strength, reproj_thr, max_iters, confidence):
         L = lib()
         h, w = frame.shape[0], frame.shape[1]
         ch = 1 if frame.dim() == 2 else frame.shape[2]

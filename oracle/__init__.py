@@ -141,7 +141,10 @@ class AkazeResult:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def akaze(img, max_points=(1 << 18) - 1, keep_planes=False):
