@@ -1,0 +1,42 @@
+"""Summarise rocprofv3 output of tools/profile_bench.sh: kernel stats table + HBM traffic of hamming_topk."""
+import csv
+import glob
+import json
+import os
+import sys
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, pattern), recursive=True))
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in find("stats/**/*kernel_stats.csv"):
+    rows = list(csv.DictReader(open(f)))
+    rows.sort(key=lambda r: -float(r.get("TotalDurationNs", 0) or 0))
+    print(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>6s}")
+    for r in rows[:25]:
+        print(f"{r['Name'][:70]:70s} {r['Calls']:>7s} {float(r['TotalDurationNs']) / 1e6:10.3f} {float(r['AverageNs']) / 1e3:10.2f} {r['Percentage']:>6s}")
+
+res = {}
+for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+    tot, n = 0.0, 0
+    for f in find(f"{name}/**/*counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            if "hamming_topk_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                tot += float(r["Counter_Value"])
+                n += 1
+    res[counter] = (tot, n)
+print("== PMC (per-dispatch sums over hamming_topk_kernel) ==")
+print(res)
+if res["FETCH_SIZE"][1]:
+    # rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB; MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes
+    # of a wide coalesced stream -> doubled here; WRITE_SIZE is exact.
+    fetch_b = res["FETCH_SIZE"][0] * 1024 * 2 / res["FETCH_SIZE"][1]
+    write_b = res["WRITE_SIZE"][0] * 1024 / max(res["WRITE_SIZE"][1], 1)
+    t = {"hamming_topk_hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes_per_launch_corrected_x2": fetch_b, "write_bytes_per_launch": write_b,
+         "launches_sampled": res["FETCH_SIZE"][1], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1"}
+    print(json.dumps(t))
+    json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
