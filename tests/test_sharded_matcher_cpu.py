@@ -1,0 +1,76 @@
+"""CPU, world_size 2 (gloo): the multi-GPU match choreography of cubesat-apds_amd/pipeline.py — DB row shards,
+all-gather of queries, per-shard top-k with global indices, all-gather of keys, per-rank merge — gives every rank
+exactly the single-device result for its own queries. The local compute is injected (oracle + numpy) because the HIP
+kernels need a GPU; what is under test is the sharding/collective logic that runs unchanged over RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, nt, nqs, result_dir):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as graft
+    import oracle
+    pkg = graft.load_package()
+    from cubesat_apds_amd import pipeline as pl
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class CpuBackend:   # stands in for HipBackend: same contract, numpy/oracle arithmetic
+        def topk(self, q, train, index_base, k):
+            idx, d = oracle.knn_hamming(q.numpy()[:, :61], train.numpy()[:, :61], k)
+            keys = (d.astype(np.uint64) << np.uint64(32)) | (idx.astype(np.int64) + index_base).astype(np.uint64)
+            keys[idx < 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+            return torch.from_numpy(keys.view(np.int64).copy())
+
+        def merge(self, parts, k):
+            p = parts.numpy().view(np.uint64)                      # [P, Q, k]
+            allk = np.sort(np.concatenate(list(p), axis=1), axis=1)[:, :k]
+            return torch.from_numpy(allk.view(np.int64).copy())
+
+    db = pkg.synth.make_descriptor_db(nt, seed=123)
+    db[nt // 2 + 5] = db[7]                                         # a cross-shard tie: lower global index must win
+    db64 = np.zeros((nt, 64), np.uint8)
+    db64[:, :61] = db
+    lo, hi = rank * nt // world, (rank + 1) * nt // world
+    q, _ = pkg.synth.make_queries(db, nqs[rank], seed=1000 + rank)
+    if rank == 0 and len(q):
+        q[0] = db[7]
+    q64 = np.zeros((len(q), 64), np.uint8)
+    q64[:, :61] = q
+    m = pl.ShardedMatcher(torch.from_numpy(db64[lo:hi].copy()), lo, group=dist.group.WORLD, backend=CpuBackend(), pad_rows=16)
+    keys = m.knn(torch.from_numpy(q64), 2).numpy().view(np.uint64)
+    want_idx, want_d = oracle.knn_hamming(q, db, 2)
+    got_idx = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    got_d = (keys >> np.uint64(32)).astype(np.int64)
+    ok = np.array_equal(got_idx, want_idx) and np.array_equal(got_d, want_d)
+    if rank == 0 and len(q):
+        ok = ok and tuple(got_idx[0]) == (7, nt // 2 + 5) and tuple(got_d[0]) == (0, 0)
+    open(os.path.join(result_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nt,nqs", [(600, (37, 90)), (1001, (0, 5))])
+def test_sharded_match_world2_gloo(tmp_path, nt, nqs):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, nt, nqs, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(tmp_path / f"rank{r}.txt").read() == "ok", r
