@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2, help="distinct frames per rank, cycled")
     ap.add_argument("--filter-strength", type=float, default=0.3, help="Lowe ratio (reference test: 0.3, lib.rs:222)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="one frame at a time (no cross-frame overlap of the three stages)")
     args = ap.parse_args()
 
     import torch
@@ -135,7 +136,10 @@ def main():
     db_xy = torch.zeros((NDB, 2), dtype=torch.float32, device=dev)
     db_xy[:P] = all_xy[:P]
     torch.cuda.synchronize()
-    pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
+    if args.serial:
+        pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
+    else:
+        pipe = pl.StreamedFramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
 
     def run_step(i):
         return pipe.step(frames[i % len(frames)], filter_strength=args.filter_strength)
@@ -146,28 +150,37 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- warmup, then EXACTLY K timed steps between barriers
-    last = None
-    for i in range(args.warmup):
-        last = run_step(i)
-    check(L.apds_dev_timing_enable(1))
-    for name in ("hamming_topk", "akaze_extract", "ransac_score"):
-        pkg._lib.kernel_ms(name)     # drop warmup events
-    fence()
-    t0 = time.perf_counter()
-    stats = []
-    for i in range(args.steps):
-        stats.append(run_step(args.warmup + i))
-    fence()
-    elapsed = time.perf_counter() - t0
-    check(L.apds_dev_timing_enable(0))
+    # ---- warmup, then EXACTLY K timed steps (K frames per rank, fully processed) between barriers
+    if args.serial:
+        for i in range(args.warmup):
+            run_step(i)
+        check(L.apds_dev_timing_enable(1))
+        for name in ("hamming_topk", "akaze_extract", "ransac_score"):
+            pkg._lib.kernel_ms(name)     # drop warmup events
+        fence()
+        t0 = time.perf_counter()
+        stats = []
+        for i in range(args.steps):
+            stats.append(run_step(args.warmup + i))
+        fence()
+        elapsed = time.perf_counter() - t0
+        check(L.apds_dev_timing_enable(0))
+        timers = {n: pkg._lib.kernel_ms(n) for n in ("hamming_topk", "akaze_extract", "ransac_score")}
+    else:
+        if args.warmup:
+            pipe.run(frames, args.warmup, filter_strength=args.filter_strength)
+        fence()
+        t0 = time.perf_counter()
+        stats, timers = pipe.run(frames, args.steps, filter_strength=args.filter_strength, timing=True)
+        fence()
+        elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    topk_ms, topk_n = pkg._lib.kernel_ms("hamming_topk")
-    akaze_ms, akaze_n = pkg._lib.kernel_ms("akaze_extract")
-    score_ms, score_n = pkg._lib.kernel_ms("ransac_score")
+    topk_ms, topk_n = timers.get("hamming_topk", (0.0, 0))
+    akaze_ms, akaze_n = timers.get("akaze_extract", (0.0, 0))
+    score_ms, score_n = timers.get("ransac_score", (0.0, 0))
 
     if rank == 0:
         K = float(np.mean([s["n_keypoints"] for s in stats]))
@@ -197,6 +210,7 @@ def main():
             "dtype": "u8/u32 popcount (match), f32 (AKAZE), f64 (homography solve)", "data": "synthetic",
             "config": {"workload": f"frame{T}x{T}_bgra_detect+describe -> hamming_top2 vs db{NDB} (sharded/{world}) -> ratio{args.filter_strength} -> ransac_homography",
                        "tile": T, "db_rows": NDB, "db_rows_per_gpu": rows_local, "frames_per_step": world, "parallelism": f"frame-dp{world}+db-shard{world}",
+                       "stage_overlap": "none (serial)" if args.serial else "extract | match | homography on 3 streams, software-pipelined over frames",
                        "keypoints_per_frame": K, "matches_per_frame": float(np.mean([s["n_matches"] for s in stats])),
                        "inliers_per_frame": float(np.mean([s["n_inliers"] for s in stats])), "homography_found": all(s["H"] is not None for s in stats)},
             "mmatches_per_s": world * K * args.steps / elapsed / 1e6,

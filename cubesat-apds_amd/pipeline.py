@@ -153,3 +153,136 @@ class FramePipeline:
             kp[:, 0:2] = self.db_xy_all
             self._db_kp = kp
         return self._db_kp
+
+
+class StreamedFramePipeline:
+    """The same path as FramePipeline, software-pipelined over a stream of frames: three host threads, each with its own
+    HIP stream and device workspace (the C ABI is re-entrant per thread): extract | match (+ratio, point gather) | homography.
+    Frame i+1 is extracted (HBM-bound stencils) while frame i is matched (integer-VALU-bound), and frame i-1's RANSAC host
+    round trips hide behind both. Stages hand over through HIP events; results come back in frame order."""
+
+    def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=3):
+        import queue
+        self.queue = queue
+        self.dev = torch.device(device)
+        self.matcher = ShardedMatcher(db_rows64, index_base, group)
+        self.n_db = db_xy.shape[0]
+        kp = torch.zeros((self.n_db, 7), dtype=torch.float32, device=self.dev)
+        kp[:, 0:2] = db_xy
+        self.db_kp = kp
+        self.cap = max_points
+        self.slots = []
+        for _ in range(slots):
+            s = dict(kps=torch.empty((self.cap, 7), dtype=torch.float32, device=self.dev),
+                     desc=torch.empty((self.cap, 64), dtype=torch.uint8, device=self.dev),
+                     matches=torch.empty((self.cap, 4), dtype=torch.int32, device=self.dev),
+                     p1=torch.empty((self.cap, 2), dtype=torch.float32, device=self.dev),
+                     p2=torch.empty((self.cap, 2), dtype=torch.float32, device=self.dev),
+                     mask=torch.empty(self.cap, dtype=torch.uint8, device=self.dev),
+                     ev_extract=torch.cuda.Event(), ev_match=torch.cuda.Event(), K=0, M=0, index=0)
+            self.slots.append(s)
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(3)]
+        torch.cuda.synchronize()
+
+    def run(self, frames, count, filter_strength=0.8, reproj_thr=3.0, max_iters=2000, confidence=0.995, timing=False):
+        """Push `count` frames (cycled from `frames`) through the three stages. Returns (results in frame order, timers)."""
+        import threading
+        L = lib()
+        q_free, q1, q2 = self.queue.Queue(), self.queue.Queue(), self.queue.Queue()
+        for s in self.slots:
+            q_free.put(s)
+        results = [None] * count
+        timers, errors = {}, []
+        dev_index = self.dev.index or 0
+
+        def guarded(fn):
+            def wrap():
+                try:
+                    torch.cuda.set_device(dev_index)
+                    check(L.apds_set_device(dev_index))
+                    check(L.apds_dev_timing_enable(1 if timing else 0))
+                    fn()
+                except BaseException as e:   # surface worker failures instead of dead-locking the queues
+                    errors.append(e)
+                    q1.put(None)
+                    q2.put(None)
+                finally:
+                    try:
+                        L.apds_dev_timing_enable(0)
+                    except Exception:
+                        pass
+            return wrap
+
+        def collect(names):
+            if timing:
+                for n in names:
+                    ms, k = _lib.kernel_ms(n)
+                    timers[n] = (ms, k)
+
+        def extract_worker():
+            with torch.cuda.stream(self.streams[0]):
+                for i in range(count):
+                    s = q_free.get()
+                    f = frames[i % len(frames)]
+                    ch = 1 if f.dim() == 2 else f.shape[2]
+                    n = C.c_int(0)
+                    check(L.apds_dev_akaze_extract(f.data_ptr(), f.shape[0], f.shape[1], ch, f.stride(0), self.cap, s["kps"].data_ptr(),
+                                                   s["desc"].data_ptr(), self.cap, C.byref(n), torch_stream()))
+                    s["K"], s["index"] = n.value, i
+                    s["ev_extract"].record(self.streams[0])
+                    q1.put(s)
+                q1.put(None)
+                collect(["akaze_extract"])
+
+        def match_worker():
+            with torch.cuda.stream(self.streams[1]):
+                while True:
+                    s = q1.get()
+                    if s is None:
+                        break
+                    self.streams[1].wait_event(s["ev_extract"])
+                    K = s["K"]
+                    keys = self.matcher.knn(s["desc"][:K], 2)
+                    M = 0
+                    if K > 0:
+                        nm = C.c_int(0)
+                        check(L.apds_dev_ratio_filter(keys.data_ptr(), K, 2, float(filter_strength), s["matches"].data_ptr(), C.byref(nm), torch_stream()))
+                        M = nm.value
+                        if M >= 4:
+                            check(L.apds_dev_points_from_matches(s["kps"].data_ptr(), K, self.db_kp.data_ptr(), self.n_db, s["matches"].data_ptr(), M, 0,
+                                                                 s["p1"].data_ptr(), s["p2"].data_ptr(), torch_stream()))
+                    s["M"] = M
+                    s["ev_match"].record(self.streams[1])
+                    q2.put(s)
+                q2.put(None)
+                collect(["hamming_topk"])
+
+        def homography_worker():
+            with torch.cuda.stream(self.streams[2]):
+                while True:
+                    s = q2.get()
+                    if s is None:
+                        break
+                    self.streams[2].wait_event(s["ev_match"])
+                    out = dict(n_keypoints=s["K"], n_matches=s["M"], H=None, n_inliers=0)
+                    if s["M"] >= 4:
+                        H = np.zeros(9, np.float64)
+                        rc = L.apds_dev_find_homography(s["p1"].data_ptr(), s["p2"].data_ptr(), s["M"], 8, float(reproj_thr), int(max_iters),
+                                                        float(confidence), _lib.ptr(H), s["mask"].data_ptr(), torch_stream())
+                        if rc == 0:
+                            out["H"] = H.reshape(3, 3)
+                            out["n_inliers"] = int(s["mask"][:s["M"]].sum().item())
+                        elif rc != _lib.ERR_EMPTY:
+                            check(rc)
+                    results[s["index"]] = out
+                    q_free.put(s)
+                collect(["ransac_score"])
+
+        threads = [threading.Thread(target=guarded(f), daemon=True) for f in (extract_worker, match_worker, homography_worker)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return results, timers
