@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--frames", type=int, default=2, help="distinct frames per rank, cycled")
     ap.add_argument("--filter-strength", type=float, default=0.3, help="Lowe ratio (reference test: 0.3, lib.rs:222)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="CUs masked out of the match stream so the other stages overlap it")
     ap.add_argument("--serial", action="store_true", help="one frame at a time (no cross-frame overlap of the three stages)")
     args = ap.parse_args()
 
@@ -69,19 +70,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    backend = os.environ.get("APDS_BENCH_BACKEND", "nccl")      # "gloo" = single-GPU rehearsal of the multi-rank path
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
     group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
         group = dist.group.WORLD
 
     pkg = graft.load_package()
     from cubesat_apds_amd import pipeline as pl
     L = pkg.lib()
     check = pkg._lib.check
-    check(L.apds_set_device(local_rank))
+    check(L.apds_set_device(dev_index))
     synth = pkg.synth
     T, NDB = args.tile, args.db_rows
 
@@ -105,17 +111,17 @@ def main():
         planted_xy.append(kps[:n.value, 0:2].clone())
     mine_rows, mine_xy = torch.cat(planted_rows), torch.cat(planted_xy)
     if world > 1:
-        cnt = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(cnt, torch.tensor([mine_rows.shape[0]], dtype=torch.int64, device=dev))
-        cnt = [int(c.item()) for c in cnt]
+        cnt_t = torch.zeros(world, dtype=torch.int64, device=dev)
+        pl._gather_into(dist, group, cnt_t, torch.tensor([mine_rows.shape[0]], dtype=torch.int64, device=dev))
+        cnt = [int(c) for c in cnt_t.tolist()]
         padn = max(cnt)
         br = torch.zeros((padn, 64), dtype=torch.uint8, device=dev)
         bx = torch.zeros((padn, 2), dtype=torch.float32, device=dev)
         br[:mine_rows.shape[0]], bx[:mine_xy.shape[0]] = mine_rows, mine_xy
         gr = torch.empty((world, padn, 64), dtype=torch.uint8, device=dev)
         gx = torch.empty((world, padn, 2), dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(gr.view(-1), br.view(-1))
-        dist.all_gather_into_tensor(gx.view(-1), bx.view(-1))
+        pl._gather_into(dist, group, gr, br)
+        pl._gather_into(dist, group, gx, bx)
         all_rows = torch.cat([gr[r, :cnt[r]] for r in range(world)])
         all_xy = torch.cat([gx[r, :cnt[r]] for r in range(world)])
     else:
@@ -139,7 +145,7 @@ def main():
     if args.serial:
         pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
     else:
-        pipe = pl.StreamedFramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
+        pipe = pl.StreamedFramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev), reserve_cus=args.reserve_cus)
 
     def run_step(i):
         return pipe.step(frames[i % len(frames)], filter_strength=args.filter_strength)
@@ -175,7 +181,7 @@ def main():
         fence()
         elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     topk_ms, topk_n = timers.get("hamming_topk", (0.0, 0))

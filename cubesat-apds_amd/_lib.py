@@ -23,7 +23,7 @@ SYMBOLS = [
     "apds_get_points_from_matches", "apds_find_homography", "apds_find_homography_ex", "apds_raster_to_mat",
     "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_ratio_filter",
     "apds_dev_cross_check", "apds_dev_akaze_extract", "apds_dev_points_from_matches", "apds_dev_find_homography",
-    "apds_dev_valu_popcount_peak", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane",
+    "apds_dev_valu_popcount_peak", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane", "apds_stream_create", "apds_stream_destroy",
 ]
 
 
@@ -79,6 +79,8 @@ def lib():
             "apds_dev_last_kernel_ms": (i, [C.c_char_p, C.POINTER(f), ip]),
             "apds_dev_timing_enable": (i, [i]),
             "apds_akaze_debug_plane": (i, [vp, i, i, i, sz, i, i, vp]),
+            "apds_stream_create": (i, [i, vp, i, pp]),
+            "apds_stream_destroy": (i, [vp]),
         }
         for name, (rt, at) in sig.items():
             fn = getattr(L, name)

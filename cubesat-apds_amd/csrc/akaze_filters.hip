@@ -24,6 +24,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 
 // ---- a1.1: BGR(A)/gray u8 -> f32 in [0,1] ----------------------------------------------------------
 __global__ void gray_kernel(const uint8_t* __restrict__ img, int rows, int cols, int channels, size_t stride, float* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= cols) return;
@@ -46,6 +47,7 @@ static constexpr int TW = 64, TH = 16;   // output tile, 256 threads
 
 template <int R>
 __global__ __launch_bounds__(256) void gauss_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, GaussTaps taps) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ float s_src[(TH + 2 * R) * (TW + 2 * R)];
     __shared__ float s_tmp[(TH + 2 * R) * TW];
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
@@ -86,6 +88,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void deriv_pair_kernel(const float* __restrict__ src, float* __restrict__ outA, float* __restrict__ outB,
                                                          int w, int h, int s, float kside, float kmid, const float* __restrict__ kptr,
                                                          unsigned int* __restrict__ hmax_bits) {
+    APDS_RAISE_WAVE_PRIORITY();
     extern __shared__ float smem[];
     const int SW = TW + 2 * s, SH = TH + 2 * s;
     float* s_src = smem;                 // SH x SW
@@ -136,16 +139,24 @@ __global__ __launch_bounds__(256) void deriv_pair_kernel(const float* __restrict
         }
     }
     if (MODE == 2) {
-        // non-negative floats order like their bit patterns
+        // non-negative floats order like their bit patterns. One atomic per BLOCK, and only if it can raise the maximum
+        // (a stale read of *hmax_bits is never larger than the truth, so no update is lost).
+        __shared__ unsigned int s_wmax[4];
         unsigned int bits = __float_as_uint(local_max);
         for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned int)__shfl_xor((int)bits, off));
-        if ((threadIdx.x & 63) == 0 && bits) atomicMax(hmax_bits, bits);
+        if ((threadIdx.x & 63) == 0) s_wmax[threadIdx.x >> 6] = bits;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned int b = max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3]));
+            if (b > *reinterpret_cast<volatile unsigned int*>(hmax_bits)) atomicMax(hmax_bits, b);
+        }
     }
 }
 
 // ---- contrast factor: 300-bin histogram of |grad|/hmax over interior pixels, 70th percentile -----------
 __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __restrict__ modg, int w, int h, const unsigned int* __restrict__ hmax_bits,
                                                               int* __restrict__ hist) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ int s_hist[300];
     for (int i = threadIdx.x; i < 300; i += 256) s_hist[i] = 0;
     __syncthreads();
@@ -168,6 +179,7 @@ __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __rest
 // single thread: kcontrast and its per-octave values k, k*0.75, (k*0.75)*0.75, ...
 __global__ void kcontrast_finish_kernel(const int* __restrict__ hist, const unsigned int* __restrict__ hmax_bits, int w, int h,
                                         float* __restrict__ k_oct, int n_oct) {
+    APDS_RAISE_WAVE_PRIORITY();
     if (threadIdx.x || blockIdx.x) return;
     const float hmax = __uint_as_float(*hmax_bits);
     float k = 0.03f;
@@ -193,6 +205,7 @@ __global__ void kcontrast_finish_kernel(const int* __restrict__ hist, const unsi
 // ---- one explicit FED diffusion step: Lnew = Lt + step_size * div(c grad Lt) -----------------------------
 __global__ __launch_bounds__(256) void nld_step_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w,
                                                        int h, float step_size) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ float s_t[(TH + 2) * (TW + 2)];
     __shared__ float s_f[(TH + 2) * (TW + 2)];
     constexpr int SW = TW + 2, SH = TH + 2;
@@ -229,6 +242,7 @@ __global__ __launch_bounds__(256) void nld_step_kernel(const float* __restrict__
 
 // ---- resize(INTER_AREA) by exactly 2: mean of 2x2 ---------------------------------------------------------
 __global__ void half_sample_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= dw || y >= dh) return;
@@ -241,6 +255,7 @@ __global__ void half_sample_kernel(const float* __restrict__ src, int sw, float*
 __global__ void area_resize_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh, const int* __restrict__ xofs,
                                    const float* __restrict__ xw, const int* __restrict__ xcnt, const int* __restrict__ yofs,
                                    const float* __restrict__ yw, const int* __restrict__ ycnt) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= dw || y >= dh) return;
@@ -259,6 +274,7 @@ __global__ void area_resize_kernel(const float* __restrict__ src, int sw, float*
 // ---- Ldet = (Lxx*Lyy - Lxy^2) * sigma_size^4 from Lx, Ly (second application of the dilated pair) -----------
 __global__ __launch_bounds__(256) void hessian_det_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, float* __restrict__ Ldet, int w,
                                                           int h, int s, float kside, float kmid, float sq) {
+    APDS_RAISE_WAVE_PRIORITY();
     extern __shared__ float smem[];
     const int SW = TW + 2 * s, SH = TH + 2 * s;
     float* s_x = smem;                 // SH x SW  (Lx)

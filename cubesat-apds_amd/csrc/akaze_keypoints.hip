@@ -17,22 +17,46 @@ namespace apds {
 __device__ __forceinline__ int clampi2(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
 // ---- a1.6 extrema: 3x3 strict maxima above the threshold, inside the level's border ----------------------
-__global__ void extrema_kernel(const float* __restrict__ Ldet, int w, int h, int border, float thr, uint8_t* __restrict__ mask,
-                               uint32_t* __restrict__ list, int* __restrict__ list_count) {
-    const int x = border + blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = border + blockIdx.y;
-    if (x >= w - border || y >= h - border) return;
-    const float* curr = Ldet + (size_t)y * w;
-    const float* prev = curr - w;
-    const float* next = curr + w;
-    const float v = curr[x];
-    if (v <= thr) return;
-    if (v <= curr[x - 1] || v <= curr[x + 1]) return;
-    if (v <= prev[x - 1] || v <= prev[x] || v <= prev[x + 1]) return;
-    if (v <= next[x - 1] || v <= next[x] || v <= next[x + 1]) return;
-    mask[(size_t)y * w + x] = 1;
-    const int slot = atomicAdd(list_count, 1);   // list order is irrelevant (only used to enumerate candidates)
-    list[slot] = (uint32_t)x | ((uint32_t)y << 16);
+__global__ __launch_bounds__(256) void extrema_kernel(const float* __restrict__ Ldet, int w, int h, int border, float thr, uint8_t* __restrict__ mask,
+                                                      uint32_t* __restrict__ list, int* __restrict__ list_count) {
+    APDS_RAISE_WAVE_PRIORITY();
+    // candidates of the block are collected in LDS and appended with ONE global atomic per block (a per-candidate
+    // atomic on the shared counter serialises: it was 1 ms per frame)
+    __shared__ uint32_t s_cand[256 * 8];   // strict 3x3 maxima are never adjacent: at most 8 per column of 16 rows
+    __shared__ int s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int x = border + blockIdx.x * 256 + threadIdx.x;
+    const int y0 = border + blockIdx.y * 16, y1 = min(y0 + 16, h - border);
+    if (x < w - border) {
+        // the thread's own column for rows y0-1 .. y1: 18 independent loads in flight, then the (rare) row neighbours
+        float col[18];
+#pragma unroll
+        for (int r = 0; r < 18; r++) {
+            const int y = min(y0 - 1 + r, h - 1);
+            col[r] = Ldet[(size_t)y * w + x];
+        }
+#pragma unroll
+        for (int r = 1; r <= 16; r++) {
+            const int y = y0 - 1 + r;
+            const float v = col[r];
+            if (y >= y1 || v <= thr || v <= col[r - 1] || v <= col[r + 1]) continue;
+            const float* curr = Ldet + (size_t)y * w;
+            const float* prev = curr - w;
+            const float* next = curr + w;
+            if (v <= curr[x - 1] || v <= curr[x + 1]) continue;
+            if (v <= prev[x - 1] || v <= prev[x + 1]) continue;
+            if (v <= next[x - 1] || v <= next[x + 1]) continue;
+            mask[(size_t)y * w + x] = 1;
+            s_cand[atomicAdd(&s_n, 1)] = (uint32_t)x | ((uint32_t)y << 16);
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(list_count, n);   // list order is irrelevant (only used to enumerate candidates)
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) list[s_base + i] = s_cand[i];
 }
 
 // ---- cross-level suppression -------------------------------------------------------------------------------
@@ -51,6 +75,7 @@ struct SuppressArgs {
 };
 
 __global__ void suppress_init_status_kernel(SuppressArgs A) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int lvl = blockIdx.y;
     const int cnt = A.list_count[lvl];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
@@ -61,6 +86,7 @@ __global__ void suppress_init_status_kernel(SuppressArgs A) {
 }
 
 __global__ void suppress_canon_kernel(SuppressArgs A) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int lvl = blockIdx.y;
     const int cnt = A.list_count[lvl];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
@@ -89,6 +115,7 @@ __device__ __forceinline__ bool find_neighbor(const uint8_t* __restrict__ mask, 
 }
 
 __global__ void suppress_round_kernel(SuppressArgs A, uint8_t stamp, int* __restrict__ pending_out) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int lvl = blockIdx.y;
     const int other = A.phase == 0 ? lvl - 1 : lvl + 1;
     if (other < 0 || other >= A.n_levels) return;
@@ -168,6 +195,7 @@ __device__ __forceinline__ Refined refine(const float* __restrict__ ldet, int co
 
 // drop candidates whose refinement is unstable, so the concatenated masks become the final keypoint flags
 __global__ void subpixel_filter_kernel(LevelTable T, const uint32_t* const* __restrict__ lists, const int* __restrict__ list_count) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int lvl = blockIdx.y;
     const int cnt = list_count[lvl];
     const uint32_t* list = lists[lvl];
@@ -186,6 +214,7 @@ static constexpr int SCAN_BLOCK = 1024;
 __global__ __launch_bounds__(SCAN_BLOCK) void emit_keypoints_kernel(LevelTable T, const uint8_t* __restrict__ flags, long long total,
                                                                     const int* __restrict__ block_offsets, apds_keypoint* __restrict__ kps,
                                                                     int capacity) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ int wsum[SCAN_BLOCK / 64];
     const long long e = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const int f = e < total ? (flags[e] != 0) : 0;
@@ -216,6 +245,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void emit_keypoints_kernel(LevelTable T
 
 // ---- max_points: keep the `keep` strongest (response desc, ties by detection order), in that order -------------
 __global__ __launch_bounds__(256) void rank_select_kernel(const apds_keypoint* __restrict__ in, int n, int keep, apds_keypoint* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ float s_resp[256];
     const int i = blockIdx.x * 256 + threadIdx.x;
     const float mine = i < n ? in[i].response : 0.f;
@@ -283,6 +313,7 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
 }
 
 __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_keypoint* __restrict__ kps, int n, float ang_step, int nkeys) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ float s_x[4][112], s_y[4][112];
     __shared__ uint8_t s_bin[4][112], s_sorted[4][112];
     __shared__ int s_start[4][44];
@@ -420,7 +451,12 @@ constexpr MldbLut make_mldb_lut() {
 }
 __constant__ MldbLut c_mldb = make_mldb_lut();
 
+// One wave per keypoint. Per grid (2x2, 3x3, 4x4 cells of 10^2, 7^2, 5^2 samples): all 64 lanes gather the samples
+// (Lt, rotated Lx/Ly) into LDS, then one lane per cell adds its samples in the reference's order (k-major, l-minor;
+// float sums are order dependent), and the 486 comparisons are done 32 per lane.
 __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, int n, uint32_t* __restrict__ desc64) {
+    APDS_RAISE_WAVE_PRIORITY();
+    __shared__ float4 s_samp[4][448];   // (ri, rrx, rry, valid) of one grid: at most 9 * 49 = 441 samples
     __shared__ int s_val[4][88];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ki = blockIdx.x * 4 + wv;
@@ -438,44 +474,58 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
     double sd, cd;
     det_sincos((double)angle, sd, cd);
     const float co = (float)cd, si = (float)sd;
-    if (lane < 29) {
-        // lane -> (grid, cell)
-        int g, cell, side, step, base;
-        if (lane < 4) g = 0, cell = lane, side = 2, step = 10, base = 0;
-        else if (lane < 13) g = 1, cell = lane - 4, side = 3, step = 7, base = 12;
-        else g = 2, cell = lane - 13, side = 4, step = 5, base = 39;
-        (void)g;
-        const int i0 = -10 + (cell / side) * step, j0 = -10 + (cell % side) * step;
-        float di = 0.0f, dx = 0.0f, dy = 0.0f;
-        int nsamples = 0;
-        for (int k = i0; k < i0 + step; k++)
-            for (int l = j0; l < j0 + step; l++) {
-                const float sample_y = yf + (l * co * scale + k * si * scale);
-                const float sample_x = xf + (-l * si * scale + k * co * scale);
-                const int y1 = __float2int_rn(sample_y), x1 = __float2int_rn(sample_x);
-                if (y1 < 0 || y1 >= h || x1 < 0 || x1 >= w) continue;
+    int base = 0;
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+        const int side = g + 2;
+        const int step = g == 0 ? 10 : (g == 1 ? 7 : 5);
+        const int per_cell = step * step, ncells = side * side, nsamp = ncells * per_cell;
+        for (int sidx = lane; sidx < nsamp; sidx += 64) {
+            const int cell = sidx / per_cell, within = sidx - cell * per_cell;
+            const int k = -10 + (cell / side) * step + within / step;
+            const int l = -10 + (cell % side) * step + within % step;
+            const float sample_y = yf + (l * co * scale + k * si * scale);
+            const float sample_x = xf + (-l * si * scale + k * co * scale);
+            const int y1 = __float2int_rn(sample_y), x1 = __float2int_rn(sample_x);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!(y1 < 0 || y1 >= h || x1 < 0 || x1 >= w)) {
                 const size_t o = (size_t)y1 * w + x1;
-                const float ri = Lt[o];
-                di += ri;
                 const float rx = Lx[o], ry = Ly[o];
-                const float rry = rx * co + ry * si;
-                const float rrx = -rx * si + ry * co;
-                dx += rrx;
-                dy += rry;
-                nsamples++;
+                v.x = Lt[o];
+                v.y = -rx * si + ry * co;   // rrx
+                v.z = rx * co + ry * si;    // rry
+                v.w = 1.0f;
             }
-        if (nsamples > 0) {
-            const float inv = 1.0f / nsamples;
-            di *= inv;
-            dx *= inv;
-            dy *= inv;
+            s_samp[wv][sidx] = v;
         }
-        const int v0 = __float_as_int(di), v1 = __float_as_int(dx), v2 = __float_as_int(dy);
-        s_val[wv][base + 3 * cell + 0] = v0 ^ (v0 < 0 ? 0x7fffffff : 0);   // CV_TOGGLE_FLT: int order == float order
-        s_val[wv][base + 3 * cell + 1] = v1 ^ (v1 < 0 ? 0x7fffffff : 0);
-        s_val[wv][base + 3 * cell + 2] = v2 ^ (v2 < 0 ? 0x7fffffff : 0);
+        __syncthreads();
+        if (lane < ncells) {
+            float di = 0.0f, dx = 0.0f, dy = 0.0f;
+            int nsamples = 0;
+            const float4* p = &s_samp[wv][lane * per_cell];
+            for (int i = 0; i < per_cell; i++) {
+                const float4 v = p[i];
+                if (v.w != 0.0f) {
+                    di += v.x;
+                    dx += v.y;
+                    dy += v.z;
+                    nsamples++;
+                }
+            }
+            if (nsamples > 0) {
+                const float inv = 1.0f / nsamples;
+                di *= inv;
+                dx *= inv;
+                dy *= inv;
+            }
+            const int v0 = __float_as_int(di), v1 = __float_as_int(dx), v2 = __float_as_int(dy);
+            s_val[wv][base + 3 * lane + 0] = v0 ^ (v0 < 0 ? 0x7fffffff : 0);   // CV_TOGGLE_FLT: int order == float order
+            s_val[wv][base + 3 * lane + 1] = v1 ^ (v1 < 0 ? 0x7fffffff : 0);
+            s_val[wv][base + 3 * lane + 2] = v2 ^ (v2 < 0 ? 0x7fffffff : 0);
+        }
+        __syncthreads();
+        base += 3 * ncells;
     }
-    __syncthreads();
     if (live && lane < 16) {
         uint32_t word = 0;
 #pragma unroll 4
@@ -490,7 +540,7 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
 // ---- host side ---------------------------------------------------------------------------------------------------
 static void launch_extrema_level(const float* Ldet, int w, int h, int border, float thr, uint8_t* mask, uint32_t* list, int* list_count, hipStream_t s) {
     if (border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0) return;
-    hipLaunchKernelGGL(extrema_kernel, dim3(ceil_div(w - 2 * border, 256), h - 2 * border), dim3(256), 0, s, Ldet, w, h, border, thr, mask, list, list_count);
+    hipLaunchKernelGGL(extrema_kernel, dim3(ceil_div(w - 2 * border, 256), ceil_div(h - 2 * border, 16)), dim3(256), 0, s, Ldet, w, h, border, thr, mask, list, list_count);
 }
 
 namespace {
@@ -578,6 +628,7 @@ T* upload(const std::vector<T>& v, hipStream_t s) {
 
 // kernels from match_hamming.hip's compaction utility, re-declared for the 64-bit flag space used here
 __global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8_t* __restrict__ flags, long long n, int* __restrict__ block_counts) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ int wsum[SCAN_BLOCK / 64];
     const long long i = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const int f = i < n ? (flags[i] != 0) : 0;
@@ -592,6 +643,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8
 }
 
 __global__ __launch_bounds__(1024) void kp_scan_offsets_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ total) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ int buf[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -617,6 +669,7 @@ __global__ __launch_bounds__(1024) void kp_scan_offsets_kernel(int* __restrict__
 }
 
 __global__ void pack_desc61_kernel(const uint8_t* __restrict__ d64, int n, uint8_t* __restrict__ d61) {
+    APDS_RAISE_WAVE_PRIORITY();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)n * 61) return;
     const long long r = i / 61;

@@ -11,6 +11,12 @@
 
 #include "../../include/apds.h"
 
+// The Hamming match grid keeps every SIMD's VALU issue slots booked for ~30 ms per frame and the hardware arbitrates
+// issue by priority, then age, so co-resident waves of the short, memory-bound kernels of the other stages (running
+// on other streams) would starve. They raise their own wave priority; they need few issue slots, so the match loses
+// almost nothing and the stages overlap.
+#define APDS_RAISE_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
+
 namespace apds {
 
 struct Error {

@@ -42,12 +42,24 @@ __host__ __device__ inline double hypot_cv(double a, double b) {
     return 0;
 }
 
+// Array accessors: the same algorithm text runs on host arrays and on per-thread arrays kept in LDS
+// (element-major, thread-minor: consecutive lanes hit consecutive banks, no scratch memory round trips).
+template <class T>
+struct PlainArr {
+    T* p;
+    __host__ __device__ T& operator[](int i) const { return p[i]; }
+};
+template <class T, int STRIDE>
+struct StridedArr {
+    T* p;
+    __host__ __device__ T& operator[](int i) const { return p[i * STRIDE]; }
+};
+
 // Symmetric eigen decomposition, pivoted Jacobi rotations (cv::eigen's JacobiImpl_ restated). A: N x N, upper
-// triangle used and destroyed. W: eigenvalues descending. V rows: eigenvectors.
-template <int N>
-__host__ __device__ inline void jacobi_eigen(double* A, double* W, double* V) {
+// triangle used and destroyed. W: eigenvalues descending. V rows: eigenvectors. indR/indC: N ints of scratch each.
+template <int N, class MA, class MW, class MV, class MI>
+__host__ __device__ inline void jacobi_eigen(MA A, MW W, MV V, MI indR, MI indC) {
     const double eps = 2.2204460492503131e-16;
-    int indR[N], indC[N];
     for (int i = 0; i < N; i++) {
         for (int j = 0; j < N; j++) V[i * N + j] = 0;
         V[i * N + i] = 1;
@@ -145,11 +157,12 @@ __host__ __device__ inline void jacobi_eigen(double* A, double* W, double* V) {
 }
 
 // smallest eigenvector of LtL -> denormalised H with H[8] == 1
-__host__ __device__ inline void homography_from_ltl(double* LtL /*81, full symmetric*/, const double* norm /*cmx,cmy,cMx,cMy,smx,smy,sMx,sMy*/,
-                                                    double* Hout) {
-    double W[9], V[81];
-    jacobi_eigen<9>(LtL, W, V);
-    const double* H0 = &V[72];
+template <class MA, class MW, class MV, class MI>
+__host__ __device__ inline void homography_from_ltl(MA LtL /*81, full symmetric*/, MW W, MV V, MI indR, MI indC,
+                                                    const double* norm /*cmx,cmy,cMx,cMy,smx,smy,sMx,sMy*/, double* Hout) {
+    jacobi_eigen<9>(LtL, W, V, indR, indC);
+    double H0[9];
+    for (int i = 0; i < 9; i++) H0[i] = V[72 + i];
     const double invHnorm[9] = {1. / norm[4], 0, norm[0], 0, 1. / norm[5], norm[1], 0, 0, 1};
     const double Hnorm2[9] = {norm[6], 0, -norm[2] * norm[6], 0, norm[7], -norm[3] * norm[7], 0, 0, 1};
     double Ht[9], H[9];
@@ -170,7 +183,8 @@ __host__ __device__ inline void homography_from_ltl(double* LtL /*81, full symme
 }
 
 // HomographyEstimatorCallback::runKernel for a small point set held by one thread
-__host__ __device__ inline int run_kernel_small(const P2* M, const P2* m, int count, double* Hout) {
+template <class MA, class MW, class MV, class MI>
+__host__ __device__ inline int run_kernel_small(const P2* M, const P2* m, int count, MA LtL, MW W, MV V, MI indR, MI indC, double* Hout) {
     double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
     for (int i = 0; i < count; i++) {
         cmx += m[i].x; cmy += m[i].y;
@@ -185,39 +199,52 @@ __host__ __device__ inline int run_kernel_small(const P2* M, const P2* m, int co
     if (fabs(smx) < eps || fabs(smy) < eps || fabs(sMx) < eps || fabs(sMy) < eps) return 0;
     smx = count / smx; smy = count / smy;
     sMx = count / sMx; sMy = count / sMy;
-    double LtL[81];
     for (int i = 0; i < 81; i++) LtL[i] = 0;
     for (int i = 0; i < count; i++) {
         const double x = (m[i].x - cmx) * smx, y = (m[i].y - cmy) * smy;
         const double X = (M[i].x - cMx) * sMx, Y = (M[i].y - cMy) * sMy;
         const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
         const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+#pragma unroll
         for (int j = 0; j < 9; j++)
+#pragma unroll
             for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
     }
     for (int j = 0; j < 9; j++)
         for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
     const double norm[8] = {cmx, cmy, cMx, cMy, smx, smy, sMx, sMy};
-    homography_from_ltl(LtL, norm, Hout);
+    homography_from_ltl(LtL, W, V, indR, indC, norm, Hout);
     return 1;
 }
 
 // ---- device kernels ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void hypothesis_kernel(const P2* __restrict__ M, const P2* __restrict__ m, const int* __restrict__ idx4, int B,
-                                                        double* __restrict__ models, uint8_t* __restrict__ valid) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+// One thread per 4-point sample. The 9x9 normal equations, eigenvectors, eigenvalues and pivot indices of every thread
+// live in LDS (171 doubles + 18 ints per thread, element-major): the pivoted Jacobi indexes them dynamically, which
+// would otherwise go through scratch (global) memory at ~1 us per dependent access.
+static constexpr int HYP_THREADS = 32;   // 46 KB of LDS per block (under the 64 KB dynamic-LDS default)
+__global__ __launch_bounds__(HYP_THREADS) void hypothesis_kernel(const P2* __restrict__ M, const P2* __restrict__ m, const int* __restrict__ idx4, int B,
+                                                                 double* __restrict__ models, uint8_t* __restrict__ valid) {
+    APDS_RAISE_WAVE_PRIORITY();
+    extern __shared__ double hyp_lds[];
+    double* base = hyp_lds + threadIdx.x;
+    StridedArr<double, HYP_THREADS> A{base}, V{base + 81 * HYP_THREADS}, W{base + 162 * HYP_THREADS};
+    int* ibase = reinterpret_cast<int*>(hyp_lds + 171 * HYP_THREADS) + threadIdx.x;
+    StridedArr<int, HYP_THREADS> indR{ibase}, indC{ibase + 9 * HYP_THREADS};
+    const int h = blockIdx.x * HYP_THREADS + threadIdx.x;
     if (h >= B) return;
     P2 ms1[4], ms2[4];
+#pragma unroll
     for (int j = 0; j < 4; j++) {
         const int id = idx4[h * 4 + j];
         ms1[j] = M[id];
         ms2[j] = m[id];
     }
     double H[9];
-    const int ok = run_kernel_small(ms1, ms2, 4, H);
+    const int ok = run_kernel_small(ms1, ms2, 4, A, W, V, indR, indC, H);
     valid[h] = (uint8_t)ok;
     for (int i = 0; i < 9; i++) models[(size_t)h * 9 + i] = ok ? H[i] : 0.0;
 }
+static constexpr size_t HYP_LDS_BYTES = (size_t)171 * HYP_THREADS * sizeof(double) + (size_t)18 * HYP_THREADS * sizeof(int);
 
 __device__ __forceinline__ float reproj_err(const float (&Hf)[8], float Mx, float My, float mx, float my) {
     const float ww = 1.f / (Hf[6] * Mx + Hf[7] * My + 1.f);
@@ -231,6 +258,7 @@ static constexpr int HT = 8;   // hypotheses per block of the scoring kernel
 // grid: x = ceil(B / HT), y = point parts. good[h] += #points with err <= t
 __global__ __launch_bounds__(256) void score_kernel(const P2* __restrict__ M, const P2* __restrict__ m, int n, const double* __restrict__ models, int B,
                                                     float t, int* __restrict__ good) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int h0 = blockIdx.x * HT;
     float Hf[HT][8];
 #pragma unroll
@@ -263,6 +291,7 @@ __global__ __launch_bounds__(256) void score_kernel(const P2* __restrict__ M, co
 
 __global__ void inlier_mask_kernel(const P2* __restrict__ M, const P2* __restrict__ m, int n, const double* __restrict__ model, float t,
                                    uint8_t* __restrict__ mask) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float Hf[8];
@@ -273,6 +302,7 @@ __global__ void inlier_mask_kernel(const P2* __restrict__ M, const P2* __restric
 
 // all errors of one hypothesis (LMEDS): err[h*n + i]
 __global__ void errors_kernel(const P2* __restrict__ M, const P2* __restrict__ m, int n, const double* __restrict__ models, float* __restrict__ err) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int h = blockIdx.y;
     float Hf[8];
 #pragma unroll
@@ -283,6 +313,7 @@ __global__ void errors_kernel(const P2* __restrict__ M, const P2* __restrict__ m
 
 // exact k-th smallest of n non-negative floats per hypothesis (radix select on the bit pattern, 3 passes of 11/11/10 bits)
 __global__ __launch_bounds__(1024) void kth_select_kernel(const float* __restrict__ err, int n, int kth, float* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ unsigned int hist[2048];
     __shared__ unsigned int s_prefix, s_k;
     const unsigned int* e = reinterpret_cast<const unsigned int*>(err + (size_t)blockIdx.x * n);
@@ -360,6 +391,7 @@ __device__ __forceinline__ void block_reduce_max_store(double v, double* __restr
 
 __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const P2* __restrict__ M, const P2* __restrict__ m, const uint8_t* __restrict__ mask, int n,
                                                              RedParams P, double* __restrict__ partials) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int stride = gridDim.x * RED_THREADS;
     const int first = blockIdx.x * RED_THREADS + threadIdx.x;
     if (P.kind == 0) {
@@ -522,8 +554,9 @@ void run_reduce(const P2* M, const P2* m, const uint8_t* mask, int n, const RedP
 // x = sum_i (v_i . b / w_i) v_i over eigenpairs with |w_i| > 2 eps sum(w)  (cv::solve / cv::invert, DECOMP_EIG)
 void eig_solve8(const double* Asym, const double* b, int nb, double* x) {
     double A[64], W[8], V[64];
+    int indR[8], indC[8];
     std::memcpy(A, Asym, sizeof(A));
-    jacobi_eigen<8>(A, W, V);
+    jacobi_eigen<8>(PlainArr<double>{A}, PlainArr<double>{W}, PlainArr<double>{V}, PlainArr<int>{indR}, PlainArr<int>{indC});
     double threshold = 0;
     for (int i = 0; i < 8; i++) threshold += W[i];
     threshold *= DBL_EPSILON * 2;
@@ -571,7 +604,9 @@ struct Refit {
         for (int j = 0; j < 9; j++)
             for (int k = j; k < 9; k++) LtL[j * 9 + k] = LtL[k * 9 + j] = r[q++];
         const double norm[8] = {cmx, cmy, cMx, cMy, smx, smy, sMx, sMy};
-        homography_from_ltl(LtL, norm, H);
+        double W9[9], V81[81];
+        int indR[9], indC[9];
+        homography_from_ltl(PlainArr<double>{LtL}, PlainArr<double>{W9}, PlainArr<double>{V81}, PlainArr<int>{indR}, PlainArr<int>{indC}, norm, H);
         return 1;
     }
 
@@ -713,7 +748,7 @@ int find_homography_device(const float* src, const float* dst, int n, int method
                 if (B > 0) {
                     HIP_CHECK(hipMemcpyAsync(idx_dev, idx.data(), (size_t)B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
                     HIP_CHECK(hipMemsetAsync(good_dev, 0, (size_t)B * sizeof(int), s));
-                    hipLaunchKernelGGL(hypothesis_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, M, m, (const int*)idx_dev, B, models_dev, valid_dev);
+                    hipLaunchKernelGGL(hypothesis_kernel, dim3(ceil_div(B, HYP_THREADS)), dim3(HYP_THREADS), HYP_LDS_BYTES, s, M, m, (const int*)idx_dev, B, models_dev, valid_dev);
                     {
                         KernelTimer timer("ransac_score", s);
                         const int parts = std::max(1, std::min(64, ceil_div(256 * 8, ceil_div(B, HT))));
@@ -757,7 +792,7 @@ int find_homography_device(const float* src, const float* dst, int n, int method
                 float* err_dev = c.alloc_n<float>((size_t)B * n);
                 float* med_dev = c.alloc_n<float>(B);
                 HIP_CHECK(hipMemcpyAsync(idx_dev, idx.data(), (size_t)B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(hypothesis_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, M, m, (const int*)idx_dev, B, models_dev, valid_dev);
+                hipLaunchKernelGGL(hypothesis_kernel, dim3(ceil_div(B, HYP_THREADS)), dim3(HYP_THREADS), HYP_LDS_BYTES, s, M, m, (const int*)idx_dev, B, models_dev, valid_dev);
                 hipLaunchKernelGGL(errors_kernel, dim3(std::min(64, ceil_div(n, 256)), B), dim3(256), 0, s, M, m, n, (const double*)models_dev, err_dev);
                 hipLaunchKernelGGL(kth_select_kernel, dim3(B), dim3(1024), 0, s, (const float*)err_dev, n, n / 2, med_dev);
                 std::vector<float> med(B);

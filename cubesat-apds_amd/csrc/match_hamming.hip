@@ -70,20 +70,17 @@ __device__ __forceinline__ void insert_hits(const int (&acc)[T], const int (&nth
     }
 }
 
-// grid: x = ceil(nq / (256*T)), y = chunks. block = 256 threads = 4 waves, each wave its own 64*T queries.
+// One work item = (64*T queries per wave, 4 waves) x (one chunk of train rows).
 template <int T, int K>
-__global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restrict__ train, int n_train,
-                                                           const u32x4* __restrict__ queries, int nq, int rows_per_chunk,
-                                                           const int* __restrict__ init_thr, uint64_t* __restrict__ out,
-                                                           uint32_t index_base) {
+__device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ train, int n_train, const u32x4* __restrict__ queries, int nq,
+                                                  int rows_per_chunk, const int* __restrict__ init_thr, uint64_t* __restrict__ out,
+                                                  uint32_t index_base, int chunk, int qblock) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int qbase = (blockIdx.x * 4 + wave) * (64 * T);
+    const int qbase = (qblock * 4 + wave) * (64 * T);
     if (qbase >= nq) return;   // wave-uniform
-    const int chunk = blockIdx.y;
     const int row0 = chunk * rows_per_chunk;
     const int row1 = min(n_train, row0 + rows_per_chunk);
-
     uint32_t q[T][16];
     int bd[T][K];
     uint32_t bi[T][K];
@@ -171,30 +168,87 @@ __global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restr
     }
 }
 
+// grid: 1-D, 8 * ceil(chunks/8) * ceil(nq / (256*T)) blocks. block = 256 threads = 4 waves, each wave its own 64*T queries.
+template <int T, int K>
+__global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restrict__ train, int n_train,
+                                                           const u32x4* __restrict__ queries, int nq, int rows_per_chunk,
+                                                           const int* __restrict__ init_thr, uint64_t* __restrict__ out,
+                                                           uint32_t index_base, int qtile_blocks, int n_chunks, int xcd_aware) {
+    // 1-D grid; optionally XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so all query tiles of one row
+    // chunk can be given the same (id % 8): the chunk is then streamed into ONE XCD's L2 instead of all eight
+    // (12x less fabric traffic, but 2.4 % slower: same-chunk waves contend for the same L2 lines; default off).
+    const int nqb = qtile_blocks;
+    int chunk, qblock;
+    if (xcd_aware) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        chunk = (slot / nqb) * 8 + xcd;
+        qblock = slot - (slot / nqb) * nqb;
+    } else {
+        chunk = blockIdx.x / nqb;
+        qblock = blockIdx.x - chunk * nqb;
+    }
+    if (chunk >= n_chunks) return;   // block-uniform
+    hamming_topk_item<T, K>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, index_base, chunk, qblock);
+}
+
+// Persistent form: a fixed number of resident workgroups pull (chunk, query tile) items from an atomic counter.
+// Every wave leaves the loop when the counter passes the item count, so the grid always drains.
+template <int T, int K>
+__global__ __launch_bounds__(256) void hamming_topk_persistent_kernel(const u32x16* __restrict__ train, int n_train,
+                                                                      const u32x4* __restrict__ queries, int nq, int rows_per_chunk,
+                                                                      const int* __restrict__ init_thr, uint64_t* __restrict__ out,
+                                                                      uint32_t index_base, int qtile_blocks, int n_chunks,
+                                                                      int* __restrict__ next_item) {
+    __shared__ int s_item;
+    const int total = qtile_blocks * n_chunks;
+    for (;;) {
+        if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1);
+        __syncthreads();
+        const int item = s_item;
+        __syncthreads();
+        if (item >= total) break;
+        const int chunk = item / qtile_blocks, qblock = item - chunk * qtile_blocks;
+        hamming_topk_item<T, K>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, index_base, chunk, qblock);
+    }
+}
+
 // merge `parts` sorted candidate lists per query into the k smallest keys
 template <int K>
 __global__ void merge_topk_kernel(const uint64_t* __restrict__ parts_keys, int parts, int nq, uint64_t* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
     uint64_t b0 = EMPTY_KEY, b1 = EMPTY_KEY;
-    for (int p = 0; p < parts; p++) {
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            const uint64_t key = parts_keys[((size_t)p * nq + qi) * K + k];
-            if (key < b0) {
-                b1 = b0;
-                b0 = key;
-            } else if (key < b1) {
-                b1 = key;
-            }
+    auto push = [&](uint64_t key) {
+        if (key < b0) {
+            b1 = b0;
+            b0 = key;
+        } else if (key < b1) {
+            b1 = key;
         }
+    };
+    int p = 0;
+    for (; p + 8 <= parts; p += 8) {   // 8 independent loads in flight per lane
+        uint64_t v[8][K];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int k = 0; k < K; k++) v[u][k] = parts_keys[((size_t)(p + u) * nq + qi) * K + k];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+#pragma unroll
+            for (int k = 0; k < K; k++) push(v[u][k]);
     }
+    for (; p < parts; p++)
+#pragma unroll
+        for (int k = 0; k < K; k++) push(parts_keys[((size_t)p * nq + qi) * K + k]);
     out[(size_t)qi * K] = b0;
     if (K == 2) out[(size_t)qi * K + 1] = b1;
 }
 
 // second-best distance of a sample of train rows -> initial thresholds for the full scan
 __global__ void thr_from_keys_kernel(const uint64_t* __restrict__ keys, int nq, int K, int* __restrict__ thr) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
     const uint64_t key = keys[(size_t)qi * K + (K - 1)];
@@ -203,6 +257,7 @@ __global__ void thr_from_keys_kernel(const uint64_t* __restrict__ keys, int nq, 
 
 __global__ void pack_rows_kernel(const uint8_t* __restrict__ src, long long n, int desc_bytes, long long src_stride,
                                  uint32_t* __restrict__ dst) {
+    APDS_RAISE_WAVE_PRIORITY();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one dword of one row
     if (i >= n * 16) return;
     const long long row = i >> 4;
@@ -216,6 +271,7 @@ __global__ void pack_rows_kernel(const uint8_t* __restrict__ src, long long n, i
 }
 
 __global__ void ratio_flag_kernel(const uint64_t* __restrict__ keys, int nq, int K, float fs, uint8_t* __restrict__ flags) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
     const uint64_t k0 = keys[(size_t)qi * K], k1 = keys[(size_t)qi * K + 1];
@@ -224,6 +280,7 @@ __global__ void ratio_flag_kernel(const uint64_t* __restrict__ keys, int nq, int
 }
 
 __global__ void crosscheck_scatter_kernel(const uint64_t* __restrict__ train_best, long long n_train, unsigned long long* __restrict__ best_per_query) {
+    APDS_RAISE_WAVE_PRIORITY();
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_train) return;
     const uint64_t key = train_best[i];
@@ -234,6 +291,7 @@ __global__ void crosscheck_scatter_kernel(const uint64_t* __restrict__ train_bes
 }
 
 __global__ void nonempty_flag_kernel(const uint64_t* __restrict__ keys, int n, uint8_t* __restrict__ flags) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = keys[i] != EMPTY_KEY;
 }
@@ -242,6 +300,7 @@ __global__ void nonempty_flag_kernel(const uint64_t* __restrict__ keys, int n, u
 static constexpr int SCAN_BLOCK = 1024;
 
 __global__ __launch_bounds__(SCAN_BLOCK) void scan_block_counts_kernel(const uint8_t* __restrict__ flags, int n, int* __restrict__ block_counts) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ int wsum[SCAN_BLOCK / 64];
     const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const int f = i < n ? (flags[i] != 0) : 0;
@@ -257,6 +316,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void scan_block_counts_kernel(const uin
 
 // single block: exclusive scan of block_counts in place, total to *total
 __global__ __launch_bounds__(1024) void scan_offsets_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ total) {
+    APDS_RAISE_WAVE_PRIORITY();
     __shared__ int buf[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -294,6 +354,7 @@ __device__ __forceinline__ int block_exclusive_pos(int f, int block_offset) {
 
 __global__ __launch_bounds__(SCAN_BLOCK) void emit_ratio_matches_kernel(const uint64_t* __restrict__ keys, int nq, int K, const uint8_t* __restrict__ flags,
                                                                         const int* __restrict__ block_offsets, apds_dmatch* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int i = blockIdx.x * SCAN_BLOCK + threadIdx.x;
     const int f = i < nq ? (flags[i] != 0) : 0;
     const int pos = block_exclusive_pos(f, block_offsets[blockIdx.x]);
@@ -347,13 +408,18 @@ static int env_int(const char* name, int dflt) {
 // Work items are (64*T queries) x (rows_per_chunk train rows) per wave. Items are kept small enough that the
 // grid is many dispatch rounds deep (the block scheduler then balances the tail), but not so small that the
 // per-chunk candidate lists dominate the merge.
-static ChunkPlan plan_chunks(int nq, long long n_train) {
+static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false) {
     ChunkPlan p;
     static const int forced_t = env_int("APDS_MATCH_T", 0);
     static const int target_waves = env_int("APDS_MATCH_TARGET_WAVES", 256 * 4 * 4 * 12);
-    static const int min_rows = env_int("APDS_MATCH_MIN_ROWS", 1024);
+    static const int min_rows_main = env_int("APDS_MATCH_MIN_ROWS", 1024);
+    static const int min_rows_sample = env_int("APDS_MATCH_SAMPLE_MIN_ROWS", 256);
+    static const int sample_t = env_int("APDS_MATCH_SAMPLE_T", 1);
+    const int min_rows = sample_pass ? min_rows_sample : min_rows_main;
     p.T = nq >= 64 * 4 * 64 ? 4 : (nq >= 64 * 2 * 64 ? 2 : 1);
     if (forced_t == 1 || forced_t == 2 || forced_t == 4) p.T = forced_t;
+    // the threshold pre-pass covers few rows: smaller items (T = 1, short chunks) keep all CUs busy
+    if (sample_pass && (sample_t == 1 || sample_t == 2 || sample_t == 4)) p.T = std::min(p.T, sample_t);
     const int waves_q = ceil_div(nq, 64 * p.T);
     p.qtiles_blocks = ceil_div(waves_q, 4);
     long long chunks = ceil_div(target_waves, waves_q);
@@ -369,14 +435,30 @@ static ChunkPlan plan_chunks(int nq, long long n_train) {
 template <int K>
 static void launch_topk(const void* q, int nq, const void* t, long long nt, uint32_t index_base, const int* init_thr,
                         uint64_t* parts, const ChunkPlan& p, hipStream_t s) {
-    dim3 grid(p.qtiles_blocks, p.chunks), block(256);
+    static const int xcd = env_int("APDS_MATCH_XCD", 0);
+    static const int persist = env_int("APDS_MATCH_PERSIST", 0);   // resident workgroups per CU (0 = plain grid)
     const u32x16* tr = static_cast<const u32x16*>(t);
     const u32x4* qq = static_cast<const u32x4*>(q);
+    const int items = p.qtiles_blocks * p.chunks;
+    if (persist > 0 && items > 256 * persist) {
+        int* counter = ctx().alloc_n<int>(1);
+        HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
+        dim3 grid(256 * persist), block(256);
+        KernelTimer timer("hamming_topk", s);
+        switch (p.T) {
+            case 4: hipLaunchKernelGGL((hamming_topk_persistent_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, counter); break;
+            case 2: hipLaunchKernelGGL((hamming_topk_persistent_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, counter); break;
+            default: hipLaunchKernelGGL((hamming_topk_persistent_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, counter); break;
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
+    dim3 grid((unsigned)(ceil_div(p.chunks, 8) * 8 * p.qtiles_blocks)), block(256);
     KernelTimer timer("hamming_topk", s);
     switch (p.T) {
-        case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base); break;
-        case 2: hipLaunchKernelGGL((hamming_topk_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base); break;
-        default: hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base); break;
+        case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
+        case 2: hipLaunchKernelGGL((hamming_topk_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
+        default: hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -395,11 +477,12 @@ void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uin
     // Phase 0 (only for large scans): exact top-k over the first `sample` rows gives per-query thresholds that
     // every chunk starts from, so the rare-hit fast path is reached immediately. The sample rows have the
     // lowest indices, hence a later row at equal distance never outranks them: strict '<' stays exact.
-    const long long sample = nt >= 8 * 16384 ? 16384 : 0;
+    static const int sample_rows = env_int("APDS_MATCH_SAMPLE", 16384);
+    const long long sample = (sample_rows > 0 && nt >= 8ll * sample_rows) ? sample_rows : 0;
     const int* thr = nullptr;
     uint64_t* sample_keys = nullptr;
     if (sample) {
-        ChunkPlan sp = plan_chunks(nq, sample);
+        ChunkPlan sp = plan_chunks(nq, sample, true);
         uint64_t* sparts = c.alloc_n<uint64_t>((size_t)sp.chunks * nq * k);
         sample_keys = c.alloc_n<uint64_t>((size_t)nq * k);
         if (k == 2) launch_topk<2>(q, nq, t, sample, index_base, nullptr, sparts, sp, s);

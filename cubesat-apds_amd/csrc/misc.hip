@@ -7,6 +7,7 @@ namespace apds {
 __global__ void points_from_matches_kernel(const apds_keypoint* __restrict__ kp1, int n1, const apds_keypoint* __restrict__ kp2, int n2,
                                            const apds_dmatch* __restrict__ m, int nm, int bug, float2* __restrict__ p1,
                                            float2* __restrict__ p2, int* __restrict__ err) {
+    APDS_RAISE_WAVE_PRIORITY();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nm) return;
     const apds_dmatch mm = m[i];
@@ -23,6 +24,7 @@ __global__ void points_from_matches_kernel(const apds_keypoint* __restrict__ kp1
 
 // homographier/src/homographier/mod.rs:183-220: RGBA8 -> BGRA (Vec4b), one dword per pixel
 __global__ void rgba_to_bgra_kernel(const uint32_t* __restrict__ in, size_t n, uint32_t* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {

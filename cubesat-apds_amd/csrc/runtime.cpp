@@ -100,6 +100,29 @@ int apds_set_device(int ordinal) {
 
 const char* apds_build_info(void) { return "libapds_hip gfx950 (CDNA4) hand-written HIP kernels; -ffp-contract=off"; }
 
+// Streams for callers that overlap stages: optional CU mask (bit i = compute unit i may run this stream's kernels)
+// and priority (0 normal, -1 high). The 30 ms match grid otherwise occupies every CU and starves the short kernels of
+// the other stages; masking a few CUs out of the MATCH stream keeps them free for those.
+int apds_stream_create(int priority, const uint32_t* cu_mask, int cu_mask_words, void** stream) {
+    return guarded([&] {
+        APDS_REQUIRE(stream, APDS_ERR_BAD_ARG, "null output");
+        ctx();   // device selected
+        hipStream_t s = nullptr;
+        if (cu_mask && cu_mask_words > 0) {
+            HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)cu_mask_words, cu_mask));
+        } else {
+            HIP_CHECK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority));
+        }
+        *stream = s;
+    });
+}
+
+int apds_stream_destroy(void* stream) {
+    return guarded([&] {
+        if (stream) HIP_CHECK(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    });
+}
+
 int apds_dev_timing_enable(int on) {
     return guarded([&] { ctx().timing = on != 0; });
 }

@@ -38,9 +38,10 @@ def torch_stream():
 class HipBackend:
     """Local compute through the C ABI (device pointers of torch tensors, launched on torch's current stream)."""
 
-    def topk(self, q_rows64, train_rows64, index_base, k):
+    def topk(self, q_rows64, train_rows64, index_base, k, out=None):
         nq, nt = q_rows64.shape[0], train_rows64.shape[0]
-        out = torch.empty((nq, k), dtype=torch.int64, device=q_rows64.device)
+        if out is None:
+            out = torch.empty((nq, k), dtype=torch.int64, device=q_rows64.device)
         check(lib().apds_dev_hamming_topk(q_rows64.data_ptr(), nq, train_rows64.data_ptr(), nt, int(index_base), k, out.data_ptr(), torch_stream()))
         return out
 
@@ -50,6 +51,16 @@ class HipBackend:
         out = torch.empty((q, k), dtype=torch.int64, device=parts.device)
         check(lib().apds_dev_merge_topk(parts.data_ptr(), p, q, k, out.data_ptr(), torch_stream()))
         return out
+
+
+def _gather_into(dist, group, dst, src):
+    """all_gather_into_tensor that also works for the gloo rehearsal backend with device tensors (staged through the host)."""
+    if dist.get_backend(group) == "gloo" and src.is_cuda:
+        d, s = torch.empty(dst.shape, dtype=dst.dtype), src.cpu()
+        dist.all_gather_into_tensor(d.view(-1), s.view(-1), group=group)
+        dst.copy_(d)
+    else:
+        dist.all_gather_into_tensor(dst.view(-1), src.view(-1), group=group)
 
 
 class ShardedMatcher:
@@ -69,29 +80,35 @@ class ShardedMatcher:
         else:
             self.dist, self.world, self.rank = None, 1, 0
 
-    def knn(self, q_rows64, k=2):
+    def knn(self, q_rows64, k=2, out=None):
         """q_rows64: this rank's queries [Q_r, 64] u8. Returns [Q_r, k] int64 keys over the WHOLE DB."""
         be = self.backend
         if self.world == 1:
+            if out is not None:
+                return be.topk(q_rows64, self.rows, self.index_base, k, out=out[:q_rows64.shape[0]])
             return be.topk(q_rows64, self.rows, self.index_base, k)
         dist, dev = self.dist, q_rows64.device
         nq = q_rows64.shape[0]
-        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
-        dist.all_gather(counts, torch.tensor([nq], dtype=torch.int64, device=dev), group=self.group)
-        counts = [int(c.item()) for c in counts]
+        cnt = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        _gather_into(dist, self.group, cnt, torch.tensor([nq], dtype=torch.int64, device=dev))
+        counts = [int(c) for c in cnt.tolist()]
         pad = max(self.pad_rows, max(counts))
         mine = torch.zeros((pad, 64), dtype=torch.uint8, device=dev)
         mine[:nq] = q_rows64
         gathered = torch.empty((self.world, pad, 64), dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(gathered.view(-1), mine.view(-1), group=self.group)
+        _gather_into(dist, self.group, gathered, mine)
         all_q = torch.cat([gathered[r, :counts[r]] for r in range(self.world)], 0).contiguous()
         local = be.topk(all_q, self.rows, self.index_base, k)            # [sum Q, k] against the local shard
         total = all_q.shape[0]
         parts = torch.empty((self.world, total, k), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(parts.view(-1), local.view(-1), group=self.group)   # per-shard top-k of every query
+        _gather_into(dist, self.group, parts, local.contiguous())   # per-shard top-k of every query
         off = sum(counts[:self.rank])
         own = parts[:, off:off + nq, :].contiguous()
-        return be.merge(own, k)
+        merged = be.merge(own, k)
+        if out is not None:
+            out[:nq].copy_(merged)
+            return out[:nq]
+        return merged
 
 
 class FramePipeline:
@@ -157,11 +174,14 @@ class FramePipeline:
 
 class StreamedFramePipeline:
     """The same path as FramePipeline, software-pipelined over a stream of frames: three host threads, each with its own
-    HIP stream and device workspace (the C ABI is re-entrant per thread): extract | match (+ratio, point gather) | homography.
-    Frame i+1 is extracted (HBM-bound stencils) while frame i is matched (integer-VALU-bound), and frame i-1's RANSAC host
-    round trips hide behind both. Stages hand over through HIP events; results come back in frame order."""
+    HIP stream and device workspace (the C ABI is re-entrant per thread): extract | match | ratio filter + point gather +
+    homography. Frame i+1 is extracted (HBM-bound stencils, raised wave priority) while frame i is matched
+    (integer-VALU-bound), and frame i-1's filter/RANSAC host round trips hide behind both. The match stage never
+    synchronises with the host (single GPU), so match kernels of consecutive frames queue back to back. Stages hand
+    over through HIP events; results come back in frame order."""
 
-    def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=3):
+    def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=4, reserve_cus=0,
+                 n_cus=256):
         import queue
         self.queue = queue
         self.dev = torch.device(device)
@@ -179,9 +199,34 @@ class StreamedFramePipeline:
                      p1=torch.empty((self.cap, 2), dtype=torch.float32, device=self.dev),
                      p2=torch.empty((self.cap, 2), dtype=torch.float32, device=self.dev),
                      mask=torch.empty(self.cap, dtype=torch.uint8, device=self.dev),
+                     keys=torch.empty((self.cap, 2), dtype=torch.int64, device=self.dev), keys_view=None,
                      ev_extract=torch.cuda.Event(), ev_match=torch.cuda.Event(), K=0, M=0, index=0)
             self.slots.append(s)
-        self.streams = [torch.cuda.Stream(self.dev) for _ in range(3)]
+        # the match kernel alone fills every CU for ~30 ms; the short extraction / homography kernels get the high-priority
+        # queues so that their blocks are dispatched as soon as match workgroups retire
+        self.streams = [torch.cuda.Stream(self.dev, priority=-1), torch.cuda.Stream(self.dev, priority=0), torch.cuda.Stream(self.dev, priority=-1)]
+        if reserve_cus > 0:
+            # keep `reserve_cus` CUs (spread evenly over the CU index space) out of the MATCH stream only
+            words = (n_cus + 31) // 32
+            mask = np.full(words, 0xFFFFFFFF, np.uint32)
+            import os
+            layout = os.environ.get("APDS_CU_MASK_LAYOUT", "spread")
+            if layout == "tail":
+                cus = range(n_cus - reserve_cus, n_cus)
+            elif layout == "head":
+                cus = range(reserve_cus)
+            elif layout == "wordtop":      # the top bits of every 32-bit word
+                per = max(1, reserve_cus // words)
+                cus = [wd * 32 + 31 - b for wd in range(words) for b in range(per)]
+            else:
+                stride = n_cus // reserve_cus
+                cus = [r * stride for r in range(reserve_cus)]
+            for cu in cus:
+                mask[cu // 32] &= ~np.uint32(1 << (cu % 32))
+            h = C.c_void_p()
+            check(lib().apds_stream_create(0, _lib.ptr(mask), words, C.byref(h)))
+            self._masked_stream_handle = h
+            self.streams[1] = torch.cuda.ExternalStream(h.value, device=self.dev)
         torch.cuda.synchronize()
 
     def run(self, frames, count, filter_strength=0.8, reproj_thr=3.0, max_iters=2000, confidence=0.995, timing=False):
@@ -241,17 +286,7 @@ class StreamedFramePipeline:
                     if s is None:
                         break
                     self.streams[1].wait_event(s["ev_extract"])
-                    K = s["K"]
-                    keys = self.matcher.knn(s["desc"][:K], 2)
-                    M = 0
-                    if K > 0:
-                        nm = C.c_int(0)
-                        check(L.apds_dev_ratio_filter(keys.data_ptr(), K, 2, float(filter_strength), s["matches"].data_ptr(), C.byref(nm), torch_stream()))
-                        M = nm.value
-                        if M >= 4:
-                            check(L.apds_dev_points_from_matches(s["kps"].data_ptr(), K, self.db_kp.data_ptr(), self.n_db, s["matches"].data_ptr(), M, 0,
-                                                                 s["p1"].data_ptr(), s["p2"].data_ptr(), torch_stream()))
-                    s["M"] = M
+                    s["keys_view"] = self.matcher.knn(s["desc"][:s["K"]], 2, out=s["keys"])
                     s["ev_match"].record(self.streams[1])
                     q2.put(s)
                 q2.put(None)
@@ -264,14 +299,22 @@ class StreamedFramePipeline:
                     if s is None:
                         break
                     self.streams[2].wait_event(s["ev_match"])
-                    out = dict(n_keypoints=s["K"], n_matches=s["M"], H=None, n_inliers=0)
-                    if s["M"] >= 4:
+                    K, M = s["K"], 0
+                    if K > 0:
+                        nm = C.c_int(0)
+                        check(L.apds_dev_ratio_filter(s["keys_view"].data_ptr(), K, 2, float(filter_strength), s["matches"].data_ptr(), C.byref(nm),
+                                                      torch_stream()))
+                        M = nm.value
+                    out = dict(n_keypoints=K, n_matches=M, H=None, n_inliers=0)
+                    if M >= 4:
+                        check(L.apds_dev_points_from_matches(s["kps"].data_ptr(), K, self.db_kp.data_ptr(), self.n_db, s["matches"].data_ptr(), M, 0,
+                                                             s["p1"].data_ptr(), s["p2"].data_ptr(), torch_stream()))
                         H = np.zeros(9, np.float64)
-                        rc = L.apds_dev_find_homography(s["p1"].data_ptr(), s["p2"].data_ptr(), s["M"], 8, float(reproj_thr), int(max_iters),
+                        rc = L.apds_dev_find_homography(s["p1"].data_ptr(), s["p2"].data_ptr(), M, 8, float(reproj_thr), int(max_iters),
                                                         float(confidence), _lib.ptr(H), s["mask"].data_ptr(), torch_stream())
                         if rc == 0:
                             out["H"] = H.reshape(3, 3)
-                            out["n_inliers"] = int(s["mask"][:s["M"]].sum().item())
+                            out["n_inliers"] = int(s["mask"][:M].sum().item())
                         elif rc != _lib.ERR_EMPTY:
                             check(rc)
                     results[s["index"]] = out

@@ -147,6 +147,11 @@ int apds_dev_points_from_matches(const void* kp1, int n1, const void* kp2, int n
 int apds_dev_find_homography(const void* input_xy, const void* reference_xy, int n, int method, double reproj_threshold,
                              int max_iters, double confidence, double* H, void* mask_dev, void* stream);
 
+/* Streams for callers that overlap stages. cu_mask (optional): bit i set = compute unit i may run the stream's kernels
+ * (hipExtStreamCreateWithCUMask); priority 0 normal, -1 high (ignored when a mask is given). */
+int apds_stream_create(int priority, const uint32_t* cu_mask, int cu_mask_words, void** stream);
+int apds_stream_destroy(void* stream);
+
 /* Test hook: run apds_akaze_extract and copy one intermediate plane of evolution level `level` to out_plane
  * (which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet as f32 w*h; 7 keypoint mask after cross-level suppression as u8 w*h; 8 contrast factor, 1 float). */
 int apds_akaze_debug_plane(const uint8_t* img, int rows, int cols, int channels, size_t stride_bytes, int level, int which, void* out_plane);
