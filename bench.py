@@ -184,6 +184,20 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    # stand-alone extraction time (no other stage on the GPU) for the detect roofline; outside the timed region
+    solo = pl.FramePipeline(db_local[:4096].contiguous(), db_xy, index_base=0, group=None, device=str(dev))
+    with torch.cuda.stream(solo.stream):
+        nk = C.c_int(0)
+        for rep in range(4):
+            if rep == 1:
+                check(L.apds_dev_timing_enable(1))
+                pkg._lib.kernel_ms("akaze_extract")
+            f = frames[rep % len(frames)]
+            check(L.apds_dev_akaze_extract(f.data_ptr(), T, T, f.shape[2], f.stride(0), solo.cap, solo.kps.data_ptr(), solo.desc.data_ptr(), solo.cap,
+                                           C.byref(nk), pl.torch_stream()))
+        torch.cuda.synchronize()
+        akaze_solo_ms, akaze_solo_n = pkg._lib.kernel_ms("akaze_extract")
+        check(L.apds_dev_timing_enable(0))
     topk_ms, topk_n = timers.get("hamming_topk", (0.0, 0))
     akaze_ms, akaze_n = timers.get("akaze_extract", (0.0, 0))
     score_ms, score_n = timers.get("ransac_score", (0.0, 0))
@@ -232,10 +246,11 @@ def main():
                      "tpairs_per_s": Q_step * rows_local / (topk_ms_step * 1e-3) / 1e12 if topk_ms_step else 0.0},
             "stages_ms_per_step": {"akaze_extract": akaze_ms / max(args.steps, 1), "hamming_topk": topk_ms_step, "ransac_score": score_ms / max(args.steps, 1)},
             "detect_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": detect_algorithmic_bytes(T, T),
-                                "achieved": detect_algorithmic_bytes(T, T) / (akaze_ms / max(akaze_n, 1) * 1e-3) / 1e9 if akaze_n else 0.0,
+                                "achieved": detect_algorithmic_bytes(T, T) / (akaze_solo_ms / max(akaze_solo_n, 1) * 1e-3) / 1e9 if akaze_solo_n else 0.0,
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                "frac": detect_algorithmic_bytes(T, T) / (akaze_ms / max(akaze_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS if akaze_n else 0.0,
-                                "note": "whole extraction incl. orientation/descriptors and host syncs, against the detect stages' algorithmic bytes"},
+                                "frac": detect_algorithmic_bytes(T, T) / (akaze_solo_ms / max(akaze_solo_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS if akaze_solo_n else 0.0,
+                                "ms_standalone": akaze_solo_ms / max(akaze_solo_n, 1),
+                                "note": "whole extraction (incl. orientation, descriptors, count read-backs) run alone after the timed region, against the detect stages' algorithmic bytes; stages_ms_per_step.akaze_extract is its wall span while overlapped with the match"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, frames_np[0], db_local, int(K), args.filter_strength, db_xy, stats[0])

@@ -7,7 +7,8 @@
 // one WAVE walks a contiguous chunk of train rows. A train row is wave-uniform, so it is fetched with
 // scalar loads (s_load_dwordx16: one 64-byte line per row) and fed to the VALU as an SGPR operand:
 //     v_xor_b32  t, s_row[j], v_q[j]      v_bcnt_u32_b32  acc, t, acc
-// = 32 VALU lane-ops per (query,row) pair, no LDS and no cross-lane traffic on the hot path. The running
+// = 30 VALU lane-ops per (query,row) pair on the fast path (15 dwords; the 16th holds 6 descriptor bits and is only
+// needed to finish a candidate hit; the algorithmic figure used for the roofline stays 32), no LDS and no cross-lane traffic on the hot path. The running
 // top-k lives per lane; the popcount chain starts at -threshold so "distance < current k-th best" is the
 // sign bit, a whole group of pairs is screened with one v_min3/v_cmp, and the insertion code runs only for
 // the rare groups that contain a hit. Train rows are split into chunks over blockIdx.y so the grid fills
@@ -34,37 +35,43 @@ __device__ __forceinline__ int bcnt_acc(uint32_t x, int acc) {
     return r;
 }
 
+// Lower bound of the distances of one train row to the lane's T queries: popcount over the first 15 dwords (480 bits)
+// on top of start[t] = -threshold. M-LDB uses 486 bits, so dword 15 holds at most 6 set bits of the XOR: if the bound
+// is already >= threshold the pair cannot be a hit, and dword 15 is only looked at in the rare hit path.
+// 30 VALU ops per pair instead of 32.
 template <int T>
 __device__ __forceinline__ void row_distances(const u32x16 row, const uint32_t (&q)[T][16], const int (&start)[T], int (&acc)[T]) {
 #pragma unroll
     for (int t = 0; t < T; t++) {
         int a = start[t];
 #pragma unroll
-        for (int j = 0; j < 16; j++) a = bcnt_acc(q[t][j] ^ row[j], a);
+        for (int j = 0; j < 15; j++) a = bcnt_acc(q[t][j] ^ row[j], a);
         acc[t] = a;
     }
 }
 
 template <int T, int K>
-__device__ __forceinline__ void insert_hits(const int (&acc)[T], const int (&nthr_old)[T], uint32_t r, int (&bd)[T][K],
-                                            uint32_t (&bi)[T][K]) {
+__device__ __forceinline__ void insert_hits(const int (&acc)[T], const int (&nthr_old)[T], const uint32_t (&q)[T][16], uint32_t row15, uint32_t r,
+                                            int (&bd)[T][K], uint32_t (&bi)[T][K]) {
 #pragma unroll
     for (int t = 0; t < T; t++) {
-        const int d = acc[t] - nthr_old[t];
-        if (d < bd[t][K - 1]) {
-            if (K == 2) {
-                if (d < bd[t][0]) {
-                    bd[t][1] = bd[t][0];
-                    bi[t][1] = bi[t][0];
+        if (acc[t] < 0) {   // the 480-bit bound is below the threshold this pair was screened with: finish the distance
+            const int d = acc[t] - nthr_old[t] + __popc(q[t][15] ^ row15);
+            if (d < bd[t][K - 1]) {
+                if (K == 2) {
+                    if (d < bd[t][0]) {
+                        bd[t][1] = bd[t][0];
+                        bi[t][1] = bi[t][0];
+                        bd[t][0] = d;
+                        bi[t][0] = r;
+                    } else {
+                        bd[t][1] = d;
+                        bi[t][1] = r;
+                    }
+                } else {
                     bd[t][0] = d;
                     bi[t][0] = r;
-                } else {
-                    bd[t][1] = d;
-                    bi[t][1] = r;
                 }
-            } else {
-                bd[t][0] = d;
-                bi[t][0] = r;
             }
         }
     }
@@ -119,8 +126,8 @@ __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ tra
             int nthr_old[T];
 #pragma unroll
             for (int t = 0; t < T; t++) nthr_old[t] = nthr[t];
-            insert_hits<T, K>(acc0, nthr_old, (uint32_t)r, bd, bi);
-            insert_hits<T, K>(acc1, nthr_old, (uint32_t)(r + 1), bd, bi);
+            insert_hits<T, K>(acc0, nthr_old, q, a0[15], (uint32_t)r, bd, bi);
+            insert_hits<T, K>(acc1, nthr_old, q, a1[15], (uint32_t)(r + 1), bd, bi);
 #pragma unroll
             for (int t = 0; t < T; t++) nthr[t] = -bd[t][K - 1];
         }
@@ -150,7 +157,7 @@ __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ tra
         const u32x16 a0 = train[r];
         int acc0[T];
         row_distances<T>(a0, q, nthr, acc0);
-        insert_hits<T, K>(acc0, nthr, (uint32_t)r, bd, bi);
+        insert_hits<T, K>(acc0, nthr, q, a0[15], (uint32_t)r, bd, bi);
 #pragma unroll
         for (int t = 0; t < T; t++) nthr[t] = -bd[t][K - 1];
     }

@@ -25,6 +25,9 @@ def main():
     for nq, nt in ((20000, 1000000), (20000, 10000000), (5000, 100000), (100000, 1000000), (262143, 262143)):
         db = torch.randint(0, 256, (nt, 64), dtype=torch.uint8, device=dev, generator=g)
         q = torch.randint(0, 256, (nq, 64), dtype=torch.uint8, device=dev, generator=g)
+        for t in (db, q):          # 486-bit M-LDB rows: bits 486.. of the 64-byte line are zero
+            t[:, 60] &= 0x3F
+            t[:, 61:] = 0
         out = torch.empty((nq, 2), dtype=torch.int64, device=dev)
         torch.cuda.synchronize()
         check(L.apds_dev_timing_enable(1))
