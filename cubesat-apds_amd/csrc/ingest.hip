@@ -1,0 +1,197 @@
+// csrc/ingest.hip — the steps on either side of the hot path (SURVEY §8f "next" rows 2 and 4):
+//   * tile ingest: per-band min-max normalisation + gamma 1/2.2 + NaN handling -> RGBA8 / BGRA8
+//     (/root/reference/geotiff_extractor/src/image_extractor/mod.rs:346-378, 402-422), one streaming kernel,
+//     optionally fused with raster_to_mat's R<->B swap (homographier mod.rs:183-220);
+//   * warp_image_perspective (homographier mod.rs:271-300): cv::warpPerspective, INTER_LINEAR fixed point,
+//     BORDER_CONSTANT (1,1,1,1), 4-channel u8 — a gather kernel, one thread per destination pixel.
+#include <climits>
+#include <cmath>
+
+#include "kernels.h"
+
+namespace apds {
+
+// f32_to_u8 (mod.rs:410-422): None -> 0 in band_merger. powf(x, 1/2.2f) is evaluated in f64 and rounded to f32: that is
+// the correctly rounded f32 result (what glibc's powf returns) except for values within ~1e-8 relative of a rounding tie.
+__device__ __forceinline__ uint32_t band_to_u8(float v, float mn, float mx) {
+    if (isnan(v)) return 0;
+    const float f = (v - mn) / (mx - mn);
+    if (!(f >= 0.0f && f <= 1.0f)) return 0;
+    const float g = (float)pow((double)f, (double)(1.0f / 2.2f));
+    const float r = roundf(g * 255.0f);
+    return r <= 0.0f ? 0u : (r >= 255.0f ? 255u : (uint32_t)r);
+}
+
+__global__ void band_merger_kernel(const float* __restrict__ red, const float* __restrict__ green, const float* __restrict__ blue, size_t n,
+                                   float rmin, float rmax, float gmin, float gmax, float bmin, float bmax, int bgra, uint32_t* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float r = red[i], g = green[i], b = blue[i];
+        const uint32_t alpha = (isnan(r) && isnan(g) && isnan(b)) ? 0u : 255u;
+        const uint32_t R = band_to_u8(r, rmin, rmax), G = band_to_u8(g, gmin, gmax), B = band_to_u8(b, bmin, bmax);
+        out[i] = bgra ? (B | (G << 8) | (R << 16) | (alpha << 24)) : (R | (G << 8) | (B << 16) | (alpha << 24));
+    }
+}
+
+__device__ __forceinline__ int sat_int_rn(double v) {
+    return v <= (double)INT_MIN ? INT_MIN : (v >= (double)INT_MAX ? INT_MAX : __double2int_rn(v));
+}
+
+__global__ void warp_perspective_kernel(const uint32_t* __restrict__ src, int rows, int cols, double m0, double m1, double m2, double m3, double m4,
+                                        double m5, double m6, double m7, double m8, const short* __restrict__ tab, int dst_rows, int dst_cols,
+                                        uint32_t* __restrict__ dst) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dst_cols || y >= dst_rows) return;
+    const double X0 = m0 * x + m1 * y + m2, Y0 = m3 * x + m4 * y + m5;
+    double W = m6 * x + m7 * y + m8;
+    W = W ? 32. / W : 0;
+    const double fX = fmax((double)INT_MIN, fmin((double)INT_MAX, X0 * W));
+    const double fY = fmax((double)INT_MIN, fmin((double)INT_MAX, Y0 * W));
+    const int X = sat_int_rn(fX), Y = sat_int_rn(fY);
+    const int sx = X >> 5, sy = Y >> 5;
+    const short* w = &tab[((Y & 31) * 32 + (X & 31)) * 4];
+    uint32_t p[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int xx = sx + (k & 1), yy = sy + (k >> 1);
+        p[k] = (xx >= 0 && xx < cols && yy >= 0 && yy < rows) ? src[(size_t)yy * cols + xx] : 0x01010101u;   // border value (1,1,1,1)
+    }
+    uint32_t out = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int v = (int)((p[0] >> (8 * c)) & 0xFF) * w[0] + (int)((p[1] >> (8 * c)) & 0xFF) * w[1] + (int)((p[2] >> (8 * c)) & 0xFF) * w[2] +
+                      (int)((p[3] >> (8 * c)) & 0xFF) * w[3];
+        out |= (uint32_t)(((v + (1 << 14)) >> 15) & 0xFF) << (8 * c);
+    }
+    dst[(size_t)y * dst_cols + x] = out;
+}
+
+namespace {
+
+// 32x32 table of 2x2 fixed-point (15 bit) bilinear weights that sum to 2^15 (OpenCV's BilinearTab_i restated)
+const short* bilinear_tab_host() {
+    static short tab[32 * 32 * 4];
+    static bool init = false;
+    if (!init) {
+        float lin[32][2];
+        for (int i = 0; i < 32; i++) {
+            const float x = i * (1.f / 32);
+            lin[i][0] = 1.f - x;
+            lin[i][1] = x;
+        }
+        for (int fy = 0; fy < 32; fy++)
+            for (int fx = 0; fx < 32; fx++) {
+                short* w = &tab[(fy * 32 + fx) * 4];
+                int isum = 0;
+                for (int k1 = 0; k1 < 2; k1++)
+                    for (int k2 = 0; k2 < 2; k2++) {
+                        const int iv = (int)lrintf(lin[fy][k1] * lin[fx][k2] * 32768.f);
+                        w[k1 * 2 + k2] = (short)(iv > 32767 ? 32767 : iv);
+                        isum += w[k1 * 2 + k2];
+                    }
+                if (isum != 32768) {
+                    const int diff = isum - 32768;
+                    int Mk = 0;
+                    for (int k = 1; k < 4; k++)
+                        if (w[k] > w[Mk]) Mk = k;
+                    if (w[Mk] - diff > 32767) Mk = 3;
+                    w[Mk] = (short)(w[Mk] - diff);
+                }
+            }
+        init = true;
+    }
+    return tab;
+}
+
+bool invert3x3(const double* m, double* inv) {
+    const double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (d == 0) return false;
+    const double id = 1. / d;
+    inv[0] = (m[4] * m[8] - m[5] * m[7]) * id;
+    inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    inv[3] = (m[5] * m[6] - m[3] * m[8]) * id;
+    inv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    inv[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+    inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return true;
+}
+
+}  // namespace
+
+void band_merger_device(const float* r, const float* g, const float* b, size_t n, const double* mm, int bgra, uint8_t* out, hipStream_t s) {
+    if (!n) return;
+    const int blocks = (int)std::min<size_t>((n + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(band_merger_kernel, dim3(blocks), dim3(256), 0, s, r, g, b, n, (float)mm[0], (float)mm[1], (float)mm[2], (float)mm[3], (float)mm[4],
+                       (float)mm[5], bgra, reinterpret_cast<uint32_t*>(out));
+    HIP_CHECK(hipGetLastError());
+}
+
+void warp_perspective_device(const uint8_t* src, int rows, int cols, const double* M, int dst_rows, int dst_cols, uint8_t* dst, hipStream_t s) {
+    double inv[9];
+    APDS_REQUIRE(invert3x3(M, inv), APDS_ERR_ASSERT, "perspective matrix is singular");
+    ThreadCtx& c = ctx();
+    short* tab = c.alloc_n<short>(32 * 32 * 4);
+    HIP_CHECK(hipMemcpyAsync(tab, bilinear_tab_host(), sizeof(short) * 32 * 32 * 4, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(warp_perspective_kernel, dim3(ceil_div(dst_cols, 256), dst_rows), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(src), rows, cols,
+                       inv[0], inv[1], inv[2], inv[3], inv[4], inv[5], inv[6], inv[7], inv[8], (const short*)tab, dst_rows, dst_cols,
+                       reinterpret_cast<uint32_t*>(dst));
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace apds
+
+using namespace apds;
+
+extern "C" {
+
+int apds_band_merger(const float* red, const float* green, const float* blue, size_t n, const double* minmax6, int bgra, uint8_t* out) {
+    return guarded([&] {
+        APDS_REQUIRE(n == 0 || (red && green && blue && out && minmax6), APDS_ERR_BAD_ARG, "null argument");
+        if (!n) return;
+        ThreadCtx& c = ctx();
+        c.ws_reset();
+        hipStream_t s = c.stream;
+        float* d = c.alloc_n<float>(3 * n);
+        uint8_t* o = c.alloc_n<uint8_t>(4 * n);
+        HIP_CHECK(hipMemcpyAsync(d, red, n * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d + n, green, n * 4, hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(d + 2 * n, blue, n * 4, hipMemcpyHostToDevice, s));
+        band_merger_device(d, d + n, d + 2 * n, n, minmax6, bgra, o, s);
+        HIP_CHECK(hipMemcpyAsync(out, o, 4 * n, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+int apds_dev_band_merger(const void* red, const void* green, const void* blue, size_t n, const double* minmax6, int bgra, void* out, void* stream) {
+    return guarded([&] {
+        APDS_REQUIRE(minmax6, APDS_ERR_BAD_ARG, "null argument");
+        band_merger_device(static_cast<const float*>(red), static_cast<const float*>(green), static_cast<const float*>(blue), n, minmax6, bgra,
+                           static_cast<uint8_t*>(out), pick_stream(stream));
+    });
+}
+
+int apds_warp_perspective(const uint8_t* src, int rows, int cols, int channels, const double* M, int dst_rows, int dst_cols, uint8_t* dst) {
+    return guarded([&] {
+        APDS_REQUIRE(src && M && dst, APDS_ERR_BAD_ARG, "null argument");
+        APDS_REQUIRE(rows > 0 && cols > 0 && dst_rows > 0 && dst_cols > 0, APDS_ERR_ASSERT, "empty image");
+        APDS_REQUIRE(channels == 4, APDS_ERR_ASSERT, "warp_perspective is implemented for 4-channel u8 images (Vec4b, the type the reference warps)");
+        ThreadCtx& c = ctx();
+        c.ws_reset();
+        hipStream_t s = c.stream;
+        uint8_t* ds = c.alloc_n<uint8_t>((size_t)rows * cols * 4);
+        uint8_t* dd = c.alloc_n<uint8_t>((size_t)dst_rows * dst_cols * 4);
+        HIP_CHECK(hipMemcpyAsync(ds, src, (size_t)rows * cols * 4, hipMemcpyHostToDevice, s));
+        warp_perspective_device(ds, rows, cols, M, dst_rows, dst_cols, dd, s);
+        HIP_CHECK(hipMemcpyAsync(dst, dd, (size_t)dst_rows * dst_cols * 4, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+}  // extern "C"

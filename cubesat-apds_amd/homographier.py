@@ -95,3 +95,22 @@ def find_homography_mat(input_pts, reference_pts, method=None, reproj_threshold=
     if method is not None and int(method) in (HomographyMethod.RANSAC, HomographyMethod.LMEDS):
         out_mask = Cmat(mask[:len(src)].reshape(-1, 1), np.uint8)
     return Cmat(H.reshape(3, 3), np.float64), out_mask
+
+
+def warp_image_perspective(src, m, size=None):
+    """mod.rs:271-300 — warpPerspective(INTER_LINEAR, BORDER_CONSTANT (1,1,1,1)). src: Cmat of HxWx4 u8, m: Cmat<f64> 3x3,
+    size: (width, height) or None (= source size). Returns a Cmat of the same element type."""
+    img = np.ascontiguousarray(src.mat, np.uint8)
+    if img.ndim != 3 or img.shape[2] != 4:
+        raise MatError("Opencv", ApdsError(_lib.ERR_ASSERT, "warp_image_perspective is implemented for Vec4b images"))
+    M = np.ascontiguousarray(m.mat, np.float64)
+    if M.shape != (3, 3):
+        raise MatError("Opencv", ApdsError(_lib.ERR_ASSERT, "m must be 3x3"))
+    h, w = img.shape[:2]
+    dw, dh = (w, h) if size is None else (int(size[0]), int(size[1]))
+    out = np.zeros((dh, dw, 4), np.uint8)
+    try:
+        check(lib().apds_warp_perspective(ptr(img), h, w, 4, ptr(M), dh, dw, ptr(out)))
+    except ApdsError as e:
+        raise MatError("Opencv", e)
+    return Cmat(out, np.uint8, 4)

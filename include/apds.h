@@ -114,6 +114,18 @@ int apds_find_homography_ex(const float* input_xy, const float* reference_xy, in
  * APDS_ERR_BAD_ARG (MatError::Unknown) when n_pixels != w*h. bgra: w*h*4 bytes, caller allocated. */
 int apds_raster_to_mat(const uint8_t* rgba, size_t n_pixels, int w, int h, uint8_t* bgra);
 
+/* ---- "next" rows either side of the path ------------------------------------------ */
+
+/* geotiff_extractor/src/image_extractor/mod.rs:346-378 band_merger (f32_to_u8 :410-422, gamma_correction :402-408): three f32 bands
+ * + min/max {red_min, red_max, green_min, green_max, blue_min, blue_max} -> n pixels of RGBA8 (bgra = 0, what band_merger returns) or
+ * BGRA8 (bgra = 1: raster_to_mat, mod.rs:183-220, fused). NaN / out-of-range -> 0; alpha 0 only if all three bands are NaN. */
+int apds_band_merger(const float* red, const float* green, const float* blue, size_t n, const double* minmax6, int bgra, uint8_t* out);
+int apds_dev_band_merger(const void* red, const void* green, const void* blue, size_t n, const double* minmax6, int bgra, void* out, void* stream);
+
+/* homographier/src/homographier/mod.rs:271-300 warp_image_perspective: warpPerspective(src, M, size, INTER_LINEAR, BORDER_CONSTANT,
+ * Scalar(1,1,1,1)). M (9 doubles) maps source to destination coordinates. channels must be 4 (Vec4b). */
+int apds_warp_perspective(const uint8_t* src, int rows, int cols, int channels, const double* M, int dst_rows, int dst_cols, uint8_t* dst);
+
 /* ---- device-resident API ------------------------------------------------------------------- */
 /* All pointers below are HIP device pointers. stream: hipStream_t or NULL (the thread's own stream).
  * Calls are asynchronous on that stream unless they return a count to the host. */

@@ -22,7 +22,7 @@ PLANE_LT, PLANE_LSMOOTH, PLANE_LX, PLANE_LY, PLANE_LDET, PLANE_LFLOW, PLANE_MASK
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("akaze_oracle.cpp", "match_oracle.cpp", "homography_oracle.cpp", "oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("akaze_oracle.cpp", "match_oracle.cpp", "homography_oracle.cpp", "ingest_oracle.cpp", "oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -73,6 +73,14 @@ def lib():
         L.oracle_ransac_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_raster_to_mat.restype = C.c_int
         L.oracle_raster_to_mat.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_band_merger.restype = None
+        L.oracle_band_merger.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.oracle_gamma_correction.restype = C.c_float
+        L.oracle_gamma_correction.argtypes = [C.c_float, C.POINTER(C.c_int)]
+        L.oracle_f32_to_u8.restype = C.c_int
+        L.oracle_f32_to_u8.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int)]
+        L.oracle_warp_perspective_8uc4.restype = C.c_int
+        L.oracle_warp_perspective_8uc4.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_get_threads.restype = C.c_int
         _LIB = L
@@ -236,4 +244,39 @@ def raster_to_mat(rgba, w, h):
     rc = lib().oracle_raster_to_mat(_ptr(rgba), rgba.shape[0], w, h, _ptr(out))
     if rc < 0:
         raise ValueError("MatError::Unknown (len != w*h)")
+    return out
+
+
+def gamma_correction(v):
+    """geotiff_extractor mod.rs:402-408: returns the corrected value or None (PixelConversion::GammaOutOfRange)."""
+    ok = C.c_int(0)
+    r = lib().oracle_gamma_correction(float(v), C.byref(ok))
+    return np.float32(r) if ok.value else None
+
+
+def f32_to_u8(v, mn, mx):
+    """mod.rs:410-422: u8 or None (Err)."""
+    ok = C.c_int(0)
+    r = lib().oracle_f32_to_u8(float(v), float(mn), float(mx), C.byref(ok))
+    return r if ok.value else None
+
+
+def band_merger(red, green, blue, minmax):
+    """mod.rs:346-378: minmax = (red_min, red_max, green_min, green_max, blue_min, blue_max) as f64. Returns n x 4 RGBA u8."""
+    r, g, b = (np.ascontiguousarray(a, np.float32).ravel() for a in (red, green, blue))
+    mm = np.ascontiguousarray(minmax, np.float64)
+    out = np.zeros((len(r), 4), np.uint8)
+    lib().oracle_band_merger(_ptr(r), _ptr(g), _ptr(b), len(r), _ptr(mm), _ptr(out))
+    return out
+
+
+def warp_perspective(src, M, size=None):
+    """homographier mod.rs:271-300 on an HxWx4 u8 image; size = (width, height) or None (source size)."""
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape[:2]
+    dw, dh = (w, h) if size is None else size
+    M = np.ascontiguousarray(M, np.float64).reshape(9)
+    out = np.zeros((dh, dw, 4), np.uint8)
+    if lib().oracle_warp_perspective_8uc4(_ptr(src), h, w, _ptr(M), dh, dw, _ptr(out)) != 0:
+        raise RuntimeError("singular matrix")
     return out

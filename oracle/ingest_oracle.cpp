@@ -1,0 +1,143 @@
+// oracle/ingest_oracle.cpp — tile ingest pixel math and perspective warp restated on the CPU. TEST INFRASTRUCTURE ONLY.
+//
+// band_merger / f32_to_u8 / gamma_correction: /root/reference/geotiff_extractor/src/image_extractor/mod.rs:346-378,
+// 402-422 (first-party Rust; pinned by its tests gamma_correct_input :517-525, convert_f32_to_u8_success :547-555,
+// merging_bands :626-646). warp_image_perspective: homographier/src/homographier/mod.rs:271-300 -> OpenCV imgproc
+// warpPerspective / remap (fixed-point bilinear), restated; pinned by warp_image_empty (mod.rs:683-707).
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "oracle.h"
+
+extern "C" {
+
+float oracle_gamma_correction(float v, int* ok) {
+    if (!(v >= 0.0f && v <= 1.0f)) {   // !(0.0..=1.0).contains(): NaN fails too
+        *ok = 0;
+        return 0.0f;
+    }
+    *ok = 1;
+    return powf(v, 1.0f / 2.2f);
+}
+
+int oracle_f32_to_u8(float v, float mn, float mx, int* ok) {
+    if (std::isnan(v)) {
+        *ok = 0;
+        return 0;
+    }
+    const float f = (v - mn) / (mx - mn);
+    const float g = oracle_gamma_correction(f, ok);
+    if (!*ok) return 0;
+    const float r = roundf(g * 255.0f);   // f32::round: half away from zero; `as u8` saturates
+    return r <= 0.0f ? 0 : (r >= 255.0f ? 255 : (int)r);
+}
+
+void oracle_band_merger(const float* red, const float* green, const float* blue, size_t n, const double* mm, uint8_t* rgba) {
+    for (size_t i = 0; i < n; i++) {
+        int ok;
+        const bool all_nan = std::isnan(red[i]) && std::isnan(green[i]) && std::isnan(blue[i]);
+        int r = oracle_f32_to_u8(red[i], (float)mm[0], (float)mm[1], &ok);
+        if (!ok) r = 0;
+        int g = oracle_f32_to_u8(green[i], (float)mm[2], (float)mm[3], &ok);
+        if (!ok) g = 0;
+        int b = oracle_f32_to_u8(blue[i], (float)mm[4], (float)mm[5], &ok);
+        if (!ok) b = 0;
+        rgba[4 * i + 0] = (uint8_t)r;
+        rgba[4 * i + 1] = (uint8_t)g;
+        rgba[4 * i + 2] = (uint8_t)b;
+        rgba[4 * i + 3] = all_nan ? 0 : 255;
+    }
+}
+
+// ---- warpPerspective, INTER_LINEAR, 8UC4, BORDER_CONSTANT ------------------------------------------------------
+static inline int sat_int(double v) { return v <= (double)INT_MIN ? INT_MIN : (v >= (double)INT_MAX ? INT_MAX : (int)lrint(v)); }
+
+static bool invert3x3(const double* m, double* inv) {
+    const double d = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+    if (d == 0) return false;
+    const double id = 1. / d;
+    inv[0] = (m[4] * m[8] - m[5] * m[7]) * id;
+    inv[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    inv[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    inv[3] = (m[5] * m[6] - m[3] * m[8]) * id;
+    inv[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    inv[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    inv[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+    inv[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    inv[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return true;
+}
+
+// 32x32 table of 2x2 fixed-point (15 bit) bilinear weights that sum to 32768
+static const short* bilinear_tab() {
+    static short tab[32 * 32 * 4];
+    static bool init = false;
+    if (!init) {
+        float lin[32][2];
+        for (int i = 0; i < 32; i++) {
+            const float x = i * (1.f / 32);
+            lin[i][0] = 1.f - x;
+            lin[i][1] = x;
+        }
+        for (int fy = 0; fy < 32; fy++)
+            for (int fx = 0; fx < 32; fx++) {
+                short* w = &tab[(fy * 32 + fx) * 4];
+                int isum = 0;
+                for (int k1 = 0; k1 < 2; k1++)
+                    for (int k2 = 0; k2 < 2; k2++) {
+                        const float v = lin[fy][k1] * lin[fx][k2];
+                        const int iv = (int)lrintf(v * 32768.f);
+                        w[k1 * 2 + k2] = (short)(iv > 32767 ? 32767 : iv);
+                        isum += w[k1 * 2 + k2];
+                    }
+                if (isum != 32768) {
+                    // OpenCV nudges one tap so the four weights sum to 2^15. Its scan for that tap is written for the
+                    // 4- and 8-tap kernels; for the 2x2 case the effective rule restated here is: correct the largest
+                    // weight, except when that would leave the 16-bit range (the exact tap (32767,0,0,0)), where the
+                    // diagonal tap takes the unit. Differences between variants are at most 1 LSB of one output byte.
+                    const int diff = isum - 32768;
+                    int Mk = 0;
+                    for (int k = 1; k < 4; k++)
+                        if (w[k] > w[Mk]) Mk = k;
+                    if (w[Mk] - diff > 32767) Mk = 3;
+                    w[Mk] = (short)(w[Mk] - diff);
+                }
+            }
+        init = true;
+    }
+    return tab;
+}
+
+int oracle_warp_perspective_8uc4(const uint8_t* src, int rows, int cols, const double* Min, int dst_rows, int dst_cols, uint8_t* dst) {
+    double M[9];
+    if (!invert3x3(Min, M)) return -1;
+    const short* tab = bilinear_tab();
+    const uint8_t border[4] = {1, 1, 1, 1};
+    for (int y = 0; y < dst_rows; y++)
+        for (int x = 0; x < dst_cols; x++) {
+            const double X0 = M[0] * x + M[1] * y + M[2], Y0 = M[3] * x + M[4] * y + M[5];
+            double W = M[6] * x + M[7] * y + M[8];
+            W = W ? 32. / W : 0;
+            const double fX = std::max((double)INT_MIN, std::min((double)INT_MAX, X0 * W));
+            const double fY = std::max((double)INT_MIN, std::min((double)INT_MAX, Y0 * W));
+            const int X = sat_int(fX), Y = sat_int(fY);
+            const int sx = X >> 5, sy = Y >> 5;
+            const short* w = &tab[((Y & 31) * 32 + (X & 31)) * 4];
+            uint8_t* d = &dst[((size_t)y * dst_cols + x) * 4];
+            const uint8_t* p[4];
+            for (int k = 0; k < 4; k++) {
+                const int xx = sx + (k & 1), yy = sy + (k >> 1);
+                p[k] = (xx >= 0 && xx < cols && yy >= 0 && yy < rows) ? &src[((size_t)yy * cols + xx) * 4] : border;
+            }
+            for (int c = 0; c < 4; c++) {
+                const int v = p[0][c] * w[0] + p[1][c] * w[1] + p[2][c] * w[2] + p[3][c] * w[3];
+                d[c] = (uint8_t)((v + (1 << 14)) >> 15);
+            }
+        }
+    return 0;
+}
+
+}  // extern "C"

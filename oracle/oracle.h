@@ -101,6 +101,16 @@ int  oracle_ransac_samples(const float* src_xy, const float* dst_xy, int n, int 
 /* mod.rs:183-220: RGBA8 slice -> BGRA rows. Returns 0 or -1 (MatError::Unknown) if len != w*h. */
 int oracle_raster_to_mat(const uint8_t* rgba, size_t n_pixels, int w, int h, uint8_t* bgra);
 
+/* geotiff_extractor/src/image_extractor/mod.rs:346-378 band_merger (+ f32_to_u8 :410-422, gamma_correction :402-408):
+ * three f32 bands + per-band min/max -> RGBA8. NaN or out-of-range -> 0; alpha 0 only when all three bands are NaN. */
+void oracle_band_merger(const float* red, const float* green, const float* blue, size_t n, const double* minmax6, uint8_t* rgba);
+float oracle_gamma_correction(float v, int* ok);
+int oracle_f32_to_u8(float v, float mn, float mx, int* ok);
+
+/* homographier mod.rs:271-300 warp_image_perspective: cv::warpPerspective(INTER_LINEAR, BORDER_CONSTANT (1,1,1,1)) on a
+ * 4-channel u8 image; M maps src -> dst (it is inverted inside, as OpenCV does without WARP_INVERSE_MAP). Returns 0 / -1. */
+int oracle_warp_perspective_8uc4(const uint8_t* src, int rows, int cols, const double* M, int dst_rows, int dst_cols, uint8_t* dst);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,35 @@ def test_akaze_blank_image(oracle_mod):
     r = oracle_mod.akaze(np.full((128, 128, 3), 77, np.uint8))
     assert len(r.keypoints) == 0 and r.descriptors.shape == (0, 61)
     assert abs(r.kcontrast - 0.03) < 1e-9
+
+
+# ---- "next" rows: geotiff_extractor pixel math and warp_image_perspective, pinned by reference KATs ----
+def test_gamma_and_f32_to_u8_kats(oracle_mod):
+    # /root/reference/geotiff_extractor/src/image_extractor/mod.rs:517-525, 527-545, 547-555
+    assert oracle_mod.gamma_correction(0.5) == np.float32(0.7297401)
+    assert oracle_mod.gamma_correction(1.5) is None and oracle_mod.gamma_correction(-0.5) is None
+    assert oracle_mod.f32_to_u8(0.2, 0.1, 0.3) == 186
+    assert oracle_mod.f32_to_u8(float("nan"), 0.1, 0.3) is None
+
+
+def test_merging_bands_kat(oracle_mod):
+    # mod.rs:626-646: bands (0, 0.5, 1) with min -1, max 2 -> first red is 155
+    out = oracle_mod.band_merger([0.0, 0.5, 1.0], [0.0, 0.5, 1.0], [0.0, 0.5, 1.0], [-1, 2, -1, 2, -1, 2])
+    assert out.shape == (3, 4) and out[0, 0] == 155 and (out[:, 3] == 255).all()
+    nan = float("nan")
+    out = oracle_mod.band_merger([nan, nan, 0.5], [nan, 0.2, 5.0], [nan, nan, -3.0], [0, 1, 0, 1, 0, 1])
+    assert out[0].tolist() == [0, 0, 0, 0]          # all three NaN -> alpha 0 (mod.rs:353-357)
+    assert out[1, 3] == 255 and out[1, 0] == 0      # a NaN band alone -> 0, alpha stays 255
+    assert out[2].tolist() == [oracle_mod.f32_to_u8(0.5, 0, 1), 0, 0, 255]   # out-of-range gamma input -> 0
+
+
+def test_warp_image_empty_kat(oracle_mod):
+    # /root/reference/homographier/src/homographier/mod.rs:683-707: the identity warp is idempotent
+    n = 4
+    img = np.array([[1, (i % n) + 1, (i // n) + 1, 1] for i in range(n * n)], np.uint8).reshape(n, n, 4)[..., [2, 1, 0, 3]].copy()
+    assert np.array_equal(oracle_mod.warp_perspective(img, np.eye(3)), img)
+    rng = np.random.default_rng(0)
+    big = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    assert np.array_equal(oracle_mod.warp_perspective(big, np.eye(3)), big)
+    shifted = oracle_mod.warp_perspective(big, np.array([[1, 0, 3.0], [0, 1, 2.0], [0, 0, 1]]))
+    assert np.array_equal(shifted[2:, 3:], big[:-2, :-3]) and (shifted[:2] == 1).all() and (shifted[:, :3] == 1).all()
