@@ -57,6 +57,9 @@ def main():
     ap.add_argument("--db-rows", type=int, default=1_000_000, help="total descriptor DB rows (sharded over the ranks)")
     ap.add_argument("--frames", type=int, default=2, help="distinct frames per rank, cycled")
     ap.add_argument("--filter-strength", type=float, default=0.3, help="Lowe ratio (reference test: 0.3, lib.rs:222)")
+    ap.add_argument("--workload", choices=["frame", "l2"], default="frame",
+                    help="frame: the north-star pipeline (default). l2: BASELINE config 3, float-descriptor L2 match as an MFMA GEMM (1 GPU)")
+    ap.add_argument("--l2-queries", type=int, default=1_048_576)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs masked out of the match stream so the other stages overlap it")
     ap.add_argument("--serial", action="store_true", help="one frame at a time (no cross-frame overlap of the three stages)")
@@ -88,6 +91,8 @@ def main():
     L = pkg.lib()
     check = pkg._lib.check
     check(L.apds_set_device(dev_index))
+    if args.workload == "l2":
+        return bench_l2(args, pkg, pl, torch, dev, world)
     synth = pkg.synth
     T, NDB = args.tile, args.db_rows
 
@@ -258,6 +263,50 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_l2(args, pkg, pl, torch, dev, world):
+    """BASELINE config 3: 256 x 1024^2 tiles' worth of float descriptors (Q = 1,048,576 x 128 f32, 30 % planted) vs a
+    1M x 128 f32 DB, top-2 by L2 distance, one MI355X. The reference has no float/L2 matcher (lib.rs:101,121)."""
+    assert world == 1, "the L2 workload is a single-GPU configuration"
+    L, check = pkg.lib(), pkg._lib.check
+    nq, nt, dim = args.l2_queries, args.db_rows, 128
+    torch.cuda.set_stream(torch.cuda.Stream(dev))
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x4C32)
+    db = torch.nn.functional.normalize(torch.randn((nt, dim), device=dev, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn((nq, dim), device=dev, generator=g), dim=1)
+    npl = int(0.3 * nq)
+    src = torch.randint(0, nt, (npl,), device=dev, generator=g)
+    q[:npl] = torch.nn.functional.normalize(db[src] + 0.05 * torch.randn((npl, dim), device=dev, generator=g), dim=1)
+    out = torch.empty((nq, 2), dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        check(L.apds_dev_l2_topk(q.data_ptr(), nq, db.data_ptr(), nt, dim, 0, 2, out.data_ptr(), pl.torch_stream()))
+
+    for _ in range(args.warmup):
+        step()
+    check(L.apds_dev_timing_enable(1))
+    pkg._lib.kernel_ms("l2_topk")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ms, n = pkg._lib.kernel_ms("l2_topk")
+    check(L.apds_dev_timing_enable(0))
+    found = int(((out[:npl, 0] & 0xFFFFFFFF) == src).sum().item())
+    flops = 2.0 * nq * nt * dim
+    achieved = flops / (ms / max(n, 1) * 1e-3) / 1e12
+    print(json.dumps({
+        "metric": "Mmatches/sec (L2 brute-force top-2, float descriptors 128-d, vs 1M-row DB)", "value": nq * args.steps / elapsed / 1e6, "unit": "Mmatches/s",
+        "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32 (v_mfma_f32_32x32x2_f32, f32 accumulate)", "data": "synthetic",
+        "config": {"workload": f"l2_top2 q{nq}x{dim} vs db{nt}x{dim} (BASELINE config 3)", "planted_recovered": found / max(npl, 1)},
+        "roofline": {"kernel": "l2_topk_kernel<2,true>", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
+                     "traffic": None, "avg_launch_ms": ms / max(n, 1), "algorithmic_flops_per_launch": flops}}), flush=True)
 
 
 def cpu_baseline(pkg, frame, db_local, K, fs, db_xy, ref_stats):

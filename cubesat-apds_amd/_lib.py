@@ -24,7 +24,7 @@ SYMBOLS = [
     "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_ratio_filter",
     "apds_dev_cross_check", "apds_dev_akaze_extract", "apds_dev_points_from_matches", "apds_dev_find_homography",
     "apds_dev_valu_popcount_peak", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane", "apds_stream_create", "apds_stream_destroy",
-    "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective",
+    "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective", "apds_l2_knn_match", "apds_dev_l2_topk",
 ]
 
 
@@ -85,6 +85,8 @@ def lib():
             "apds_band_merger": (i, [vp, vp, vp, sz, vp, i, vp]),
             "apds_dev_band_merger": (i, [vp, vp, vp, sz, vp, i, vp, vp]),
             "apds_warp_perspective": (i, [vp, i, i, i, vp, i, i, vp]),
+            "apds_l2_knn_match": (i, [vp, i, vp, i, i, i, vp, vp]),
+            "apds_dev_l2_topk": (i, [vp, i, vp, i64, i, u32, i, vp, vp]),
         }
         for name, (rt, at) in sig.items():
             fn = getattr(L, name)

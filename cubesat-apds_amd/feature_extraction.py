@@ -119,3 +119,16 @@ def get_points_from_matches(img1_keypoints, img2_keypoints, matches, bug_compati
     p2 = np.zeros((len(m), 2), np.float32)
     check(lib().apds_get_points_from_matches(ptr(k1), len(k1), ptr(k2), len(k2), ptr(m), len(m), int(bug_compatible), ptr(p1), ptr(p2)))
     return p1, p2
+
+
+def l2_knn_match(query_desc, train_desc, k):
+    """NOT in the reference (it matches Hamming only, lib.rs:101,121): BFMatcher(NORM_L2).knnMatch for float descriptors
+    (BASELINE config 3), computed as an MFMA distance GEMM. Returns (idx int32, dist float32) of shape (nq, k)."""
+    q = np.ascontiguousarray(query_desc, np.float32)
+    t = np.ascontiguousarray(train_desc, np.float32)
+    if q.ndim != 2 or t.ndim != 2 or (q.shape[0] and t.shape[0] and q.shape[1] != t.shape[1]):
+        raise ApdsError(_lib.ERR_ASSERT, "descriptor matrices must be 2-D float32 with equal row length")
+    idx = np.zeros((q.shape[0], k), np.int32)
+    dist = np.zeros((q.shape[0], k), np.float32)
+    check(lib().apds_l2_knn_match(ptr(q), q.shape[0], ptr(t), t.shape[0], q.shape[1], int(k), ptr(idx), ptr(dist)))
+    return idx, dist

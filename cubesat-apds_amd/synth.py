@@ -128,3 +128,20 @@ def make_ransac_set(n=50000, seed=RANSAC_SEED, inlier_frac=0.4, noise=0.5, exten
     inl = u[:, 4] < inlier_frac
     dst[~inl] = u[~inl, 5:7] * extent
     return src.astype(np.float32), dst.astype(np.float32), H, inl
+
+
+def make_l2_set(n_db, n_query, dim=128, seed=L2_SEED, planted=0.3, noise=0.05):
+    """SURVEY §8d synthetic L2 data: unit-norm N(0,1) rows; `planted` of the queries are a DB row + N(0, noise^2), renormalised."""
+    def normal(sd, n):
+        u = uniform01(sd, 2 * n).reshape(2, n)
+        return np.sqrt(-2 * np.log(np.maximum(u[0], 1e-300))) * np.cos(2 * np.pi * u[1])
+    db = normal(seed, n_db * dim).reshape(n_db, dim)
+    db /= np.linalg.norm(db, axis=1, keepdims=True)
+    q = normal(seed ^ 0x1111, n_query * dim).reshape(n_query, dim)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    u = uniform01(seed ^ 0x2222, n_query * 2).reshape(n_query, 2)
+    src = np.minimum((u[:, 1] * n_db).astype(np.int64), n_db - 1)
+    pl = u[:, 0] < planted
+    pq = db[src[pl]] + noise * normal(seed ^ 0x3333, int(pl.sum()) * dim).reshape(-1, dim)
+    q[pl] = pq / np.linalg.norm(pq, axis=1, keepdims=True)
+    return db.astype(np.float32), q.astype(np.float32), np.where(pl, src, -1)

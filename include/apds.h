@@ -126,6 +126,14 @@ int apds_dev_band_merger(const void* red, const void* green, const void* blue, s
  * Scalar(1,1,1,1)). M (9 doubles) maps source to destination coordinates. channels must be 4 (Vec4b). */
 int apds_warp_perspective(const uint8_t* src, int rows, int cols, int channels, const double* M, int dst_rows, int dst_cols, uint8_t* dst);
 
+/* BASELINE config 3 (no reference call site: the reference matches Hamming only, lib.rs:101,121): brute-force L2 k-NN of float
+ * descriptors (dim <= 128) as an MFMA distance GEMM with a fused top-k; semantics of BFMatcher(NORM_L2).knnMatch
+ * (dist = sqrt(sum (q-t)^2), ties to the lower train index). k in {1,2}. idx/dist: n_query*k. */
+int apds_l2_knn_match(const float* query, int n_query, const float* train, int n_train, int dim, int k, int32_t* idx, float* dist);
+/* device form: out_keys = n_query*k uint64 (f32 bits of the SQUARED distance << 32 | train_index + index_base), ascending */
+int apds_dev_l2_topk(const void* query, int n_query, const void* train, int64_t n_train, int dim, uint32_t index_base, int k, void* out_keys,
+                     void* stream);
+
 /* ---- device-resident API ------------------------------------------------------------------- */
 /* All pointers below are HIP device pointers. stream: hipStream_t or NULL (the thread's own stream).
  * Calls are asynchronous on that stream unless they return a count to the host. */

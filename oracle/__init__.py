@@ -73,6 +73,8 @@ def lib():
         L.oracle_ransac_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_raster_to_mat.restype = C.c_int
         L.oracle_raster_to_mat.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+        L.oracle_knn_l2.restype = None
+        L.oracle_knn_l2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.oracle_band_merger.restype = None
         L.oracle_band_merger.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
         L.oracle_gamma_correction.restype = C.c_float
@@ -280,3 +282,13 @@ def warp_perspective(src, M, size=None):
     if lib().oracle_warp_perspective_8uc4(_ptr(src), h, w, _ptr(M), dh, dw, _ptr(out)) != 0:
         raise RuntimeError("singular matrix")
     return out
+
+
+def knn_l2(q, t, k):
+    """BFMatcher(NORM_L2).knnMatch semantics for float descriptors (BASELINE config 3; no reference call site)."""
+    q = np.ascontiguousarray(q, np.float32)
+    t = np.ascontiguousarray(t, np.float32)
+    idx = np.zeros((q.shape[0], k), np.int32)
+    dist = np.zeros((q.shape[0], k), np.float32)
+    lib().oracle_knn_l2(_ptr(q), q.shape[0], _ptr(t), t.shape[0], q.shape[1], k, _ptr(idx), _ptr(dist))
+    return idx, dist

@@ -7,6 +7,7 @@
 #include "oracle.h"
 
 #include <climits>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -122,6 +123,39 @@ int oracle_get_points_from_matches(const oracle_keypoint* kp1, int n1, const ora
         }
     }
     return 0;
+}
+
+void oracle_knn_l2(const float* q, int nq, const float* t, int nt, int dim, int k, int32_t* idx, float* dist) {
+    const int nth = oracle_get_threads();
+    (void)nth;
+#pragma omp parallel for num_threads(nth) schedule(static)
+    for (int i = 0; i < nq; i++) {
+        int32_t* bi = idx + (size_t)i * k;
+        float* bd = dist + (size_t)i * k;
+        for (int j = 0; j < k; j++) {
+            bi[j] = -1;
+            bd[j] = INFINITY;
+        }
+        const float* qi = q + (size_t)i * dim;
+        for (int r = 0; r < nt; r++) {
+            const float* tr = t + (size_t)r * dim;
+            float s = 0.f;
+            for (int c = 0; c < dim; c++) {
+                const float d = qi[c] - tr[c];
+                s += d * d;
+            }
+            const float d = sqrtf(s);
+            if (d < bd[k - 1]) {
+                int j = k - 2;
+                for (; j >= 0 && bd[j] > d; j--) {
+                    bd[j + 1] = bd[j];
+                    bi[j + 1] = bi[j];
+                }
+                bd[j + 1] = d;
+                bi[j + 1] = r;
+            }
+        }
+    }
 }
 
 int oracle_raster_to_mat(const uint8_t* rgba, size_t n_pixels, int w, int h, uint8_t* bgra) {

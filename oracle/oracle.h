@@ -101,6 +101,10 @@ int  oracle_ransac_samples(const float* src_xy, const float* dst_xy, int n, int 
 /* mod.rs:183-220: RGBA8 slice -> BGRA rows. Returns 0 or -1 (MatError::Unknown) if len != w*h. */
 int oracle_raster_to_mat(const uint8_t* rgba, size_t n_pixels, int w, int h, uint8_t* bgra);
 
+/* BASELINE config 3 (no reference call site; semantics of cv::BFMatcher(NORM_L2).knnMatch): dist = sqrtf(sum (q-t)^2) accumulated in
+ * f32 in index order, k smallest, ties to the lower train index. PARITY UNPINNED. */
+void oracle_knn_l2(const float* q, int nq, const float* t, int nt, int dim, int k, int32_t* idx, float* dist);
+
 /* geotiff_extractor/src/image_extractor/mod.rs:346-378 band_merger (+ f32_to_u8 :410-422, gamma_correction :402-408):
  * three f32 bands + per-band min/max -> RGBA8. NaN or out-of-range -> 0; alpha 0 only when all three bands are NaN. */
 void oracle_band_merger(const float* red, const float* green, const float* blue, size_t n, const double* minmax6, uint8_t* rgba);
