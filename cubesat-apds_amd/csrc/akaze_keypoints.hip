@@ -10,6 +10,8 @@
 // exactly by dependency rounds: a keypoint is processed in the first round in which no EARLIER (row-major)
 // keypoint of its own level with an overlapping search window is still pending. All levels run in the same
 // rounds because the passes of one phase only read snapshots of the level they iterate over.
+#include <cstdlib>
+
 #include "akaze.h"
 
 namespace apds {
@@ -114,54 +116,86 @@ __device__ __forceinline__ bool find_neighbor(const uint8_t* __restrict__ mask, 
     return false;
 }
 
-__global__ void suppress_round_kernel(SuppressArgs A, uint8_t stamp, int* __restrict__ pending_out) {
+// One WAVE per candidate keypoint: the readiness window (up to 37 x 19 status bytes) and the neighbour search window
+// (up to 16 x 16 mask bytes) are scanned 64 elements at a time; "first hit in row-major order" is the lowest set bit
+// of the ballot of the first 64-element slab that has one. (A single thread walking these windows byte by byte took
+// ~48 us per round; a frame needs ~20 rounds.)
+__global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uint8_t stamp, int* __restrict__ pending_out) {
     APDS_RAISE_WAVE_PRIORITY();
     const int lvl = blockIdx.y;
     const int other = A.phase == 0 ? lvl - 1 : lvl + 1;
     if (other < 0 || other >= A.n_levels) return;
     const int cnt = A.list_count[lvl];
-    const int w = A.w[lvl];
+    const int w = A.w[lvl], h = A.h[lvl];
+    const int lane = threadIdx.x & 63;
     uint8_t* status = A.status[lvl];
+    // interaction distance in this level's pixels (conservative superset of "search windows overlap")
+    int D, diff, radius;
+    if (A.phase == 0) {
+        diff = A.iratio[lvl] / A.iratio[other];
+        radius = A.sigma_size[lvl] * diff;
+        D = 2 * A.sigma_size[lvl];
+    } else {
+        diff = A.iratio[other] / A.iratio[lvl];
+        radius = A.sigma_size[other];
+        D = (2 * radius + 1) * diff;
+    }
+    const int W = 2 * D + 1, total = W * (D + 1);
+    const int side = 2 * radius, total2 = side * side;
+    const int ow = A.w[other], oh = A.h[other];
+    const uint8_t* __restrict__ omask = A.mask[other];
     int local_pending = 0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < cnt; i += gridDim.x * 4) {
         const uint32_t e = A.list[lvl][i];
         const int x = e & 0xFFFF, y = e >> 16;
         const size_t p = (size_t)y * w + x;
-        if (status[p] != ST_PENDING) continue;
-        // interaction distance in this level's pixels (conservative superset of "search windows overlap")
-        int D, diff, radius;
-        if (A.phase == 0) {
-            diff = A.iratio[lvl] / A.iratio[other];
-            radius = A.sigma_size[lvl] * diff;
-            D = 2 * A.sigma_size[lvl];
-        } else {
-            diff = A.iratio[other] / A.iratio[lvl];
-            radius = A.sigma_size[other];
-            D = (2 * radius + 1) * diff;
-        }
-        bool ready = true;
-        for (int yy = max(y - D, 0); yy <= y && ready; yy++) {
-            const int xe = yy == y ? x - 1 : min(x + D, w - 1);
-            for (int xx = max(x - D, 0); xx <= xe; xx++) {
-                const uint8_t s = status[(size_t)yy * w + xx];
-                if (s == ST_PENDING || s == stamp) {   // still pending, or finished only in this very round
-                    ready = false;
-                    break;
+        if (status[p] != ST_PENDING) continue;   // wave-uniform
+        // ready iff no EARLIER (row-major) keypoint of this level within D is pending or finished only in this round
+        bool blocked = false;
+        for (int base = 0; base < total && !blocked; base += 64) {
+            const int idx = base + lane;
+            bool hit = false;
+            if (idx < total) {
+                const int ry = idx / W, rx = idx - ry * W;
+                const int yy = y - D + ry, xx = x - D + rx;
+                if (yy >= 0 && xx >= 0 && xx < w && (yy < y || xx < x)) {
+                    const uint8_t s = status[(size_t)yy * w + xx];
+                    hit = s == ST_PENDING || s == stamp;
                 }
             }
+            blocked = __any(hit);
         }
-        if (!ready) {
+        if (blocked) {
             local_pending++;
             continue;
         }
-        int idx = 0;
         const int px = A.phase == 0 ? x * diff : x / diff, py = A.phase == 0 ? y * diff : y / diff;
-        if (find_neighbor(A.mask[other], A.w[other], A.h[other], px, py, radius, idx)) {
-            if (A.Ldet[lvl][p] > A.Ldet[other][idx]) A.mask[other][idx] = 0;
+        int found = -1;
+        for (int base = 0; base < total2 && found < 0; base += 64) {
+            const int idx = base + lane;
+            bool ok = false;
+            if (idx < total2) {
+                const int iy = idx / side, ix = idx - iy * side;
+                const int ii = py - radius + iy, jj = px - radius + ix;
+                if (ii >= 0 && ii < oh && jj >= 0 && jj < ow && omask[(size_t)ii * ow + jj]) {
+                    const int dx = jj - px, dy = ii - py;
+                    ok = dx * dx + dy * dy <= radius * radius;
+                }
+            }
+            const unsigned long long b = __ballot(ok);
+            if (b) {
+                const int first = base + __ffsll((long long)b) - 1;
+                const int iy = first / side, ix = first - iy * side;
+                found = (py - radius + iy) * ow + (px - radius + ix);
+            }
         }
-        status[p] = stamp;
+        if (lane == 0) {
+            if (found >= 0 && A.Ldet[lvl][p] > A.Ldet[other][found]) A.mask[other][found] = 0;
+            status[p] = stamp;
+        }
     }
-    if (local_pending) atomicAdd(pending_out, local_pending);
+    (void)h;
+    if (lane == 0 && local_pending) atomicAdd(pending_out, local_pending);
 }
 
 // ---- a1.7 sub-pixel refinement ---------------------------------------------------------------------------------
@@ -216,31 +250,52 @@ __global__ __launch_bounds__(SCAN_BLOCK) void emit_keypoints_kernel(LevelTable T
                                                                     int capacity) {
     APDS_RAISE_WAVE_PRIORITY();
     __shared__ int wsum[SCAN_BLOCK / 64];
-    const long long e = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    const int f = e < total ? (flags[e] != 0) : 0;
-    const unsigned long long b = __ballot(f);
+    const long long base = ((long long)blockIdx.x * SCAN_BLOCK + threadIdx.x) * 16;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (base < total) {
+        const uint8_t* p = flags + base;
+        if (base + 16 <= total) v = *reinterpret_cast<const uint4*>(p);
+        else {
+            uint32_t w[4] = {0, 0, 0, 0};
+            for (int b = 0; b < 16; b++)
+                if (base + b < total && p[b]) w[b >> 2] |= 1u << (8 * (b & 3));
+            v = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    const int mine = __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
+    // exclusive position of this thread's first keypoint inside the block: wave prefix (shuffles) + earlier waves
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) wsum[wv] = __popcll(b);
+    int incl = mine;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
     __syncthreads();
-    if (!f) return;
+    if (!mine) return;
     int before = 0;
     for (int k = 0; k < wv; k++) before += wsum[k];
-    const int pos = block_offsets[blockIdx.x] + before + __popcll(b & ((1ull << lane) - 1ull));
-    if (pos >= capacity) return;
-    int lvl = 0;
-    while (lvl + 1 < T.n && e >= T.pix_offset[lvl + 1]) lvl++;
-    const long long pix = e - T.pix_offset[lvl];
-    const int y = (int)(pix / T.w[lvl]), x = (int)(pix - (long long)y * T.w[lvl]);
-    const Refined r = refine(T.Ldet[lvl], T.w[lvl], x, y, T.ratio[lvl]);
-    apds_keypoint kp;
-    kp.x = r.x;
-    kp.y = r.y;
-    kp.size = (T.esigma[lvl] * 1.5f) * 2.0f;
-    kp.angle = 0.0f;
-    kp.response = r.response;
-    kp.octave = T.octave[lvl];
-    kp.class_id = lvl;
-    kps[pos] = kp;
+    int pos = block_offsets[blockIdx.x] + before + incl - mine;
+    const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+    for (int b = 0; b < 16; b++) {
+        if (!((words[b >> 2] >> (8 * (b & 3))) & 0xFF)) continue;
+        if (pos >= capacity) return;
+        const long long e = base + b;
+        int lvl = 0;
+        while (lvl + 1 < T.n && e >= T.pix_offset[lvl + 1]) lvl++;
+        const long long pix = e - T.pix_offset[lvl];
+        const int y = (int)(pix / T.w[lvl]), x = (int)(pix - (long long)y * T.w[lvl]);
+        const Refined r = refine(T.Ldet[lvl], T.w[lvl], x, y, T.ratio[lvl]);
+        apds_keypoint kp;
+        kp.x = r.x;
+        kp.y = r.y;
+        kp.size = (T.esigma[lvl] * 1.5f) * 2.0f;
+        kp.angle = 0.0f;
+        kp.response = r.response;
+        kp.octave = T.octave[lvl];
+        kp.class_id = lvl;
+        kps[pos++] = kp;
+    }
 }
 
 // ---- max_points: keep the `keep` strongest (response desc, ties by detection order), in that order -------------
@@ -626,14 +681,33 @@ T* upload(const std::vector<T>& v, hipStream_t s) {
 
 }  // namespace
 
-// kernels from match_hamming.hip's compaction utility, re-declared for the 64-bit flag space used here
+// Ordered compaction over the concatenated level masks: every thread owns 16 consecutive mask bytes (one 16-byte load),
+// a block 16 KiB; per-block counts -> exclusive offsets (single block) -> emit.
+static constexpr int KP_BYTES_PER_BLOCK = SCAN_BLOCK * 16;
+
+__device__ __forceinline__ uint4 load_flags16(const uint8_t* __restrict__ flags, long long base, long long n) {
+    if (base + 16 <= n) return *reinterpret_cast<const uint4*>(flags + base);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int b = 0; b < 16; b++)
+        if (base + b < n && flags[base + b]) w[b >> 2] |= 1u << (8 * (b & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+__device__ __forceinline__ int nonzero_bytes(uint32_t w) {
+    // mask bytes are 0 or 1
+    return __popc(w & 0x01010101u);
+}
+
 __global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8_t* __restrict__ flags, long long n, int* __restrict__ block_counts) {
     APDS_RAISE_WAVE_PRIORITY();
     __shared__ int wsum[SCAN_BLOCK / 64];
-    const long long i = (long long)blockIdx.x * SCAN_BLOCK + threadIdx.x;
-    const int f = i < n ? (flags[i] != 0) : 0;
-    const unsigned long long b = __ballot(f);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+    const long long base = ((long long)blockIdx.x * SCAN_BLOCK + threadIdx.x) * 16;
+    int c = 0;
+    if (base < n) {
+        const uint4 v = load_flags16(flags, base, n);
+        c = nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
+    }
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) {
         int sum = 0;
@@ -853,18 +927,33 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
 
     // ---- cross-level suppression: phase 0 (vs previous level), then phase 1 (vs next level)
     if (L > 1) {
-        const dim3 lgrid(64, L), lblock(256);
+        const dim3 lgrid(256, L), lblock(256);   // 1024 waves per level, one candidate keypoint per wave at a time
         for (int phase = 0; phase < 2; phase++) {
             A.phase = phase;
             hipLaunchKernelGGL(suppress_init_status_kernel, lgrid, lblock, 0, s, A);
             int round = 0;
+            static const bool dbg_rounds = getenv("APDS_AKAZE_DEBUG") != nullptr;
+            if (dbg_rounds) {
+                int counts[AKAZE_MAX_LEVELS];
+                HIP_CHECK(hipMemcpyAsync(counts, list_count, sizeof(counts), hipMemcpyDeviceToHost, s));
+                HIP_CHECK(hipStreamSynchronize(s));
+                fprintf(stderr, "[apds] phase %d candidates per level:", phase);
+                for (int i = 0; i < L; i++) fprintf(stderr, " %d", counts[i]);
+                fprintf(stderr, "\n");
+            }
             for (;;) {
                 for (int b = 0; b < 4; b++) {
-                    if (b == 3) HIP_CHECK(hipMemsetAsync(pending_dev, 0, sizeof(int), s));
+                    if (b == 3 || dbg_rounds) HIP_CHECK(hipMemsetAsync(pending_dev, 0, sizeof(int), s));
                     const uint8_t stamp = (uint8_t)(round % 253 + 1);
                     hipLaunchKernelGGL(suppress_round_kernel, lgrid, lblock, 0, s, A, stamp, pending_dev);
                     round++;
                     if (round % 253 == 0) hipLaunchKernelGGL(suppress_canon_kernel, lgrid, lblock, 0, s, A);
+                    if (dbg_rounds) {
+                        int pend = 0;
+                        HIP_CHECK(hipMemcpyAsync(&pend, pending_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+                        HIP_CHECK(hipStreamSynchronize(s));
+                        fprintf(stderr, "[apds]   phase %d round %d pending %d\n", phase, round, pend);
+                    }
                 }
                 int pending = 0;
                 HIP_CHECK(hipMemcpyAsync(&pending, pending_dev, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -898,7 +987,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     uint32_t** lists_dev = c.alloc_n<uint32_t*>(L);
     HIP_CHECK(hipMemcpyAsync(lists_dev, lists.data(), L * sizeof(uint32_t*), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(subpixel_filter_kernel, dim3(64, L), dim3(256), 0, s, T, (const uint32_t* const*)lists_dev, (const int*)list_count);
-    const int nblocks = ceil_div(total_pix, SCAN_BLOCK);
+    const int nblocks = ceil_div(total_pix, KP_BYTES_PER_BLOCK);
     int* block_counts = c.alloc_n<int>(nblocks + 1);
     int* total_dev = block_counts + nblocks;
     hipLaunchKernelGGL(kp_block_counts_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, mask_all, total_pix, block_counts);
