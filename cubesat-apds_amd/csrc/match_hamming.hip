@@ -441,7 +441,7 @@ static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false
 
 template <int K>
 static void launch_topk(const void* q, int nq, const void* t, long long nt, uint32_t index_base, const int* init_thr,
-                        uint64_t* parts, const ChunkPlan& p, hipStream_t s) {
+                        uint64_t* parts, const ChunkPlan& p, hipStream_t s, const char* timer_name = "hamming_topk") {
     static const int xcd = env_int("APDS_MATCH_XCD", 0);
     static const int persist = env_int("APDS_MATCH_PERSIST", 0);   // resident workgroups per CU (0 = plain grid)
     const u32x16* tr = static_cast<const u32x16*>(t);
@@ -451,7 +451,7 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, uint
         int* counter = ctx().alloc_n<int>(1);
         HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
         dim3 grid(256 * persist), block(256);
-        KernelTimer timer("hamming_topk", s);
+        KernelTimer timer(timer_name, s);
         switch (p.T) {
             case 4: hipLaunchKernelGGL((hamming_topk_persistent_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, counter); break;
             case 2: hipLaunchKernelGGL((hamming_topk_persistent_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, counter); break;
@@ -461,7 +461,7 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, uint
         return;
     }
     dim3 grid((unsigned)(ceil_div(p.chunks, 8) * 8 * p.qtiles_blocks)), block(256);
-    KernelTimer timer("hamming_topk", s);
+    KernelTimer timer(timer_name, s);
     switch (p.T) {
         case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
         case 2: hipLaunchKernelGGL((hamming_topk_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
@@ -492,8 +492,8 @@ void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uin
         ChunkPlan sp = plan_chunks(nq, sample, true);
         uint64_t* sparts = c.alloc_n<uint64_t>((size_t)sp.chunks * nq * k);
         sample_keys = c.alloc_n<uint64_t>((size_t)nq * k);
-        if (k == 2) launch_topk<2>(q, nq, t, sample, index_base, nullptr, sparts, sp, s);
-        else launch_topk<1>(q, nq, t, sample, index_base, nullptr, sparts, sp, s);
+        if (k == 2) launch_topk<2>(q, nq, t, sample, index_base, nullptr, sparts, sp, s, "hamming_topk_sample");
+        else launch_topk<1>(q, nq, t, sample, index_base, nullptr, sparts, sp, s, "hamming_topk_sample");
         if (k == 2) hipLaunchKernelGGL((merge_topk_kernel<2>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, sparts, sp.chunks, nq, sample_keys);
         else hipLaunchKernelGGL((merge_topk_kernel<1>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, sparts, sp.chunks, nq, sample_keys);
         int* thr_buf = c.alloc_n<int>(nq);

@@ -290,7 +290,7 @@ class StreamedFramePipeline:
                     s["ev_match"].record(self.streams[1])
                     q2.put(s)
                 q2.put(None)
-                collect(["hamming_topk"])
+                collect(["hamming_topk", "hamming_topk_sample"])
 
         def homography_worker():
             with torch.cuda.stream(self.streams[2]):

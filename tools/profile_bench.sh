@@ -8,6 +8,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof
 rm -rf $OUT && mkdir -p $OUT
 ARGS="--steps 5 --warmup 2 --no-cpu-baseline"
+# serial run first: per-kernel durations without cross-stage overlap (the streamed run stretches the short kernels)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -- python3 $R/bench.py --serial $ARGS > $OUT/bench_stats_serial.log 2>&1
+echo "serial stats rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/bench_stats.log 2>&1
 echo "stats rc=$?"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
@@ -16,6 +19,7 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/b
 echo "write rc=$?"
 find $OUT -name "*.csv" | head -20
 python3 $R/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+mkdir -p $OUT/tmp_serial && cp -r $OUT/stats_serial $OUT/tmp_serial/stats && python3 $R/tools/summarize_profile.py $OUT/tmp_serial > $OUT/summary_serial.txt 2>&1; rm -rf $OUT/tmp_serial
 cat $OUT/summary.txt | head -60
 # keep the merged output small: drop the raw per-dispatch traces after summarising
 find $OUT -name "*kernel_trace.csv" -size +20M -delete

@@ -25,11 +25,11 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     tot, n = 0.0, 0
     for f in find(f"{name}/**/*counter_collection.csv"):
         for r in csv.DictReader(open(f)):
-            if "hamming_topk_kernel" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+            if "hamming_topk_kernel<4, 2>" in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:   # the main launch (the <1,2> instance is the threshold pre-pass)
                 tot += float(r["Counter_Value"])
                 n += 1
     res[counter] = (tot, n)
-print("== PMC (per-dispatch sums over hamming_topk_kernel) ==")
+print("== PMC (per-dispatch sums over hamming_topk_kernel<4, 2>, the main match launch) ==")
 print(res)
 if res["FETCH_SIZE"][1]:
     # rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB; MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes
