@@ -73,7 +73,6 @@ struct SuppressArgs {
     uint8_t* status[AKAZE_MAX_LEVELS];   // snapshot of the iterated level: 0 none, 255 pending, else done stamp
     const uint32_t* list[AKAZE_MAX_LEVELS];
     const int* list_count;               // [n_levels]
-    int list_base[AKAZE_MAX_LEVELS + 1]; // prefix of per-level list capacities in the flattened thread space
 };
 
 __global__ void suppress_init_status_kernel(SuppressArgs A) {
@@ -97,23 +96,6 @@ __global__ void suppress_canon_kernel(SuppressArgs A) {
         const uint8_t s = A.status[lvl][p];
         if (s >= 1 && s <= 253) A.status[lvl][p] = ST_DONE_OLD;
     }
-}
-
-// first set mask pixel in [x-r,x+r) x [y-r,y+r) (row-major scan) that lies within radius r
-__device__ __forceinline__ bool find_neighbor(const uint8_t* __restrict__ mask, int w, int h, int x, int y, int r, int& idx) {
-    for (int i = y - r; i < y + r; ++i) {
-        if (i < 0 || i >= h) continue;
-        for (int j = x - r; j < x + r; ++j) {
-            if (j < 0 || j >= w) continue;
-            if (!mask[(size_t)i * w + j]) continue;
-            const int dx = j - x, dy = i - y;
-            if (dx * dx + dy * dy <= r * r) {
-                idx = i * w + j;
-                return true;
-            }
-        }
-    }
-    return false;
 }
 
 // One WAVE per candidate keypoint: the readiness window (up to 37 x 19 status bytes) and the neighbour search window

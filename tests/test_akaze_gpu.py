@@ -95,3 +95,35 @@ def test_to_db_type(gpu_pkg):
     r = rows[0]
     assert r.image_id == 42 and len(r.descriptor) == 61 and r.descriptor == bytes(ex.descriptors[0])
     assert r.x_coord == float(ex.keypoints["x"][0]) and r.class_id == int(ex.keypoints["class_id"][0])
+
+
+def test_noise_image_many_keypoints_and_large_max_points(gpu_pkg, oracle_mod):
+    """Pure noise: tens of thousands of keypoints per megapixel, dense cross-level interaction, and a max_points cut that
+    goes through the rank-select kernel at scale (ties in response are broken by detection order)."""
+    rng = np.random.default_rng(12)
+    tile = rng.integers(0, 256, (768, 1024), dtype=np.uint8)
+    oracle_mod.set_threads(8)
+    ref = oracle_mod.akaze(tile)
+    got = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(tile, None)
+    assert len(ref.keypoints) > 5000
+    _assert_same_extraction(got, ref)
+    cut = len(ref.keypoints) // 3
+    _assert_same_extraction(gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(tile, cut), oracle_mod.akaze(tile, max_points=cut))
+
+
+def test_strided_rows_and_channel_orders(gpu_pkg, oracle_mod):
+    """Mat rows may be padded (step > cols * channels); BGR weights differ per channel."""
+    rng = np.random.default_rng(13)
+    base = gpu_pkg.synth.make_tile(200, 264, frame_index=21, channels=3).astype(np.int32)
+    base[..., 0] = np.clip(base[..., 0] + rng.integers(-40, 40, base.shape[:2]), 0, 255)
+    base[..., 2] = np.clip(255 - base[..., 2], 0, 255)
+    img = base.astype(np.uint8)
+    padded = np.zeros((200, 264 + 9, 3), np.uint8)
+    padded[:, :264] = img
+    view = padded[:, :264]                       # non-contiguous rows: stride 273*3
+    assert not view.flags["C_CONTIGUOUS"]
+    got = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(view, None)
+    ref = oracle_mod.akaze(img)
+    _assert_same_extraction(got, ref)
+    bgra = np.dstack([img, np.full(img.shape[:2], 255, np.uint8)])
+    _assert_same_extraction(gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(bgra, None), ref)
