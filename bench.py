@@ -51,8 +51,8 @@ def detect_algorithmic_bytes(w, h):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--tile", type=int, default=4096)
     ap.add_argument("--db-rows", type=int, default=1_000_000, help="total descriptor DB rows (sharded over the ranks)")
     ap.add_argument("--frames", type=int, default=2, help="distinct frames per rank, cycled")

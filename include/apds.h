@@ -134,6 +134,22 @@ int apds_l2_knn_match(const float* query, int n_query, const float* train, int n
 int apds_dev_l2_topk(const void* query, int n_query, const void* train, int64_t n_train, int dim, uint32_t index_base, int k, void* out_keys,
                      void* stream);
 
+/* GPU-resident keypoint table: the reference's `keypoint` table and its access paths without Postgres.
+ * insert: preprocessor/src/main.rs:296-324 (x,y lifted to level-of-detail-0 pixels: v * 2^lod + index * tile * 2^lod).
+ * select: feature_database/src/keypointdb.rs:38-90, mode 0 by image id, 1 by level of detail, 2 by level of detail and bounding box
+ * (floor(start) <= v <= ceil(end)); always ORDER BY response DESC LIMIT 262143 (keypointdb.rs:12). The selection stays on the
+ * device as the table's "view": 64-byte descriptor rows ready to be a train set for apds_dev_hamming_topk. */
+int apds_db_create(void** db, int64_t capacity);
+int apds_db_destroy(void* db);
+int64_t apds_db_rows(const void* db);
+int apds_db_insert_image(void* db, const apds_keypoint* kps, const uint8_t* desc61, int n, int image_id, int level_of_detail, uint64_t column,
+                         uint64_t row, uint64_t tile_w, uint64_t tile_h);
+int apds_db_select(void* db, int mode, int value, float x_start, float y_start, float x_end, float y_end, int* n_out);
+int apds_db_view(void* db, void** rows64_dev, void** kps_dev, void** row_ids_dev, void** image_ids_dev, int* n);
+int apds_db_view_download(void* db, apds_keypoint* kps, uint8_t* desc61, int32_t* ids, int32_t* image_ids);
+/* knnMatch (k in {1,2}) of host query descriptors against the current view; idx = position in the view (= trainIdx of the Vec the reference would hold) */
+int apds_db_knn_match(void* db, const uint8_t* query_desc, int n_query, int desc_bytes, int k, int32_t* idx, int32_t* dist);
+
 /* ---- device-resident API ------------------------------------------------------------------- */
 /* All pointers below are HIP device pointers. stream: hipStream_t or NULL (the thread's own stream).
  * Calls are asynchronous on that stream unless they return a count to the host. */
