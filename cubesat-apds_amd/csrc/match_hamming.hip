@@ -58,17 +58,22 @@ __device__ __forceinline__ void insert_hits(const int (&acc)[T], const int (&nth
         if (acc[t] < 0) {   // the 480-bit bound is below the threshold this pair was screened with: finish the distance
             const int d = acc[t] - nthr_old[t] + __popc(q[t][15] ^ row15);
             if (d < bd[t][K - 1]) {
-                if (K == 2) {
-                    if (d < bd[t][0]) {
-                        bd[t][1] = bd[t][0];
-                        bi[t][1] = bi[t][0];
-                        bd[t][0] = d;
-                        bi[t][0] = r;
-                    } else {
-                        bd[t][1] = d;
-                        bi[t][1] = r;
+                // insertion with strict '<': a later row never moves ahead of an equal earlier one
+                bool placed = false;
+#pragma unroll
+                for (int j = K - 1; j > 0; j--) {
+                    if (!placed) {
+                        if (bd[t][j - 1] > d) {
+                            bd[t][j] = bd[t][j - 1];
+                            bi[t][j] = bi[t][j - 1];
+                        } else {
+                            bd[t][j] = d;
+                            bi[t][j] = r;
+                            placed = true;
+                        }
                     }
-                } else {
+                }
+                if (!placed) {
                     bd[t][0] = d;
                     bi[t][0] = r;
                 }
@@ -225,32 +230,50 @@ __global__ void merge_topk_kernel(const uint64_t* __restrict__ parts_keys, int p
     APDS_RAISE_WAVE_PRIORITY();
     const int qi = blockIdx.x * blockDim.x + threadIdx.x;
     if (qi >= nq) return;
-    uint64_t b0 = EMPTY_KEY, b1 = EMPTY_KEY;
+    uint64_t best[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) best[k] = EMPTY_KEY;
     auto push = [&](uint64_t key) {
-        if (key < b0) {
-            b1 = b0;
-            b0 = key;
-        } else if (key < b1) {
-            b1 = key;
+        if (key < best[K - 1]) {
+            bool placed = false;
+#pragma unroll
+            for (int j = K - 1; j > 0; j--) {
+                if (!placed) {
+                    if (best[j - 1] > key) best[j] = best[j - 1];
+                    else {
+                        best[j] = key;
+                        placed = true;
+                    }
+                }
+            }
+            if (!placed) best[0] = key;
         }
     };
+    constexpr int U = K <= 2 ? 8 : 2;   // independent loads in flight per lane
     int p = 0;
-    for (; p + 8 <= parts; p += 8) {   // 8 independent loads in flight per lane
-        uint64_t v[8][K];
+    for (; p + U <= parts; p += U) {
+        uint64_t v[U][K];
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < U; u++)
 #pragma unroll
             for (int k = 0; k < K; k++) v[u][k] = parts_keys[((size_t)(p + u) * nq + qi) * K + k];
 #pragma unroll
-        for (int u = 0; u < 8; u++)
+        for (int u = 0; u < U; u++)
 #pragma unroll
             for (int k = 0; k < K; k++) push(v[u][k]);
     }
     for (; p < parts; p++)
 #pragma unroll
         for (int k = 0; k < K; k++) push(parts_keys[((size_t)p * nq + qi) * K + k]);
-    out[(size_t)qi * K] = b0;
-    if (K == 2) out[(size_t)qi * K + 1] = b1;
+#pragma unroll
+    for (int k = 0; k < K; k++) out[(size_t)qi * K + k] = best[k];
+}
+
+__global__ void take_first_columns_kernel(const uint64_t* __restrict__ in, int nq, int kin, int kout, uint64_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nq * kout) return;
+    const int q = (int)(i / kout), c = (int)(i - (long long)q * kout);
+    out[i] = in[(size_t)q * kin + c];
 }
 
 // second-best distance of a sample of train rows -> initial thresholds for the full scan
@@ -415,7 +438,7 @@ static int env_int(const char* name, int dflt) {
 // Work items are (64*T queries) x (rows_per_chunk train rows) per wave. Items are kept small enough that the
 // grid is many dispatch rounds deep (the block scheduler then balances the tail), but not so small that the
 // per-chunk candidate lists dominate the merge.
-static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false) {
+static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false, bool one_query_per_lane = false) {
     ChunkPlan p;
     static const int forced_t = env_int("APDS_MATCH_T", 0);
     static const int target_waves = env_int("APDS_MATCH_TARGET_WAVES", 256 * 4 * 4 * 12);
@@ -427,6 +450,7 @@ static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false
     if (forced_t == 1 || forced_t == 2 || forced_t == 4) p.T = forced_t;
     // the threshold pre-pass covers few rows: smaller items (T = 1, short chunks) keep all CUs busy
     if (sample_pass && (sample_t == 1 || sample_t == 2 || sample_t == 4)) p.T = std::min(p.T, sample_t);
+    if (one_query_per_lane) p.T = 1;
     const int waves_q = ceil_div(nq, 64 * p.T);
     p.qtiles_blocks = ceil_div(waves_q, 4);
     long long chunks = ceil_div(target_waves, waves_q);
@@ -447,6 +471,14 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, uint
     const u32x16* tr = static_cast<const u32x16*>(t);
     const u32x4* qq = static_cast<const u32x4*>(q);
     const int items = p.qtiles_blocks * p.chunks;
+    if (K > 2) {   // larger k keeps K (distance, index) pairs per query in registers: one query per lane
+        dim3 grid((unsigned)(ceil_div(p.chunks, 8) * 8 * p.qtiles_blocks)), block(256);
+        KernelTimer timer(timer_name, s);
+        hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks,
+                           p.chunks, 0);
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     if (persist > 0 && items > 256 * persist) {
         int* counter = ctx().alloc_n<int>(1);
         HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
@@ -470,16 +502,13 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, uint
     HIP_CHECK(hipGetLastError());
 }
 
-// Full top-k of nq queries over nt train rows (device, 64-byte rows). out: nq*k keys.
-void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out,
-                         hipStream_t s) {
-    APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "device top-k supports k in {1,2}");
-    APDS_REQUIRE(nt < (1ll << 31), APDS_ERR_ASSERT, "train set too large for one call; shard it");
-    if (nq <= 0) return;
-    if (nt <= 0) {
-        HIP_CHECK(hipMemsetAsync(out, 0xFF, (size_t)nq * k * 8, s));
-        return;
-    }
+template <int K>
+static void merge_launch(const uint64_t* parts, int nparts, int nq, uint64_t* out, hipStream_t s) {
+    hipLaunchKernelGGL((merge_topk_kernel<K>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, nq, out);
+}
+
+template <int K>
+static void topk_device_k(const void* q, int nq, const void* t, long long nt, uint32_t index_base, uint64_t* out, hipStream_t s) {
     ThreadCtx& c = ctx();
     // Phase 0 (only for large scans): exact top-k over the first `sample` rows gives per-query thresholds that
     // every chunk starts from, so the rare-hit fast path is reached immediately. The sample rows have the
@@ -489,39 +518,65 @@ void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uin
     const int* thr = nullptr;
     uint64_t* sample_keys = nullptr;
     if (sample) {
-        ChunkPlan sp = plan_chunks(nq, sample, true);
-        uint64_t* sparts = c.alloc_n<uint64_t>((size_t)sp.chunks * nq * k);
-        sample_keys = c.alloc_n<uint64_t>((size_t)nq * k);
-        if (k == 2) launch_topk<2>(q, nq, t, sample, index_base, nullptr, sparts, sp, s, "hamming_topk_sample");
-        else launch_topk<1>(q, nq, t, sample, index_base, nullptr, sparts, sp, s, "hamming_topk_sample");
-        if (k == 2) hipLaunchKernelGGL((merge_topk_kernel<2>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, sparts, sp.chunks, nq, sample_keys);
-        else hipLaunchKernelGGL((merge_topk_kernel<1>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, sparts, sp.chunks, nq, sample_keys);
+        ChunkPlan sp = plan_chunks(nq, sample, true, K > 2);
+        uint64_t* sparts = c.alloc_n<uint64_t>((size_t)sp.chunks * nq * K);
+        sample_keys = c.alloc_n<uint64_t>((size_t)nq * K);
+        launch_topk<K>(q, nq, t, sample, index_base, nullptr, sparts, sp, s, "hamming_topk_sample");
+        merge_launch<K>(sparts, sp.chunks, nq, sample_keys, s);
         int* thr_buf = c.alloc_n<int>(nq);
-        hipLaunchKernelGGL(thr_from_keys_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, sample_keys, nq, k, thr_buf);
+        hipLaunchKernelGGL(thr_from_keys_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, sample_keys, nq, K, thr_buf);
         thr = thr_buf;
     }
     const char* rest = static_cast<const char*>(t) + (size_t)sample * 64;
     const long long nrest = nt - sample;
-    ChunkPlan p = plan_chunks(nq, nrest);
-    // parts: [chunks (+1 for the sample result)][nq][k]
-    uint64_t* parts = c.alloc_n<uint64_t>((size_t)(p.chunks + 1) * nq * k);
-    if (k == 2) launch_topk<2>(q, nq, rest, nrest, index_base + (uint32_t)sample, thr, parts, p, s);
-    else launch_topk<1>(q, nq, rest, nrest, index_base + (uint32_t)sample, thr, parts, p, s);
+    ChunkPlan p = plan_chunks(nq, nrest, false, K > 2);
+    uint64_t* parts = c.alloc_n<uint64_t>((size_t)(p.chunks + 1) * nq * K);   // [chunks (+1 for the sample result)][nq][K]
+    launch_topk<K>(q, nq, rest, nrest, index_base + (uint32_t)sample, thr, parts, p, s);
     int nparts = p.chunks;
     if (sample) {
-        HIP_CHECK(hipMemcpyAsync(parts + (size_t)p.chunks * nq * k, sample_keys, (size_t)nq * k * 8, hipMemcpyDeviceToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(parts + (size_t)p.chunks * nq * K, sample_keys, (size_t)nq * K * 8, hipMemcpyDeviceToDevice, s));
         nparts++;
     }
-    if (k == 2) hipLaunchKernelGGL((merge_topk_kernel<2>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, nq, out);
-    else hipLaunchKernelGGL((merge_topk_kernel<1>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, nq, out);
+    merge_launch<K>(parts, nparts, nq, out, s);
     HIP_CHECK(hipGetLastError());
 }
 
-void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_t* out, hipStream_t s) {
-    APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "k in {1,2}");
+// Full top-k of nq queries over nt train rows (device, 64-byte rows). out: nq*k keys. k <= 16; k in {1,2} is the tuned path
+// (the reference only ever consumes the two nearest, lib.rs:107-111); other k run with one query per lane.
+void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out,
+                         hipStream_t s) {
+    APDS_REQUIRE(k >= 1 && k <= 16, APDS_ERR_ASSERT, "top-k supports 1 <= k <= 16");
+    APDS_REQUIRE(nt < (1ll << 31), APDS_ERR_ASSERT, "train set too large for one call; shard it");
     if (nq <= 0) return;
-    if (k == 2) hipLaunchKernelGGL((merge_topk_kernel<2>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, nq, out);
-    else hipLaunchKernelGGL((merge_topk_kernel<1>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, nq, out);
+    if (nt <= 0) {
+        HIP_CHECK(hipMemsetAsync(out, 0xFF, (size_t)nq * k * 8, s));
+        return;
+    }
+    const int K = k <= 2 ? k : (k <= 4 ? 4 : (k <= 8 ? 8 : 16));
+    uint64_t* dst = K == k ? out : ctx().alloc_n<uint64_t>((size_t)nq * K);
+    switch (K) {
+        case 1: topk_device_k<1>(q, nq, t, nt, index_base, dst, s); break;
+        case 2: topk_device_k<2>(q, nq, t, nt, index_base, dst, s); break;
+        case 4: topk_device_k<4>(q, nq, t, nt, index_base, dst, s); break;
+        case 8: topk_device_k<8>(q, nq, t, nt, index_base, dst, s); break;
+        default: topk_device_k<16>(q, nq, t, nt, index_base, dst, s); break;
+    }
+    if (K != k) {
+        hipLaunchKernelGGL(take_first_columns_kernel, dim3(ceil_div((long long)nq * k, 256)), dim3(256), 0, s, (const uint64_t*)dst, nq, K, k, out);
+        HIP_CHECK(hipGetLastError());
+    }
+}
+
+void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_t* out, hipStream_t s) {
+    if (nq <= 0) return;
+    switch (k) {
+        case 1: merge_launch<1>(parts, nparts, nq, out, s); break;
+        case 2: merge_launch<2>(parts, nparts, nq, out, s); break;
+        case 4: merge_launch<4>(parts, nparts, nq, out, s); break;
+        case 8: merge_launch<8>(parts, nparts, nq, out, s); break;
+        case 16: merge_launch<16>(parts, nparts, nq, out, s); break;
+        default: fail(APDS_ERR_ASSERT, "merge supports k in {1,2,4,8,16}");
+    }
     HIP_CHECK(hipGetLastError());
 }
 

@@ -104,3 +104,22 @@ def test_raster_to_mat(gpu_pkg, oracle_mod):
     rng = np.random.default_rng(2)
     big = rng.integers(0, 256, (333 * 517, 4), dtype=np.uint8)
     assert np.array_equal(gpu_pkg.homographier.raster_to_mat(big, 517, 333).mat, oracle_mod.raster_to_mat(big, 517, 333))
+
+
+@pytest.mark.parametrize("k", [3, 4, 5, 8, 16])
+def test_larger_k(gpu_pkg, oracle_mod, k):
+    """k > 2 (the reference's `k: i32` is free; its own code only consumes two): one query per lane, K slots in registers."""
+    db = gpu_pkg.synth.make_descriptor_db(150000 if k == 4 else 3000, seed=99 + k)
+    db[1000] = db[10]
+    db[2000] = db[10]          # ties must stay in train-index order at every rank
+    q, _ = gpu_pkg.synth.make_queries(db, 700, seed=5 + k)
+    q[0] = db[10]
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q, db, k)
+    oracle_mod.set_threads(8)
+    oi, od = oracle_mod.knn_hamming(q, db, k)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi)
+    assert tuple(idx[0, :3]) == (10, 1000, 2000)
+    few = db[:k - 1]           # fewer train rows than k: the tail is (-1, INT_MAX)
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q[:50], few, k)
+    oi, od = oracle_mod.knn_hamming(q[:50], few, k)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi) and (idx[:, -1] == -1).all()
