@@ -150,35 +150,53 @@ __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ 
         commit(tile);
         __syncthreads();
         if (tile + 1 < tile_end) prefetch(tile + 1); // global loads fly under the MFMAs below
+        // K loop: operand registers ping-pong between two sets; the ds_read_b128s of the next group are issued before the
+        // 16 MFMAs of the current one (sched_barrier pins that order), so LDS latency sits under ~1000 cycles of MFMA.
         f32x16 acc[2][2];
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float4 A0 = *reinterpret_cast<const float4*>(aBase), A1 = *reinterpret_cast<const float4*>(aBase + 32 * ST);
+        float4 B0 = *reinterpret_cast<const float4*>(bBase), B1 = *reinterpret_cast<const float4*>(bBase + 32 * ST);
+        float4 C0, C1, D0, D1;
+#define L2_LOAD(X0, X1, Y0, Y1, G)                                             \
+    X0 = *reinterpret_cast<const float4*>(aBase + (G) * 4);                    \
+    X1 = *reinterpret_cast<const float4*>(aBase + 32 * ST + (G) * 4);          \
+    Y0 = *reinterpret_cast<const float4*>(bBase + (G) * 4);                    \
+    Y1 = *reinterpret_cast<const float4*>(bBase + 32 * ST + (G) * 4);
+#define L2_STEP(X0, X1, Y0, Y1, c)                                                          \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X0.c, Y0.c, acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(X0.c, Y1.c, acc[0][1], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X1.c, Y0.c, acc[1][0], 0, 0, 0);      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(X1.c, Y1.c, acc[1][1], 0, 0, 0);
+#define L2_GROUP(X0, X1, Y0, Y1) L2_STEP(X0, X1, Y0, Y1, x) L2_STEP(X0, X1, Y0, Y1, y) L2_STEP(X0, X1, Y0, Y1, z) L2_STEP(X0, X1, Y0, Y1, w)
+        // group 0: the first step starts the accumulators from an inline zero instead of 64 register writes
+        L2_LOAD(C0, C1, D0, D1, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x, B0.x, zero, 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x, B1.x, zero, 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x, B0.x, zero, 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x, B1.x, zero, 0, 0, 0);
+        L2_STEP(A0, A1, B0, B1, y) L2_STEP(A0, A1, B0, B1, z) L2_STEP(A0, A1, B0, B1, w)
+        for (int g = 1; g < groups; g += 2) {      // groups is 8 or 16: (g, g+1) pairs, g odd
+            const int g2 = min(g + 1, groups - 1), g3 = min(g + 2, groups - 1);
+            L2_LOAD(A0, A1, B0, B1, g2)
+            __builtin_amdgcn_sched_barrier(0);
+            L2_GROUP(C0, C1, D0, D1)               // group g
+            if (g + 1 < groups) {
+                L2_LOAD(C0, C1, D0, D1, g3)
+                __builtin_amdgcn_sched_barrier(0);
+                L2_GROUP(A0, A1, B0, B1)           // group g + 1
+            }
+        }
+#undef L2_GROUP
+#undef L2_STEP
+#undef L2_LOAD
+        // epilogue: candidates are ranked on u = |t|^2 - 2 q.t (|q|^2 is constant per query and added once at the end);
+        // the lane's 32 train rows per n are screened with one min chain and inserted only on a hit
+        float4 tt[2][4];
 #pragma unroll
         for (int m = 0; m < 2; m++)
 #pragma unroll
-            for (int n = 0; n < 2; n++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[m][n][r] = 0.f;
-        float4 A0 = *reinterpret_cast<const float4*>(aBase), A1 = *reinterpret_cast<const float4*>(aBase + 32 * ST);
-        float4 B0 = *reinterpret_cast<const float4*>(bBase), B1 = *reinterpret_cast<const float4*>(bBase + 32 * ST);
-        for (int g = 0; g < groups; g++) {
-            const int gn = min(g + 1, groups - 1) * 4;
-            const float4 nA0 = *reinterpret_cast<const float4*>(aBase + gn), nA1 = *reinterpret_cast<const float4*>(aBase + 32 * ST + gn);
-            const float4 nB0 = *reinterpret_cast<const float4*>(bBase + gn), nB1 = *reinterpret_cast<const float4*>(bBase + 32 * ST + gn);
-#define L2_STEP(c)                                                                          \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B0.c, acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.c, B1.c, acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B0.c, acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.c, B1.c, acc[1][1], 0, 0, 0);
-            L2_STEP(x)
-            L2_STEP(y)
-            L2_STEP(z)
-            L2_STEP(w)
-#undef L2_STEP
-            A0 = nA0;
-            A1 = nA1;
-            B0 = nB0;
-            B1 = nB1;
-        }
-        // epilogue: d^2 = max(|q|^2 + (|t|^2 - 2 q.t), 0) for this lane's query column and its 32 train rows per n
+            for (int rb = 0; rb < 4; rb++) tt[m][rb] = *reinterpret_cast<const float4*>(&sTT[wr * 64 + m * 32 + 8 * rb + 4 * (lane >> 5)]);
 #pragma unroll
         for (int n = 0; n < 2; n++) {
             float vals[2][16];
@@ -187,8 +205,9 @@ __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ 
             for (int m = 0; m < 2; m++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
-                    const int rl = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    const float v = fmaxf(qq[n] + (sTT[rl] - 2.0f * acc[m][n][r]), 0.f);
+                    const float4 t4 = tt[m][r >> 2];
+                    const float tr = (r & 3) == 0 ? t4.x : ((r & 3) == 1 ? t4.y : ((r & 3) == 2 ? t4.z : t4.w));
+                    const float v = __builtin_fmaf(-2.0f, acc[m][n][r], tr);
                     vals[m][r] = v;
                     mn = fminf(mn, v);
                 }
@@ -202,6 +221,12 @@ __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ 
                     }
             }
         }
+    }
+    // d^2 = max(|q|^2 + u, 0): same value as ranking on d^2 directly, the add is monotone
+#pragma unroll
+    for (int n = 0; n < 2; n++) {
+        best[n].d0 = fmaxf(qq[n] + best[n].d0, 0.f);
+        best[n].d1 = fmaxf(qq[n] + best[n].d1, 0.f);
     }
     // merge the 4 partial lists of every query (2 lane halves x 2 row-waves) through LDS (reusing sT)
     __syncthreads();
