@@ -240,6 +240,62 @@ __global__ __launch_bounds__(256) void nld_step_kernel(const float* __restrict__
     }
 }
 
+// Two FED steps in one pass (temporal blocking): the tile is loaded with a 2-pixel halo, step 1 is evaluated on the tile
+// + 1 ring into LDS, step 2 on the tile from that. Every intermediate value is exactly what the single-step kernel
+// produces (same expression, same inputs), so results are bit-identical; HBM traffic per two steps drops from
+// 24 to ~15 B/pixel and the launch count of the (launch-bound) small octaves halves.
+static constexpr int T2W = 64, T2H = 32;
+
+__device__ __forceinline__ float nld_point(const float* __restrict__ st, const float* __restrict__ sf, int c, int pitch, int x, int y, int w, int h,
+                                           float step_size) {
+    const float tc = st[c], fc = sf[c];
+    const bool top = y == 0, bot = y == h - 1, left = x == 0, right = x == w - 1;
+    const float xp = (fc + sf[c + 1]) * (st[c + 1] - tc);
+    const float xm = (fc + sf[c - 1]) * (st[c - 1] - tc);
+    const float yp = (fc + sf[c + pitch]) * (st[c + pitch] - tc);
+    const float ym = (fc + sf[c - pitch]) * (st[c - pitch] - tc);
+    float step_r;
+    if ((top || bot) && (left || right)) step_r = 0.0f;
+    else if (top) step_r = xp + xm + yp;
+    else if (bot) step_r = xp + xm + ym;
+    else if (left) step_r = xp + yp + ym;
+    else if (right) step_r = xm + yp + ym;
+    else step_r = xp + xm + yp + ym;
+    return tc + step_r * step_size;
+}
+
+__global__ __launch_bounds__(256) void nld_step2_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
+                                                        float step1, float step2) {
+    APDS_RAISE_WAVE_PRIORITY();
+    constexpr int SW = T2W + 4, SH = T2H + 4;      // inputs with halo 2
+    constexpr int MW = T2W + 4, MH = T2H + 4;      // step-1 plane kept at the same pitch (outer ring unused)
+    __shared__ float s_t[SH * SW];
+    __shared__ float s_f[SH * SW];
+    __shared__ float s_m[MH * MW];
+    const int x0 = blockIdx.x * T2W, y0 = blockIdx.y * T2H;
+    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+        const int ly = i / SW, lx = i - ly * SW;
+        const int gx = clampi(x0 - 2 + lx, w), gy = clampi(y0 - 2 + ly, h);   // clamped values are never used by a border case
+        const size_t o = (size_t)gy * w + gx;
+        s_t[i] = Lt[o];
+        s_f[i] = Lf[o];
+    }
+    __syncthreads();
+    // step 1 on the tile + 1 ring (local coordinates 1 .. SW-2, 1 .. SH-2), only at positions inside the image
+    for (int i = threadIdx.x; i < (SW - 2) * (SH - 2); i += 256) {
+        const int ry = i / (SW - 2), rx = i - ry * (SW - 2);
+        const int lx = rx + 1, ly = ry + 1;
+        const int gx = x0 - 2 + lx, gy = y0 - 2 + ly;
+        if (gx >= 0 && gx < w && gy >= 0 && gy < h) s_m[ly * MW + lx] = nld_point(s_t, s_f, ly * SW + lx, SW, gx, gy, w, h, step1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < T2W * T2H; i += 256) {
+        const int ly = i / T2W, lx = i - ly * T2W;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < w && gy < h) Lnew[(size_t)gy * w + gx] = nld_point(s_m, s_f, (ly + 2) * MW + lx + 2, MW, gx, gy, w, h, step2);
+    }
+}
+
 // ---- resize(INTER_AREA) by exactly 2: mean of 2x2 ---------------------------------------------------------
 __global__ void half_sample_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh) {
     APDS_RAISE_WAVE_PRIORITY();
@@ -350,6 +406,9 @@ void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsign
 }
 void launch_nld_step(const float* Lt, const float* Lf, float* Lnew, int w, int h, float step_size, hipStream_t s) {
     hipLaunchKernelGGL(nld_step_kernel, dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), 0, s, Lt, Lf, Lnew, w, h, step_size);
+}
+void launch_nld_step2(const float* Lt, const float* Lf, float* Lnew, int w, int h, float step1, float step2, hipStream_t s) {
+    hipLaunchKernelGGL(nld_step2_kernel, dim3(ceil_div(w, T2W), ceil_div(h, T2H)), dim3(256), 0, s, Lt, Lf, Lnew, w, h, step1, step2);
 }
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s) {
     hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, src, sw, dst, dw, dh);

@@ -839,8 +839,11 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         } else {
             const LevelDesc& p = ev[i - 1];
             const float* P;   // the level's starting image
+            // FED steps are issued as fused pairs (+ one single step when the count is odd): `launches` passes ping-pong
+            // between e.Lt and tmpP and must end in e.Lt
+            const int launches = (e.nsteps + 1) / 2;
             if (e.octave > p.octave) {
-                float* dstP = (e.nsteps % 2 == 0) ? e.Lt : tmpP;   // so that the last FED step lands in e.Lt
+                float* dstP = (launches % 2 == 0) ? e.Lt : tmpP;   // so that the last pass lands in e.Lt
                 if (p.w == 2 * e.w && p.h == 2 * e.h) {
                     launch_half_sample(p.Lt, p.w, dstP, e.w, e.h, s);
                 } else {
@@ -860,9 +863,16 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
             smooth = tmpS;
             launch_flow(tmpS, tmpF, e.w, e.h, k_oct + e.octave, s);
             const float* in = P;
-            for (int k = 1; k <= e.nsteps; k++) {
-                float* out = ((e.nsteps - k) % 2 == 0) ? e.Lt : tmpP;
-                launch_nld_step(in, tmpF, out, e.w, e.h, e.tau[k - 1] * 0.5f, s);
+            int pass = 0;
+            for (int k = 0; k < e.nsteps; pass++) {
+                float* out = ((launches - 1 - pass) % 2 == 0) ? e.Lt : tmpP;
+                if (k + 1 < e.nsteps) {
+                    launch_nld_step2(in, tmpF, out, e.w, e.h, e.tau[k] * 0.5f, e.tau[k + 1] * 0.5f, s);
+                    k += 2;
+                } else {
+                    launch_nld_step(in, tmpF, out, e.w, e.h, e.tau[k] * 0.5f, s);
+                    k += 1;
+                }
                 in = out;
             }
             if (e.nsteps == 0 && P != e.Lt) HIP_CHECK(hipMemcpyAsync(e.Lt, P, (size_t)e.w * e.h * 4, hipMemcpyDeviceToDevice, s));
