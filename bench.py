@@ -215,7 +215,7 @@ def main():
         # The match of one step = a threshold pre-pass over the first `sample_rows` rows (kernel instance <1,2>, timed as
         # "hamming_topk_sample") + ONE main launch over the remaining rows (instance <4,2>, "hamming_topk"): the roofline
         # object is for the main launch. SURVEY §8d algorithmic work: 64 B per train row + 64 B per query + 8 B per key.
-        sample_rows = 16384 if rows_local >= 8 * 16384 else 0
+        sample_rows = min(16384, (rows_local // 16) & ~1023) if rows_local >= 32768 else 0      # match_hamming.hip: topk_device_k
         rows_main = rows_local - sample_rows
         match_bytes = 64.0 * rows_main + 64.0 * Q_step + 8.0 * Q_step * 2
         match_ops = 32.0 * Q_step * rows_main

@@ -513,8 +513,10 @@ static void topk_device_k(const void* q, int nq, const void* t, long long nt, ui
     // Phase 0 (only for large scans): exact top-k over the first `sample` rows gives per-query thresholds that
     // every chunk starts from, so the rare-hit fast path is reached immediately. The sample rows have the
     // lowest indices, hence a later row at equal distance never outranks them: strict '<' stays exact.
+    // (1/16 of the rows, at most APDS_MATCH_SAMPLE = 16384, from 32768 rows up: a 125k-row shard of an 8-GPU run still gets one)
     static const int sample_rows = env_int("APDS_MATCH_SAMPLE", 16384);
-    const long long sample = (sample_rows > 0 && nt >= 8ll * sample_rows) ? sample_rows : 0;
+    long long sample = 0;
+    if (sample_rows > 0 && nt >= 32768) sample = std::min<long long>(sample_rows, (nt / 16) & ~1023ll);
     const int* thr = nullptr;
     uint64_t* sample_keys = nullptr;
     if (sample) {

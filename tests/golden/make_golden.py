@@ -1,0 +1,55 @@
+"""Regenerates the golden fixtures in this directory from the CPU oracle (oracle/, a restatement: the reference cannot be
+built or imported here — it is Rust over OpenCV). Fixtures are DATA: seeded inputs' expected outputs.
+
+    python tests/golden/make_golden.py
+
+akaze_256.npz      : synthetic 256x256 BGRA tile (frame 5) -> keypoints (cv::KeyPoint rows) + 61-byte descriptors
+hamming_1k_4k.npz  : 1000 queries x 4000 train rows (seeded) -> top-2 indices and distances, ratio(0.3) and cross-check matches
+homography_200.npz : 200 point pairs (40 % inliers) -> H (RANSAC, thr 3) and inlier mask
+ingest.npz         : band_merger / warp_perspective expected bytes for seeded inputs
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as graft  # noqa: E402
+import oracle  # noqa: E402
+
+synth = graft.load_package().synth
+
+
+def inputs():
+    tile = synth.make_tile(256, 256, frame_index=5)
+    db = synth.make_descriptor_db(4000, seed=0x44420001 + 4000)
+    q, _ = synth.make_queries(db, 1000, seed=0x51550001 + 1000)
+    src, dst, _, _ = synth.make_ransac_set(200, seed=0x52410001 + 200)
+    rng = np.random.default_rng(20261003)
+    bands = [rng.normal(0.4, 0.3, 5000).astype(np.float32) for _ in range(3)]
+    bands[0][::97] = np.nan
+    bands[1][::97] = np.nan
+    bands[2][::97] = np.nan
+    bands[1][5::131] = np.nan
+    mm = np.array([0.0017, 0.93, -0.2, 1.1, 0.05, 0.8])
+    img = rng.integers(0, 256, (48, 64, 4), dtype=np.uint8)
+    M = np.array([[0.9, -0.2, 6.0], [0.25, 1.1, -3.0], [1e-3, -2e-3, 1.0]])
+    return tile, db, q, src, dst, bands, mm, img, M
+
+
+def main():
+    tile, db, q, src, dst, bands, mm, img, M = inputs()
+    r = oracle.akaze(tile)
+    np.savez_compressed(os.path.join(HERE, "akaze_256.npz"), keypoints=r.keypoints, descriptors=r.descriptors)
+    idx, dist = oracle.knn_hamming(q, db, 2)
+    np.savez_compressed(os.path.join(HERE, "hamming_1k_4k.npz"), idx=idx, dist=dist, ratio=oracle.get_knn_matches(q, db, 2, 0.3),
+                        cross=oracle.get_bruteforce_matches(q, db))
+    found, H, mask = oracle.find_homography(src, dst, 8, 3.0)
+    np.savez_compressed(os.path.join(HERE, "homography_200.npz"), found=found, H=H, mask=mask)
+    np.savez_compressed(os.path.join(HERE, "ingest.npz"), rgba=oracle.band_merger(*bands, mm), warped=oracle.warp_perspective(img, M))
+
+
+if __name__ == "__main__":
+    main()
