@@ -186,9 +186,10 @@ __global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restr
                                                            const u32x4* __restrict__ queries, int nq, int rows_per_chunk,
                                                            const int* __restrict__ init_thr, uint64_t* __restrict__ out,
                                                            uint32_t index_base, int qtile_blocks, int n_chunks, int xcd_aware) {
-    // 1-D grid; optionally XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so all query tiles of one row
-    // chunk can be given the same (id % 8): the chunk is then streamed into ONE XCD's L2 instead of all eight
-    // (12x less fabric traffic, but 2.4 % slower: same-chunk waves contend for the same L2 lines; default off).
+    // 1-D grid, XCD-aware by default: workgroups are dealt round-robin over the 8 XCDs, so all query tiles of one row
+    // chunk are given the same (id % 8): the chunk is then streamed into ONE XCD's L2 instead of all eight (13x less
+    // L2->fabric traffic at equal speed, once the chunk count is a multiple of 8 so that no XCD gets extra chunks).
+    // APDS_MATCH_XCD=0 restores the plain (chunk-major) order. Placement only affects speed, never results.
     const int nqb = qtile_blocks;
     int chunk, qblock;
     if (xcd_aware) {
@@ -456,6 +457,9 @@ static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false
     long long chunks = ceil_div(target_waves, waves_q);
     const long long max_chunks = std::max<long long>(1, n_train / min_rows);
     chunks = std::min<long long>(std::max<long long>(chunks, 1), std::min<long long>(max_chunks, 65535));
+    // chunk c runs on XCD (c % 8) when the XCD-aware placement is on: keep the chunk count a multiple of 8 so that every
+    // XCD gets the same number of rows (3 extra chunks on 3 XCDs was a 2 % tail)
+    if (chunks >= 8) chunks = (chunks + 7) & ~7ll;
     long long rpc = (n_train + chunks - 1) / chunks;
     rpc = (rpc + 3) & ~3ll;
     p.rows_per_chunk = (int)rpc;
@@ -466,7 +470,7 @@ static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false
 template <int K>
 static void launch_topk(const void* q, int nq, const void* t, long long nt, uint32_t index_base, const int* init_thr,
                         uint64_t* parts, const ChunkPlan& p, hipStream_t s, const char* timer_name = "hamming_topk") {
-    static const int xcd = env_int("APDS_MATCH_XCD", 0);
+    static const int xcd = env_int("APDS_MATCH_XCD", 1);
     static const int persist = env_int("APDS_MATCH_PERSIST", 0);   // resident workgroups per CU (0 = plain grid)
     const u32x16* tr = static_cast<const u32x16*>(t);
     const u32x4* qq = static_cast<const u32x4*>(q);
