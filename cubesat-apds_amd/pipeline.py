@@ -180,7 +180,7 @@ class StreamedFramePipeline:
     synchronises with the host (single GPU), so match kernels of consecutive frames queue back to back. Stages hand
     over through HIP events; results come back in frame order."""
 
-    def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=4, reserve_cus=0,
+    def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=5, reserve_cus=0,
                  n_cus=256):
         import queue
         self.queue = queue
@@ -205,6 +205,13 @@ class StreamedFramePipeline:
         # the match kernel alone fills every CU for ~30 ms; the short extraction / homography kernels get the high-priority
         # queues so that their blocks are dispatched as soon as match workgroups retire
         self.streams = [torch.cuda.Stream(self.dev, priority=-1), torch.cuda.Stream(self.dev, priority=0), torch.cuda.Stream(self.dev, priority=-1)]
+        # Optional (APDS_MATCH_WORKERS=2, single GPU only): two match workers alternate frames on two streams, so the short,
+        # poorly filled phases of one frame's match (threshold pre-pass, merges, grid tail) run under the other frame's
+        # main kernel: +1 % frames/s, but per-launch kernel times then overlap and no longer read as kernel efficiency,
+        # so the default is one worker. With a sharded DB the collectives must be issued in frame order by one thread.
+        import os
+        self.match_workers = 2 if (group is None and os.environ.get("APDS_MATCH_WORKERS", "1") == "2") else 1
+        self.match_streams = [self.streams[1]] + [torch.cuda.Stream(self.dev, priority=0) for _ in range(self.match_workers - 1)]
         if reserve_cus > 0:
             # keep `reserve_cus` CUs (spread evenly over the CU index space) out of the MATCH stream only
             words = (n_cus + 31) // 32
@@ -279,18 +286,33 @@ class StreamedFramePipeline:
                 q1.put(None)
                 collect(["akaze_extract"])
 
-        def match_worker():
-            with torch.cuda.stream(self.streams[1]):
-                while True:
-                    s = q1.get()
-                    if s is None:
-                        break
-                    self.streams[1].wait_event(s["ev_extract"])
-                    s["keys_view"] = self.matcher.knn(s["desc"][:s["K"]], 2, out=s["keys"])
-                    s["ev_match"].record(self.streams[1])
-                    q2.put(s)
-                q2.put(None)
-                collect(["hamming_topk", "hamming_topk_sample"])
+        done_lock = threading.Lock()
+        alive = [self.match_workers]
+
+        def make_match_worker(stream):
+            def match_worker():
+                with torch.cuda.stream(stream):
+                    while True:
+                        s = q1.get()
+                        if s is None:
+                            q1.put(None)            # let the other match worker see the end marker too
+                            break
+                        stream.wait_event(s["ev_extract"])
+                        s["keys_view"] = self.matcher.knn(s["desc"][:s["K"]], 2, out=s["keys"])
+                        s["ev_match"].record(stream)
+                        q2.put(s)
+                    with done_lock:
+                        alive[0] -= 1
+                        last = alive[0] == 0
+                    if timing:
+                        for n in ("hamming_topk", "hamming_topk_sample"):
+                            ms, k = _lib.kernel_ms(n)
+                            with done_lock:
+                                old = timers.get(n, (0.0, 0))
+                                timers[n] = (old[0] + ms, old[1] + k)
+                    if last:
+                        q2.put(None)
+            return match_worker
 
         def homography_worker():
             with torch.cuda.stream(self.streams[2]):
@@ -321,7 +343,8 @@ class StreamedFramePipeline:
                     q_free.put(s)
                 collect(["ransac_score"])
 
-        threads = [threading.Thread(target=guarded(f), daemon=True) for f in (extract_worker, match_worker, homography_worker)]
+        workers = [extract_worker] + [make_match_worker(st) for st in self.match_streams] + [homography_worker]
+        threads = [threading.Thread(target=guarded(f), daemon=True) for f in workers]
         for t in threads:
             t.start()
         for t in threads:
