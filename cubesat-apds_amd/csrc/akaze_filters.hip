@@ -327,51 +327,75 @@ __global__ void area_resize_kernel(const float* __restrict__ src, int sw, float*
     dst[(size_t)y * dw + x] = sum;
 }
 
-// ---- Ldet = (Lxx*Lyy - Lxy^2) * sigma_size^4 from Lx, Ly (second application of the dilated pair) -----------
-__global__ __launch_bounds__(256) void hessian_det_kernel(const float* __restrict__ Lx, const float* __restrict__ Ly, float* __restrict__ Ldet, int w,
-                                                          int h, int s, float kside, float kmid, float sq) {
+// ---- a1.5 fused: Lsmooth -> Lx, Ly (dilated Scharr pair at scale s) -> Lxx, Lxy, Lyy -> Ldet, one pass -------------
+// The reference applies sepFilter2D twice (derivatives of derivatives), each with BORDER_REFLECT_101 on ITS input. Fused,
+// that means: the Lx/Ly values a tile needs within s pixels beyond the image are the values AT the reflected positions
+// (Lx(reflect(p)), not a stencil evaluated on a reflected Lsmooth). So: Lsmooth tile with a 2s halo (reflect on load),
+// then Lx/Ly on the tile + s ring evaluated at the reflected coordinate of every ring position, then the second
+// derivatives on the tile. Lsmooth is read once (24 -> ~19 B/pixel incl. halo) and one launch per level disappears.
+static constexpr int DW = 64, DH = 32;
+
+__global__ __launch_bounds__(256) void doh_fused_kernel(const float* __restrict__ Lsmooth, float* __restrict__ Lx, float* __restrict__ Ly,
+                                                        float* __restrict__ Ldet, int w, int h, int s, float kside, float kmid, float sq) {
     APDS_RAISE_WAVE_PRIORITY();
     extern __shared__ float smem[];
-    const int SW = TW + 2 * s, SH = TH + 2 * s;
-    float* s_x = smem;                 // SH x SW  (Lx)
-    float* s_y = s_x + SH * SW;        // SH x SW  (Ly)
-    float* r_xd = s_y + SH * SW;       // SH x TW  row-diff of Lx   -> Lxx
-    float* r_xs = r_xd + SH * TW;      // SH x TW  row-smooth of Lx -> Lxy
-    float* r_ys = r_xs + SH * TW;      // SH x TW  row-smooth of Ly -> Lyy
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int SW = DW + 4 * s, SH = DH + 4 * s;      // Lsmooth tile, halo 2s
+    const int MW = DW + 2 * s, MH = DH + 2 * s;      // first derivatives, halo s
+    float* s_src = smem;
+    float* s_mx = s_src + SW * SH;
+    float* s_my = s_mx + MW * MH;
+    const int x0 = blockIdx.x * DW, y0 = blockIdx.y * DH;
+    const int ox = x0 - 2 * s, oy = y0 - 2 * s;      // global coordinate of s_src[0]
     for (int i = threadIdx.x; i < SW * SH; i += 256) {
         const int ly = i / SW, lx = i - ly * SW;
-        const int gx = reflect101(x0 - s + lx, w), gy = reflect101(y0 - s + ly, h);
-        const size_t o = (size_t)gy * w + gx;
-        s_x[i] = Lx[o];
-        s_y[i] = Ly[o];
+        s_src[i] = Lsmooth[(size_t)reflect101(oy + ly, h) * w + reflect101(ox + lx, w)];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < SH * TW; i += 256) {
-        const int ly = i / TW, lx = i - ly * TW;
-        const float* p = &s_x[ly * SW + lx + s];
-        const float lo = p[-s], hi = p[s];
-        r_xd[i] = hi - lo;
-        float acc = kmid * p[0];
-        acc += kside * (lo + hi);
-        r_xs[i] = acc;
-        const float* q = &s_y[ly * SW + lx + s];
-        float acy = kmid * q[0];
-        acy += kside * (q[-s] + q[s]);
-        r_ys[i] = acy;
+    for (int i = threadIdx.x; i < MW * MH; i += 256) {
+        const int my = i / MW, mx = i - my * MW;
+        // the first-derivative value this ring position stands for lives at the reflected coordinate
+        const int cx = reflect101(x0 - s + mx, w) - ox, cy = reflect101(y0 - s + my, h) - oy;
+        const float* r0 = &s_src[(cy - s) * SW + cx];
+        const float* r1 = &s_src[cy * SW + cx];
+        const float* r2 = &s_src[(cy + s) * SW + cx];
+        const float rd0 = r0[s] - r0[-s], rd1 = r1[s] - r1[-s], rd2 = r2[s] - r2[-s];
+        float ax = kmid * rd1;
+        ax += kside * (rd0 + rd2);
+        float rs0 = kmid * r0[0];
+        rs0 += kside * (r0[-s] + r0[s]);
+        float rs2 = kmid * r2[0];
+        rs2 += kside * (r2[-s] + r2[s]);
+        s_mx[i] = ax;
+        s_my[i] = rs2 - rs0;
     }
     __syncthreads();
-    const int lx = threadIdx.x & 63;
-    for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
+    for (int i = threadIdx.x; i < DW * DH; i += 256) {
+        const int ly = i / DW, lx = i - ly * DW;
         const int gx = x0 + lx, gy = y0 + ly;
-        if (gx < w && gy < h) {
-            const int c = (ly + s) * TW + lx;
-            float lxx = kmid * r_xd[c];
-            lxx += kside * (r_xd[c - s * TW] + r_xd[c + s * TW]);
-            const float lxy = r_xs[c + s * TW] - r_xs[c - s * TW];
-            const float lyy = r_ys[c + s * TW] - r_ys[c - s * TW];
-            Ldet[(size_t)gy * w + gx] = (lxx * lyy - lxy * lxy) * sq;
-        }
+        if (gx >= w || gy >= h) continue;
+        const int c = (ly + s) * MW + lx + s;
+        const float* x0r = &s_mx[c - s * MW];
+        const float* x1r = &s_mx[c];
+        const float* x2r = &s_mx[c + s * MW];
+        const float rd0 = x0r[s] - x0r[-s], rd1 = x1r[s] - x1r[-s], rd2 = x2r[s] - x2r[-s];
+        float lxx = kmid * rd1;
+        lxx += kside * (rd0 + rd2);
+        float rsx0 = kmid * x0r[0];
+        rsx0 += kside * (x0r[-s] + x0r[s]);
+        float rsx2 = kmid * x2r[0];
+        rsx2 += kside * (x2r[-s] + x2r[s]);
+        const float lxy = rsx2 - rsx0;
+        const float* y0r = &s_my[c - s * MW];
+        const float* y2r = &s_my[c + s * MW];
+        float rsy0 = kmid * y0r[0];
+        rsy0 += kside * (y0r[-s] + y0r[s]);
+        float rsy2 = kmid * y2r[0];
+        rsy2 += kside * (y2r[-s] + y2r[s]);
+        const float lyy = rsy2 - rsy0;
+        const size_t o = (size_t)gy * w + gx;
+        Lx[o] = s_mx[c];
+        Ly[o] = s_my[c];
+        Ldet[o] = (lxx * lyy - lxy * lxy) * sq;
     }
 }
 
@@ -417,9 +441,9 @@ void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, co
                         const float* yw, const int* ycnt, hipStream_t s) {
     hipLaunchKernelGGL(area_resize_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, src, sw, dst, dw, dh, xofs, xw, xcnt, yofs, yw, ycnt);
 }
-void launch_hessian_det(const float* Lx, const float* Ly, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s) {
-    const size_t lds = (size_t)(2 * (TH + 2 * sc) * (TW + 2 * sc) + 3 * (TH + 2 * sc) * TW) * sizeof(float);
-    hipLaunchKernelGGL(hessian_det_kernel, dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), lds, s, Lx, Ly, Ldet, w, h, sc, kside, kmid,
+void launch_doh_fused(const float* Lsmooth, float* Lx, float* Ly, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s) {
+    const size_t lds = (size_t)((DW + 4 * sc) * (DH + 4 * sc) + 2 * (DW + 2 * sc) * (DH + 2 * sc)) * sizeof(float);
+    hipLaunchKernelGGL(doh_fused_kernel, dim3(ceil_div(w, DW), ceil_div(h, DH)), dim3(256), lds, s, Lsmooth, Lx, Ly, Ldet, w, h, sc, kside, kmid,
                        (float)(sc * sc * sc * sc));
 }
 

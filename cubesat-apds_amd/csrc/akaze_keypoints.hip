@@ -879,8 +879,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         }
         float kside, kmid;
         deriv_weights(e.sigma_size, kside, kmid);
-        launch_deriv_pair(smooth, e.Lx, e.Ly, e.w, e.h, e.sigma_size, kside, kmid, s);
-        launch_hessian_det(e.Lx, e.Ly, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, s);
+        launch_doh_fused(smooth, e.Lx, e.Ly, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, s);
     }
     HIP_CHECK(hipGetLastError());
 
