@@ -28,4 +28,9 @@ void warp_perspective_device(const uint8_t* src, int rows, int cols, const doubl
 int find_homography_device(const float* src, const float* dst, int n, int method, double thr, int max_iters, double confidence,
                            double* H_host, uint8_t* mask_dev, hipStream_t s);
 
+// pnp.hip
+int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const double* K, int iterations, float reproj_thr, double confidence, int method,
+                      double* rvec, double* tvec, int32_t* inliers, int* n_inliers, hipStream_t s);
+void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, const double* K, const int32_t* idx5, int B, double* models_host, hipStream_t s);
+
 }  // namespace apds

@@ -1,0 +1,266 @@
+// csrc/pnp.hip — homographier::pnp_solver_ransac (homographier/src/homographier/mod.rs:320-369) on the device.
+//
+// The reference forwards to cv::solvePnPRansac with distCoeffs = zeros(4,1) (mod.rs:344 shadows the argument),
+// useExtrinsicGuess = false and SOLVEPNP_EPNP unless the caller names a method. OpenCV's loop is sequential: draw 5
+// correspondences, EPnP on them, project every point, count inliers, shorten the iteration budget when a better model
+// appears. Here the cv::RNG sample stream is generated ahead on the host (it does not depend on the scores), a batch of
+// samples is solved one thread per sample (12x12 system in LDS), every hypothesis of the batch is scored against all
+// points in one launch, and the host replays the sequential accept/shorten logic over the batch's counts; the result is
+// the model and inlier set the sequential loop would have produced. The final EPnP over the inliers runs on the host in
+// the same code (pnp_core.h), as OpenCV does it once, in index order.
+#include "kernels.h"
+#include "pnp_core.h"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+namespace apds {
+
+using pnp::Camera;
+
+namespace {
+
+// One thread per sample; per-thread LDS: 156 doubles (system / singular vectors / values) + 64 of solver workspace.
+constexpr int PNP_THREADS = 32;
+constexpr int PNP_LDS_DOUBLES = 220;
+constexpr size_t PNP_LDS_BYTES = (size_t)PNP_LDS_DOUBLES * PNP_THREADS * sizeof(double);
+
+__global__ __launch_bounds__(PNP_THREADS) void pnp_hypothesis_kernel(const float* __restrict__ obj, const float* __restrict__ img, const int* __restrict__ idx5,
+                                                                     int B, Camera cam, double* __restrict__ models) {
+    APDS_RAISE_WAVE_PRIORITY();
+    extern __shared__ double pnp_lds[];
+    const int h = blockIdx.x * PNP_THREADS + threadIdx.x;
+    if (h >= B) return;
+    pnp::Strided<double, PNP_THREADS> big{pnp_lds + threadIdx.x}, wrk{pnp_lds + 156 * PNP_THREADS + threadIdx.x};
+    double pws[15], us[10], alphas[20], pcs[15];
+    const double ifx = 1. / cam.fu, ify = 1. / cam.fv;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int id = idx5[h * 5 + j];
+        pws[3 * j] = obj[3 * (size_t)id];
+        pws[3 * j + 1] = obj[3 * (size_t)id + 1];
+        pws[3 * j + 2] = obj[3 * (size_t)id + 2];
+        // undistortPoints with k = 0 stores (u - cx)/fx as float; epnp maps it back to pixels in double
+        const float xn = (float)(((double)img[2 * (size_t)id] - cam.uc) * ifx);
+        const float yn = (float)(((double)img[2 * (size_t)id + 1] - cam.vc) * ify);
+        us[2 * j] = xn * cam.fu + cam.uc;
+        us[2 * j + 1] = yn * cam.fv + cam.vc;
+    }
+    double R[9], t[3], rv[3];
+    pnp::epnp_pose(5, pnp::Plain<double>{pws}, pnp::Plain<double>{us}, pnp::Plain<double>{alphas}, pnp::Plain<double>{pcs}, cam, big, wrk, R, t);
+    pnp::rvec_from_rotation(R, rv);
+    double* m = models + (size_t)h * 6;
+    m[0] = rv[0];
+    m[1] = rv[1];
+    m[2] = rv[2];
+    m[3] = t[0];
+    m[4] = t[1];
+    m[5] = t[2];
+}
+
+constexpr int PNP_HT = 4;   // hypotheses per block of the scoring kernel
+
+// grid: x = ceil(B / PNP_HT), y = point parts. good[h] += #points whose float squared reprojection error is <= t
+__global__ __launch_bounds__(256) void pnp_score_kernel(const float* __restrict__ obj, const float* __restrict__ img, int n, const double* __restrict__ models,
+                                                        int B, Camera cam, float t, int* __restrict__ good) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int h0 = blockIdx.x * PNP_HT;
+    double R[PNP_HT][9], tv[PNP_HT][3];
+#pragma unroll
+    for (int h = 0; h < PNP_HT; h++) {
+        const double* m = models + (size_t)min(h0 + h, B - 1) * 6;
+        const double rv[3] = {m[0], m[1], m[2]};
+        pnp::rotation_from_rvec(rv, R[h]);
+        tv[h][0] = m[3];
+        tv[h][1] = m[4];
+        tv[h][2] = m[5];
+    }
+    int cnt[PNP_HT];
+#pragma unroll
+    for (int h = 0; h < PNP_HT; h++) cnt[h] = 0;
+    const int per = (n + gridDim.y - 1) / gridDim.y;
+    const int i0 = blockIdx.y * per, i1 = min(n, i0 + per);
+    for (int base = i0; base < i1; base += 256) {
+        const int i = base + threadIdx.x;
+        const bool in = i < i1;
+        const size_t q = in ? i : i0;
+        const float X = obj[3 * q], Y = obj[3 * q + 1], Z = obj[3 * q + 2], u = img[2 * q], v = img[2 * q + 1];
+#pragma unroll
+        for (int h = 0; h < PNP_HT; h++) {
+            const float e = pnp::reprojection_sqerr(R[h], tv[h], cam, X, Y, Z, u, v);
+            cnt[h] += __popcll(__ballot(in && e <= t));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int h = 0; h < PNP_HT; h++)
+            if (h0 + h < B && cnt[h]) atomicAdd(&good[h0 + h], cnt[h]);
+    }
+}
+
+__global__ void pnp_mask_kernel(const float* __restrict__ obj, const float* __restrict__ img, int n, const double* __restrict__ model, Camera cam, float t,
+                                uint8_t* __restrict__ mask) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double R[9];
+    const double rv[3] = {model[0], model[1], model[2]}, tv[3] = {model[3], model[4], model[5]};
+    pnp::rotation_from_rvec(rv, R);
+    mask[i] = pnp::reprojection_sqerr(R, tv, cam, obj[3 * (size_t)i], obj[3 * (size_t)i + 1], obj[3 * (size_t)i + 2], img[2 * (size_t)i], img[2 * (size_t)i + 1]) <= t;
+}
+
+// getSubset with the default checkSubset: 5 distinct indices from the cv::RNG stream
+void next_sample(int count, int* idx, pnp::MwcRng& rng) {
+    for (int i = 0; i < 5; ++i) {
+        int v;
+        for (;;) {
+            v = (int)(rng.next() % (unsigned)count);
+            bool dup = false;
+            for (int j = 0; j < i; j++) dup |= idx[j] == v;
+            if (!dup) break;
+        }
+        idx[i] = v;
+    }
+}
+
+int update_num_iters(double p, double ep, int modelPoints, int maxIters) {   // ptsetreg.cpp RANSACUpdateNumIters
+    p = std::min(std::max(p, 0.), 1.);
+    ep = std::min(std::max(ep, 0.), 1.);
+    double num = std::max(1. - p, DBL_MIN);
+    double denom = 1. - std::pow(1. - ep, modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = std::log(num);
+    denom = std::log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)lrint(num / denom);
+}
+
+// EPnP on host arrays (float for the n == 5 shortcut, double for the all-inlier solve), then Rodrigues
+template <typename T>
+void host_epnp(const T* obj, const T* img, int n, const Camera& cam, double* rvec, double* tvec) {
+    std::vector<double> pws(3 * (size_t)n), us(2 * (size_t)n), alphas(4 * (size_t)n), pcs(3 * (size_t)n), big(156), wrk(64);
+    const double ifx = 1. / cam.fu, ify = 1. / cam.fv;
+    for (int i = 0; i < n; i++) {
+        for (int c = 0; c < 3; c++) pws[3 * (size_t)i + c] = obj[3 * (size_t)i + c];
+        const T xn = (T)(((double)img[2 * (size_t)i] - cam.uc) * ifx);
+        const T yn = (T)(((double)img[2 * (size_t)i + 1] - cam.vc) * ify);
+        us[2 * (size_t)i] = xn * cam.fu + cam.uc;
+        us[2 * (size_t)i + 1] = yn * cam.fv + cam.vc;
+    }
+    double R[9];
+    pnp::epnp_pose(n, pnp::Plain<double>{pws.data()}, pnp::Plain<double>{us.data()}, pnp::Plain<double>{alphas.data()}, pnp::Plain<double>{pcs.data()}, cam,
+                   pnp::Plain<double>{big.data()}, pnp::Plain<double>{wrk.data()}, R, tvec);
+    pnp::rvec_from_rotation(R, rvec);
+}
+
+}  // namespace
+
+int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const double* K, int iterations, float reproj_thr, double confidence, int method,
+                      double* rvec, double* tvec, int32_t* inliers, int* n_inliers, hipStream_t s) {
+    APDS_REQUIRE(n_inliers, APDS_ERR_BAD_ARG, "null argument");
+    *n_inliers = 0;
+    APDS_REQUIRE(obj_xyz && img_xy && K && rvec && tvec && inliers, APDS_ERR_BAD_ARG, "null argument");
+    APDS_REQUIRE(n >= 4, APDS_ERR_ASSERT, "solvePnPRansac needs at least 4 correspondences");
+    APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP, APDS_ERR_NOT_IMPLEMENTED, "only SOLVEPNP_EPNP (the reference's default) is implemented");
+    APDS_REQUIRE(n != 4, APDS_ERR_NOT_IMPLEMENTED, "4 correspondences go through the P3P kernel, which is not implemented");
+    const Camera cam{K[0], K[4], K[2], K[5]};
+    // solvePnPRansac converts CV_64F points to CV_32F before anything else
+    std::vector<float> op(3 * (size_t)n), ip(2 * (size_t)n);
+    for (size_t i = 0; i < op.size(); i++) op[i] = (float)obj_xyz[i];
+    for (size_t i = 0; i < ip.size(); i++) ip[i] = (float)img_xy[i];
+    if (n == 5) {   // model_points == npoints: one direct solve, every point an inlier
+        host_epnp<float>(op.data(), ip.data(), n, cam, rvec, tvec);
+        for (int i = 0; i < n; i++) inliers[i] = i;
+        *n_inliers = n;
+        return 1;
+    }
+    ThreadCtx& c = ctx();
+    float* obj_dev = c.alloc_n<float>(op.size());
+    float* img_dev = c.alloc_n<float>(ip.size());
+    HIP_CHECK(hipMemcpyAsync(obj_dev, op.data(), op.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(img_dev, ip.data(), ip.size() * sizeof(float), hipMemcpyHostToDevice, s));
+
+    static const int batch_env = getenv("APDS_RANSAC_BATCH") ? atoi(getenv("APDS_RANSAC_BATCH")) : 512;
+    int niters = std::max(iterations, 1), maxGood = 0, iter = 0;
+    const int batch = std::max(PNP_HT, std::min(batch_env, niters));
+    const float t = (float)((double)reproj_thr * (double)reproj_thr);
+    int* idx_dev = c.alloc_n<int>((size_t)batch * 5);
+    double* models_dev = c.alloc_n<double>((size_t)batch * 6);
+    int* good_dev = c.alloc_n<int>(batch);
+    uint8_t* mask_dev = c.alloc_n<uint8_t>(n);
+    std::vector<int> idx((size_t)batch * 5), good(batch);
+    std::vector<double> models((size_t)batch * 6);
+    double best[6] = {0, 0, 0, 0, 0, 0};
+    pnp::MwcRng rng{(uint64_t)-1};
+    while (iter < niters) {
+        const int B = std::min(batch, niters - iter);
+        for (int b = 0; b < B; b++) next_sample(n, &idx[(size_t)b * 5], rng);
+        HIP_CHECK(hipMemcpyAsync(idx_dev, idx.data(), (size_t)B * 5 * sizeof(int), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemsetAsync(good_dev, 0, (size_t)B * sizeof(int), s));
+        hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(ceil_div(B, PNP_THREADS)), dim3(PNP_THREADS), PNP_LDS_BYTES, s, (const float*)obj_dev, (const float*)img_dev,
+                           (const int*)idx_dev, B, cam, models_dev);
+        {
+            KernelTimer timer("pnp_score", s);
+            const int parts = std::max(1, std::min(64, ceil_div(256 * 8, ceil_div(B, PNP_HT))));
+            hipLaunchKernelGGL(pnp_score_kernel, dim3(ceil_div(B, PNP_HT), parts), dim3(256), 0, s, (const float*)obj_dev, (const float*)img_dev, n,
+                               (const double*)models_dev, B, cam, t, good_dev);
+        }
+        HIP_CHECK(hipMemcpyAsync(good.data(), good_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(models.data(), models_dev, (size_t)B * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        // replay the sequential loop over the speculated iterations (samples beyond a shortened budget are discarded)
+        for (int b = 0; b < B && iter < niters; b++, iter++) {
+            if (good[b] > std::max(maxGood, 4)) {
+                std::memcpy(best, &models[(size_t)b * 6], sizeof(best));
+                maxGood = good[b];
+                niters = update_num_iters(confidence, (double)(n - good[b]) / n, 5, niters);
+            }
+        }
+    }
+    HIP_CHECK(hipGetLastError());
+    if (maxGood <= 0) return 0;
+    std::vector<uint8_t> mask(n);
+    HIP_CHECK(hipMemcpyAsync(models_dev, best, sizeof(best), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(pnp_mask_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, (const float*)obj_dev, (const float*)img_dev, n, (const double*)models_dev, cam, t,
+                       mask_dev);
+    HIP_CHECK(hipMemcpyAsync(mask.data(), mask_dev, n, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    // final pose from all inliers (as doubles converted back from the float copies), in index order
+    std::vector<double> oi, ii;
+    int cnt = 0;
+    for (int i = 0; i < n; i++)
+        if (mask[i]) {
+            for (int k = 0; k < 3; k++) oi.push_back((double)op[3 * (size_t)i + k]);
+            for (int k = 0; k < 2; k++) ii.push_back((double)ip[2 * (size_t)i + k]);
+            inliers[cnt++] = i;
+        }
+    APDS_REQUIRE(cnt == maxGood, APDS_ERR_INTERNAL, "inlier mask disagrees with the scored count");
+    host_epnp<double>(oi.data(), ii.data(), cnt, cam, rvec, tvec);
+    *n_inliers = cnt;
+    return 1;
+}
+
+// per-stage hooks for the parity tests: the pose of explicit 5-point samples
+void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, const double* K, const int32_t* idx5, int B, double* models_host, hipStream_t s) {
+    APDS_REQUIRE(obj_xyz && img_xy && K && idx5 && models_host && n >= 5 && B >= 1, APDS_ERR_BAD_ARG, "bad argument");
+    for (int i = 0; i < B * 5; i++) APDS_REQUIRE(idx5[i] >= 0 && idx5[i] < n, APDS_ERR_OUT_OF_RANGE, "sample index out of range");
+    const Camera cam{K[0], K[4], K[2], K[5]};
+    std::vector<float> op(3 * (size_t)n), ip(2 * (size_t)n);
+    for (size_t i = 0; i < op.size(); i++) op[i] = (float)obj_xyz[i];
+    for (size_t i = 0; i < ip.size(); i++) ip[i] = (float)img_xy[i];
+    ThreadCtx& c = ctx();
+    float* obj_dev = c.alloc_n<float>(op.size());
+    float* img_dev = c.alloc_n<float>(ip.size());
+    int* idx_dev = c.alloc_n<int>((size_t)B * 5);
+    double* models_dev = c.alloc_n<double>((size_t)B * 6);
+    HIP_CHECK(hipMemcpyAsync(obj_dev, op.data(), op.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(img_dev, ip.data(), ip.size() * sizeof(float), hipMemcpyHostToDevice, s));
+    HIP_CHECK(hipMemcpyAsync(idx_dev, idx5, (size_t)B * 5 * sizeof(int), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(ceil_div(B, PNP_THREADS)), dim3(PNP_THREADS), PNP_LDS_BYTES, s, (const float*)obj_dev, (const float*)img_dev,
+                       (const int*)idx_dev, B, cam, models_dev);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(models_host, models_dev, (size_t)B * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+}  // namespace apds

@@ -1,5 +1,7 @@
 """Host-side mirror of the reference crate `homographier` (/root/reference/homographier/src/homographier/mod.rs)
-for the rows on the hot path: HomographyMethod, MatError, Cmat, raster_to_mat, find_homography_mat."""
+for the rows on the hot path: HomographyMethod, MatError, Cmat, raster_to_mat, find_homography_mat, and the crate's remaining
+public functions warp_image_perspective and pnp_solver_ransac."""
+import ctypes as C
 import enum
 
 import numpy as np
@@ -114,3 +116,53 @@ def warp_image_perspective(src, m, size=None):
     except ApdsError as e:
         raise MatError("Opencv", e)
     return Cmat(out, np.uint8, 4)
+
+
+class SolvePnPMethod(enum.IntEnum):
+    """opencv::calib3d::SolvePnPMethod values the reference can pass (mod.rs:4,327)."""
+    SOLVEPNP_ITERATIVE = 0
+    SOLVEPNP_EPNP = 1
+    SOLVEPNP_P3P = 2
+    SOLVEPNP_AP3P = 5
+
+
+class ImgObjCorrespondence:
+    """mod.rs:52-65 — a 3D object point and the 2D image point it projects to."""
+
+    def __init__(self, obj_point, img_point):
+        self.obj_point = tuple(float(v) for v in obj_point)
+        self.img_point = tuple(float(v) for v in img_point)
+        if len(self.obj_point) != 3 or len(self.img_point) != 2:
+            raise ValueError("obj_point is (x, y, z), img_point is (x, y)")
+
+
+class PNPRANSACSolution:
+    """mod.rs:46-51 — rvec, tvec: Cmat<f64> 3x1; inliers: Cmat<i32> n_inliers x 1 (indices into point_correspondences)."""
+
+    def __init__(self, rvec, tvec, inliers):
+        self.rvec, self.tvec, self.inliers = rvec, tvec, inliers
+
+
+def pnp_solver_ransac(point_correspondences, camera_intrinsic, iter_count, reproj_thres, confidence, dist_coeffs=None, method=None):
+    """mod.rs:320-369 — solvePnPRansac(useExtrinsicGuess = false). Returns a PNPRANSACSolution, or None when no pose was found
+    (Ok(None)); raises MatError("Opencv") for fewer than 4 correspondences (mod.rs:627-638). `dist_coeffs` is accepted and ignored,
+    as in the reference, which shadows it with zeros(4,1) before the call (mod.rs:344). Only SOLVEPNP_EPNP (the default) is built."""
+    del dist_coeffs
+    n = len(point_correspondences)
+    obj = np.ascontiguousarray([p.obj_point for p in point_correspondences], np.float64).reshape(n, 3)
+    img = np.ascontiguousarray([p.img_point for p in point_correspondences], np.float64).reshape(n, 2)
+    K = np.ascontiguousarray(camera_intrinsic.mat, np.float64)
+    if K.shape != (3, 3):
+        raise MatError("Opencv", ApdsError(_lib.ERR_ASSERT, "camera_intrinsic must be 3x3"))
+    method_i = int(SolvePnPMethod.SOLVEPNP_EPNP if method is None else method)      # mod.rs:360
+    rvec, tvec = np.zeros((3, 1), np.float64), np.zeros((3, 1), np.float64)
+    inliers = np.zeros(max(n, 1), np.int32)
+    n_inl, found = C.c_int(0), C.c_int(0)
+    try:
+        check(lib().apds_pnp_solver_ransac(ptr(obj), ptr(img), n, ptr(K), int(iter_count), float(reproj_thres), float(confidence), method_i,
+                                           ptr(rvec), ptr(tvec), ptr(inliers), C.byref(n_inl), C.byref(found)))
+    except ApdsError as e:
+        raise MatError("Opencv", e)
+    if not found.value:
+        return None
+    return PNPRANSACSolution(Cmat(rvec, np.float64), Cmat(tvec, np.float64), Cmat(inliers[:n_inl.value].reshape(-1, 1).copy(), np.int32))

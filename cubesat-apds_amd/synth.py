@@ -10,6 +10,7 @@ DB_SEED = 0x44420001
 QUERY_SEED = 0x51550001
 RANSAC_SEED = 0x52410001
 L2_SEED = 0x4C320001
+PNP_SEED = 0x504E0001
 
 
 def splitmix64(seed, n, offset=0):
@@ -145,3 +146,26 @@ def make_l2_set(n_db, n_query, dim=128, seed=L2_SEED, planted=0.3, noise=0.05):
     pq = db[src[pl]] + noise * normal(seed ^ 0x3333, int(pl.sum()) * dim).reshape(-1, dim)
     q[pl] = pq / np.linalg.norm(pq, axis=1, keepdims=True)
     return db.astype(np.float32), q.astype(np.float32), np.where(pl, src, -1)
+
+
+def make_pnp_set(n=2000, seed=PNP_SEED, inlier_frac=0.6, noise=0.5, width=4096.0, height=4096.0, focal=3500.0):
+    """3D-2D correspondences for pnp_solver_ransac: object points in a 400 x 400 x 60 slab (terrain-like: wide, shallow), a camera about
+    900 units above it with a small tilt, Gaussian pixel noise on the inliers and uniformly random image points for the outliers.
+    Returns obj (n x 3 f64), img (n x 2 f64), K (3 x 3), rvec_true, tvec_true, inlier flag."""
+    u = uniform01(seed, n * 8).reshape(n, 8)
+    p = uniform01(seed ^ 0xBEEF, 8)
+    K = np.array([[focal, 0.0, width / 2], [0.0, focal * 0.99, height / 2], [0.0, 0.0, 1.0]])
+    rvec = np.array([-0.12 + 0.24 * p[0], -0.12 + 0.24 * p[1], -0.5 + 1.0 * p[2]])
+    tvec = np.array([-20 + 40 * p[3], -20 + 40 * p[4], 850 + 100 * p[5]])
+    th = np.linalg.norm(rvec)
+    k = rvec / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+    obj = np.stack([-200 + 400 * u[:, 0], -200 + 400 * u[:, 1], -30 + 60 * u[:, 2]], 1)
+    cam = obj @ R.T + tvec
+    img = cam[:, :2] / cam[:, 2:3] * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]])
+    r = np.sqrt(-2 * np.log(np.maximum(u[:, 3], 1e-300)))
+    img = img + noise * np.stack([r * np.cos(2 * np.pi * u[:, 4]), r * np.sin(2 * np.pi * u[:, 4])], 1)
+    inl = u[:, 5] < inlier_frac
+    img[~inl] = u[~inl, 6:8] * np.array([width, height])
+    return obj, img, K, rvec, tvec, inl

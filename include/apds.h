@@ -39,6 +39,7 @@ extern "C" {
 #define APDS_ERR_NO_DEVICE (-216)   /* cv::Error::GpuNotSupported: no HIP device / kernels not loadable */
 #define APDS_ERR_OUT_OF_RANGE (-211)/* cv::Error::StsOutOfRange */
 #define APDS_ERR_ASSERT (-215)      /* cv::Error::StsAssert (bad shapes, k < 1, too few points) */
+#define APDS_ERR_NOT_IMPLEMENTED (-213) /* cv::Error::StsNotImplemented (a method of the reference surface that is not built) */
 #define APDS_ERR_EMPTY (-1000)      /* no model found: the shim maps it to MatError::Empty (mod.rs:114-119,258) */
 
 /* feature_extraction/src/lib.rs:12-13  MAX_POINTS_SHIFT / MAX_POINTS (twin: feature_database/src/keypointdb.rs:12) */
@@ -126,6 +127,20 @@ int apds_dev_band_merger(const void* red, const void* green, const void* blue, s
  * Scalar(1,1,1,1)). M (9 doubles) maps source to destination coordinates. channels must be 4 (Vec4b). */
 int apds_warp_perspective(const uint8_t* src, int rows, int cols, int channels, const double* M, int dst_rows, int dst_cols, uint8_t* dst);
 
+/* homographier/src/homographier/mod.rs:320-369 pnp_solver_ransac(point_correspondences, camera_intrinsic, iter_count, reproj_thres,
+ * confidence, dist_coeffs, method) -> Result<Option<PNPRANSACSolution>, MatError>: cv::solvePnPRansac with useExtrinsicGuess = false and
+ * distCoeffs = zeros(4,1) (mod.rs:344 shadows the dist_coeffs argument with zeros, so it never reaches OpenCV and is not part of this ABI).
+ * obj_xyz: n Point3d (ImgObjCorrespondence::obj_point, mod.rs:53-65), img_xy: n Point2d, camera_intrinsic: 3x3 f64 row major.
+ * method: cv::SolvePnPMethod; the shim passes method.unwrap_or(SOLVEPNP_EPNP) (mod.rs:360). Only APDS_SOLVEPNP_EPNP is built; P3P / AP3P
+ * and n == 4 (which OpenCV routes through P3P) return APDS_ERR_NOT_IMPLEMENTED. n < 4 -> APDS_ERR_ASSERT (mod.rs:627-638).
+ * *found = 1: rvec[3], tvec[3], inliers[0..*n_inliers) filled (inliers: caller allocated, n ints); *found = 0: Ok(None). */
+#define APDS_SOLVEPNP_ITERATIVE 0
+#define APDS_SOLVEPNP_EPNP 1
+#define APDS_SOLVEPNP_P3P 2
+#define APDS_SOLVEPNP_AP3P 5
+int apds_pnp_solver_ransac(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, int iter_count, float reproj_thres,
+                           double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers, int* found);
+
 /* BASELINE config 3 (no reference call site: the reference matches Hamming only, lib.rs:101,121): brute-force L2 k-NN of float
  * descriptors (dim <= 128) as an MFMA distance GEMM with a fused top-k; semantics of BFMatcher(NORM_L2).knnMatch
  * (dist = sqrt(sum (q-t)^2), ties to the lower train index). k in {1,2}. idx/dist: n_query*k. */
@@ -191,6 +206,10 @@ int apds_stream_destroy(void* stream);
 /* Test hook: run apds_akaze_extract and copy one intermediate plane of evolution level `level` to out_plane
  * (which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet as f32 w*h; 7 keypoint mask after cross-level suppression as u8 w*h; 8 contrast factor, 1 float). */
 int apds_akaze_debug_plane(const uint8_t* img, int rows, int cols, int channels, size_t stride_bytes, int level, int which, void* out_plane);
+
+/* Test hook: EPnP pose (rvec, tvec: 6 doubles per sample) of n_samples explicit 5-correspondence samples, as the RANSAC kernel computes them. */
+int apds_pnp_hypotheses(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, const int32_t* idx5, int n_samples,
+                        double* models);
 
 /* Measurement helpers used by bench.py (not part of the reference surface). */
 /* Register-only xor+popcount loop: returns measured lane-ops/s (32-bit xor + bcnt counted as 2 ops). */

@@ -22,7 +22,7 @@ PLANE_LT, PLANE_LSMOOTH, PLANE_LX, PLANE_LY, PLANE_LDET, PLANE_LFLOW, PLANE_MASK
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("akaze_oracle.cpp", "match_oracle.cpp", "homography_oracle.cpp", "ingest_oracle.cpp", "oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("akaze_oracle.cpp", "match_oracle.cpp", "homography_oracle.cpp", "ingest_oracle.cpp", "pnp_oracle.cpp", "oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
@@ -67,6 +67,19 @@ def lib():
         L.oracle_find_homography.restype = C.c_int
         L.oracle_find_homography.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double,
                                              C.c_void_p, C.c_void_p]
+        L.oracle_solve_pnp_ransac.restype = C.c_int
+        L.oracle_solve_pnp_ransac.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_int,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_solve_pnp_epnp.restype = C.c_int
+        L.oracle_solve_pnp_epnp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_pnp_ransac_samples.restype = C.c_int
+        L.oracle_pnp_ransac_samples.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.oracle_pnp_hypothesis.restype = C.c_int
+        L.oracle_pnp_hypothesis.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_rodrigues.restype = None
+        L.oracle_rodrigues.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_det_acos.restype = None
+        L.oracle_det_acos.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_homography_4pt.restype = C.c_int
         L.oracle_homography_4pt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_ransac_samples.restype = C.c_int
@@ -292,3 +305,59 @@ def knn_l2(q, t, k):
     dist = np.zeros((q.shape[0], k), np.float32)
     lib().oracle_knn_l2(_ptr(q), q.shape[0], _ptr(t), t.shape[0], q.shape[1], k, _ptr(idx), _ptr(dist))
     return idx, dist
+
+
+def solve_pnp_ransac(obj, img, K, iterations=100, reproj_thr=8.0, confidence=0.99, method=1):
+    """Returns (rc, rvec[3], tvec[3], inliers int32[]); rc 1 found / 0 none / <0 cv error code."""
+    obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    inl = np.zeros(max(len(obj), 1), np.int32)
+    n_inl = C.c_int(0)
+    rc = lib().oracle_solve_pnp_ransac(_ptr(obj), _ptr(img), len(obj), _ptr(K), iterations, reproj_thr, confidence, method, _ptr(rvec),
+                                   _ptr(tvec), _ptr(inl), C.cast(C.byref(n_inl), C.c_void_p))
+    return rc, rvec, tvec, inl[:n_inl.value].copy()
+
+
+def solve_pnp_epnp(obj, img, K):
+    obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    rc = lib().oracle_solve_pnp_epnp(_ptr(obj), _ptr(img), len(obj), _ptr(K), _ptr(rvec), _ptr(tvec))
+    return rc, rvec, tvec
+
+
+def pnp_ransac_samples(n, iters):
+    idx = np.zeros((iters, 5), np.int32)
+    lib().oracle_pnp_ransac_samples(n, iters, _ptr(idx))
+    return idx
+
+
+def pnp_hypothesis(obj, img, idx5, K):
+    obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+    idx5 = np.ascontiguousarray(idx5, np.int32)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    lib().oracle_pnp_hypothesis(_ptr(obj), _ptr(img), _ptr(idx5), _ptr(K), _ptr(rvec), _ptr(tvec))
+    return rvec, tvec
+
+
+def rodrigues(x):
+    x = np.ascontiguousarray(x, np.float64)
+    if x.size == 9:
+        out = np.zeros(3)
+        lib().oracle_rodrigues(_ptr(x), 1, _ptr(out))
+        return out
+    out = np.zeros(9)
+    lib().oracle_rodrigues(_ptr(x), 0, _ptr(out))
+    return out.reshape(3, 3)
+
+
+def det_acos(c):
+    c = np.ascontiguousarray(c, np.float64).reshape(-1)
+    out = np.zeros_like(c)
+    lib().oracle_det_acos(_ptr(c), len(c), _ptr(out))
+    return out

@@ -175,3 +175,62 @@ def test_warp_image_empty_kat(oracle_mod):
     assert np.array_equal(oracle_mod.warp_perspective(big, np.eye(3)), big)
     shifted = oracle_mod.warp_perspective(big, np.array([[1, 0, 3.0], [0, 1, 2.0], [0, 0, 1]]))
     assert np.array_equal(shifted[2:, 3:], big[:-2, :-3]) and (shifted[:2] == 1).all() and (shifted[:, :3] == 1).all()
+
+
+# ---- pnp_solver_ransac ----------------------------------------------------------------------------------
+def test_pnp_fewer_than_4_points_is_an_error_kat(oracle_mod):
+    # /root/reference/homographier/src/homographier/mod.rs:627-638: 2 correspondences, zero camera matrix -> Err
+    obj = np.array([[1, 2, 3], [4, 5, 6]], np.float64)
+    img = np.array([[1, 2], [4, 5]], np.float64)
+    rc, _, _, inl = oracle_mod.solve_pnp_ransac(obj, img, np.zeros((3, 3)), 50, 2.0, 0.99)
+    assert rc == -215 and len(inl) == 0
+
+
+def test_pnp_ignored_reference_case_finds_a_pose(oracle_mod):
+    # mod.rs:640-682 (#[ignore]d upstream, P3P requested there; EPnP here): 5 correspondences, no assertion on values upstream.
+    obj = np.array([[0, 5, 1], [5, 0, 0], [5, 5, 1.5], [0, 0, 1], [2, 8, -2]], np.float64)
+    img = np.array([[-1.48, 0.39], [2.14, -1.92], [1.74, 0.56], [-2, -1.62], [-0.16, 0.3]], np.float64)
+    K = np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1]])
+    rc, rvec, tvec, inl = oracle_mod.solve_pnp_ransac(obj, img, K, 10000, 100.0, 0.5)
+    assert rc == 1 and list(inl) == [0, 1, 2, 3, 4] and np.isfinite(rvec).all() and np.isfinite(tvec).all()
+
+
+def test_pnp_fixed_elementary_functions(oracle_mod):
+    c = np.concatenate([np.linspace(-1, 1, 20001), [1 - 1e-12, -1 + 1e-12, 1 - 1e-9]])
+    assert np.abs(oracle_mod.det_acos(c) - np.arccos(c)).max() < 2e-15
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        rv = rng.normal(size=3)
+        rv *= rng.uniform(0.01, 3.1) / np.linalg.norm(rv)
+        R = oracle_mod.rodrigues(rv)
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-14) and abs(np.linalg.det(R) - 1) < 1e-14
+        assert np.allclose(oracle_mod.rodrigues(R), rv, rtol=0, atol=1e-13)
+    assert np.array_equal(oracle_mod.rodrigues(np.zeros(3)), np.eye(3))
+    assert np.array_equal(oracle_mod.rodrigues(np.eye(3)), np.zeros(3))
+
+
+def test_epnp_recovers_exact_pose(oracle_mod, pkg):
+    for n in (5, 6, 12, 300):
+        obj, img, K, rvec, tvec, _ = pkg.synth.make_pnp_set(n, seed=100 + n, inlier_frac=1.1, noise=0.0)
+        rc, r, t = oracle_mod.solve_pnp_epnp(obj, img, K)
+        assert rc == 1
+        assert np.allclose(r, rvec, rtol=0, atol=1e-7), (n, np.abs(r - rvec).max())
+        assert np.allclose(t, tvec, rtol=1e-7, atol=1e-5), (n, np.abs(t - tvec).max())
+    assert oracle_mod.solve_pnp_epnp(obj[:3], img[:3], K)[0] == -215
+
+
+def test_pnp_ransac_recovers_planted_pose(oracle_mod, pkg):
+    obj, img, K, rvec, tvec, inl = pkg.synth.make_pnp_set(3000, inlier_frac=0.6, noise=0.5)
+    rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, 1000, 3.0, 0.99)
+    assert rc == 1
+    got = np.zeros(len(obj), bool)
+    got[idx] = True
+    assert (got & inl).sum() > 0.97 * inl.sum()            # nearly every true inlier (0.5 px noise, 3 px gate)
+    assert (got & ~inl).sum() <= 0.002 * len(obj) + 2      # chance hits of uniformly random outliers only
+    assert np.allclose(r, rvec, atol=2e-3) and np.allclose(t, tvec, rtol=2e-3, atol=0.5)
+    # n == 4 and the P3P family are not restated
+    assert oracle_mod.solve_pnp_ransac(obj[:4], img[:4], K)[0] == -213
+    assert oracle_mod.solve_pnp_ransac(obj, img, K, method=2)[0] == -213
+    # all outliers: no model gathers more than the 4 points that define it ... or only by chance; the call must not fail
+    rc2, _, _, idx2 = oracle_mod.solve_pnp_ransac(obj[~inl][:200], img[~inl][:200], K, 200, 1.0, 0.99)
+    assert rc2 in (0, 1) and (rc2 == 0) == (len(idx2) == 0)

@@ -1,0 +1,75 @@
+"""GPU: pnp_solver_ransac parity, HIP path through the C ABI vs the oracle.
+Bar: every 5-point hypothesis (rvec, tvec) bit-identical (both sides evaluate the same IEEE double operations in the same order); inlier
+index lists identical; final pose bit-identical (the all-inlier solve runs on the host in index order). Tolerance against the planted pose
+is stated per test. PARITY UNPINNED against OpenCV itself (oracle/pnp_oracle.cpp header)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _hyp(pkg, obj, img, K, idx):
+    idx = np.ascontiguousarray(idx, np.int32)
+    out = np.zeros((len(idx), 6))
+    K = np.ascontiguousarray(K, np.float64)
+    rc = pkg.lib().apds_pnp_hypotheses(pkg._lib.ptr(obj), pkg._lib.ptr(img), len(obj), pkg._lib.ptr(K), pkg._lib.ptr(idx), len(idx), pkg._lib.ptr(out))
+    assert rc == 0, pkg.lib().apds_last_error()
+    return out
+
+
+def _solve(pkg, obj, img, K, iters, thr, conf, method=None):
+    hg = pkg.homographier
+    corr = [hg.ImgObjCorrespondence(o, i) for o, i in zip(obj, img)]
+    return hg.pnp_solver_ransac(corr, hg.Cmat(np.ascontiguousarray(K, np.float64), np.float64), iters, thr, conf, None, method)
+
+
+def test_reference_kat_fewer_than_4_points(gpu_pkg):
+    # /root/reference/homographier/src/homographier/mod.rs:627-638
+    hg = gpu_pkg.homographier
+    corr = [hg.ImgObjCorrespondence((1, 2, 3), (1, 2)), hg.ImgObjCorrespondence((4, 5, 6), (4, 5))]
+    with pytest.raises(hg.MatError) as e:
+        hg.pnp_solver_ransac(corr, hg.Cmat.zeros(3, 3, np.float64), 50, 2.0, 0.99, None, None)
+    assert e.value.kind == "Opencv" and e.value.inner.code == -215
+
+
+def test_hypotheses_bit_identical_to_oracle(gpu_pkg, oracle_mod):
+    obj, img, K, _, _, _ = gpu_pkg.synth.make_pnp_set(2000, inlier_frac=0.6, noise=0.5)
+    idx = oracle_mod.pnp_ransac_samples(len(obj), 300)
+    got = _hyp(gpu_pkg, obj, img, K, idx)
+    for b in range(len(idx)):
+        r, t = oracle_mod.pnp_hypothesis(obj, img, idx[b], K)
+        want = np.concatenate([r, t])
+        assert np.array_equal(got[b], want, equal_nan=True), (b, got[b], want)
+
+
+@pytest.mark.parametrize("n,frac,noise,iters,thr,conf", [(2000, 0.6, 0.5, 1000, 3.0, 0.99), (50000, 0.4, 0.5, 2000, 2.0, 0.995),
+                                                        (300, 0.9, 0.2, 100, 8.0, 0.99), (6, 1.1, 0.0, 50, 2.0, 0.99),
+                                                        (5, 1.1, 0.0, 50, 2.0, 0.99)])
+def test_ransac_matches_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, thr, conf):
+    obj, img, K, rvec, tvec, inl = gpu_pkg.synth.make_pnp_set(n, seed=7 + n, inlier_frac=frac, noise=noise)
+    sol = _solve(gpu_pkg, obj, img, K, iters, thr, conf)
+    rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, iters, thr, conf)
+    assert (sol is not None) == (rc == 1)
+    assert np.array_equal(sol.inliers.mat.ravel(), idx)
+    assert np.array_equal(sol.rvec.mat.ravel(), r) and np.array_equal(sol.tvec.mat.ravel(), t)
+    # and the answer is the planted pose (pixel-noise limited)
+    assert np.allclose(r, rvec, atol=3e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.0)
+
+
+def test_unbuilt_methods_and_no_solution(gpu_pkg, oracle_mod):
+    hg = gpu_pkg.homographier
+    obj, img, K, _, _, inl = gpu_pkg.synth.make_pnp_set(400, inlier_frac=0.5, noise=0.5)
+    for method in (hg.SolvePnPMethod.SOLVEPNP_P3P, hg.SolvePnPMethod.SOLVEPNP_AP3P, hg.SolvePnPMethod.SOLVEPNP_ITERATIVE):
+        with pytest.raises(hg.MatError) as e:
+            _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, method)
+        assert e.value.inner.code == -213
+    with pytest.raises(hg.MatError) as e:
+        _solve(gpu_pkg, obj[:4], img[:4], K, 100, 3.0, 0.99)
+    assert e.value.inner.code == -213
+    # outliers only: same outcome (usually Ok(None)) as the oracle
+    o, i = obj[~inl][:150], img[~inl][:150]
+    sol = _solve(gpu_pkg, o, i, K, 150, 0.5, 0.99)
+    rc, r, t, idx = oracle_mod.solve_pnp_ransac(o, i, K, 150, 0.5, 0.99)
+    assert (sol is not None) == (rc == 1)
+    if sol is not None:
+        assert np.array_equal(sol.inliers.mat.ravel(), idx)
