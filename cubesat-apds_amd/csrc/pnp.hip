@@ -180,7 +180,8 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     HIP_CHECK(hipMemcpyAsync(obj_dev, op.data(), op.size() * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(img_dev, ip.data(), ip.size() * sizeof(float), hipMemcpyHostToDevice, s));
 
-    static const int batch_env = getenv("APDS_RANSAC_BATCH") ? atoi(getenv("APDS_RANSAC_BATCH")) : 512;
+    // a batch costs about the same wall time up to ~16 k samples (one thread each, latency-bound): speculate deep
+    static const int batch_env = getenv("APDS_PNP_BATCH") ? atoi(getenv("APDS_PNP_BATCH")) : 2048;
     int niters = std::max(iterations, 1), maxGood = 0, iter = 0;
     const int batch = std::max(PNP_HT, std::min(batch_env, niters));
     const float t = (float)((double)reproj_thr * (double)reproj_thr);

@@ -517,13 +517,17 @@ PNP_HD void epnp_pose(int n, const PW& pws, const US& us, AL alphas, PC pcs, con
     }
     // M^T M and its singular vectors; the four with the smallest singular values span the candidate solutions
     BIG ut = big, d = big.sub(144);
+    // (row-outer accumulation: every entry still sums its products in row order k = 0..2n-1, as cvMulTransposed does)
     for (int i = 0; i < 12; i++)
-        for (int j = i; j < 12; j++) {
-            double s = 0;
-            for (int k = 0; k < 2 * n; k++) s += m_entry(alphas, us, cam, k, i) * m_entry(alphas, us, cam, k, j);
-            ut[i * 12 + j] = s;
-            ut[j * 12 + i] = s;
-        }
+        for (int j = i; j < 12; j++) ut[i * 12 + j] = 0;
+    for (int k = 0; k < 2 * n; k++) {
+        double row[12];
+        for (int c = 0; c < 12; c++) row[c] = m_entry(alphas, us, cam, k, c);
+        for (int i = 0; i < 12; i++)
+            for (int j = i; j < 12; j++) ut[i * 12 + j] += row[i] * row[j];
+    }
+    for (int i = 0; i < 12; i++)
+        for (int j = i + 1; j < 12; j++) ut[j * 12 + i] = ut[i * 12 + j];
     svd_rows<false>(ut, 12, 12, d, d);
     double L[60], rho[6];
     {

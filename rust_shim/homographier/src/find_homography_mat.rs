@@ -1,5 +1,5 @@
 //! Replacement bodies for two functions of /root/reference/homographier/src/homographier/mod.rs; everything else in
-//! that module (Cmat, MatError, HomographyMethod, warp_image_perspective, pnp_solver_ransac) stays as it is.
+//! that module (Cmat, MatError, HomographyMethod, warp_image_perspective) stays as it is; pnp_solver_ransac.rs replaces a third.
 //! NOT compiled in the build container (no Rust toolchain there).
 use super::{Cmat, HomographyMethod, MatError};
 use opencv::core::{Mat, Point2f, Vec4b};
