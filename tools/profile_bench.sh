@@ -13,9 +13,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_serial -- pyt
 echo "serial stats rc=$?"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py $ARGS > $OUT/bench_stats.log 2>&1
 echo "stats rc=$?"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
+# counter passes run --serial: TCC counters are device-wide, so with the stages overlapped the extraction's HBM traffic would be
+# charged to whichever match launch it ran under
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
 echo "fetch rc=$?"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_write.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --serial --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_write.log 2>&1
 echo "write rc=$?"
 find $OUT -name "*.csv" | head -20
 python3 $R/tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1

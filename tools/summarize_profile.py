@@ -37,6 +37,6 @@ if res["FETCH_SIZE"][1]:
     fetch_b = res["FETCH_SIZE"][0] * 1024 * 2 / res["FETCH_SIZE"][1]
     write_b = res["WRITE_SIZE"][0] * 1024 / max(res["WRITE_SIZE"][1], 1)
     t = {"hamming_topk_hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes_per_launch_corrected_x2": fetch_b, "write_bytes_per_launch": write_b,
-         "launches_sampled": res["FETCH_SIZE"][1], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --steps 2 --warmup 1"}
+         "launches_sampled": res["FETCH_SIZE"][1], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --serial --steps 2 --warmup 1 (serial: the counters are device-wide)"}
     print(json.dumps(t))
     json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
