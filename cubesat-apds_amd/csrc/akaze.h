@@ -17,7 +17,8 @@ struct LevelDesc {
     int nsteps;
     float tau[64];
     // device planes
-    float *Lt, *Lx, *Ly, *Ldet;
+    float *Lt, *Ldet;
+    float2* Lxy;   // (Lx, Ly) interleaved
     uint8_t* mask;      // extrema / suppression state
     uint8_t* mask_aux;  // scratch copy for the suppression rounds
     long long pix_offset;   // offset of this level in the level-major concatenated pixel index space
@@ -30,8 +31,7 @@ struct LevelTable {
     float esigma[AKAZE_MAX_LEVELS], ratio[AKAZE_MAX_LEVELS];
     long long pix_offset[AKAZE_MAX_LEVELS + 1];
     const float* Lt[AKAZE_MAX_LEVELS];
-    const float* Lx[AKAZE_MAX_LEVELS];
-    const float* Ly[AKAZE_MAX_LEVELS];
+    const float2* Lxy[AKAZE_MAX_LEVELS];   // (Lx, Ly) interleaved
     const float* Ldet[AKAZE_MAX_LEVELS];
     uint8_t* mask[AKAZE_MAX_LEVELS];
 };
@@ -47,7 +47,7 @@ void launch_nld_step2(const float* Lt, const float* Lf, float* Lnew, int w, int 
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s);
 void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, const int* xofs, const float* xw, const int* xcnt, const int* yofs,
                         const float* yw, const int* ycnt, hipStream_t s);
-void launch_doh_fused(const float* Lsmooth, float* Lx, float* Ly, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s);
+void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s);
 
 // Test hook: when armed (per thread) the next akaze_extract_device copies one intermediate plane to the host.
 // which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet (f32), 7 keypoint mask after cross-level suppression (u8), 8 kcontrast (1 float)

@@ -335,8 +335,8 @@ __global__ void area_resize_kernel(const float* __restrict__ src, int sw, float*
 // derivatives on the tile. Lsmooth is read once (24 -> ~19 B/pixel incl. halo) and one launch per level disappears.
 static constexpr int DW = 64, DH = 32;
 
-__global__ __launch_bounds__(256) void doh_fused_kernel(const float* __restrict__ Lsmooth, float* __restrict__ Lx, float* __restrict__ Ly,
-                                                        float* __restrict__ Ldet, int w, int h, int s, float kside, float kmid, float sq) {
+__global__ __launch_bounds__(256) void doh_fused_kernel(const float* __restrict__ Lsmooth, float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h,
+                                                        int s, float kside, float kmid, float sq) {
     APDS_RAISE_WAVE_PRIORITY();
     extern __shared__ float smem[];
     const int SW = DW + 4 * s, SH = DH + 4 * s;      // Lsmooth tile, halo 2s
@@ -393,8 +393,7 @@ __global__ __launch_bounds__(256) void doh_fused_kernel(const float* __restrict_
         rsy2 += kside * (y2r[-s] + y2r[s]);
         const float lyy = rsy2 - rsy0;
         const size_t o = (size_t)gy * w + gx;
-        Lx[o] = s_mx[c];
-        Ly[o] = s_my[c];
+        Lxy[o] = make_float2(s_mx[c], s_my[c]);   // interleaved: orientation and M-LDB gather both with one 8-byte load
         Ldet[o] = (lxx * lyy - lxy * lxy) * sq;
     }
 }
@@ -441,9 +440,9 @@ void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, co
                         const float* yw, const int* ycnt, hipStream_t s) {
     hipLaunchKernelGGL(area_resize_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, src, sw, dst, dw, dh, xofs, xw, xcnt, yofs, yw, ycnt);
 }
-void launch_doh_fused(const float* Lsmooth, float* Lx, float* Ly, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s) {
+void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s) {
     const size_t lds = (size_t)((DW + 4 * sc) * (DH + 4 * sc) + 2 * (DW + 2 * sc) * (DH + 2 * sc)) * sizeof(float);
-    hipLaunchKernelGGL(doh_fused_kernel, dim3(ceil_div(w, DW), ceil_div(h, DH)), dim3(256), lds, s, Lsmooth, Lx, Ly, Ldet, w, h, sc, kside, kmid,
+    hipLaunchKernelGGL(doh_fused_kernel, dim3(ceil_div(w, DW), ceil_div(h, DH)), dim3(256), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
                        (float)(sc * sc * sc * sc));
 }
 

@@ -363,14 +363,14 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
     const float ratio = T.ratio[lvl];
     const int scale = __float2int_rn(0.5f * kp.size / ratio);
     const int x0 = __float2int_rn(kp.x / ratio), y0 = __float2int_rn(kp.y / ratio);
-    const float* __restrict__ Lx = T.Lx[lvl];
-    const float* __restrict__ Ly = T.Ly[lvl];
+    const float2* __restrict__ Lxy = T.Lxy[lvl];
     const float rad = (float)(3.14159265358979323846 / 180);
     for (int k = lane; k < 109; k += 64) {
         const int i = c_orient.dy[k], j = c_orient.dx[k];
         const float wgt = c_gauss25[i < 0 ? -i : i][j < 0 ? -j : j];
         const int y = clampi2(y0 + i * scale, h), x = clampi2(x0 + j * scale, w);
-        const float rx = wgt * Lx[(size_t)y * w + x], ry = wgt * Ly[(size_t)y * w + x];
+        const float2 d = Lxy[(size_t)y * w + x];
+        const float rx = wgt * d.x, ry = wgt * d.y;
         const float ang = fast_atan2_deg(ry, rx) * rad;
         int b = (int)(ang / ang_step);
         if (b < 0 || b >= nkeys) b = 0;
@@ -502,8 +502,7 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
     const int lvl = kp.class_id;
     const int w = T.w[lvl], h = T.h[lvl];
     const float* __restrict__ Lt = T.Lt[lvl];
-    const float* __restrict__ Lx = T.Lx[lvl];
-    const float* __restrict__ Ly = T.Ly[lvl];
+    const float2* __restrict__ Lxy = T.Lxy[lvl];
     const float ratio = (float)(1 << kp.octave);
     const float scale = (float)__float2int_rn(0.5f * kp.size / ratio);
     const float xf = kp.x / ratio, yf = kp.y / ratio;
@@ -527,7 +526,8 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!(y1 < 0 || y1 >= h || x1 < 0 || x1 >= w)) {
                 const size_t o = (size_t)y1 * w + x1;
-                const float rx = Lx[o], ry = Ly[o];
+                const float2 d = Lxy[o];
+                const float rx = d.x, ry = d.y;
                 v.x = Lt[o];
                 v.y = -rx * si + ry * co;   // rrx
                 v.z = rx * co + ry * si;    // rry
@@ -797,8 +797,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     for (auto& e : ev) {
         const size_t n = (size_t)e.w * e.h;
         e.Lt = c.alloc_n<float>(n);
-        e.Lx = c.alloc_n<float>(n);
-        e.Ly = c.alloc_n<float>(n);
+        e.Lxy = c.alloc_n<float2>(n);
         e.Ldet = c.alloc_n<float>(n);
         e.pix_offset = total_pix;
         total_pix += (long long)n;
@@ -879,7 +878,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         }
         float kside, kmid;
         deriv_weights(e.sigma_size, kside, kmid);
-        launch_doh_fused(smooth, e.Lx, e.Ly, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, s);
+        launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, s);
     }
     HIP_CHECK(hipGetLastError());
 
@@ -900,8 +899,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         A.iratio[i] = (int)e.ratio;
         T.pix_offset[i] = e.pix_offset;
         T.Lt[i] = e.Lt;
-        T.Lx[i] = e.Lx;
-        T.Ly[i] = e.Ly;
+        T.Lxy[i] = e.Lxy;
         T.Ldet[i] = A.Ldet[i] = e.Ldet;
         T.mask[i] = A.mask[i] = mask_all + e.pix_offset;
         A.status[i] = status_all + e.pix_offset;
@@ -961,10 +959,10 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         const size_t n = (size_t)e.w * e.h;
         const void* src = nullptr;
         size_t bytes = n * 4;
+        if (dbg.which == 2 || dbg.which == 3)   // de-interleave one component of (Lx, Ly)
+            HIP_CHECK(hipMemcpy2DAsync(dbg.host_out, 4, reinterpret_cast<const char*>(e.Lxy) + (dbg.which == 3 ? 4 : 0), 8, 4, n, hipMemcpyDeviceToHost, s));
         switch (dbg.which) {
             case 0: src = e.Lt; break;
-            case 2: src = e.Lx; break;
-            case 3: src = e.Ly; break;
             case 4: src = e.Ldet; break;
             case 7: src = T.mask[dbg.level]; bytes = n; break;
             case 8: src = k_oct; bytes = 4; break;
