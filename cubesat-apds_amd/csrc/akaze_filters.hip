@@ -202,48 +202,10 @@ __global__ void kcontrast_finish_kernel(const int* __restrict__ hist, const unsi
     }
 }
 
-// ---- one explicit FED diffusion step: Lnew = Lt + step_size * div(c grad Lt) -----------------------------
-__global__ __launch_bounds__(256) void nld_step_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w,
-                                                       int h, float step_size) {
-    APDS_RAISE_WAVE_PRIORITY();
-    __shared__ float s_t[(TH + 2) * (TW + 2)];
-    __shared__ float s_f[(TH + 2) * (TW + 2)];
-    constexpr int SW = TW + 2, SH = TH + 2;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
-    for (int i = threadIdx.x; i < SW * SH; i += 256) {
-        const int ly = i / SW, lx = i - ly * SW;
-        const int gx = clampi(x0 - 1 + lx, w), gy = clampi(y0 - 1 + ly, h);   // clamped values are never used by a border case
-        const size_t o = (size_t)gy * w + gx;
-        s_t[i] = Lt[o];
-        s_f[i] = Lf[o];
-    }
-    __syncthreads();
-    const int lx = threadIdx.x & 63;
-    for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
-        const int x = x0 + lx, y = y0 + ly;
-        if (x >= w || y >= h) continue;
-        const int c = (ly + 1) * SW + lx + 1;
-        const float tc = s_t[c], fc = s_f[c];
-        const bool top = y == 0, bot = y == h - 1, left = x == 0, right = x == w - 1;
-        const float xp = (fc + s_f[c + 1]) * (s_t[c + 1] - tc);
-        const float xm = (fc + s_f[c - 1]) * (s_t[c - 1] - tc);
-        const float yp = (fc + s_f[c + SW]) * (s_t[c + SW] - tc);   // row below
-        const float ym = (fc + s_f[c - SW]) * (s_t[c - SW] - tc);   // row above
-        float step_r;
-        if ((top || bot) && (left || right)) step_r = 0.0f;
-        else if (top) step_r = xp + xm + yp;
-        else if (bot) step_r = xp + xm + ym;
-        else if (left) step_r = xp + yp + ym;
-        else if (right) step_r = xm + yp + ym;
-        else step_r = xp + xm + yp + ym;
-        Lnew[(size_t)y * w + x] = tc + step_r * step_size;
-    }
-}
-
-// Two FED steps in one pass (temporal blocking): the tile is loaded with a 2-pixel halo, step 1 is evaluated on the tile
-// + 1 ring into LDS, step 2 on the tile from that. Every intermediate value is exactly what the single-step kernel
-// produces (same expression, same inputs), so results are bit-identical; HBM traffic per two steps drops from
-// 24 to ~15 B/pixel and the launch count of the (launch-bound) small octaves halves.
+// ---- explicit FED diffusion steps: Lnew = Lt + step_size * div(c grad Lt), several steps per pass (temporal blocking) ----
+// Every intermediate value is exactly what a one-step-per-launch formulation produces (same expression, same inputs), so
+// results do not depend on how the steps are grouped; HBM traffic and the launch count of the latency-bound small octaves
+// drop with the group size.
 static constexpr int T2W = 64, T2H = 32;
 
 __device__ __forceinline__ float nld_point(const float* __restrict__ st, const float* __restrict__ sf, int c, int pitch, int x, int y, int w, int h,
@@ -264,35 +226,49 @@ __device__ __forceinline__ float nld_point(const float* __restrict__ st, const f
     return tc + step_r * step_size;
 }
 
-__global__ __launch_bounds__(256) void nld_step2_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
-                                                        float step1, float step2) {
+// S FED steps in one pass: inputs are loaded with an S-pixel halo; step j is evaluated on the tile + (S - j) rings, ping-ponging
+// between two LDS planes; the last step writes the tile. Only positions inside the image are evaluated; a border pixel's
+// out-of-image neighbour is read (whatever LDS holds) but never used, exactly as in the single-step kernel.
+struct NldSteps {
+    float v[8];
+};
+
+template <int S, int NT>
+__global__ __launch_bounds__(NT) void nld_multi_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
+                                                        NldSteps steps) {
     APDS_RAISE_WAVE_PRIORITY();
-    constexpr int SW = T2W + 4, SH = T2H + 4;      // inputs with halo 2
-    constexpr int MW = T2W + 4, MH = T2H + 4;      // step-1 plane kept at the same pitch (outer ring unused)
-    __shared__ float s_t[SH * SW];
+    constexpr int SW = T2W + 2 * S, SH = T2H + 2 * S;
     __shared__ float s_f[SH * SW];
-    __shared__ float s_m[MH * MW];
-    const int x0 = blockIdx.x * T2W, y0 = blockIdx.y * T2H;
-    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+    __shared__ float s_a[SH * SW];
+    __shared__ float s_b[SH * SW];
+    const int x0 = blockIdx.x * T2W - S, y0 = blockIdx.y * T2H - S;   // global coordinate of local (0, 0)
+    for (int i = threadIdx.x; i < SW * SH; i += NT) {
         const int ly = i / SW, lx = i - ly * SW;
-        const int gx = clampi(x0 - 2 + lx, w), gy = clampi(y0 - 2 + ly, h);   // clamped values are never used by a border case
-        const size_t o = (size_t)gy * w + gx;
-        s_t[i] = Lt[o];
+        const size_t o = (size_t)clampi(y0 + ly, h) * w + clampi(x0 + lx, w);
+        s_a[i] = Lt[o];
         s_f[i] = Lf[o];
     }
     __syncthreads();
-    // step 1 on the tile + 1 ring (local coordinates 1 .. SW-2, 1 .. SH-2), only at positions inside the image
-    for (int i = threadIdx.x; i < (SW - 2) * (SH - 2); i += 256) {
-        const int ry = i / (SW - 2), rx = i - ry * (SW - 2);
-        const int lx = rx + 1, ly = ry + 1;
-        const int gx = x0 - 2 + lx, gy = y0 - 2 + ly;
-        if (gx >= 0 && gx < w && gy >= 0 && gy < h) s_m[ly * MW + lx] = nld_point(s_t, s_f, ly * SW + lx, SW, gx, gy, w, h, step1);
+    const float* src = s_a;
+    float* dst = s_b;
+#pragma unroll
+    for (int j = 1; j < S; j++) {
+        const int rw = SW - 2 * j, rh = SH - 2 * j;   // region of this step: local [j, SW - j) x [j, SH - j)
+        for (int i = threadIdx.x; i < rw * rh; i += NT) {
+            const int ry = i / rw, rx = i - ry * rw;
+            const int lx = rx + j, ly = ry + j;
+            const int gx = x0 + lx, gy = y0 + ly;
+            if (gx >= 0 && gx < w && gy >= 0 && gy < h) dst[ly * SW + lx] = nld_point(src, s_f, ly * SW + lx, SW, gx, gy, w, h, steps.v[j - 1]);
+        }
+        __syncthreads();
+        const float* t = src;
+        src = dst;
+        dst = const_cast<float*>(t);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < T2W * T2H; i += 256) {
+    for (int i = threadIdx.x; i < T2W * T2H; i += NT) {
         const int ly = i / T2W, lx = i - ly * T2W;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx < w && gy < h) Lnew[(size_t)gy * w + gx] = nld_point(s_m, s_f, (ly + 2) * MW + lx + 2, MW, gx, gy, w, h, step2);
+        const int gx = x0 + S + lx, gy = y0 + S + ly;
+        if (gx < w && gy < h) Lnew[(size_t)gy * w + gx] = nld_point(src, s_f, (ly + S) * SW + lx + S, SW, gx, gy, w, h, steps.v[S - 1]);
     }
 }
 
@@ -427,11 +403,29 @@ void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsign
     hipLaunchKernelGGL(kcontrast_hist_kernel, dim3(1024), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist);
     hipLaunchKernelGGL(kcontrast_finish_kernel, dim3(1), dim3(64), 0, s, hist, hmax_bits, w, h, k_oct, n_oct);
 }
-void launch_nld_step(const float* Lt, const float* Lf, float* Lnew, int w, int h, float step_size, hipStream_t s) {
-    hipLaunchKernelGGL(nld_step_kernel, dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), 0, s, Lt, Lf, Lnew, w, h, step_size);
+template <int S>
+static void nld_multi_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s) {
+    // 1024 threads per 64x32 tile: each step is ~3 short dependent LDS passes, so what matters is waves in flight per CU
+    static const int nt = getenv("APDS_NLD_THREADS") ? atoi(getenv("APDS_NLD_THREADS")) : 1024;
+    const dim3 grid(ceil_div(w, T2W), ceil_div(h, T2H));
+    if (nt == 256) hipLaunchKernelGGL((nld_multi_kernel<S, 256>), grid, dim3(256), 0, s, Lt, Lf, Lnew, w, h, st);
+    else if (nt == 512) hipLaunchKernelGGL((nld_multi_kernel<S, 512>), grid, dim3(512), 0, s, Lt, Lf, Lnew, w, h, st);
+    else hipLaunchKernelGGL((nld_multi_kernel<S, 1024>), grid, dim3(1024), 0, s, Lt, Lf, Lnew, w, h, st);
 }
-void launch_nld_step2(const float* Lt, const float* Lf, float* Lnew, int w, int h, float step1, float step2, hipStream_t s) {
-    hipLaunchKernelGGL(nld_step2_kernel, dim3(ceil_div(w, T2W), ceil_div(h, T2H)), dim3(256), 0, s, Lt, Lf, Lnew, w, h, step1, step2);
+void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s) {
+    NldSteps st{};
+    for (int i = 0; i < nsteps; i++) st.v[i] = step_sizes[i];
+    switch (nsteps) {
+        case 1: nld_multi_launch<1>(Lt, Lf, Lnew, w, h, st, s); break;
+        case 2: nld_multi_launch<2>(Lt, Lf, Lnew, w, h, st, s); break;
+        case 3: nld_multi_launch<3>(Lt, Lf, Lnew, w, h, st, s); break;
+        case 4: nld_multi_launch<4>(Lt, Lf, Lnew, w, h, st, s); break;
+        case 5: nld_multi_launch<5>(Lt, Lf, Lnew, w, h, st, s); break;
+        case 6: nld_multi_launch<6>(Lt, Lf, Lnew, w, h, st, s); break;
+        case 7: nld_multi_launch<7>(Lt, Lf, Lnew, w, h, st, s); break;
+        case 8: nld_multi_launch<8>(Lt, Lf, Lnew, w, h, st, s); break;
+        default: fail(APDS_ERR_INTERNAL, "nld_multi: 1..8 steps per launch");
+    }
 }
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s) {
     hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, src, sw, dst, dw, dh);

@@ -838,9 +838,12 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         } else {
             const LevelDesc& p = ev[i - 1];
             const float* P;   // the level's starting image
-            // FED steps are issued as fused pairs (+ one single step when the count is odd): `launches` passes ping-pong
-            // between e.Lt and tmpP and must end in e.Lt
-            const int launches = (e.nsteps + 1) / 2;
+            // FED steps are issued in fused groups of up to `fuse` steps (temporal blocking in LDS): `launches` passes ping-pong
+            // between e.Lt and tmpP and must end in e.Lt. Deeper fusion for the small octaves, whose launches are latency-bound.
+            static const int fuse_big = getenv("APDS_NLD_FUSE_BIG") ? atoi(getenv("APDS_NLD_FUSE_BIG")) : 4;
+            static const int fuse_small = getenv("APDS_NLD_FUSE_SMALL") ? atoi(getenv("APDS_NLD_FUSE_SMALL")) : 8;
+            const int fuse = std::min(8, std::max(1, (size_t)e.w * e.h <= (size_t)1 << 20 ? fuse_small : fuse_big));
+            const int launches = (e.nsteps + fuse - 1) / fuse;
             if (e.octave > p.octave) {
                 float* dstP = (launches % 2 == 0) ? e.Lt : tmpP;   // so that the last pass lands in e.Lt
                 if (p.w == 2 * e.w && p.h == 2 * e.h) {
@@ -865,13 +868,12 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
             int pass = 0;
             for (int k = 0; k < e.nsteps; pass++) {
                 float* out = ((launches - 1 - pass) % 2 == 0) ? e.Lt : tmpP;
-                if (k + 1 < e.nsteps) {
-                    launch_nld_step2(in, tmpF, out, e.w, e.h, e.tau[k] * 0.5f, e.tau[k + 1] * 0.5f, s);
-                    k += 2;
-                } else {
-                    launch_nld_step(in, tmpF, out, e.w, e.h, e.tau[k] * 0.5f, s);
-                    k += 1;
-                }
+                // spread the steps evenly over the launches (e.g. 11 steps, fuse 8 -> 6 + 5)
+                const int g = (e.nsteps - k + (launches - pass) - 1) / (launches - pass);
+                float st[8];
+                for (int j = 0; j < g; j++) st[j] = e.tau[k + j] * 0.5f;
+                launch_nld_multi(in, tmpF, out, e.w, e.h, st, g, s);
+                k += g;
                 in = out;
             }
             if (e.nsteps == 0 && P != e.Lt) HIP_CHECK(hipMemcpyAsync(e.Lt, P, (size_t)e.w * e.h * 4, hipMemcpyDeviceToDevice, s));
