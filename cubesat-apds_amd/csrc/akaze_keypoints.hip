@@ -73,7 +73,12 @@ struct SuppressArgs {
     uint8_t* status[AKAZE_MAX_LEVELS];   // snapshot of the iterated level: 0 none, 255 pending, else done stamp
     const uint32_t* list[AKAZE_MAX_LEVELS];
     const int* list_count;               // [n_levels]
+    // candidates still pending after a round, three rotating buffers per level (read / append / being zeroed)
+    uint32_t* pend[AKAZE_MAX_LEVELS];    // 3 * pend_cap[lvl] entries
+    int pend_cap[AKAZE_MAX_LEVELS];
+    int* pend_count;                     // [3][AKAZE_MAX_LEVELS] counters, one 128-byte line each (PEND_PITCH ints apart)
 };
+static constexpr int PEND_PITCH = 32;   // same-line atomics serialise in L2 (~12 ns each, measured): one line per counter
 
 __global__ void suppress_init_status_kernel(SuppressArgs A) {
     APDS_RAISE_WAVE_PRIORITY();
@@ -102,12 +107,24 @@ __global__ void suppress_canon_kernel(SuppressArgs A) {
 // (up to 16 x 16 mask bytes) are scanned 64 elements at a time; "first hit in row-major order" is the lowest set bit
 // of the ballot of the first 64-element slab that has one. (A single thread walking these windows byte by byte took
 // ~48 us per round; a frame needs ~20 rounds.)
-__global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uint8_t stamp, int* __restrict__ pending_out) {
+// Round r reads the candidates that were still pending after round r-1 (in_sel: -1 = the level's full candidate list) and
+// appends the ones that are still blocked to buffer out_sel; the counter of buffer zero_sel is cleared for the round after.
+__global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uint8_t stamp, int in_sel, int out_sel, int zero_sel) {
     APDS_RAISE_WAVE_PRIORITY();
     const int lvl = blockIdx.y;
     const int other = A.phase == 0 ? lvl - 1 : lvl + 1;
     if (other < 0 || other >= A.n_levels) return;
-    const int cnt = A.list_count[lvl];
+    const uint32_t* __restrict__ in = in_sel < 0 ? A.list[lvl] : A.pend[lvl] + (size_t)in_sel * A.pend_cap[lvl];
+    const int cnt = in_sel < 0 ? A.list_count[lvl] : A.pend_count[(in_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH];
+    uint32_t* __restrict__ out = A.pend[lvl] + (size_t)out_sel * A.pend_cap[lvl];
+    int* out_count = &A.pend_count[(out_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH];
+    if (blockIdx.x == 0 && threadIdx.x == 0) A.pend_count[(zero_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH] = 0;
+    // still-blocked candidates are staged per block and appended with one global atomic
+    constexpr int STAGE = 192;
+    __shared__ uint32_t s_stage[STAGE];
+    __shared__ int s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
     const int w = A.w[lvl], h = A.h[lvl];
     const int lane = threadIdx.x & 63;
     uint8_t* status = A.status[lvl];
@@ -126,50 +143,63 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
     const int side = 2 * radius, total2 = side * side;
     const int ow = A.w[other], oh = A.h[other];
     const uint8_t* __restrict__ omask = A.mask[other];
-    int local_pending = 0;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < cnt; i += gridDim.x * 4) {
-        const uint32_t e = A.list[lvl][i];
+        const uint32_t e = in[i];
         const int x = e & 0xFFFF, y = e >> 16;
         const size_t p = (size_t)y * w + x;
         if (status[p] != ST_PENDING) continue;   // wave-uniform
         // ready iff no EARLIER (row-major) keypoint of this level within D is pending or finished only in this round
+        // (four 64-element slabs per trip: the loads of a trip are independent, so their latencies overlap)
         bool blocked = false;
-        for (int base = 0; base < total && !blocked; base += 64) {
-            const int idx = base + lane;
+        for (int base = 0; base < total && !blocked; base += 256) {
             bool hit = false;
-            if (idx < total) {
-                const int ry = idx / W, rx = idx - ry * W;
-                const int yy = y - D + ry, xx = x - D + rx;
-                if (yy >= 0 && xx >= 0 && xx < w && (yy < y || xx < x)) {
-                    const uint8_t s = status[(size_t)yy * w + xx];
-                    hit = s == ST_PENDING || s == stamp;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + u * 64 + lane;
+                if (idx < total) {
+                    const int ry = idx / W, rx = idx - ry * W;
+                    const int yy = y - D + ry, xx = x - D + rx;
+                    if (yy >= 0 && xx >= 0 && xx < w && (yy < y || xx < x)) {
+                        const uint8_t s = status[(size_t)yy * w + xx];
+                        hit |= s == ST_PENDING || s == stamp;
+                    }
                 }
             }
             blocked = __any(hit);
         }
         if (blocked) {
-            local_pending++;
+            if (lane == 0) {
+                const int slot = atomicAdd(&s_n, 1);
+                if (slot < STAGE) s_stage[slot] = e;
+                else out[atomicAdd(out_count, 1)] = e;   // staging full (dense clusters): append directly
+            }
             continue;
         }
         const int px = A.phase == 0 ? x * diff : x / diff, py = A.phase == 0 ? y * diff : y / diff;
         int found = -1;
-        for (int base = 0; base < total2 && found < 0; base += 64) {
-            const int idx = base + lane;
-            bool ok = false;
-            if (idx < total2) {
-                const int iy = idx / side, ix = idx - iy * side;
-                const int ii = py - radius + iy, jj = px - radius + ix;
-                if (ii >= 0 && ii < oh && jj >= 0 && jj < ow && omask[(size_t)ii * ow + jj]) {
-                    const int dx = jj - px, dy = ii - py;
-                    ok = dx * dx + dy * dy <= radius * radius;
+        for (int base = 0; base < total2 && found < 0; base += 256) {
+            unsigned long long b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int idx = base + u * 64 + lane;
+                bool ok = false;
+                if (idx < total2) {
+                    const int iy = idx / side, ix = idx - iy * side;
+                    const int ii = py - radius + iy, jj = px - radius + ix;
+                    if (ii >= 0 && ii < oh && jj >= 0 && jj < ow && omask[(size_t)ii * ow + jj]) {
+                        const int dx = jj - px, dy = ii - py;
+                        ok = dx * dx + dy * dy <= radius * radius;
+                    }
                 }
+                b[u] = __ballot(ok);
             }
-            const unsigned long long b = __ballot(ok);
-            if (b) {
-                const int first = base + __ffsll((long long)b) - 1;
-                const int iy = first / side, ix = first - iy * side;
-                found = (py - radius + iy) * ow + (px - radius + ix);
-            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (found < 0 && b[u]) {   // first hit in row-major order: lowest slab, lowest lane
+                    const int first = base + u * 64 + __ffsll((long long)b[u]) - 1;
+                    const int iy = first / side, ix = first - iy * side;
+                    found = (py - radius + iy) * ow + (px - radius + ix);
+                }
         }
         if (lane == 0) {
             if (found >= 0 && A.Ldet[lvl][p] > A.Ldet[other][found]) A.mask[other][found] = 0;
@@ -177,7 +207,11 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
         }
     }
     (void)h;
-    if (lane == 0 && local_pending) atomicAdd(pending_out, local_pending);
+    __syncthreads();
+    const int staged = min(s_n, STAGE);
+    if (threadIdx.x == 0 && staged) s_base = atomicAdd(out_count, staged);
+    __syncthreads();
+    for (int i = threadIdx.x; i < staged; i += 256) out[s_base + i] = s_stage[i];
 }
 
 // ---- a1.7 sub-pixel refinement ---------------------------------------------------------------------------------
@@ -808,7 +842,6 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     int* hist = c.alloc_n<int>(300);
     float* k_oct = c.alloc_n<float>(8);
     int* list_count = c.alloc_n<int>(AKAZE_MAX_LEVELS);
-    int* pending_dev = c.alloc_n<int>(1);
 
     // ---- a1.1 / a1.2 / a1.3
     launch_gray(img, H, W, channels, stride, gray, s);
@@ -907,7 +940,11 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         A.status[i] = status_all + e.pix_offset;
         lists[i] = c.alloc_n<uint32_t>((size_t)((e.w + 1) / 2) * ((e.h + 1) / 2));   // strict 3x3 maxima are never adjacent
         A.list[i] = lists[i];
+        A.pend_cap[i] = ((e.w + 1) / 2) * ((e.h + 1) / 2);
+        A.pend[i] = c.alloc_n<uint32_t>((size_t)3 * A.pend_cap[i]);
     }
+    int* pend_count = c.alloc_n<int>(3 * AKAZE_MAX_LEVELS * PEND_PITCH);
+    A.pend_count = pend_count;
     T.pix_offset[L] = total_pix;
     A.list_count = list_count;
     HIP_CHECK(hipMemsetAsync(mask_all, 0, (size_t)total_pix, s));
@@ -932,23 +969,29 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
                 for (int i = 0; i < L; i++) fprintf(stderr, " %d", counts[i]);
                 fprintf(stderr, "\n");
             }
-            for (;;) {
-                for (int b = 0; b < 4; b++) {
-                    if (b == 3 || dbg_rounds) HIP_CHECK(hipMemsetAsync(pending_dev, 0, sizeof(int), s));
+            HIP_CHECK(hipMemsetAsync(pend_count, 0, 3 * AKAZE_MAX_LEVELS * PEND_PITCH * sizeof(int), s));
+            // rounds are cheap once only the still-pending candidates are visited, a host check costs a stream sync: run 8
+            // rounds before the first look, then 4 at a time (a typical frame needs ~6 rounds in phase 0 and ~16 in phase 1)
+            for (int batch = 8;; batch = 4) {
+                for (int b = 0; b < batch; b++) {
                     const uint8_t stamp = (uint8_t)(round % 253 + 1);
-                    hipLaunchKernelGGL(suppress_round_kernel, lgrid, lblock, 0, s, A, stamp, pending_dev);
+                    // after a few rounds only a handful of candidates are left: a small grid keeps the launch itself short
+                    hipLaunchKernelGGL(suppress_round_kernel, round < 8 ? lgrid : dim3(16, L), lblock, 0, s, A, stamp, round == 0 ? -1 : (round - 1) % 3, round % 3,
+                                       (round + 1) % 3);
                     round++;
                     if (round % 253 == 0) hipLaunchKernelGGL(suppress_canon_kernel, lgrid, lblock, 0, s, A);
                     if (dbg_rounds) {
-                        int pend = 0;
-                        HIP_CHECK(hipMemcpyAsync(&pend, pending_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+                        int pc[AKAZE_MAX_LEVELS * PEND_PITCH], pend = 0;
+                        HIP_CHECK(hipMemcpyAsync(pc, pend_count + ((round - 1) % 3) * AKAZE_MAX_LEVELS * PEND_PITCH, sizeof(pc), hipMemcpyDeviceToHost, s));
                         HIP_CHECK(hipStreamSynchronize(s));
+                        for (int i = 0; i < L; i++) pend += pc[i * PEND_PITCH];
                         fprintf(stderr, "[apds]   phase %d round %d pending %d\n", phase, round, pend);
                     }
                 }
-                int pending = 0;
-                HIP_CHECK(hipMemcpyAsync(&pending, pending_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+                int pc[AKAZE_MAX_LEVELS * PEND_PITCH], pending = 0;
+                HIP_CHECK(hipMemcpyAsync(pc, pend_count + ((round - 1) % 3) * AKAZE_MAX_LEVELS * PEND_PITCH, sizeof(pc), hipMemcpyDeviceToHost, s));
                 HIP_CHECK(hipStreamSynchronize(s));
+                for (int i = 0; i < L; i++) pending += pc[i * PEND_PITCH];
                 if (pending == 0) break;
                 APDS_REQUIRE(round < 1000000, APDS_ERR_INTERNAL, "cross-level suppression did not converge");
             }
