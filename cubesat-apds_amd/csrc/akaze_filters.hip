@@ -310,8 +310,12 @@ __global__ void area_resize_kernel(const float* __restrict__ src, int sw, float*
 // then Lx/Ly on the tile + s ring evaluated at the reflected coordinate of every ring position, then the second
 // derivatives on the tile. Lsmooth is read once (24 -> ~19 B/pixel incl. halo) and one launch per level disappears.
 static constexpr int DW = 64, DH = 32;
+#ifndef APDS_DOH_THREADS
+#define APDS_DOH_THREADS 1024
+#endif
+static constexpr int DNT = APDS_DOH_THREADS;
 
-__global__ __launch_bounds__(256) void doh_fused_kernel(const float* __restrict__ Lsmooth, float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h,
+__global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict__ Lsmooth, float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h,
                                                         int s, float kside, float kmid, float sq) {
     APDS_RAISE_WAVE_PRIORITY();
     extern __shared__ float smem[];
@@ -322,12 +326,12 @@ __global__ __launch_bounds__(256) void doh_fused_kernel(const float* __restrict_
     float* s_my = s_mx + MW * MH;
     const int x0 = blockIdx.x * DW, y0 = blockIdx.y * DH;
     const int ox = x0 - 2 * s, oy = y0 - 2 * s;      // global coordinate of s_src[0]
-    for (int i = threadIdx.x; i < SW * SH; i += 256) {
+    for (int i = threadIdx.x; i < SW * SH; i += DNT) {
         const int ly = i / SW, lx = i - ly * SW;
         s_src[i] = Lsmooth[(size_t)reflect101(oy + ly, h) * w + reflect101(ox + lx, w)];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < MW * MH; i += 256) {
+    for (int i = threadIdx.x; i < MW * MH; i += DNT) {
         const int my = i / MW, mx = i - my * MW;
         // the first-derivative value this ring position stands for lives at the reflected coordinate
         const int cx = reflect101(x0 - s + mx, w) - ox, cy = reflect101(y0 - s + my, h) - oy;
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256) void doh_fused_kernel(const float* __restrict_
         s_my[i] = rs2 - rs0;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < DW * DH; i += 256) {
+    for (int i = threadIdx.x; i < DW * DH; i += DNT) {
         const int ly = i / DW, lx = i - ly * DW;
         const int gx = x0 + lx, gy = y0 + ly;
         if (gx >= w || gy >= h) continue;
@@ -436,7 +440,7 @@ void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, co
 }
 void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s) {
     const size_t lds = (size_t)((DW + 4 * sc) * (DH + 4 * sc) + 2 * (DW + 2 * sc) * (DH + 2 * sc)) * sizeof(float);
-    hipLaunchKernelGGL(doh_fused_kernel, dim3(ceil_div(w, DW), ceil_div(h, DH)), dim3(256), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
+    hipLaunchKernelGGL(doh_fused_kernel, dim3(ceil_div(w, DW), ceil_div(h, DH)), dim3(DNT), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
                        (float)(sc * sc * sc * sc));
 }
 
