@@ -497,9 +497,14 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, uint
         return;
     }
     dim3 grid((unsigned)(ceil_div(p.chunks, 8) * 8 * p.qtiles_blocks)), block(256);
+    // Occupancy cap: the kernel uses no LDS, so an (unused) dynamic LDS request of `cap` bytes per workgroup bounds the
+    // workgroups resident per CU (160 KB / cap). Two waves per SIMD already issue at full VALU rate; capping there leaves
+    // registers, wave slots and the rest of the LDS free, so the short kernels of the other pipeline stages are dispatched
+    // at once instead of waiting for a match wave to retire.
+    static const int cap = env_int("APDS_MATCH_LDS_CAP", 0);
     KernelTimer timer(timer_name, s);
     switch (p.T) {
-        case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
+        case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, (size_t)cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
         case 2: hipLaunchKernelGGL((hamming_topk_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
         default: hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
     }
