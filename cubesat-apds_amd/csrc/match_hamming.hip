@@ -26,6 +26,10 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 static constexpr uint64_t EMPTY_KEY = ~0ull;
 static constexpr int INF_THR = 1 << 20;          // > any Hamming distance of a 512-bit row
 static constexpr uint32_t NO_INDEX = 0xFFFFFFFFu;
+// Per-chunk candidate lists are written as 32-bit keys: distance (<= 512, 10 bits) << 22 | row offset inside the chunk
+// (chunks hold at most 2^22 rows). Same order as the 64-bit (distance << 32 | global row) keys they expand to in the merge.
+static constexpr int PART_ROW_BITS = 22;
+static constexpr uint32_t EMPTY_PART = 0xFFFFFFFFu;
 
 // acc + popcount(x) in ONE VALU op. hipcc otherwise splits the accumulate into v_bcnt(x,0) + v_add3 (5 ops per
 // two dwords instead of 4), so the accumulate form is spelled out.
@@ -85,8 +89,8 @@ __device__ __forceinline__ void insert_hits(const int (&acc)[T], const int (&nth
 // One work item = (64*T queries per wave, 4 waves) x (one chunk of train rows).
 template <int T, int K>
 __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ train, int n_train, const u32x4* __restrict__ queries, int nq,
-                                                  int rows_per_chunk, const int* __restrict__ init_thr, uint64_t* __restrict__ out,
-                                                  uint32_t index_base, int chunk, int qblock) {
+                                                  int rows_per_chunk, const int* __restrict__ init_thr, uint32_t* __restrict__ out, int chunk,
+                                                  int qblock) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int qbase = (qblock * 4 + wave) * (64 * T);
@@ -173,8 +177,8 @@ __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ tra
         if (qi < nq) {
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const uint64_t key = bi[t][k] == NO_INDEX ? EMPTY_KEY : ((uint64_t)(uint32_t)bd[t][k] << 32) | (uint64_t)(bi[t][k] + index_base);
-                out[((size_t)chunk * nq + qi) * K + k] = key;
+                out[((size_t)chunk * nq + qi) * K + k] =
+                    bi[t][k] == NO_INDEX ? EMPTY_PART : ((uint32_t)bd[t][k] << PART_ROW_BITS) | (bi[t][k] - (uint32_t)row0);
             }
         }
     }
@@ -184,8 +188,8 @@ __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ tra
 template <int T, int K>
 __global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restrict__ train, int n_train,
                                                            const u32x4* __restrict__ queries, int nq, int rows_per_chunk,
-                                                           const int* __restrict__ init_thr, uint64_t* __restrict__ out,
-                                                           uint32_t index_base, int qtile_blocks, int n_chunks, int xcd_aware) {
+                                                           const int* __restrict__ init_thr, uint32_t* __restrict__ out, int qtile_blocks,
+                                                           int n_chunks, int xcd_aware) {
     // 1-D grid, XCD-aware by default: workgroups are dealt round-robin over the 8 XCDs, so all query tiles of one row
     // chunk are given the same (id % 8): the chunk is then streamed into ONE XCD's L2 instead of all eight (13x less
     // L2->fabric traffic at equal speed, once the chunk count is a multiple of 8 so that no XCD gets extra chunks).
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restr
         qblock = blockIdx.x - chunk * nqb;
     }
     if (chunk >= n_chunks) return;   // block-uniform
-    hamming_topk_item<T, K>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, index_base, chunk, qblock);
+    hamming_topk_item<T, K>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, chunk, qblock);
 }
 
 // Persistent form: a fixed number of resident workgroups pull (chunk, query tile) items from an atomic counter.
@@ -209,9 +213,8 @@ __global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restr
 template <int T, int K>
 __global__ __launch_bounds__(256) void hamming_topk_persistent_kernel(const u32x16* __restrict__ train, int n_train,
                                                                       const u32x4* __restrict__ queries, int nq, int rows_per_chunk,
-                                                                      const int* __restrict__ init_thr, uint64_t* __restrict__ out,
-                                                                      uint32_t index_base, int qtile_blocks, int n_chunks,
-                                                                      int* __restrict__ next_item) {
+                                                                      const int* __restrict__ init_thr, uint32_t* __restrict__ out,
+                                                                      int qtile_blocks, int n_chunks, int* __restrict__ next_item) {
     __shared__ int s_item;
     const int total = qtile_blocks * n_chunks;
     for (;;) {
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(256) void hamming_topk_persistent_kernel(const u32x
         __syncthreads();
         if (item >= total) break;
         const int chunk = item / qtile_blocks, qblock = item - chunk * qtile_blocks;
-        hamming_topk_item<T, K>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, index_base, chunk, qblock);
+        hamming_topk_item<T, K>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, chunk, qblock);
     }
 }
 
@@ -266,6 +269,56 @@ __global__ void merge_topk_kernel(const uint64_t* __restrict__ parts_keys, int p
     for (; p < parts; p++)
 #pragma unroll
         for (int k = 0; k < K; k++) push(parts_keys[((size_t)p * nq + qi) * K + k]);
+#pragma unroll
+    for (int k = 0; k < K; k++) out[(size_t)qi * K + k] = best[k];
+}
+
+// Same merge over the 32-bit per-chunk lists of hamming_topk_kernel: chunk p's keys expand to (distance << 32 | row offset + p *
+// rows_per_chunk + row_base); `extra` (nq x K 64-bit keys, may be null) is one more already-expanded list (the sample pass).
+template <int K>
+__global__ void merge_parts_kernel(const uint32_t* __restrict__ parts_keys, int parts, int rows_per_chunk, uint32_t row_base,
+                                   const uint64_t* __restrict__ extra, int nq, uint64_t* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    uint64_t best[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) best[k] = extra ? extra[(size_t)qi * K + k] : EMPTY_KEY;   // a sorted list: a valid start
+    auto push = [&](uint32_t part, int p) {
+        if (part == EMPTY_PART) return;
+        const uint64_t key = ((uint64_t)(part >> PART_ROW_BITS) << 32) |
+                             (uint64_t)(uint32_t)((part & ((1u << PART_ROW_BITS) - 1)) + (uint32_t)p * (uint32_t)rows_per_chunk + row_base);
+        if (key < best[K - 1]) {
+            bool placed = false;
+#pragma unroll
+            for (int j = K - 1; j > 0; j--) {
+                if (!placed) {
+                    if (best[j - 1] > key) best[j] = best[j - 1];
+                    else {
+                        best[j] = key;
+                        placed = true;
+                    }
+                }
+            }
+            if (!placed) best[0] = key;
+        }
+    };
+    constexpr int U = K <= 2 ? 8 : 2;   // independent loads in flight per lane
+    int p = 0;
+    for (; p + U <= parts; p += U) {
+        uint32_t v[U][K];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < K; k++) v[u][k] = parts_keys[((size_t)(p + u) * nq + qi) * K + k];
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+            for (int k = 0; k < K; k++) push(v[u][k], p + u);
+    }
+    for (; p < parts; p++)
+#pragma unroll
+        for (int k = 0; k < K; k++) push(parts_keys[((size_t)p * nq + qi) * K + k], p);
 #pragma unroll
     for (int k = 0; k < K; k++) out[(size_t)qi * K + k] = best[k];
 }
@@ -459,6 +512,7 @@ static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false
     chunks = std::min<long long>(std::max<long long>(chunks, 1), std::min<long long>(max_chunks, 65535));
     // chunk c runs on XCD (c % 8) when the XCD-aware placement is on: keep the chunk count a multiple of 8 so that every
     // XCD gets the same number of rows (3 extra chunks on 3 XCDs was a 2 % tail)
+    chunks = std::max<long long>(chunks, ceil_div(n_train, 1ll << PART_ROW_BITS));   // 22-bit row offsets in the per-chunk keys
     if (chunks >= 8) chunks = (chunks + 7) & ~7ll;
     long long rpc = (n_train + chunks - 1) / chunks;
     rpc = (rpc + 3) & ~3ll;
@@ -468,8 +522,8 @@ static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false
 }
 
 template <int K>
-static void launch_topk(const void* q, int nq, const void* t, long long nt, uint32_t index_base, const int* init_thr,
-                        uint64_t* parts, const ChunkPlan& p, hipStream_t s, const char* timer_name = "hamming_topk") {
+static void launch_topk(const void* q, int nq, const void* t, long long nt, const int* init_thr, uint32_t* parts, const ChunkPlan& p, hipStream_t s,
+                        const char* timer_name = "hamming_topk") {
     static const int xcd = env_int("APDS_MATCH_XCD", 1);
     static const int persist = env_int("APDS_MATCH_PERSIST", 0);   // resident workgroups per CU (0 = plain grid)
     const u32x16* tr = static_cast<const u32x16*>(t);
@@ -478,7 +532,7 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, uint
     if (K > 2) {   // larger k keeps K (distance, index) pairs per query in registers: one query per lane
         dim3 grid((unsigned)(ceil_div(p.chunks, 8) * 8 * p.qtiles_blocks)), block(256);
         KernelTimer timer(timer_name, s);
-        hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks,
+        hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks,
                            p.chunks, 0);
         HIP_CHECK(hipGetLastError());
         return;
@@ -489,9 +543,9 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, uint
         dim3 grid(256 * persist), block(256);
         KernelTimer timer(timer_name, s);
         switch (p.T) {
-            case 4: hipLaunchKernelGGL((hamming_topk_persistent_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, counter); break;
-            case 2: hipLaunchKernelGGL((hamming_topk_persistent_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, counter); break;
-            default: hipLaunchKernelGGL((hamming_topk_persistent_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, counter); break;
+            case 4: hipLaunchKernelGGL((hamming_topk_persistent_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
+            case 2: hipLaunchKernelGGL((hamming_topk_persistent_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
+            default: hipLaunchKernelGGL((hamming_topk_persistent_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
         }
         HIP_CHECK(hipGetLastError());
         return;
@@ -504,11 +558,17 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, uint
     static const int cap = env_int("APDS_MATCH_LDS_CAP", 0);
     KernelTimer timer(timer_name, s);
     switch (p.T) {
-        case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, (size_t)cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
-        case 2: hipLaunchKernelGGL((hamming_topk_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
-        default: hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, index_base, p.qtiles_blocks, p.chunks, xcd); break;
+        case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, (size_t)cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;
+        case 2: hipLaunchKernelGGL((hamming_topk_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;
+        default: hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;
     }
     HIP_CHECK(hipGetLastError());
+}
+
+template <int K>
+static void merge_parts_launch(const uint32_t* parts, int nparts, int rows_per_chunk, uint32_t row_base, const uint64_t* extra, int nq, uint64_t* out,
+                               hipStream_t s) {
+    hipLaunchKernelGGL((merge_parts_kernel<K>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, rows_per_chunk, row_base, extra, nq, out);
 }
 
 template <int K>
@@ -530,10 +590,10 @@ static void topk_device_k(const void* q, int nq, const void* t, long long nt, ui
     uint64_t* sample_keys = nullptr;
     if (sample) {
         ChunkPlan sp = plan_chunks(nq, sample, true, K > 2);
-        uint64_t* sparts = c.alloc_n<uint64_t>((size_t)sp.chunks * nq * K);
+        uint32_t* sparts = c.alloc_n<uint32_t>((size_t)sp.chunks * nq * K);
         sample_keys = c.alloc_n<uint64_t>((size_t)nq * K);
-        launch_topk<K>(q, nq, t, sample, index_base, nullptr, sparts, sp, s, "hamming_topk_sample");
-        merge_launch<K>(sparts, sp.chunks, nq, sample_keys, s);
+        launch_topk<K>(q, nq, t, sample, nullptr, sparts, sp, s, "hamming_topk_sample");
+        merge_parts_launch<K>(sparts, sp.chunks, sp.rows_per_chunk, index_base, nullptr, nq, sample_keys, s);
         int* thr_buf = c.alloc_n<int>(nq);
         hipLaunchKernelGGL(thr_from_keys_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, sample_keys, nq, K, thr_buf);
         thr = thr_buf;
@@ -541,14 +601,10 @@ static void topk_device_k(const void* q, int nq, const void* t, long long nt, ui
     const char* rest = static_cast<const char*>(t) + (size_t)sample * 64;
     const long long nrest = nt - sample;
     ChunkPlan p = plan_chunks(nq, nrest, false, K > 2);
-    uint64_t* parts = c.alloc_n<uint64_t>((size_t)(p.chunks + 1) * nq * K);   // [chunks (+1 for the sample result)][nq][K]
-    launch_topk<K>(q, nq, rest, nrest, index_base + (uint32_t)sample, thr, parts, p, s);
-    int nparts = p.chunks;
-    if (sample) {
-        HIP_CHECK(hipMemcpyAsync(parts + (size_t)p.chunks * nq * K, sample_keys, (size_t)nq * K * 8, hipMemcpyDeviceToDevice, s));
-        nparts++;
-    }
-    merge_launch<K>(parts, nparts, nq, out, s);
+    uint32_t* parts = c.alloc_n<uint32_t>((size_t)p.chunks * nq * K);   // [chunks][nq][K] 32-bit keys
+    launch_topk<K>(q, nq, rest, nrest, thr, parts, p, s);
+    // the sample pass's result joins the merge as one more (already expanded) list
+    merge_parts_launch<K>(parts, p.chunks, p.rows_per_chunk, index_base + (uint32_t)sample, sample_keys, nq, out, s);
     HIP_CHECK(hipGetLastError());
 }
 
