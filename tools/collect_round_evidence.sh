@@ -11,6 +11,9 @@ cp gpurun_out/prof/stats_serial/*/*_kernel_stats.csv $O/bench_serial_kernel_stat
 cp gpurun_out/prof/stats/*/*_kernel_stats.csv $O/bench_kernel_stats.csv 2>/dev/null
 cp gpurun_out/prof/traffic.json $O/traffic_hamming_topk.json
 bash tools/xcd_ab.sh > $O/match_xcd_placement_ab.log 2>&1
+bash tools/pmc_util.sh > $O/pmc_utilisation.log 2>&1
+bash tools/pnp_stats.sh > $O/pnp_probe.log 2>&1
+cd $R
 python3 tools/match_probe.py > $O/match_probe.log 2>&1
 python3 tools/l2_probe.py > $O/l2_probe.log 2>&1
 python3 bench.py --serial --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_serial.json 2>/dev/null
