@@ -77,7 +77,7 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
-    group = None
+    group = meta_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -85,6 +85,7 @@ def main():
         else:
             dist.init_process_group(backend)
         group = dist.group.WORLD
+        meta_group = dist.new_group(backend="gloo")   # host-side exchange of the per-frame query counts (no device sync)
 
     pkg = graft.load_package()
     from cubesat_apds_amd import pipeline as pl
@@ -150,7 +151,7 @@ def main():
     if args.serial:
         pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
     else:
-        pipe = pl.StreamedFramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev), reserve_cus=args.reserve_cus)
+        pipe = pl.StreamedFramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev), reserve_cus=args.reserve_cus, meta_group=meta_group)
 
     def run_step(i):
         return pipe.step(frames[i % len(frames)], filter_strength=args.filter_strength)

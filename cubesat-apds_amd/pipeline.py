@@ -66,10 +66,11 @@ def _gather_into(dist, group, dst, src):
 class ShardedMatcher:
     """Hamming k-NN of per-rank query sets against a row-sharded resident DB."""
 
-    def __init__(self, local_rows64, index_base, group=None, backend=None, pad_rows=32768):
+    def __init__(self, local_rows64, index_base, group=None, backend=None, pad_rows=32768, meta_group=None):
         self.rows = local_rows64
         self.index_base = int(index_base)
         self.group = group
+        self.meta_group = meta_group      # optional host-side (gloo) group for the per-frame query counts
         self.backend = backend or HipBackend()
         self.pad_rows = pad_rows
         if group is not None:
@@ -80,8 +81,22 @@ class ShardedMatcher:
         else:
             self.dist, self.world, self.rank = None, 1, 0
 
-    def knn(self, q_rows64, k=2, out=None):
-        """q_rows64: this rank's queries [Q_r, 64] u8. Returns [Q_r, k] int64 keys over the WHOLE DB."""
+    def exchange_counts(self, nq):
+        """Every rank's query count for one frame, as host ints, through the host-side group: no device work and no stream
+        synchronisation, so the thread that later issues the match keeps queueing kernels ahead of the GPU. Must be called
+        once per frame, in frame order, by the same thread on every rank."""
+        if self.world == 1:
+            return [int(nq)]
+        if self.meta_group is None:
+            return None
+        t = torch.tensor([int(nq)], dtype=torch.int64)
+        o = torch.empty(self.world, dtype=torch.int64)
+        self.dist.all_gather_into_tensor(o, t, group=self.meta_group)
+        return [int(v) for v in o.tolist()]
+
+    def knn(self, q_rows64, k=2, out=None, counts=None):
+        """q_rows64: this rank's queries [Q_r, 64] u8. Returns [Q_r, k] int64 keys over the WHOLE DB. `counts`: every rank's
+        query count (exchange_counts); without it the counts are gathered on the device, which costs a host synchronisation."""
         be = self.backend
         if self.world == 1:
             if out is not None:
@@ -89,9 +104,11 @@ class ShardedMatcher:
             return be.topk(q_rows64, self.rows, self.index_base, k)
         dist, dev = self.dist, q_rows64.device
         nq = q_rows64.shape[0]
-        cnt = torch.zeros(self.world, dtype=torch.int64, device=dev)
-        _gather_into(dist, self.group, cnt, torch.tensor([nq], dtype=torch.int64, device=dev))
-        counts = [int(c) for c in cnt.tolist()]
+        if counts is None:
+            cnt = torch.zeros(self.world, dtype=torch.int64, device=dev)
+            _gather_into(dist, self.group, cnt, torch.tensor([nq], dtype=torch.int64, device=dev))
+            counts = [int(c) for c in cnt.tolist()]
+        assert counts[self.rank] == nq
         pad = max(self.pad_rows, max(counts))
         mine = torch.zeros((pad, 64), dtype=torch.uint8, device=dev)
         mine[:nq] = q_rows64
@@ -181,11 +198,11 @@ class StreamedFramePipeline:
     over through HIP events; results come back in frame order."""
 
     def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=5, reserve_cus=0,
-                 n_cus=256):
+                 n_cus=256, meta_group=None):
         import queue
         self.queue = queue
         self.dev = torch.device(device)
-        self.matcher = ShardedMatcher(db_rows64, index_base, group)
+        self.matcher = ShardedMatcher(db_rows64, index_base, group, meta_group=meta_group)
         self.n_db = db_xy.shape[0]
         kp = torch.zeros((self.n_db, 7), dtype=torch.float32, device=self.dev)
         kp[:, 0:2] = db_xy
@@ -281,6 +298,7 @@ class StreamedFramePipeline:
                     check(L.apds_dev_akaze_extract(f.data_ptr(), f.shape[0], f.shape[1], ch, f.stride(0), self.cap, s["kps"].data_ptr(),
                                                    s["desc"].data_ptr(), self.cap, C.byref(n), torch_stream()))
                     s["K"], s["index"] = n.value, i
+                    s["counts"] = self.matcher.exchange_counts(n.value)   # host-side, keeps the match thread free of syncs
                     s["ev_extract"].record(self.streams[0])
                     q1.put(s)
                 q1.put(None)
@@ -298,7 +316,7 @@ class StreamedFramePipeline:
                             q1.put(None)            # let the other match worker see the end marker too
                             break
                         stream.wait_event(s["ev_extract"])
-                        s["keys_view"] = self.matcher.knn(s["desc"][:s["K"]], 2, out=s["keys"])
+                        s["keys_view"] = self.matcher.knn(s["desc"][:s["K"]], 2, out=s["keys"], counts=s["counts"])
                         s["ev_match"].record(stream)
                         q2.put(s)
                     with done_lock:

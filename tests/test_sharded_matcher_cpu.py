@@ -54,12 +54,16 @@ def _worker(rank, world, port, nt, nqs, result_dir):
         q[0] = db[7]
     q64 = np.zeros((len(q), 64), np.uint8)
     q64[:, :61] = q
-    m = pl.ShardedMatcher(torch.from_numpy(db64[lo:hi].copy()), lo, group=dist.group.WORLD, backend=CpuBackend(), pad_rows=16)
+    meta = dist.new_group(backend="gloo")                          # the host-side group bench.py uses for the per-frame counts
+    m = pl.ShardedMatcher(torch.from_numpy(db64[lo:hi].copy()), lo, group=dist.group.WORLD, backend=CpuBackend(), pad_rows=16, meta_group=meta)
     keys = m.knn(torch.from_numpy(q64), 2).numpy().view(np.uint64)
+    counts = m.exchange_counts(len(q64))                            # second form: counts exchanged ahead on the host
+    keys2 = m.knn(torch.from_numpy(q64), 2, counts=counts).numpy().view(np.uint64)
     want_idx, want_d = oracle.knn_hamming(q, db, 2)
     got_idx = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
     got_d = (keys >> np.uint64(32)).astype(np.int64)
     ok = np.array_equal(got_idx, want_idx) and np.array_equal(got_d, want_d)
+    ok = ok and counts == list(nqs) and np.array_equal(keys, keys2)
     if rank == 0 and len(q):
         ok = ok and tuple(got_idx[0]) == (7, nt // 2 + 5) and tuple(got_d[0]) == (0, 0)
     open(os.path.join(result_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "mismatch")
