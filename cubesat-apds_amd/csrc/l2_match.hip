@@ -92,23 +92,30 @@ __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ 
     const int groups_per_row = 1 << gshift;
     const int pieces = (L2_TM << gshift) >> 8;       // 16 for kp = 128, 8 for kp = 64
     float4 pre[16];
+    float pre_norm = INFINITY;                       // this thread's row norm of the prefetched tile (threads < 128)
     auto prefetch = [&](int tile) {
+        if (tid < L2_TM) {
+            const int row = tile * L2_TM + tid;
+            pre_norm = tnorm[min(row, n_train - 1)];
+            if (row >= n_train) pre_norm = INFINITY;
+        }
 #pragma unroll
         for (int p = 0; p < 16; p++) {
             if (p < pieces) {
                 const int piece = p * 256 + tid;
                 const int r = piece >> gshift, g = piece & (groups_per_row - 1);
-                const int row = tile * L2_TM + r, c = g * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < n_train) {
-                    const float* src = train + (size_t)row * dim + c;
-                    if (FULL_ROWS) v = *reinterpret_cast<const float4*>(src);
-                    else {
-                        if (c < dim) v.x = src[0];
-                        if (c + 1 < dim) v.y = src[1];
-                        if (c + 2 < dim) v.z = src[2];
-                        if (c + 3 < dim) v.w = src[3];
-                    }
+                // rows past the end re-read the last row: their norm is staged as +inf, so they are never selected, and an
+                // unconditional load lets all 16 loads of a thread fly together under the MFMAs (a branch around the load
+                // made the compiler wait for each one right after issuing it)
+                const int row = min(tile * L2_TM + r, n_train - 1), c = g * 4;
+                const float* src = train + (size_t)row * dim + c;
+                float4 v;
+                if (FULL_ROWS) v = *reinterpret_cast<const float4*>(src);
+                else {
+                    v.x = c < dim ? src[0] : 0.f;
+                    v.y = c + 1 < dim ? src[1] : 0.f;
+                    v.z = c + 2 < dim ? src[2] : 0.f;
+                    v.w = c + 3 < dim ? src[3] : 0.f;
                 }
                 pre[p] = v;
             }
@@ -125,10 +132,7 @@ __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ 
                 *reinterpret_cast<float2*>(d + half) = make_float2(pre[p].y, pre[p].w);
             }
         }
-        if (tid < L2_TM) {
-            const int row = tile * L2_TM + tid;
-            sTT[tid] = row < n_train ? tnorm[row] : INFINITY;
-        }
+        if (tid < L2_TM) sTT[tid] = pre_norm;
     };
 
     Top2 best[2];
