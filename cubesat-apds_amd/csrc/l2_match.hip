@@ -64,13 +64,15 @@ __device__ __forceinline__ uint64_t l2_key(float d, uint32_t idx) {
 }
 
 // grid: x = query tiles (128 queries), y = splits of the train tiles. out: [split][nq][K] keys
-template <int K, bool FULL_ROWS>   // FULL_ROWS: dim == kp (no zero padding of the k axis, rows 16-byte aligned)
+// FULL_ROWS: dim == KP (no zero padding of the k axis, rows 16-byte aligned). KP: k extent staged in LDS (64 or 128).
+template <int K, bool FULL_ROWS, int KP>
 __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ train, const float* __restrict__ tnorm, int n_train,
-                                                      const float* __restrict__ queries, const float* __restrict__ qnorm, int nq, int dim, int kp,
+                                                      const float* __restrict__ queries, const float* __restrict__ qnorm, int nq, int dim,
                                                       int tiles_per_split, uint32_t index_base, uint64_t* __restrict__ out) {
     extern __shared__ float l2_lds[];
-    const int ST = kp + 4;                           // LDS row pitch in floats (multiple of 4: 16-byte aligned rows)
-    const int half = kp >> 1;                        // columns [0, half): even k, [half, kp): odd k
+    constexpr int kp = KP;
+    constexpr int ST = KP + 4;                       // LDS row pitch in floats (multiple of 4: 16-byte aligned rows)
+    constexpr int half = KP >> 1;                    // columns [0, half): even k, [half, kp): odd k
     float* sQ = l2_lds;                              // 128 x ST
     float* sT = sQ + L2_TN * ST;                     // 128 x ST
     float* sTT = sT + L2_TM * ST;                    // 128 train norms (+inf for rows past the end)
@@ -87,52 +89,48 @@ __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ 
         const int qi = min(q0 + r, nq - 1);
         sQ[r * ST + (c & 1) * half + (c >> 1)] = c < dim ? queries[(size_t)qi * dim + c] : 0.f;
     }
-    // each thread stages a fixed set of (row, 4-column group) pieces of a train tile: 128 * kp / 4 float4 / 256 threads
-    const int gshift = kp == 128 ? 5 : 4;            // float4 groups per row = kp / 4 = 32 or 16
-    const int groups_per_row = 1 << gshift;
-    const int pieces = (L2_TM << gshift) >> 8;       // 16 for kp = 128, 8 for kp = 64
-    float4 pre[16];
+    // each thread stages a fixed set of (row, 4-column group) pieces of a train tile: 128 * KP / 4 float4 / 256 threads = KP / 8
+    // pieces, i.e. exactly one per MFMA group of the K loop
+    constexpr int gshift = KP == 128 ? 5 : 4;        // float4 groups per row = KP / 4 = 32 or 16
+    constexpr int groups_per_row = 1 << gshift;
+    constexpr int pieces = (L2_TM << gshift) >> 8;   // 16 for KP = 128, 8 for KP = 64
+    float4 pre[pieces];
     float pre_norm = INFINITY;                       // this thread's row norm of the prefetched tile (threads < 128)
-    auto prefetch = [&](int tile) {
+    bool pre_valid = false;                          // ... and whether that row exists (resolved at commit: no use of the load here)
+    // rows past the end re-read the last row: their norm is staged as +inf, so they are never selected, and an
+    // unconditional load keeps the loads free of branches (a branch around a load made the compiler wait for it at once)
+    auto prefetch_piece = [&](int p, int tile) {
+        const int piece = p * 256 + tid;
+        const int r = piece >> gshift, g = piece & (groups_per_row - 1);
+        const int row = min(tile * L2_TM + r, n_train - 1), c = g * 4;
+        const float* src = train + (size_t)row * dim + c;
+        float4 v;
+        if (FULL_ROWS) v = *reinterpret_cast<const float4*>(src);
+        else {
+            v.x = c < dim ? src[0] : 0.f;
+            v.y = c + 1 < dim ? src[1] : 0.f;
+            v.z = c + 2 < dim ? src[2] : 0.f;
+            v.w = c + 3 < dim ? src[3] : 0.f;
+        }
+        pre[p] = v;
+    };
+    auto prefetch_norm = [&](int tile) {
         if (tid < L2_TM) {
             const int row = tile * L2_TM + tid;
             pre_norm = tnorm[min(row, n_train - 1)];
-            if (row >= n_train) pre_norm = INFINITY;
-        }
-#pragma unroll
-        for (int p = 0; p < 16; p++) {
-            if (p < pieces) {
-                const int piece = p * 256 + tid;
-                const int r = piece >> gshift, g = piece & (groups_per_row - 1);
-                // rows past the end re-read the last row: their norm is staged as +inf, so they are never selected, and an
-                // unconditional load lets all 16 loads of a thread fly together under the MFMAs (a branch around the load
-                // made the compiler wait for each one right after issuing it)
-                const int row = min(tile * L2_TM + r, n_train - 1), c = g * 4;
-                const float* src = train + (size_t)row * dim + c;
-                float4 v;
-                if (FULL_ROWS) v = *reinterpret_cast<const float4*>(src);
-                else {
-                    v.x = c < dim ? src[0] : 0.f;
-                    v.y = c + 1 < dim ? src[1] : 0.f;
-                    v.z = c + 2 < dim ? src[2] : 0.f;
-                    v.w = c + 3 < dim ? src[3] : 0.f;
-                }
-                pre[p] = v;
-            }
+            pre_valid = row < n_train;
         }
     };
     auto commit = [&](int tile) {
 #pragma unroll
-        for (int p = 0; p < 16; p++) {
-            if (p < pieces) {
-                const int piece = p * 256 + tid;
-                const int r = piece >> gshift, g = piece & (groups_per_row - 1);
-                float* d = &sT[r * ST + g * 2];          // k = 4g..4g+3 -> even slots 2g, 2g+1 and odd slots half+2g, half+2g+1
-                *reinterpret_cast<float2*>(d) = make_float2(pre[p].x, pre[p].z);
-                *reinterpret_cast<float2*>(d + half) = make_float2(pre[p].y, pre[p].w);
-            }
+        for (int p = 0; p < pieces; p++) {
+            const int piece = p * 256 + tid;
+            const int r = piece >> gshift, g = piece & (groups_per_row - 1);
+            float* d = &sT[r * ST + g * 2];          // k = 4g..4g+3 -> even slots 2g, 2g+1 and odd slots half+2g, half+2g+1
+            *reinterpret_cast<float2*>(d) = make_float2(pre[p].x, pre[p].z);
+            *reinterpret_cast<float2*>(d + half) = make_float2(pre[p].y, pre[p].w);
         }
-        if (tid < L2_TM) sTT[tid] = pre_norm;
+        if (tid < L2_TM) sTT[tid] = pre_valid ? pre_norm : INFINITY;
     };
 
     Top2 best[2];
@@ -146,52 +144,56 @@ __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ 
     const int kk = lane >> 5;                        // this lane's k parity within a k-step of 2
     const float* aBase = &sT[(wr * 64 + (lane & 31)) * ST + kk * half];
     const float* bBase = &sQ[(wc * 64 + (lane & 31)) * ST + kk * half];
-    const int groups = kp >> 3;                      // 4 k-steps (8 k values) per group
+    constexpr int groups = KP >> 3;                  // 4 k-steps (8 k values) per group; == pieces
 
-    prefetch(tile_begin);
+#pragma unroll
+    for (int p = 0; p < pieces; p++) prefetch_piece(p, tile_begin);
+    prefetch_norm(tile_begin);
     for (int tile = tile_begin; tile < tile_end; tile++) {
         __syncthreads();                             // everyone is done reading sT of the previous tile
         commit(tile);
         __syncthreads();
-        if (tile + 1 < tile_end) prefetch(tile + 1); // global loads fly under the MFMAs below
-        // K loop: operand registers ping-pong between two sets; the ds_read_b128s of the next group are issued before the
-        // 16 MFMAs of the current one (sched_barrier pins that order), so LDS latency sits under ~1000 cycles of MFMA.
+        const bool more = tile + 1 < tile_end;
+        if (more) prefetch_norm(tile + 1);
+        // K loop, fully unrolled: operand registers ping-pong between two sets; the ds_read_b128s of the next group and ONE
+        // global load of the next train tile are issued before the 16 MFMAs of the current group (sched_barrier pins that
+        // order), so LDS latency and the issue cost of the vector-memory instructions sit under ~1000 cycles of MFMA
+        // (all 16 loads in front of the loop kept the matrix pipe idle for ~8 % of the tile).
         f32x16 acc[2][2];
         const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float4 A0 = *reinterpret_cast<const float4*>(aBase), A1 = *reinterpret_cast<const float4*>(aBase + 32 * ST);
-        float4 B0 = *reinterpret_cast<const float4*>(bBase), B1 = *reinterpret_cast<const float4*>(bBase + 32 * ST);
-        float4 C0, C1, D0, D1;
-#define L2_LOAD(X0, X1, Y0, Y1, G)                                             \
-    X0 = *reinterpret_cast<const float4*>(aBase + (G) * 4);                    \
-    X1 = *reinterpret_cast<const float4*>(aBase + 32 * ST + (G) * 4);          \
-    Y0 = *reinterpret_cast<const float4*>(bBase + (G) * 4);                    \
-    Y1 = *reinterpret_cast<const float4*>(bBase + 32 * ST + (G) * 4);
-#define L2_STEP(X0, X1, Y0, Y1, c)                                                          \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X0.c, Y0.c, acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(X0.c, Y1.c, acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(X1.c, Y0.c, acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(X1.c, Y1.c, acc[1][1], 0, 0, 0);
-#define L2_GROUP(X0, X1, Y0, Y1) L2_STEP(X0, X1, Y0, Y1, x) L2_STEP(X0, X1, Y0, Y1, y) L2_STEP(X0, X1, Y0, Y1, z) L2_STEP(X0, X1, Y0, Y1, w)
-        // group 0: the first step starts the accumulators from an inline zero instead of 64 register writes
-        L2_LOAD(C0, C1, D0, D1, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x, B0.x, zero, 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A0.x, B1.x, zero, 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x, B0.x, zero, 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(A1.x, B1.x, zero, 0, 0, 0);
-        L2_STEP(A0, A1, B0, B1, y) L2_STEP(A0, A1, B0, B1, z) L2_STEP(A0, A1, B0, B1, w)
-        for (int g = 1; g < groups; g += 2) {      // groups is 8 or 16: (g, g+1) pairs, g odd
-            const int g2 = min(g + 1, groups - 1), g3 = min(g + 2, groups - 1);
-            L2_LOAD(A0, A1, B0, B1, g2)
-            __builtin_amdgcn_sched_barrier(0);
-            L2_GROUP(C0, C1, D0, D1)               // group g
+        float4 opA[2][2], opB[2][2];                 // [set][row block]
+#define L2_LOAD(S, G)                                                                  \
+    opA[S][0] = *reinterpret_cast<const float4*>(aBase + (G) * 4);                     \
+    opA[S][1] = *reinterpret_cast<const float4*>(aBase + 32 * ST + (G) * 4);           \
+    opB[S][0] = *reinterpret_cast<const float4*>(bBase + (G) * 4);                     \
+    opB[S][1] = *reinterpret_cast<const float4*>(bBase + 32 * ST + (G) * 4);
+#define L2_STEP(S, c)                                                                                      \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[S][0].c, opB[S][0].c, acc[0][0], 0, 0, 0);      \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[S][0].c, opB[S][1].c, acc[0][1], 0, 0, 0);      \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[S][1].c, opB[S][0].c, acc[1][0], 0, 0, 0);      \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[S][1].c, opB[S][1].c, acc[1][1], 0, 0, 0);
+        L2_LOAD(0, 0)
+#pragma unroll
+        for (int g = 0; g < groups; g++) {
+            const int cur = g & 1, nxt = cur ^ 1;
             if (g + 1 < groups) {
-                L2_LOAD(C0, C1, D0, D1, g3)
-                __builtin_amdgcn_sched_barrier(0);
-                L2_GROUP(A0, A1, B0, B1)           // group g + 1
+                if (nxt) { L2_LOAD(1, g + 1) } else { L2_LOAD(0, g + 1) }
             }
+            if (more) prefetch_piece(g, tile + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g == 0) {   // the first step starts the accumulators from an inline zero instead of 64 register writes
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][0].x, opB[0][0].x, zero, 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][0].x, opB[0][1].x, zero, 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][1].x, opB[0][0].x, zero, 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][1].x, opB[0][1].x, zero, 0, 0, 0);
+                L2_STEP(0, y) L2_STEP(0, z) L2_STEP(0, w)
+            } else if (cur) {
+                L2_STEP(1, x) L2_STEP(1, y) L2_STEP(1, z) L2_STEP(1, w)
+            } else {
+                L2_STEP(0, x) L2_STEP(0, y) L2_STEP(0, z) L2_STEP(0, w)
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-#undef L2_GROUP
 #undef L2_STEP
 #undef L2_LOAD
         // epilogue: candidates are ranked on u = |t|^2 - 2 q.t (|q|^2 is constant per query and added once at the end);
@@ -283,27 +285,29 @@ void l2_topk_device(const float* q, int nq, const float* t, long long nt, int di
     splits = ceil_div(t_tiles, tiles_per_split);
     uint64_t* parts = splits == 1 ? out : c.alloc_n<uint64_t>((size_t)splits * nq * k);
     const size_t lds = (size_t)(2 * 128 * (kp + 4) + 128) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_topk_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_topk_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_topk_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_topk_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
-        attr_set = true;
-    }
     {
         KernelTimer timer("l2_topk", s);
         const bool full = dim == kp && (reinterpret_cast<uintptr_t>(t) & 15) == 0;
-#define L2_LAUNCH(KK, FF)                                                                                                                       \
-    hipLaunchKernelGGL((l2_topk_kernel<KK, FF>), dim3(q_tiles, splits), dim3(256), lds, s, t, (const float*)tn, (int)nt, q, (const float*)qn, nq, dim, \
-                       kp, tiles_per_split, index_base, parts)
-        if (k == 2) {
-            if (full) L2_LAUNCH(2, true);
-            else L2_LAUNCH(2, false);
-        } else {
-            if (full) L2_LAUNCH(1, true);
-            else L2_LAUNCH(1, false);
-        }
+        // the 128-wide tiles need more than the default 64 KB of dynamic LDS: opt in per instantiation (cheap, idempotent)
+#define L2_LAUNCH(KK, FF, PP)                                                                                                                            \
+    do {                                                                                                                                                 \
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_topk_kernel<KK, FF, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); \
+        hipLaunchKernelGGL((l2_topk_kernel<KK, FF, PP>), dim3(q_tiles, splits), dim3(256), lds, s, t, (const float*)tn, (int)nt, q, (const float*)qn, nq, \
+                           dim, tiles_per_split, index_base, parts);                                                                                     \
+    } while (0)
+#define L2_LAUNCH_K(KK)                       \
+    do {                                      \
+        if (kp == 128) {                      \
+            if (full) L2_LAUNCH(KK, true, 128);  \
+            else L2_LAUNCH(KK, false, 128);      \
+        } else {                              \
+            if (full) L2_LAUNCH(KK, true, 64);   \
+            else L2_LAUNCH(KK, false, 64);       \
+        }                                     \
+    } while (0)
+        if (k == 2) L2_LAUNCH_K(2);
+        else L2_LAUNCH_K(1);
+#undef L2_LAUNCH_K
 #undef L2_LAUNCH
     }
     HIP_CHECK(hipGetLastError());
