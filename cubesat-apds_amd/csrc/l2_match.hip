@@ -6,15 +6,10 @@
 //
 //   d^2(q,t) = |q|^2 + |t|^2 - 2 q.t      -> the Q x N dot products are one GEMM, fused with a running top-k so the
 //                                            distance matrix never leaves the registers.
-// v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain, 157 TFLOP/s peak on MI355X).
+// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate: bit-for-bit an fmaf chain, 157 TFLOP/s peak on MI355X).
 // Orientation: train rows are the M dimension, queries the N dimension, so that an accumulator LANE owns ONE query
-// column (col = lane & 31) and 16 train rows per 32x32 tile: the running top-2 of a query lives in the lane that
-// owns it, with no cross-lane traffic until the end (same trick as the Hamming kernel).
-// Block = 4 waves, tile = 128 train rows x 128 queries x K (<= 128) resident in LDS. A 32x32x2 operand lane needs
-// k = 2*step + (lane >> 5): rows are stored with the k axis split into [even k | odd k], so four consecutive steps of
-// one lane are 16 contiguous bytes -> one ds_read_b128 per operand per four steps (row pitch K+4 floats: the 16 lanes
-// of a b128 group cover all 64 banks), issued one group ahead of the MFMAs that consume them. The next train tile is
-// prefetched into registers under the MFMAs.
+// column per 16x16 tile (col = lane & 15) and 4 train rows: the running top-2 of a query lives in the lanes that own
+// it, with no cross-lane traffic until the end (same trick as the Hamming kernel). Kernel structure: see l2_topk_kernel.
 #include <cmath>
 
 #include "kernels.h"
@@ -64,45 +59,58 @@ __device__ __forceinline__ uint64_t l2_key(float d, uint32_t idx) {
 }
 
 // grid: x = query tiles (128 queries), y = splits of the train tiles. out: [split][nq][K] keys
+//
+// Block = 8 waves = two per SIMD. The block's 128 queries are resident in LDS for the whole kernel; a block tile is 128 train
+// rows, of which wave w owns rows [16w, 16w+16): it loads them, stages them in its own LDS slice, multiplies them against
+// all 128 queries (eight 16x16 accumulators, v_mfma_f32_16x16x4_f32) and screens the results. Nothing in the tile loop is
+// shared between waves, so there is no barrier in it: the two waves of a SIMD drift apart and one wave's non-MFMA work
+// (top-2 screening, LDS commit of the next tile, pipeline fill/drain) runs under the other's MFMAs.
+// LDS rows keep the k axis as four classes [k%4 == 0 | 1 | 2 | 3] (a 16x16x4 operand lane needs k = 4*step + (lane >> 4)),
+// so four consecutive steps of one lane are 16 contiguous bytes: one ds_read_b128 per operand per four steps; row pitch
+// KP+4 floats: the 16 lanes of a b128 group cover all 64 banks.
 // FULL_ROWS: dim == KP (no zero padding of the k axis, rows 16-byte aligned). KP: k extent staged in LDS (64 or 128).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 template <int K, bool FULL_ROWS, int KP>
-__global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ train, const float* __restrict__ tnorm, int n_train,
+__global__ __launch_bounds__(512) void l2_topk_kernel(const float* __restrict__ train, const float* __restrict__ tnorm, int n_train,
                                                       const float* __restrict__ queries, const float* __restrict__ qnorm, int nq, int dim,
                                                       int tiles_per_split, uint32_t index_base, uint64_t* __restrict__ out) {
     extern __shared__ float l2_lds[];
-    constexpr int kp = KP;
     constexpr int ST = KP + 4;                       // LDS row pitch in floats (multiple of 4: 16-byte aligned rows)
-    constexpr int half = KP >> 1;                    // columns [0, half): even k, [half, kp): odd k
+    constexpr int Q4 = KP >> 2;                      // floats per k class
     float* sQ = l2_lds;                              // 128 x ST
-    float* sT = sQ + L2_TN * ST;                     // 128 x ST
-    float* sTT = sT + L2_TM * ST;                    // 128 train norms (+inf for rows past the end)
+    float* sT = sQ + L2_TN * ST;                     // 8 waves x 16 rows x ST
+    float* sTT = sT + L2_TM * ST;                    // 8 x 16 train norms (+inf for rows past the end)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
     const int q0 = blockIdx.x * L2_TN;
     const int n_tiles = (n_train + L2_TM - 1) / L2_TM;
     const int tile_begin = blockIdx.y * tiles_per_split, tile_end = min(n_tiles, tile_begin + tiles_per_split);
     if (tile_begin >= tile_end) return;
 
-    // queries -> LDS (zero padded to kp columns, rows past nq replicate the last query)
-    for (int i = tid; i < L2_TN * kp; i += 256) {
-        const int r = i / kp, c = i - r * kp;
+    // queries -> LDS (zero padded to KP columns, rows past nq replicate the last query)
+    for (int i = tid; i < L2_TN * KP; i += 512) {
+        const int r = i / KP, c = i - r * KP;
         const int qi = min(q0 + r, nq - 1);
-        sQ[r * ST + (c & 1) * half + (c >> 1)] = c < dim ? queries[(size_t)qi * dim + c] : 0.f;
+        sQ[r * ST + (c & 3) * Q4 + (c >> 2)] = c < dim ? queries[(size_t)qi * dim + c] : 0.f;
     }
-    // each thread stages a fixed set of (row, 4-column group) pieces of a train tile: 128 * KP / 4 float4 / 256 threads = KP / 8
-    // pieces, i.e. exactly one per MFMA group of the K loop
+    // a wave stages its 16 rows as (row, 4-column group) pieces: 16 * KP / 4 float4 / 64 lanes = KP / 16 pieces per lane,
+    // exactly one per MFMA group of the K loop
     constexpr int gshift = KP == 128 ? 5 : 4;        // float4 groups per row = KP / 4 = 32 or 16
     constexpr int groups_per_row = 1 << gshift;
-    constexpr int pieces = (L2_TM << gshift) >> 8;   // 16 for KP = 128, 8 for KP = 64
+    constexpr int pieces = (16 << gshift) >> 6;      // 8 for KP = 128, 4 for KP = 64
+    constexpr int groups = KP >> 4;                  // K-loop groups of 4 k-steps (16 k values)
+    static_assert(pieces == groups, "one staged piece per MFMA group");
+    float* wT = sT + wave * 16 * ST;
+    float* wTT = sTT + wave * 16;
     float4 pre[pieces];
-    float pre_norm = INFINITY;                       // this thread's row norm of the prefetched tile (threads < 128)
-    bool pre_valid = false;                          // ... and whether that row exists (resolved at commit: no use of the load here)
+    float pre_norm = INFINITY;                       // lane < 16: the norm of its row of the tile being staged
+    bool pre_valid = false;                          // ... and whether that row exists (resolved at the LDS write)
     // rows past the end re-read the last row: their norm is staged as +inf, so they are never selected, and an
     // unconditional load keeps the loads free of branches (a branch around a load made the compiler wait for it at once)
-    auto prefetch_piece = [&](int p, int tile) {
-        const int piece = p * 256 + tid;
+    auto load_piece = [&](int p, int tile) {
+        const int piece = p * 64 + lane;
         const int r = piece >> gshift, g = piece & (groups_per_row - 1);
-        const int row = min(tile * L2_TM + r, n_train - 1), c = g * 4;
+        const int row = min(tile * L2_TM + wave * 16 + r, n_train - 1), c = g * 4;
         const float* src = train + (size_t)row * dim + c;
         float4 v;
         if (FULL_ROWS) v = *reinterpret_cast<const float4*>(src);
@@ -114,78 +122,76 @@ __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ 
         }
         pre[p] = v;
     };
-    auto prefetch_norm = [&](int tile) {
-        if (tid < L2_TM) {
-            const int row = tile * L2_TM + tid;
+    auto load_norm = [&](int tile) {
+        if (lane < 16) {
+            const int row = tile * L2_TM + wave * 16 + lane;
             pre_norm = tnorm[min(row, n_train - 1)];
             pre_valid = row < n_train;
         }
     };
-    auto commit = [&](int tile) {
+    auto commit = [&]() {   // wave-local: a wave's LDS operations complete in order, no barrier needed
 #pragma unroll
         for (int p = 0; p < pieces; p++) {
-            const int piece = p * 256 + tid;
+            const int piece = p * 64 + lane;
             const int r = piece >> gshift, g = piece & (groups_per_row - 1);
-            float* d = &sT[r * ST + g * 2];          // k = 4g..4g+3 -> even slots 2g, 2g+1 and odd slots half+2g, half+2g+1
-            *reinterpret_cast<float2*>(d) = make_float2(pre[p].x, pre[p].z);
-            *reinterpret_cast<float2*>(d + half) = make_float2(pre[p].y, pre[p].w);
+            float* d = &wT[r * ST + g];              // k = 4g + j -> class j, slot g
+            d[0] = pre[p].x;
+            d[Q4] = pre[p].y;
+            d[2 * Q4] = pre[p].z;
+            d[3 * Q4] = pre[p].w;
         }
-        if (tid < L2_TM) sTT[tid] = pre_valid ? pre_norm : INFINITY;
+        if (lane < 16) wTT[lane] = pre_valid ? pre_norm : INFINITY;
     };
 
-    Top2 best[2];
-    float qq[2];
+    Top2 best[8];
+    float qq[8];
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
+    for (int n = 0; n < 8; n++) {
         best[n].d0 = best[n].d1 = INFINITY;
         best[n].i0 = best[n].i1 = 0xFFFFFFFFu;
-        qq[n] = qnorm[min(q0 + wc * 64 + n * 32 + (lane & 31), nq - 1)];
+        qq[n] = qnorm[min(q0 + n * 16 + (lane & 15), nq - 1)];
     }
-    const int kk = lane >> 5;                        // this lane's k parity within a k-step of 2
-    const float* aBase = &sT[(wr * 64 + (lane & 31)) * ST + kk * half];
-    const float* bBase = &sQ[(wc * 64 + (lane & 31)) * ST + kk * half];
-    constexpr int groups = KP >> 3;                  // 4 k-steps (8 k values) per group; == pieces
+    const int kc = lane >> 4;                        // this lane's k class
+    const float* aBase = &wT[(lane & 15) * ST + kc * Q4];
+    const float* bBase = &sQ[(lane & 15) * ST + kc * Q4];
 
 #pragma unroll
-    for (int p = 0; p < pieces; p++) prefetch_piece(p, tile_begin);
-    prefetch_norm(tile_begin);
+    for (int p = 0; p < pieces; p++) load_piece(p, tile_begin);
+    load_norm(tile_begin);
+    commit();
+    __syncthreads();                                 // publishes sQ (the only data shared between waves)
+
     for (int tile = tile_begin; tile < tile_end; tile++) {
-        __syncthreads();                             // everyone is done reading sT of the previous tile
-        commit(tile);
-        __syncthreads();
         const bool more = tile + 1 < tile_end;
-        if (more) prefetch_norm(tile + 1);
-        // K loop, fully unrolled: operand registers ping-pong between two sets; the ds_read_b128s of the next group and ONE
-        // global load of the next train tile are issued before the 16 MFMAs of the current group (sched_barrier pins that
-        // order), so LDS latency and the issue cost of the vector-memory instructions sit under ~1000 cycles of MFMA
-        // (all 16 loads in front of the loop kept the matrix pipe idle for ~8 % of the tile).
-        f32x16 acc[2][2];
-        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        float4 opA[2][2], opB[2][2];                 // [set][row block]
-#define L2_LOAD(S, G)                                                                  \
-    opA[S][0] = *reinterpret_cast<const float4*>(aBase + (G) * 4);                     \
-    opA[S][1] = *reinterpret_cast<const float4*>(aBase + 32 * ST + (G) * 4);           \
-    opB[S][0] = *reinterpret_cast<const float4*>(bBase + (G) * 4);                     \
-    opB[S][1] = *reinterpret_cast<const float4*>(bBase + 32 * ST + (G) * 4);
-#define L2_STEP(S, c)                                                                                      \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[S][0].c, opB[S][0].c, acc[0][0], 0, 0, 0);      \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[S][0].c, opB[S][1].c, acc[0][1], 0, 0, 0);      \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[S][1].c, opB[S][0].c, acc[1][0], 0, 0, 0);      \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[S][1].c, opB[S][1].c, acc[1][1], 0, 0, 0);
+        if (more) load_norm(tile + 1);
+        // K loop, fully unrolled: operand registers ping-pong between two sets; the nine ds_read_b128s of the next group are
+        // issued before the 32 MFMAs of the current group (sched_barrier pins that order)
+        f32x4 acc[8];
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        float4 opA[2], opB[2][8];
+#define L2_LOAD(S, G)                                                                                        \
+    opA[S] = *reinterpret_cast<const float4*>(aBase + (G) * 4);                                              \
+    _Pragma("unroll") for (int n = 0; n < 8; n++) opB[S][n] = *reinterpret_cast<const float4*>(bBase + n * 16 * ST + (G) * 4);
+#define L2_STEP(S, c) \
+    _Pragma("unroll") for (int n = 0; n < 8; n++) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(opA[S].c, opB[S][n].c, acc[n], 0, 0, 0);
         L2_LOAD(0, 0)
 #pragma unroll
         for (int g = 0; g < groups; g++) {
-            const int cur = g & 1, nxt = cur ^ 1;
+            const int cur = g & 1;
             if (g + 1 < groups) {
-                if (nxt) { L2_LOAD(1, g + 1) } else { L2_LOAD(0, g + 1) }
+                if (cur) { L2_LOAD(0, g + 1) } else { L2_LOAD(1, g + 1) }
             }
-            if (more) prefetch_piece(g, tile + 1);
+                // all global loads of the next tile go out with the first group: the commit at the end of this tile consumes them,
+            // and every later group that carried a load cost a fixed ~300 cycles (1 / 2 / 4 / 8 groups with loads:
+            // 86.9 / 85.8 / 83.9 / 81.6 % of the MFMA peak)
+            if (more && g == 0) {
+#pragma unroll
+                for (int p = 0; p < pieces; p++) load_piece(p, tile + 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            if (g == 0) {   // the first step starts the accumulators from an inline zero instead of 64 register writes
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][0].x, opB[0][0].x, zero, 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][0].x, opB[0][1].x, zero, 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][1].x, opB[0][0].x, zero, 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(opA[0][1].x, opB[0][1].x, zero, 0, 0, 0);
+            if (g == 0) {   // the first step starts the accumulators from an inline zero instead of register writes
+#pragma unroll
+                for (int n = 0; n < 8; n++) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(opA[0].x, opB[0][n].x, zero, 0, 0, 0);
                 L2_STEP(0, y) L2_STEP(0, z) L2_STEP(0, w)
             } else if (cur) {
                 L2_STEP(1, x) L2_STEP(1, y) L2_STEP(1, z) L2_STEP(1, w)
@@ -196,60 +202,54 @@ __global__ __launch_bounds__(256) void l2_topk_kernel(const float* __restrict__ 
         }
 #undef L2_STEP
 #undef L2_LOAD
-        // epilogue: candidates are ranked on u = |t|^2 - 2 q.t (|q|^2 is constant per query and added once at the end);
-        // the lane's 32 train rows per n are screened with one min chain and inserted only on a hit
-        float4 tt[2][4];
+        // epilogue: candidates are ranked on u = |t|^2 - 2 q.t (|q|^2 is constant per query and added once at the end).
+        // A lane holds rows 4*(lane>>4) + r of the wave's 16 for its query column of each of the 8 column blocks:
+        // screen all 32 values with min chains, insert only when some lane has a hit
+        const float4 t4 = *reinterpret_cast<const float4*>(&wTT[4 * kc]);
+        float vals[8][4];
+        bool hit = false;
 #pragma unroll
-        for (int m = 0; m < 2; m++)
-#pragma unroll
-            for (int rb = 0; rb < 4; rb++) tt[m][rb] = *reinterpret_cast<const float4*>(&sTT[wr * 64 + m * 32 + 8 * rb + 4 * (lane >> 5)]);
-#pragma unroll
-        for (int n = 0; n < 2; n++) {
-            float vals[2][16];
-            float mn = INFINITY;
-#pragma unroll
-            for (int m = 0; m < 2; m++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const float4 t4 = tt[m][r >> 2];
-                    const float tr = (r & 3) == 0 ? t4.x : ((r & 3) == 1 ? t4.y : ((r & 3) == 2 ? t4.z : t4.w));
-                    const float v = __builtin_fmaf(-2.0f, acc[m][n][r], tr);
-                    vals[m][r] = v;
-                    mn = fminf(mn, v);
-                }
-            if (__any(mn < best[n].d1)) {
-#pragma unroll
-                for (int m = 0; m < 2; m++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int rl = wr * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        top2_insert(best[n], vals[m][r], (uint32_t)(tile * L2_TM + rl) + index_base);
-                    }
-            }
+        for (int n = 0; n < 8; n++) {
+            vals[n][0] = __builtin_fmaf(-2.0f, acc[n][0], t4.x);
+            vals[n][1] = __builtin_fmaf(-2.0f, acc[n][1], t4.y);
+            vals[n][2] = __builtin_fmaf(-2.0f, acc[n][2], t4.z);
+            vals[n][3] = __builtin_fmaf(-2.0f, acc[n][3], t4.w);
+            const float mn = fminf(fminf(vals[n][0], vals[n][1]), fminf(vals[n][2], vals[n][3]));
+            hit |= mn < best[n].d1;
         }
+        if (__any(hit)) {
+            const uint32_t row0 = (uint32_t)(tile * L2_TM + wave * 16 + 4 * kc) + index_base;
+#pragma unroll
+            for (int n = 0; n < 8; n++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) top2_insert(best[n], vals[n][r], row0 + r);
+        }
+        if (more) commit();
     }
     // d^2 = max(|q|^2 + u, 0): same value as ranking on d^2 directly, the add is monotone
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
+    for (int n = 0; n < 8; n++) {
         best[n].d0 = fmaxf(qq[n] + best[n].d0, 0.f);
         best[n].d1 = fmaxf(qq[n] + best[n].d1, 0.f);
     }
-    // merge the 4 partial lists of every query (2 lane halves x 2 row-waves) through LDS (reusing sT)
+    // merge the 32 partial lists of every query (8 waves x 4 row classes) through LDS, source-major so that the final scan
+    // reads conflict-free; the LDS is reused from its start, hence the barrier (slower waves may still read sQ)
     __syncthreads();
-    uint64_t* cand = reinterpret_cast<uint64_t*>(sT);           // [128 queries][4 sources][2]
+    uint64_t* cand = reinterpret_cast<uint64_t*>(l2_lds);      // [32 sources][2][128 queries] = 64 KB
+    {
+        const int src = wave * 4 + kc;
 #pragma unroll
-    for (int n = 0; n < 2; n++) {
-        const int ql = wc * 64 + n * 32 + (lane & 31);
-        const int srcslot = wr * 2 + (lane >> 5);
-        cand[(ql * 4 + srcslot) * 2 + 0] = l2_key(best[n].d0, best[n].i0);
-        cand[(ql * 4 + srcslot) * 2 + 1] = l2_key(best[n].d1, best[n].i1);
+        for (int n = 0; n < 8; n++) {
+            const int ql = n * 16 + (lane & 15);
+            cand[(src * 2 + 0) * L2_TN + ql] = l2_key(best[n].d0, best[n].i0);
+            cand[(src * 2 + 1) * L2_TN + ql] = l2_key(best[n].d1, best[n].i1);
+        }
     }
     __syncthreads();
     if (tid < L2_TN && q0 + tid < nq) {
         uint64_t b0 = L2_EMPTY, b1 = L2_EMPTY;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const uint64_t key = cand[tid * 8 + j];
+        for (int j = 0; j < 64; j++) {
+            const uint64_t key = cand[j * L2_TN + tid];
             if (key < b0) {
                 b1 = b0;
                 b0 = key;
@@ -292,7 +292,7 @@ void l2_topk_device(const float* q, int nq, const float* t, long long nt, int di
 #define L2_LAUNCH(KK, FF, PP)                                                                                                                            \
     do {                                                                                                                                                 \
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_topk_kernel<KK, FF, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024)); \
-        hipLaunchKernelGGL((l2_topk_kernel<KK, FF, PP>), dim3(q_tiles, splits), dim3(256), lds, s, t, (const float*)tn, (int)nt, q, (const float*)qn, nq, \
+        hipLaunchKernelGGL((l2_topk_kernel<KK, FF, PP>), dim3(q_tiles, splits), dim3(512), lds, s, t, (const float*)tn, (int)nt, q, (const float*)qn, nq, \
                            dim, tiles_per_split, index_base, parts);                                                                                     \
     } while (0)
 #define L2_LAUNCH_K(KK)                       \
