@@ -127,3 +127,17 @@ def test_strided_rows_and_channel_orders(gpu_pkg, oracle_mod):
     _assert_same_extraction(got, ref)
     bgra = np.dstack([img, np.full(img.shape[:2], 255, np.uint8)])
     _assert_same_extraction(gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(bgra, None), ref)
+
+
+def test_full_size_4096_frame_equals_oracle(gpu_pkg, oracle_mod):
+    # BASELINE config 2 size: one 4096 x 4096 BGRA tile, every keypoint field and descriptor bit-equal to the oracle
+    # (the oracle needs a few seconds on the host cores)
+    tile = gpu_pkg.synth.make_tile(4096, 4096, frame_index=0, channels=4)
+    got = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(tile, None)
+    oracle_mod.set_threads(16)
+    ref = oracle_mod.akaze(tile)
+    assert len(ref.keypoints) > 20000
+    _assert_same_extraction(got, ref)
+    # extraction is a pure function of the image: a second run gives the same bytes
+    again = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(tile, None)
+    assert np.array_equal(again.descriptors, got.descriptors) and np.array_equal(again.keypoints, got.keypoints)

@@ -123,3 +123,36 @@ def test_larger_k(gpu_pkg, oracle_mod, k):
     idx, dist = gpu_pkg.feature_extraction.knn_match(q[:50], few, k)
     oi, od = oracle_mod.knn_hamming(q[:50], few, k)
     assert np.array_equal(dist, od) and np.array_equal(idx, oi) and (idx[:, -1] == -1).all()
+
+
+def test_full_size_properties_1m_rows(gpu_pkg, oracle_mod):
+    """BASELINE size (1 M-row DB) through size-independent properties: (a) a query that is a DB row finds itself at distance 0, and a
+    duplicated row resolves to the lower index; (b) planted neighbours are recovered; (c) sharding consistency: top-2 over the whole
+    DB == u64-key merge of the top-2 over its two halves (what the multi-GPU path computes); (d) a bounded sample of the queries
+    equals the oracle exactly."""
+    n = 1_000_000
+    db = gpu_pkg.synth.make_descriptor_db(n)
+    db[700_001] = db[123]                                   # duplicate across the halves: index 123 must win
+    q, src = gpu_pkg.synth.make_queries(db, 8192)
+    q[0], q[1], q[2] = db[123], db[999_999], db[500_000]    # exact copies: first row region, last row, first row of the 2nd half
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q, db, 2)
+    assert tuple(idx[0]) == (123, 700_001) and tuple(dist[0]) == (0, 0)
+    assert idx[1, 0] == 999_999 and dist[1, 0] == 0 and idx[2, 0] == 500_000 and dist[2, 0] == 0
+    planted = np.nonzero(src >= 0)[0]
+    planted = planted[planted > 2]
+    assert len(planted) > 2000 and np.array_equal(idx[planted, 0], src[planted])
+    assert (np.diff(dist.astype(np.int64), axis=1) >= 0).all()
+    # (c) halves + merge on u64 keys (distance << 32 | global index)
+    h = n // 2
+    ia, da = gpu_pkg.feature_extraction.knn_match(q, db[:h], 2)
+    ib, db_ = gpu_pkg.feature_extraction.knn_match(q, db[h:], 2)
+    keys = np.concatenate([(da.astype(np.uint64) << np.uint64(32)) | ia.astype(np.uint64),
+                           (db_.astype(np.uint64) << np.uint64(32)) | (ib.astype(np.uint64) + np.uint64(h))], axis=1)
+    keys.sort(axis=1)
+    assert np.array_equal((keys[:, :2] & np.uint64(0xFFFFFFFF)).astype(np.int64), idx.astype(np.int64))
+    assert np.array_equal((keys[:, :2] >> np.uint64(32)).astype(np.int64), dist.astype(np.int64))
+    # (d) exact against the oracle on a sample the CPU finishes in seconds
+    oracle_mod.set_threads(8)
+    sel = np.arange(0, len(q), 64)
+    oi, od = oracle_mod.knn_hamming(q[sel], db, 2)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od)
