@@ -85,7 +85,14 @@ def main():
         else:
             dist.init_process_group(backend)
         group = dist.group.WORLD
-        meta_group = dist.new_group(backend="gloo")   # host-side exchange of the per-frame query counts (no device sync)
+        # host-side exchange of the per-frame query counts (no device sync). Single node: loopback is always usable, the
+        # container hostname may not resolve. If gloo cannot be set up the pipeline falls back to a device-side count gather.
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+        try:
+            meta_group = dist.new_group(backend="gloo")
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] gloo meta group unavailable ({e}); using device-side counts", file=sys.stderr, flush=True)
+            meta_group = None
 
     pkg = graft.load_package()
     from cubesat_apds_amd import pipeline as pl
