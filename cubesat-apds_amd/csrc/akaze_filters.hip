@@ -153,6 +153,72 @@ __global__ __launch_bounds__(256) void deriv_pair_kernel(const float* __restrict
     }
 }
 
+// ---- per level: Lsmooth = Gaussian(5 taps, replicate) of the level's start image, and the PM-g2 conductivity from the
+// Scharr gradient of Lsmooth (reflect-101), in one pass: the start image is read once, Lsmooth never comes back from HBM
+// (16 -> 12 B/pixel and one launch less per level). Lsmooth is evaluated on the tile + 1 ring at in-image positions; a ring
+// position outside the image is, under reflect-101, an in-image position at most one pixel inside the border, i.e. part of
+// the same region, so the gradient stencil simply indexes it through the reflected coordinate. Arithmetic per value is
+// that of gauss_kernel<2> followed by deriv_pair_kernel<1>.
+static constexpr int FW = 64, FH = 32, FNT = 1024;
+
+__global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow, int w, int h,
+                                                          GaussTaps taps, const float* __restrict__ kptr) {
+    APDS_RAISE_WAVE_PRIORITY();
+    constexpr int SW = FW + 6, SH = FH + 6;      // start image, halo 3 (= ring 1 + Gaussian radius 2), replicate on load
+    constexpr int TWD = FW + 2;                  // row-pass / Lsmooth width: tile + ring 1
+    constexpr int MH = FH + 2;
+    __shared__ float s_src[SH * SW];
+    __shared__ float s_tmp[SH * TWD];
+    __shared__ float s_sm[MH * TWD];
+    const int x0 = blockIdx.x * FW, y0 = blockIdx.y * FH;
+    for (int i = threadIdx.x; i < SW * SH; i += FNT) {
+        const int ly = i / SW, lx = i - ly * SW;
+        s_src[i] = src[(size_t)clampi(y0 - 3 + ly, h) * w + clampi(x0 - 3 + lx, w)];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SH * TWD; i += FNT) {
+        const int ly = i / TWD, lx = i - ly * TWD;
+        const float* p = &s_src[ly * SW + lx + 2];
+        float acc = taps.k[0] * p[0];
+        acc += taps.k[1] * (p[-1] + p[1]);
+        acc += taps.k[2] * (p[-2] + p[2]);
+        s_tmp[i] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < MH * TWD; i += FNT) {
+        const int ly = i / TWD, lx = i - ly * TWD;
+        const float* p = &s_tmp[(ly + 2) * TWD + lx];
+        float acc = taps.k[0] * p[0];
+        acc += taps.k[1] * (p[-TWD] + p[TWD]);
+        acc += taps.k[2] * (p[-2 * TWD] + p[2 * TWD]);
+        s_sm[i] = acc;
+        const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+        if (lx >= 1 && lx <= FW && ly >= 1 && ly <= FH && gx < w && gy < h) smooth[(size_t)gy * w + gx] = acc;
+    }
+    __syncthreads();
+    const float k = *kptr;
+    const float k2inv = 1.0f / (k * k);
+    const float kside = 3.0f, kmid = 10.0f;      // unnormalised Scharr, as launch_flow passes them
+    for (int i = threadIdx.x; i < FW * FH; i += FNT) {
+        const int ly = i / FW, lx = i - ly * FW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx >= w || gy >= h) continue;
+        const int cx = lx + 1, cxm = reflect101(gx - 1, w) - (x0 - 1), cxp = reflect101(gx + 1, w) - (x0 - 1);
+        const float* r0 = &s_sm[(reflect101(gy - 1, h) - (y0 - 1)) * TWD];
+        const float* r1 = &s_sm[(ly + 1) * TWD];
+        const float* r2 = &s_sm[(reflect101(gy + 1, h) - (y0 - 1)) * TWD];
+        const float rd0 = r0[cxp] - r0[cxm], rd1 = r1[cxp] - r1[cxm], rd2 = r2[cxp] - r2[cxm];
+        float ax = kmid * rd1;
+        ax += kside * (rd0 + rd2);
+        float rs0 = kmid * r0[cx];
+        rs0 += kside * (r0[cxm] + r0[cxp]);
+        float rs2 = kmid * r2[cx];
+        rs2 += kside * (r2[cxm] + r2[cxp]);
+        const float ay = rs2 - rs0;
+        flow[(size_t)gy * w + gx] = 1.0f / (1.0f + ((ax * ax + ay * ay) * k2inv));
+    }
+}
+
 // ---- contrast factor: 300-bin histogram of |grad|/hmax over interior pixels, 70th percentile -----------
 __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __restrict__ modg, int w, int h, const unsigned int* __restrict__ hmax_bits,
                                                               int* __restrict__ hist) {
@@ -398,6 +464,9 @@ void launch_deriv_pair(const float* src, float* outA, float* outB, int w, int h,
 void launch_flow(const float* src, float* flow, int w, int h, const float* kptr, hipStream_t s) {
     hipLaunchKernelGGL((deriv_pair_kernel<1>), dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), deriv_lds_bytes(1), s, src, flow, (float*)nullptr, w, h, 1,
                        3.0f, 10.0f, kptr, (unsigned int*)nullptr);
+}
+void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int h, const GaussTaps& taps, const float* kptr, hipStream_t s) {
+    hipLaunchKernelGGL(smooth_flow_kernel, dim3(ceil_div(w, FW), ceil_div(h, FH)), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr);
 }
 void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s) {
     HIP_CHECK(hipMemsetAsync(hmax_bits, 0, sizeof(unsigned int), s));

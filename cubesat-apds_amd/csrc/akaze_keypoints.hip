@@ -894,9 +894,8 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
             } else {
                 P = p.Lt;
             }
-            launch_gauss(P, tmpS, e.w, e.h, g10, 2, s);
+            launch_smooth_flow(P, tmpS, tmpF, e.w, e.h, g10, k_oct + e.octave, s);   // Lsmooth and the conductivity in one pass
             smooth = tmpS;
-            launch_flow(tmpS, tmpF, e.w, e.h, k_oct + e.octave, s);
             const float* in = P;
             int pass = 0;
             for (int k = 0; k < e.nsteps; pass++) {
