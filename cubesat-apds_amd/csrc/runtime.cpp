@@ -127,6 +127,27 @@ int apds_dev_timing_enable(int on) {
     return guarded([&] { ctx().timing = on != 0; });
 }
 
+int apds_thread_release(void) {
+    return guarded([&] {
+        ThreadCtx& c = g_ctx;
+        if (!c.ready) return;
+        HIP_CHECK(hipSetDevice(c.device));
+        (void)hipStreamSynchronize(c.stream);
+        for (auto& kv : c.events)
+            for (auto& ev : kv.second) {
+                (void)hipEventDestroy(ev.a);
+                (void)hipEventDestroy(ev.b);
+            }
+        c.events.clear();
+        for (auto& s : c.slabs) (void)hipFree(s.first);
+        c.slabs.clear();
+        c.slab_used = 0;
+        (void)hipStreamDestroy(c.stream);
+        c.stream = nullptr;
+        c.ready = false;
+    });
+}
+
 int apds_dev_last_kernel_ms(const char* which, float* ms, int* launches) {
     return guarded([&] {
         APDS_REQUIRE(which && ms, APDS_ERR_BAD_ARG, "null argument");

@@ -278,6 +278,8 @@ class StreamedFramePipeline:
                 finally:
                     try:
                         L.apds_dev_timing_enable(0)
+                        torch.cuda.synchronize()
+                        L.apds_thread_release()      # this worker's stream + device workspace (threads are per run())
                     except Exception:
                         pass
             return wrap

@@ -203,6 +203,11 @@ int apds_dev_find_homography(const void* input_xy, const void* reference_xy, int
 int apds_stream_create(int priority, const uint32_t* cu_mask, int cu_mask_words, void** stream);
 int apds_stream_destroy(void* stream);
 
+/* Releases the calling thread's HIP stream and device workspace (they are created lazily by the first call on a thread and
+ * otherwise live as long as the thread; nothing is freed from thread-exit destructors, which may run after the HIP runtime has
+ * shut down). Call it before a worker thread that used the library exits; the thread may use the library again afterwards. */
+int apds_thread_release(void);
+
 /* Test hook: run apds_akaze_extract and copy one intermediate plane of evolution level `level` to out_plane
  * (which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet as f32 w*h; 7 keypoint mask after cross-level suppression as u8 w*h; 8 contrast factor, 1 float). */
 int apds_akaze_debug_plane(const uint8_t* img, int rows, int cols, int channels, size_t stride_bytes, int level, int which, void* out_plane);
