@@ -279,7 +279,9 @@ class StreamedFramePipeline:
                     try:
                         L.apds_dev_timing_enable(0)
                         torch.cuda.synchronize()
-                        L.apds_thread_release()      # this worker's stream + device workspace (threads are per run())
+                        # this worker's stream + device workspace (threads are per run(); long-lived stage threads that keep their
+                        # workspaces across runs measured 0.5 ms/frame SLOWER, reproducibly, so each run starts from fresh ones)
+                        L.apds_thread_release()
                     except Exception:
                         pass
             return wrap
