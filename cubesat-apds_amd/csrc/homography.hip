@@ -728,16 +728,22 @@ int find_homography_device(const float* src, const float* dst, int n, int method
             int niters = std::max(max_iters, 1), maxGood = 0, iter = 0;
             bool stop = false, any = false;
             const float t = (float)(thr * thr);
-            const int batch = std::max(8, std::min(batch_env, std::max(max_iters, 8)));
-            int* idx_dev = c.alloc_n<int>((size_t)batch * 4);
-            double* models_dev = c.alloc_n<double>((size_t)batch * 9);
-            uint8_t* valid_dev = c.alloc_n<uint8_t>(batch);
-            int* good_dev = c.alloc_n<int>(batch);
-            std::vector<int> idx((size_t)batch * 4), good(batch);
-            std::vector<uint8_t> valid(batch);
-            std::vector<double> models((size_t)batch * 9);
+            // First batch: batch_env samples (with a fair inlier ratio the budget collapses to a few dozen iterations after the
+            // first good model). Later batches cover the whole remaining budget, up to 4096 at once: a batch costs about the
+            // same wall time whatever its size (one thread per sample, latency-bound), so low-inlier inputs that keep the
+            // full budget finish in two round trips instead of max_iters / 512.
+            const int first_batch = std::max(8, std::min(batch_env, std::max(max_iters, 8)));
+            const int max_batch = std::max(first_batch, std::min(4096, std::max(max_iters, 8)));
+            int* idx_dev = c.alloc_n<int>((size_t)max_batch * 4);
+            double* models_dev = c.alloc_n<double>((size_t)max_batch * 9);
+            uint8_t* valid_dev = c.alloc_n<uint8_t>(max_batch);
+            int* good_dev = c.alloc_n<int>(max_batch);
+            std::vector<int> idx((size_t)max_batch * 4), good(max_batch);
+            std::vector<uint8_t> valid(max_batch);
+            std::vector<double> models((size_t)max_batch * 9);
             while (!stop && iter < niters) {
                 // speculate: samples for the next `batch` iterations (the RNG stream does not depend on the scores)
+                const int batch = iter == 0 ? first_batch : max_batch;
                 int B = 0;
                 bool subset_failed = false;
                 for (; B < batch && iter + B < niters; B++)

@@ -14,7 +14,7 @@ pkg = graft.load_package()
 import oracle  # noqa: E402
 
 L, ptr = pkg.lib(), pkg._lib.ptr
-for n, frac, iters, conf in ((50000, 0.4, 4096, 0.9999999999), (50000, 0.4, 2000, 0.995), (26000, 0.99, 2000, 0.995)):
+for n, frac, iters, conf in ((50000, 0.4, 4096, 0.9999999999), (50000, 0.15, 4096, 0.995), (50000, 0.4, 2000, 0.995), (26000, 0.99, 2000, 0.995)):
     src, dst, Ht, inl = pkg.synth.make_ransac_set(n, inlier_frac=frac)
     H, mask = np.zeros(9), np.zeros(n, np.uint8)
     L.apds_find_homography_ex(ptr(src), ptr(dst), n, 8, 3.0, iters, conf, ptr(H), ptr(mask))     # warm-up
