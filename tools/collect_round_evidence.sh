@@ -13,6 +13,7 @@ cp gpurun_out/prof/traffic.json $O/traffic_hamming_topk.json
 bash tools/xcd_ab.sh > $O/match_xcd_placement_ab.log 2>&1
 bash tools/pmc_util.sh > $O/pmc_utilisation.log 2>&1
 bash tools/pnp_stats.sh > $O/pnp_probe.log 2>&1
+bash tools/ransac_stats.sh > $O/ransac_probe.log 2>&1
 cd $R
 python3 tools/match_probe.py > $O/match_probe.log 2>&1
 python3 tools/l2_probe.py > $O/l2_probe.log 2>&1
