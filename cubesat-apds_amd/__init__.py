@@ -11,7 +11,7 @@ There is no CPU fallback: importing works anywhere, but every compute call needs
 The directory name has a hyphen, so import it through `__graft_entry__.load_package()` (module name
 `cubesat_apds_amd`).
 """
-from . import _lib, feature_database, feature_extraction, geotiff_extractor, homographier, synth  # noqa: F401
+from . import _lib, feature_database, feature_extraction, geotiff_extractor, homographier, preprocessor, synth  # noqa: F401
 from ._lib import ApdsError, lib, build_library  # noqa: F401
 
-__all__ = ["feature_extraction", "homographier", "geotiff_extractor", "feature_database", "synth", "ApdsError", "lib", "build_library"]
+__all__ = ["feature_extraction", "homographier", "geotiff_extractor", "feature_database", "preprocessor", "synth", "ApdsError", "lib", "build_library"]
