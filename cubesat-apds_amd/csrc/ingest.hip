@@ -8,8 +8,13 @@
 #include <cmath>
 
 #include "kernels.h"
+#include "pnp_core.h"
 
 namespace apds {
+
+struct GeoTransform {
+    double c[6];
+};
 
 // f32_to_u8 (mod.rs:410-422): None -> 0 in band_merger. powf(x, 1/2.2f) is evaluated in f64 and rounded to f32: that is
 // the correctly rounded f32 result (what glibc's powf returns) except for values within ~1e-8 relative of a rounding tie.
@@ -143,6 +148,87 @@ void warp_perspective_device(const uint8_t* src, int rows, int cols, const doubl
                        inv[0], inv[1], inv[2], inv[3], inv[4], inv[5], inv[6], inv[7], inv[8], (const short*)tab, dst_rows, dst_cols,
                        reinterpret_cast<uint32_t*>(dst));
     HIP_CHECK(hipGetLastError());
+}
+
+// ---- feature_database/src/elevationdb.rs:64-104 get_world_coordinates, batched -----------------------------------------
+// mosaic pixel -> dataset geotransform -> (lon, lat); elevation through the inverse elevation geotransform and the reference's
+// row id (elevationdb.rs:240: round(y) * x_size + round(x) + 1); EPSG:4326 -> EPSG:4978 (PROJ's geodetic -> geocentric closed
+// form, WGS 84). One thread per point, f64; sin/cos are the fixed polynomials of pnp_core.h so the CPU oracle agrees bit for bit.
+__device__ __forceinline__ void signed_sincos(double a, double& s, double& c) {
+    const bool neg = a < 0;
+    pnp::sincos_fixed(neg ? -a : a, s, c);
+    if (neg) s = -s;
+}
+
+__global__ void world_coordinates_kernel(const double* __restrict__ xy, int n, GeoTransform dgt, GeoTransform inv_egt, int has_elev,
+                                         const double* __restrict__ elev, int ew, int eh, double* __restrict__ xyz, int* __restrict__ missing) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = xy[2 * i], y = xy[2 * i + 1];
+    const double gx = dgt.c[0] + x * dgt.c[1] + y * dgt.c[2];
+    const double gy = dgt.c[3] + x * dgt.c[4] + y * dgt.c[5];
+    double h = 0.0;
+    if (has_elev) {
+        const double px = inv_egt.c[0] + gx * inv_egt.c[1] + gy * inv_egt.c[2];
+        const double py = inv_egt.c[3] + gx * inv_egt.c[4] + gy * inv_egt.c[5];
+        const long long id0 = (long long)(int)round(py) * ew + (long long)(int)round(px);
+        if (id0 < 0 || id0 >= (long long)ew * eh) {
+            *missing = 1;
+            const double nanv = __longlong_as_double(0x7FF8000000000000ll);
+            xyz[3 * i] = xyz[3 * i + 1] = xyz[3 * i + 2] = nanv;
+            return;
+        }
+        h = elev[id0];
+    }
+    const double a = 6378137.0, f = 1.0 / 298.257223563, es = f * (2.0 - f), deg = 0.017453292519943296;
+    double sp, cp, sl, cl;
+    signed_sincos(gy * deg, sp, cp);
+    signed_sincos(gx * deg, sl, cl);
+    const double N = a / sqrt(1.0 - es * sp * sp);
+    xyz[3 * i] = (N + h) * cp * cl;
+    xyz[3 * i + 1] = (N + h) * cp * sl;
+    xyz[3 * i + 2] = (N * (1.0 - es) + h) * sp;
+}
+
+bool invert_geotransform(const double* gt, double* out) {   // GDALInvGeoTransform
+    if (gt[2] == 0.0 && gt[4] == 0.0 && gt[1] != 0.0 && gt[5] != 0.0) {
+        out[0] = -gt[0] / gt[1];
+        out[1] = 1.0 / gt[1];
+        out[2] = 0.0;
+        out[3] = -gt[3] / gt[5];
+        out[4] = 0.0;
+        out[5] = 1.0 / gt[5];
+        return true;
+    }
+    const double det = gt[1] * gt[5] - gt[2] * gt[4];
+    const double mag = fmax(fmax(fabs(gt[1]), fabs(gt[2])), fmax(fabs(gt[4]), fabs(gt[5])));
+    if (fabs(det) <= 1e-10 * mag * mag) return false;
+    const double inv_det = 1.0 / det;
+    out[1] = gt[5] * inv_det;
+    out[4] = -gt[4] * inv_det;
+    out[2] = -gt[2] * inv_det;
+    out[5] = gt[1] * inv_det;
+    out[0] = (gt[2] * gt[3] - gt[0] * gt[5]) * inv_det;
+    out[3] = (-gt[1] * gt[3] + gt[0] * gt[4]) * inv_det;
+    return true;
+}
+
+// all pointers device; returns 1 if some elevation lookup missed (those points are NaN)
+int world_coordinates_device(const double* xy, int n, const double* dgt_host, const double* egt_host, const double* elev, int ew, int eh, double* xyz,
+                             hipStream_t s) {
+    GeoTransform d{}, inv{};
+    for (int i = 0; i < 6; i++) d.c[i] = dgt_host[i];
+    if (egt_host) APDS_REQUIRE(invert_geotransform(egt_host, inv.c), APDS_ERR_BAD_ARG, "elevation geotransform is not invertible");
+    int* missing = ctx().alloc_n<int>(1);
+    HIP_CHECK(hipMemsetAsync(missing, 0, sizeof(int), s));
+    if (n > 0)
+        hipLaunchKernelGGL(world_coordinates_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, xy, n, d, inv, egt_host ? 1 : 0, elev, ew, eh, xyz, missing);
+    HIP_CHECK(hipGetLastError());
+    int m = 0;
+    HIP_CHECK(hipMemcpyAsync(&m, missing, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return m;
 }
 
 }  // namespace apds

@@ -24,6 +24,9 @@ void rgba_to_bgra_device(const uint8_t* rgba, size_t n_pixels, uint8_t* bgra, hi
 void band_merger_device(const float* r, const float* g, const float* b, size_t n, const double* mm, int bgra, uint8_t* out, hipStream_t s);
 void warp_perspective_device(const uint8_t* src, int rows, int cols, const double* M, int dst_rows, int dst_cols, uint8_t* dst, hipStream_t s);
 
+int world_coordinates_device(const double* xy, int n, const double* dgt_host, const double* egt_host, const double* elev, int ew, int eh, double* xyz,
+                             hipStream_t s);
+
 // homography.hip
 int find_homography_device(const float* src, const float* dst, int n, int method, double thr, int max_iters, double confidence,
                            double* H_host, uint8_t* mask_dev, hipStream_t s);

@@ -85,3 +85,43 @@ class KeypointTable:
         dist = np.zeros((q.shape[0], k), np.int32)
         check(lib().apds_db_knn_match(self._h, ptr(q), q.shape[0], q.shape[1], int(k), ptr(idx), ptr(dist)))
         return idx, dist
+
+
+class ElevationTable:
+    """The `geotransform` and `elevation` tables of feature_database/src/elevationdb.rs (create_geotransform :20-45,
+    add_elevation_data :196-232, get_world_coordinates :64-104) held in memory; the conversion runs on the GPU."""
+
+    def __init__(self):
+        self.transforms = {}
+        self.elevation = None
+
+    def create_geotransform(self, dataset_name, transform):
+        """elevationdb.rs:20-45 — `transform`: GDAL's six coefficients."""
+        t = np.ascontiguousarray(transform, np.float64)
+        if t.shape != (6,):
+            raise ValueError("a geotransform has six coefficients")
+        self.transforms[dataset_name] = t
+
+    def add_elevation_data(self, raster):
+        """elevationdb.rs:196-232 — heights row by row (ids are 1-based row-major positions)."""
+        self.elevation = np.ascontiguousarray(raster, np.float64)
+        if self.elevation.ndim != 2:
+            raise ValueError("elevation raster: H x W")
+
+    def get_world_coordinates_batch(self, xy):
+        """elevationdb.rs:64-104 for n pixel positions at once -> n x 3 ECEF metres. Raises ApdsError(ERR_OUT_OF_RANGE) where the
+        reference returns Err (a lookup outside the elevation table)."""
+        xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+        out = np.zeros((len(xy), 3), np.float64)
+        dgt = self.transforms["dataset"]
+        egt = self.transforms.get("elevation") if self.elevation is not None else None
+        if egt is None:
+            check(lib().apds_get_world_coordinates(ptr(xy), len(xy), ptr(dgt), None, None, 0, 0, ptr(out)))
+        else:
+            check(lib().apds_get_world_coordinates(ptr(xy), len(xy), ptr(dgt), ptr(egt), ptr(self.elevation), self.elevation.shape[1],
+                                                   self.elevation.shape[0], ptr(out)))
+        return out
+
+    def get_world_coordinates(self, x, y):
+        """elevationdb.rs:64 — one point, (x, y, z) as the reference returns it."""
+        return tuple(self.get_world_coordinates_batch([[x, y]])[0])

@@ -141,6 +141,15 @@ int apds_warp_perspective(const uint8_t* src, int rows, int cols, int channels, 
 int apds_pnp_solver_ransac(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, int iter_count, float reproj_thres,
                            double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers, int* found);
 
+/* feature_database/src/elevationdb.rs:64-104 get_world_coordinates, batched (the object points pnp_solver_ransac consumes): pixel
+ * (x, y) of the reference mosaic -> dataset geotransform -> elevation through the inverse elevation geotransform (row id of
+ * elevationdb.rs:240) -> EPSG:4326 -> EPSG:4978 (ECEF metres). xy: n x 2, xyz: n x 3 doubles; geotransforms: GDAL's 6 doubles;
+ * elevation_gt NULL = no elevation data -> height 0 (elevationdb.rs:74-77); elevation: eh x ew doubles, row major.
+ * APDS_ERR_OUT_OF_RANGE if a lookup misses the elevation table (the reference returns Err; those points are NaN here),
+ * APDS_ERR_BAD_ARG if elevation_gt is singular (the reference panics). */
+int apds_get_world_coordinates(const double* xy, int n, const double* dataset_gt, const double* elevation_gt, const double* elevation, int ew, int eh,
+                               double* xyz);
+
 /* BASELINE config 3 (no reference call site: the reference matches Hamming only, lib.rs:101,121): brute-force L2 k-NN of float
  * descriptors (dim <= 128) as an MFMA distance GEMM with a fused top-k; semantics of BFMatcher(NORM_L2).knnMatch
  * (dist = sqrt(sum (q-t)^2), ties to the lower train index). k in {1,2}. idx/dist: n_query*k. */

@@ -80,6 +80,8 @@ def lib():
         L.oracle_rodrigues.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_det_acos.restype = None
         L.oracle_det_acos.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.oracle_world_coordinates.restype = C.c_int
+        L.oracle_world_coordinates.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_homography_4pt.restype = C.c_int
         L.oracle_homography_4pt.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_ransac_samples.restype = C.c_int
@@ -361,3 +363,17 @@ def det_acos(c):
     out = np.zeros_like(c)
     lib().oracle_det_acos(_ptr(c), len(c), _ptr(out))
     return out
+
+
+def world_coordinates(xy, dataset_gt, elevation_gt=None, elevation=None):
+    """elevationdb.rs:64-104, batched. Returns (rc, xyz n x 3)."""
+    xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+    dgt = np.ascontiguousarray(dataset_gt, np.float64)
+    out = np.zeros((len(xy), 3))
+    if elevation_gt is None:
+        rc = lib().oracle_world_coordinates(_ptr(xy), len(xy), _ptr(dgt), None, None, 0, 0, _ptr(out))
+    else:
+        egt = np.ascontiguousarray(elevation_gt, np.float64)
+        el = np.ascontiguousarray(elevation, np.float64)
+        rc = lib().oracle_world_coordinates(_ptr(xy), len(xy), _ptr(dgt), _ptr(egt), _ptr(el), el.shape[1], el.shape[0], _ptr(out))
+    return rc, out

@@ -4,6 +4,7 @@
 // 402-422 (first-party Rust; pinned by its tests gamma_correct_input :517-525, convert_f32_to_u8_success :547-555,
 // merging_bands :626-646). warp_image_perspective: homographier/src/homographier/mod.rs:271-300 -> OpenCV imgproc
 // warpPerspective / remap (fixed-point bilinear), restated; pinned by warp_image_empty (mod.rs:683-707).
+#include <algorithm>
 #include <cfloat>
 #include <climits>
 #include <cmath>
@@ -138,6 +139,104 @@ int oracle_warp_perspective_8uc4(const uint8_t* src, int rows, int cols, const d
             }
         }
     return 0;
+}
+
+// ---- feature_database/src/elevationdb.rs:64-104 get_world_coordinates (first-party Rust over GDAL/PROJ) ---------------------
+// pixel -> geotransform -> (optional) elevation lookup through the inverse elevation geotransform -> EPSG:4326 -> EPSG:4978.
+// GDAL GeoTransform::apply / invert (GDALInvGeoTransform) and PROJ's geodetic -> geocentric conversion (pj_cart) are absent
+// here and restated; sin/cos are the fixed polynomials shared with the GPU. PARITY UNPINNED (the reference's tests need Postgres).
+static void fixed_sincos(double a, double* s, double* c) {
+    const bool neg = a < 0;
+    if (neg) a = -a;
+    const double two_over_pi = 0.63661977236758134308;
+    const double pio2_hi = 1.57079632673412561417e+00, pio2_lo = 6.07710050650619224932e-11;
+    const int k = (int)(a * two_over_pi + 0.5);
+    const double r = (a - k * pio2_hi) - k * pio2_lo;
+    const double r2 = r * r;
+    double ps = -7.6471637318198164759e-13;
+    ps = ps * r2 + 1.6059043836821614599e-10;
+    ps = ps * r2 + -2.5052108385441718775e-08;
+    ps = ps * r2 + 2.7557319223985890653e-06;
+    ps = ps * r2 + -1.9841269841269841270e-04;
+    ps = ps * r2 + 8.3333333333333333333e-03;
+    ps = ps * r2 + -1.6666666666666666667e-01;
+    const double sr = r + r * (r2 * ps);
+    double pc = 4.7794773323873852974e-14;
+    pc = pc * r2 + -1.1470745597729724714e-11;
+    pc = pc * r2 + 2.0876756987868098979e-09;
+    pc = pc * r2 + -2.7557319223985890653e-07;
+    pc = pc * r2 + 2.4801587301587301587e-05;
+    pc = pc * r2 + -1.3888888888888888889e-03;
+    pc = pc * r2 + 4.1666666666666666667e-02;
+    pc = pc * r2 + -0.5;
+    const double cr = 1.0 + r2 * pc;
+    double sv, cv;
+    switch (k & 3) {
+        case 0: sv = sr; cv = cr; break;
+        case 1: sv = cr; cv = -sr; break;
+        case 2: sv = -sr; cv = -cr; break;
+        default: sv = -cr; cv = sr; break;
+    }
+    *s = neg ? -sv : sv;
+    *c = cv;
+}
+
+int oracle_invert_geotransform(const double* gt, double* out) {   // GDALInvGeoTransform
+    if (gt[2] == 0.0 && gt[4] == 0.0 && gt[1] != 0.0 && gt[5] != 0.0) {
+        out[0] = -gt[0] / gt[1];
+        out[1] = 1.0 / gt[1];
+        out[2] = 0.0;
+        out[3] = -gt[3] / gt[5];
+        out[4] = 0.0;
+        out[5] = 1.0 / gt[5];
+        return 1;
+    }
+    const double det = gt[1] * gt[5] - gt[2] * gt[4];
+    const double magnitude = std::max(std::max(std::fabs(gt[1]), std::fabs(gt[2])), std::max(std::fabs(gt[4]), std::fabs(gt[5])));
+    if (std::fabs(det) <= 1e-10 * magnitude * magnitude) return 0;
+    const double inv_det = 1.0 / det;
+    out[1] = gt[5] * inv_det;
+    out[4] = -gt[4] * inv_det;
+    out[2] = -gt[2] * inv_det;
+    out[5] = gt[1] * inv_det;
+    out[0] = (gt[2] * gt[3] - gt[0] * gt[5]) * inv_det;
+    out[3] = (-gt[1] * gt[3] + gt[0] * gt[4]) * inv_det;
+    return 1;
+}
+
+int oracle_world_coordinates(const double* xy, int n, const double* dgt, const double* egt, const double* elev, int ew, int eh, double* xyz) {
+    double inv[6] = {0, 0, 0, 0, 0, 0};
+    const bool has_elev = egt != nullptr;
+    if (has_elev && !oracle_invert_geotransform(egt, inv)) return -5;
+    const double a = 6378137.0, f = 1.0 / 298.257223563, es = f * (2.0 - f), deg = 0.017453292519943296;
+    int missing = 0;
+    for (int i = 0; i < n; i++) {
+        const double x = xy[2 * i], y = xy[2 * i + 1];
+        const double gx = dgt[0] + x * dgt[1] + y * dgt[2];
+        const double gy = dgt[3] + x * dgt[4] + y * dgt[5];
+        double h = 0.0;
+        if (has_elev) {
+            const double px = inv[0] + gx * inv[1] + gy * inv[2];
+            const double py = inv[3] + gx * inv[4] + gy * inv[5];
+            // elevationdb.rs:240: id = y.round() as i32 * x_size + x.round() as i32 + 1 (1-based row id; no per-axis bounds check)
+            const long long id0 = (long long)(int)std::round(py) * ew + (long long)(int)std::round(px);
+            if (id0 < 0 || id0 >= (long long)ew * eh) {
+                missing = 1;
+                xyz[3 * i] = xyz[3 * i + 1] = xyz[3 * i + 2] = NAN;
+                continue;
+            }
+            h = elev[id0];
+        }
+        // convert_coordinates(coordinates.1, coordinates.0, height): (lat, lon, h) EPSG:4326 -> EPSG:4978
+        double sp, cp, sl, cl;
+        fixed_sincos(gy * deg, &sp, &cp);
+        fixed_sincos(gx * deg, &sl, &cl);
+        const double N = a / std::sqrt(1.0 - es * sp * sp);
+        xyz[3 * i] = (N + h) * cp * cl;
+        xyz[3 * i + 1] = (N + h) * cp * sl;
+        xyz[3 * i + 2] = (N * (1.0 - es) + h) * sp;
+    }
+    return missing ? -211 : 0;
 }
 
 }  // extern "C"

@@ -115,6 +115,13 @@ void oracle_det_acos(const double* c, int n, double* out);
 /* mod.rs:183-220: RGBA8 slice -> BGRA rows. Returns 0 or -1 (MatError::Unknown) if len != w*h. */
 int oracle_raster_to_mat(const uint8_t* rgba, size_t n_pixels, int w, int h, uint8_t* bgra);
 
+/* feature_database/src/elevationdb.rs:64-104 get_world_coordinates, batched: pixel (x, y) of the reference mosaic -> ECEF metres.
+ * dataset_gt / elevation_gt: GDAL geotransforms (6 doubles); elevation_gt NULL -> height 0 (elevationdb.rs:74-77); elev: eh x ew f64.
+ * Returns 0, -211 if an elevation lookup misses (Diesel NotFound in the reference; those points are NaN), -5 if elevation_gt is singular.
+ * PARITY UNPINNED (GDAL / PROJ absent; see ingest_oracle.cpp). */
+int oracle_world_coordinates(const double* xy, int n, const double* dataset_gt, const double* elevation_gt, const double* elev, int ew, int eh, double* xyz);
+int oracle_invert_geotransform(const double* gt, double* out);
+
 /* BASELINE config 3 (no reference call site; semantics of cv::BFMatcher(NORM_L2).knnMatch): dist = sqrtf(sum (q-t)^2) accumulated in
  * f32 in index order, k smallest, ties to the lower train index. PARITY UNPINNED. */
 void oracle_knn_l2(const float* q, int nq, const float* t, int nt, int dim, int k, int32_t* idx, float* dist);

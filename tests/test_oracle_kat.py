@@ -234,3 +234,32 @@ def test_pnp_ransac_recovers_planted_pose(oracle_mod, pkg):
     # all outliers: no model gathers more than the 4 points that define it ... or only by chance; the call must not fail
     rc2, _, _, idx2 = oracle_mod.solve_pnp_ransac(obj[~inl][:200], img[~inl][:200], K, 200, 1.0, 0.99)
     assert rc2 in (0, 1) and (rc2 == 0) == (len(idx2) == 0)
+
+
+def test_world_coordinates_closed_form(oracle_mod):
+    # feature_database/src/elevationdb.rs:64-104; no runnable reference KAT (its tests need Postgres + a DEM file): checked against
+    # the WGS 84 geodetic -> ECEF closed form in numpy, incl. the row-id lookup of elevationdb.rs:240 and both hemispheres
+    rng = np.random.default_rng(9)
+    el = rng.uniform(-20, 2500, (400, 400))
+    for dgt, egt in (([9.0, 1e-4, 0, 57.0, 0, -1e-4], [8.99, 3e-4, 0, 57.01, 0, -3e-4]),
+                     ([-70.6, 2e-4, 1e-6, -33.3, -2e-6, -2e-4], [-70.7, 1e-3, 0, -33.2, 0, -1e-3])):
+        xy = rng.uniform(0, 900, (500, 2))
+        rc, xyz = oracle_mod.world_coordinates(xy, dgt, egt, el)
+        assert rc == 0
+        lon = dgt[0] + xy[:, 0] * dgt[1] + xy[:, 1] * dgt[2]
+        lat = dgt[3] + xy[:, 0] * dgt[4] + xy[:, 1] * dgt[5]
+        inv = np.linalg.inv(np.array([[egt[1], egt[2]], [egt[4], egt[5]]]))
+        p = (np.stack([lon - egt[0], lat - egt[3]], 1) @ inv.T)
+        ix, iy = np.floor(np.abs(p[:, 0]) + 0.5) * np.sign(p[:, 0]), np.floor(np.abs(p[:, 1]) + 0.5) * np.sign(p[:, 1])
+        h = el.ravel()[(iy * 400 + ix).astype(int)]
+        a, f = 6378137.0, 1 / 298.257223563
+        es = f * (2 - f)
+        ph, la = np.radians(lat), np.radians(lon)
+        N = a / np.sqrt(1 - es * np.sin(ph) ** 2)
+        ref = np.stack([(N + h) * np.cos(ph) * np.cos(la), (N + h) * np.cos(ph) * np.sin(la), (N * (1 - es) + h) * np.sin(ph)], 1)
+        assert np.abs(xyz - ref).max() < 5e-8                      # metres, at |xyz| ~ 6.4e6
+    rc, xyz = oracle_mod.world_coordinates([[0, 0]], [9.0, 1e-4, 0, 57.0, 0, -1e-4])          # no elevation data -> height 0
+    assert rc == 0 and abs(np.linalg.norm(xyz[0]) - 6363.2e3) < 1e3
+    rc, xyz = oracle_mod.world_coordinates([[1e7, 1e7]], [9.0, 1e-4, 0, 57.0, 0, -1e-4], [8.99, 3e-4, 0, 57.01, 0, -3e-4], el)
+    assert rc == -211 and np.isnan(xyz).all()
+    assert oracle_mod.world_coordinates([[0, 0]], [9.0, 1e-4, 0, 57.0, 0, -1e-4], [0, 0, 0, 0, 0, 0], el)[0] == -5
