@@ -42,6 +42,9 @@ extern "C" {
     pub fn apds_find_homography(input_xy: *const f32, reference_xy: *const f32, n: c_int, method: c_int, reproj_threshold: c_double,
                                 h: *mut f64, mask: *mut u8) -> c_int;
     pub fn apds_raster_to_mat(rgba: *const u8, n_pixels: usize, w: c_int, h: c_int, bgra: *mut u8) -> c_int;
+    pub fn apds_get_world_coordinates(xy: *const f64, n: c_int, dataset_gt: *const f64, elevation_gt: *const f64, elevation: *const f64,
+                                      ew: c_int, eh: c_int, xyz: *mut f64) -> c_int;
+    pub fn apds_thread_release() -> c_int;
     pub fn apds_pnp_solver_ransac(obj_xyz: *const f64, img_xy: *const f64, n: c_int, camera_intrinsic: *const f64, iter_count: c_int,
                                   reproj_thres: f32, confidence: c_double, method: c_int, rvec: *mut f64, tvec: *mut f64,
                                   inliers: *mut i32, n_inliers: *mut c_int, found: *mut c_int) -> c_int;
