@@ -89,7 +89,7 @@ def lib():
             "apds_dev_band_merger": (i, [vp, vp, vp, sz, vp, i, vp, vp]),
             "apds_warp_perspective": (i, [vp, i, i, i, vp, i, i, vp]),
             "apds_pnp_solver_ransac": (i, [vp, vp, i, vp, i, f, d, i, vp, vp, vp, ip, ip]),
-            "apds_pnp_hypotheses": (i, [vp, vp, i, vp, vp, i, vp]),
+            "apds_pnp_hypotheses": (i, [vp, vp, i, vp, vp, i, i, vp]),
             "apds_get_world_coordinates": (i, [vp, i, vp, vp, vp, i, i, vp]),
             "apds_l2_knn_match": (i, [vp, i, vp, i, i, i, vp, vp]),
             "apds_dev_l2_topk": (i, [vp, i, vp, i64, i, u32, i, vp, vp]),

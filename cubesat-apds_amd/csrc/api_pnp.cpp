@@ -17,11 +17,11 @@ int apds_pnp_solver_ransac(const double* obj_xyz, const double* img_xy, int n, c
 }
 
 int apds_pnp_hypotheses(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, const int32_t* idx5, int n_samples,
-                        double* models) {
+                        int model_points, double* models) {
     return guarded([&] {
         ThreadCtx& c = ctx();
         c.ws_reset();
-        pnp_hypotheses_device(obj_xyz, img_xy, n, camera_intrinsic, idx5, n_samples, models, c.stream);
+        pnp_hypotheses_device(obj_xyz, img_xy, n, camera_intrinsic, idx5, n_samples, model_points, models, c.stream);
     });
 }
 

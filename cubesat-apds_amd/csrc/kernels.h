@@ -34,6 +34,7 @@ int find_homography_device(const float* src, const float* dst, int n, int method
 // pnp.hip
 int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const double* K, int iterations, float reproj_thr, double confidence, int method,
                       double* rvec, double* tvec, int32_t* inliers, int* n_inliers, hipStream_t s);
-void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, const double* K, const int32_t* idx5, int B, double* models_host, hipStream_t s);
+void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, const double* K, const int32_t* idx5, int B, int model_points,
+                           double* models_host, hipStream_t s);
 
 }  // namespace apds

@@ -59,6 +59,39 @@ __global__ __launch_bounds__(PNP_THREADS) void pnp_hypothesis_kernel(const float
     m[5] = t[2];
 }
 
+// P3P kernel of the RANSAC loop: one thread per 4-point sample, everything in registers (closed form). valid[h] = 0 when the
+// three-point system has no admissible solution (runKernel then returns no model and the iteration is skipped).
+__global__ __launch_bounds__(64) void p3p_hypothesis_kernel(const float* __restrict__ obj, const float* __restrict__ img, const int* __restrict__ idx4, int B,
+                                                            Camera cam, double* __restrict__ models, uint8_t* __restrict__ valid) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int h = blockIdx.x * 64 + threadIdx.x;
+    if (h >= B) return;
+    double mu[4], mv[4], P[12];
+    const double ifx = 1. / cam.fu, ify = 1. / cam.fv;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int id = idx4[h * 4 + j];
+        P[3 * j] = obj[3 * (size_t)id];
+        P[3 * j + 1] = obj[3 * (size_t)id + 1];
+        P[3 * j + 2] = obj[3 * (size_t)id + 2];
+        // undistortPoints(k = 0, P = cameraMatrix): back to pixels, stored as float
+        const double xn = ((double)img[2 * (size_t)id] - cam.uc) * ifx, yn = ((double)img[2 * (size_t)id + 1] - cam.vc) * ify;
+        mu[j] = (float)(cam.fu * xn + cam.uc);
+        mv[j] = (float)(cam.fv * yn + cam.vc);
+    }
+    double R[9], t[3], rv[3] = {0, 0, 0};
+    const bool ok = pnp::p3p_best_pose(cam, mu, mv, P, R, t);
+    if (ok) pnp::rvec_from_rotation(R, rv);
+    double* m = models + (size_t)h * 6;
+    m[0] = rv[0];
+    m[1] = rv[1];
+    m[2] = rv[2];
+    m[3] = ok ? t[0] : 0.0;
+    m[4] = ok ? t[1] : 0.0;
+    m[5] = ok ? t[2] : 0.0;
+    valid[h] = ok ? 1 : 0;
+}
+
 constexpr int PNP_HT = 4;   // hypotheses per block of the scoring kernel
 
 // grid: x = ceil(B / PNP_HT), y = point parts. good[h] += #points whose float squared reprojection error is <= t
@@ -110,9 +143,9 @@ __global__ void pnp_mask_kernel(const float* __restrict__ obj, const float* __re
     mask[i] = pnp::reprojection_sqerr(R, tv, cam, obj[3 * (size_t)i], obj[3 * (size_t)i + 1], obj[3 * (size_t)i + 2], img[2 * (size_t)i], img[2 * (size_t)i + 1]) <= t;
 }
 
-// getSubset with the default checkSubset: 5 distinct indices from the cv::RNG stream
-void next_sample(int count, int* idx, pnp::MwcRng& rng) {
-    for (int i = 0; i < 5; ++i) {
+// getSubset with the default checkSubset: `model_points` distinct indices from the cv::RNG stream
+void next_sample(int count, int* idx, pnp::MwcRng& rng, int model_points) {
+    for (int i = 0; i < model_points; ++i) {
         int v;
         for (;;) {
             v = (int)(rng.next() % (unsigned)count);
@@ -153,6 +186,23 @@ void host_epnp(const T* obj, const T* img, int n, const Camera& cam, double* rve
     pnp::rvec_from_rotation(R, rvec);
 }
 
+// solvePnP(4 points, SOLVEPNP_P3P) on host arrays
+template <typename T>
+bool host_p3p(const T* obj, const T* img, const Camera& cam, double* rvec, double* tvec) {
+    const double ifx = 1. / cam.fu, ify = 1. / cam.fv;
+    double mu[4], mv[4], P[12];
+    for (int i = 0; i < 4; i++) {
+        const double xn = ((double)img[2 * i] - cam.uc) * ifx, yn = ((double)img[2 * i + 1] - cam.vc) * ify;
+        mu[i] = (T)(cam.fu * xn + cam.uc);
+        mv[i] = (T)(cam.fv * yn + cam.vc);
+        for (int c = 0; c < 3; c++) P[3 * i + c] = obj[3 * i + c];
+    }
+    double R[9];
+    if (!pnp::p3p_best_pose(cam, mu, mv, P, R, tvec)) return false;
+    pnp::rvec_from_rotation(R, rvec);
+    return true;
+}
+
 }  // namespace
 
 int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const double* K, int iterations, float reproj_thr, double confidence, int method,
@@ -161,15 +211,22 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     *n_inliers = 0;
     APDS_REQUIRE(obj_xyz && img_xy && K && rvec && tvec && inliers, APDS_ERR_BAD_ARG, "null argument");
     APDS_REQUIRE(n >= 4, APDS_ERR_ASSERT, "solvePnPRansac needs at least 4 correspondences");
-    APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP, APDS_ERR_NOT_IMPLEMENTED, "only SOLVEPNP_EPNP (the reference's default) is implemented");
-    APDS_REQUIRE(n != 4, APDS_ERR_NOT_IMPLEMENTED, "4 correspondences go through the P3P kernel, which is not implemented");
+    APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP || method == APDS_SOLVEPNP_P3P, APDS_ERR_NOT_IMPLEMENTED,
+                 "only SOLVEPNP_EPNP (the reference's default) and SOLVEPNP_P3P are implemented");
+    // kernel choice of solvePnPRansac: P3P on 4 points when asked for, or when there are only 4 points; EPnP on 5 otherwise
+    const bool p3p = method == APDS_SOLVEPNP_P3P || n == 4;
+    const int model_points = p3p ? 4 : 5;
     const Camera cam{K[0], K[4], K[2], K[5]};
     // solvePnPRansac converts CV_64F points to CV_32F before anything else
     std::vector<float> op(3 * (size_t)n), ip(2 * (size_t)n);
     for (size_t i = 0; i < op.size(); i++) op[i] = (float)obj_xyz[i];
     for (size_t i = 0; i < ip.size(); i++) ip[i] = (float)img_xy[i];
-    if (n == 5) {   // model_points == npoints: one direct solve, every point an inlier
-        host_epnp<float>(op.data(), ip.data(), n, cam, rvec, tvec);
+    if (n == model_points) {   // model_points == npoints: one direct solve, every point an inlier
+        if (p3p) {
+            if (!host_p3p<float>(op.data(), ip.data(), cam, rvec, tvec)) return 0;
+        } else {
+            host_epnp<float>(op.data(), ip.data(), n, cam, rvec, tvec);
+        }
         for (int i = 0; i < n; i++) inliers[i] = i;
         *n_inliers = n;
         return 1;
@@ -185,21 +242,27 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     int niters = std::max(iterations, 1), maxGood = 0, iter = 0;
     const int batch = std::max(PNP_HT, std::min(batch_env, niters));
     const float t = (float)((double)reproj_thr * (double)reproj_thr);
-    int* idx_dev = c.alloc_n<int>((size_t)batch * 5);
+    int* idx_dev = c.alloc_n<int>((size_t)batch * model_points);
     double* models_dev = c.alloc_n<double>((size_t)batch * 6);
     int* good_dev = c.alloc_n<int>(batch);
+    uint8_t* valid_dev = c.alloc_n<uint8_t>(batch);
     uint8_t* mask_dev = c.alloc_n<uint8_t>(n);
-    std::vector<int> idx((size_t)batch * 5), good(batch);
+    std::vector<int> idx((size_t)batch * model_points), good(batch);
+    std::vector<uint8_t> valid(batch, 1);
     std::vector<double> models((size_t)batch * 6);
     double best[6] = {0, 0, 0, 0, 0, 0};
     pnp::MwcRng rng{(uint64_t)-1};
     while (iter < niters) {
         const int B = std::min(batch, niters - iter);
-        for (int b = 0; b < B; b++) next_sample(n, &idx[(size_t)b * 5], rng);
-        HIP_CHECK(hipMemcpyAsync(idx_dev, idx.data(), (size_t)B * 5 * sizeof(int), hipMemcpyHostToDevice, s));
+        for (int b = 0; b < B; b++) next_sample(n, &idx[(size_t)b * model_points], rng, model_points);
+        HIP_CHECK(hipMemcpyAsync(idx_dev, idx.data(), (size_t)B * model_points * sizeof(int), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemsetAsync(good_dev, 0, (size_t)B * sizeof(int), s));
-        hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(ceil_div(B, PNP_THREADS)), dim3(PNP_THREADS), PNP_LDS_BYTES, s, (const float*)obj_dev, (const float*)img_dev,
-                           (const int*)idx_dev, B, cam, models_dev);
+        if (p3p)
+            hipLaunchKernelGGL(p3p_hypothesis_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const float*)obj_dev, (const float*)img_dev, (const int*)idx_dev, B, cam,
+                               models_dev, valid_dev);
+        else
+            hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(ceil_div(B, PNP_THREADS)), dim3(PNP_THREADS), PNP_LDS_BYTES, s, (const float*)obj_dev,
+                               (const float*)img_dev, (const int*)idx_dev, B, cam, models_dev);
         {
             KernelTimer timer("pnp_score", s);
             const int parts = std::max(1, std::min(64, ceil_div(256 * 8, ceil_div(B, PNP_HT))));
@@ -208,13 +271,15 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
         }
         HIP_CHECK(hipMemcpyAsync(good.data(), good_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(models.data(), models_dev, (size_t)B * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+        if (p3p) HIP_CHECK(hipMemcpyAsync(valid.data(), valid_dev, (size_t)B, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
         // replay the sequential loop over the speculated iterations (samples beyond a shortened budget are discarded)
         for (int b = 0; b < B && iter < niters; b++, iter++) {
-            if (good[b] > std::max(maxGood, 4)) {
+            if (!valid[b]) continue;   // P3P found no pose for this sample: the iteration yields no model
+            if (good[b] > std::max(maxGood, model_points - 1)) {
                 std::memcpy(best, &models[(size_t)b * 6], sizeof(best));
                 maxGood = good[b];
-                niters = update_num_iters(confidence, (double)(n - good[b]) / n, 5, niters);
+                niters = update_num_iters(confidence, (double)(n - good[b]) / n, model_points, niters);
             }
         }
     }
@@ -241,10 +306,13 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     return 1;
 }
 
-// per-stage hooks for the parity tests: the pose of explicit 5-point samples
-void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, const double* K, const int32_t* idx5, int B, double* models_host, hipStream_t s) {
-    APDS_REQUIRE(obj_xyz && img_xy && K && idx5 && models_host && n >= 5 && B >= 1, APDS_ERR_BAD_ARG, "bad argument");
-    for (int i = 0; i < B * 5; i++) APDS_REQUIRE(idx5[i] >= 0 && idx5[i] < n, APDS_ERR_OUT_OF_RANGE, "sample index out of range");
+// per-stage hooks for the parity tests: the pose of explicit samples (model_points 5: EPnP, 4: P3P; a P3P sample without a pose
+// comes back as NaNs)
+void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, const double* K, const int32_t* idx5, int B, int model_points,
+                           double* models_host, hipStream_t s) {
+    APDS_REQUIRE(obj_xyz && img_xy && K && idx5 && models_host && (model_points == 4 || model_points == 5) && n >= model_points && B >= 1, APDS_ERR_BAD_ARG,
+                 "bad argument");
+    for (int i = 0; i < B * model_points; i++) APDS_REQUIRE(idx5[i] >= 0 && idx5[i] < n, APDS_ERR_OUT_OF_RANGE, "sample index out of range");
     const Camera cam{K[0], K[4], K[2], K[5]};
     std::vector<float> op(3 * (size_t)n), ip(2 * (size_t)n);
     for (size_t i = 0; i < op.size(); i++) op[i] = (float)obj_xyz[i];
@@ -252,15 +320,28 @@ void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, c
     ThreadCtx& c = ctx();
     float* obj_dev = c.alloc_n<float>(op.size());
     float* img_dev = c.alloc_n<float>(ip.size());
-    int* idx_dev = c.alloc_n<int>((size_t)B * 5);
+    int* idx_dev = c.alloc_n<int>((size_t)B * model_points);
     double* models_dev = c.alloc_n<double>((size_t)B * 6);
+    uint8_t* valid_dev = c.alloc_n<uint8_t>(B);
     HIP_CHECK(hipMemcpyAsync(obj_dev, op.data(), op.size() * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(img_dev, ip.data(), ip.size() * sizeof(float), hipMemcpyHostToDevice, s));
-    HIP_CHECK(hipMemcpyAsync(idx_dev, idx5, (size_t)B * 5 * sizeof(int), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(ceil_div(B, PNP_THREADS)), dim3(PNP_THREADS), PNP_LDS_BYTES, s, (const float*)obj_dev, (const float*)img_dev,
-                       (const int*)idx_dev, B, cam, models_dev);
+    HIP_CHECK(hipMemcpyAsync(idx_dev, idx5, (size_t)B * model_points * sizeof(int), hipMemcpyHostToDevice, s));
+    if (model_points == 4)
+        hipLaunchKernelGGL(p3p_hypothesis_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const float*)obj_dev, (const float*)img_dev, (const int*)idx_dev, B, cam,
+                           models_dev, valid_dev);
+    else
+        hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(ceil_div(B, PNP_THREADS)), dim3(PNP_THREADS), PNP_LDS_BYTES, s, (const float*)obj_dev,
+                           (const float*)img_dev, (const int*)idx_dev, B, cam, models_dev);
     HIP_CHECK(hipGetLastError());
     HIP_CHECK(hipMemcpyAsync(models_host, models_dev, (size_t)B * 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (model_points == 4) {
+        std::vector<uint8_t> valid(B);
+        HIP_CHECK(hipMemcpyAsync(valid.data(), valid_dev, (size_t)B, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+        for (int b = 0; b < B; b++)
+            if (!valid[b])
+                for (int k = 0; k < 6; k++) models_host[(size_t)b * 6 + k] = NAN;
+    }
     HIP_CHECK(hipStreamSynchronize(s));
 }
 

@@ -608,5 +608,375 @@ PNP_HD void epnp_pose(int n, const PW& pws, const US& us, AL alphas, PC pcs, con
     }
 }
 
+// ---- P3P (p3p.cpp: Gao, Hou, Tang, Cheng 2003; polynom_solver.cpp) -------------------------------------------------------
+// The kernel solvePnPRansac uses for SOLVEPNP_P3P and whenever only four correspondences exist: up to four poses from three
+// points (a quartic in the ratio of two of the camera-point distances, Horn's quaternion alignment), ranked by the fourth.
+PNP_HD double cbrt_fixed(double x) {   // x > 0; OpenCV calls pow(x, 1/3.): bit-level first guess + 6 Newton steps, fixed order
+    union {
+        double d;
+        uint64_t u;
+    } v;
+    v.d = x;
+    v.u = v.u / 3 + 0x2A9F7893782DA1CEull;
+    double y = v.d;
+    for (int k = 0; k < 6; k++) y = y - (y * y * y - x) / (3.0 * (y * y));
+    return y;
+}
+PNP_HD double cos_fixed(double a) {   // a in [0, 2 pi]
+    double s, c;
+    sincos_fixed(a, s, c);
+    return c;
+}
+PNP_HD double nan_value() {
+    union {
+        uint64_t u;
+        double d;
+    } v;
+    v.u = 0x7FF8000000000000ull;
+    return v.d;
+}
+
+PNP_HD int poly_deg2(double a, double b, double c, double& x1, double& x2) {
+    const double delta = b * b - 4 * a * c;
+    if (delta < 0) return 0;
+    const double inv_2a = 0.5 / a;
+    if (delta == 0) {
+        x1 = -b * inv_2a;
+        x2 = x1;
+        return 1;
+    }
+    const double sqrt_delta = sqrt(delta);
+    x1 = (-b + sqrt_delta) * inv_2a;
+    x2 = (-b - sqrt_delta) * inv_2a;
+    return 2;
+}
+
+PNP_HD int poly_deg3(double a, double b, double c, double d, double& x0, double& x1, double& x2) {
+    if (a == 0) {
+        if (b == 0) {
+            if (c == 0) return 0;
+            x0 = -d / c;
+            return 1;
+        }
+        x2 = 0;
+        return poly_deg2(b, c, d, x0, x1);
+    }
+    const double inv_a = 1. / a;
+    const double b_a = inv_a * b, b_a2 = b_a * b_a;
+    const double c_a = inv_a * c;
+    const double d_a = inv_a * d;
+    const double Q = (3 * c_a - b_a2) / 9;
+    const double R = (9 * b_a * c_a - 27 * d_a - 2 * b_a * b_a2) / 54;
+    const double Q3 = Q * Q * Q;
+    const double D = Q3 + R * R;
+    const double b_a_3 = (1. / 3.) * b_a;
+    if (Q == 0) {
+        if (R == 0) {
+            x0 = x1 = x2 = -b_a_3;
+            return 3;
+        }
+        x0 = (2 * R > 0 ? cbrt_fixed(2 * R) : nan_value()) - b_a_3;   // pow(negative, 1/3.) is NaN
+        return 1;
+    }
+    if (D <= 0) {   // three real roots
+        const double theta = acos_fixed(R / sqrt(-Q3));
+        const double sqrt_Q = sqrt(-Q);
+        x0 = 2 * sqrt_Q * cos_fixed(theta / 3.0) - b_a_3;
+        x1 = 2 * sqrt_Q * cos_fixed((theta + 2 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+        x2 = 2 * sqrt_Q * cos_fixed((theta + 4 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+        return 3;
+    }
+    const double AD = cbrt_fixed(fabs(R) + sqrt(D)) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+    const double BD = (AD == 0) ? 0 : -Q / AD;
+    x0 = AD + BD - b_a_3;
+    return 1;
+}
+
+PNP_HD int poly_deg4(double a, double b, double c, double d, double e, double& x0, double& x1, double& x2, double& x3) {
+    if (a == 0) {
+        x3 = 0;
+        return poly_deg3(b, c, d, e, x0, x1, x2);
+    }
+    const double inv_a = 1. / a;
+    b *= inv_a;
+    c *= inv_a;
+    d *= inv_a;
+    e *= inv_a;
+    const double b2 = b * b, bc = b * c, b3 = b2 * b;
+    double r0, r1, r2;
+    const int n = poly_deg3(1, -c, d * b - 4 * e, 4 * c * e - d * d - b2 * e, r0, r1, r2);
+    if (n == 0) return 0;
+    const double R2 = 0.25 * b2 - c + r0;
+    if (R2 < 0) return 0;
+    const double R = sqrt(R2);
+    const double inv_R = 1. / R;
+    int nb_real_roots = 0;
+    double D2, E2;
+    if (R < 10E-12) {
+        const double temp = r0 * r0 - 4 * e;
+        if (temp < 0) D2 = E2 = -1;
+        else {
+            const double sqrt_temp = sqrt(temp);
+            D2 = 0.75 * b2 - 2 * c + 2 * sqrt_temp;
+            E2 = D2 - 4 * sqrt_temp;
+        }
+    } else {
+        const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * inv_R * (4 * bc - 8 * d - b3);
+        D2 = u + v;
+        E2 = u - v;
+    }
+    const double b_4 = 0.25 * b, R_2 = 0.5 * R;
+    if (D2 >= 0) {
+        const double D = sqrt(D2);
+        nb_real_roots = 2;
+        const double D_2 = 0.5 * D;
+        x0 = R_2 + D_2 - b_4;
+        x1 = x0 - D;
+    }
+    if (E2 >= 0) {
+        const double E = sqrt(E2);
+        const double E_2 = 0.5 * E;
+        if (nb_real_roots == 0) {
+            x0 = -R_2 + E_2 - b_4;
+            x1 = x0 - E;
+            nb_real_roots = 2;
+        } else {
+            x2 = -R_2 + E_2 - b_4;
+            x3 = x2 - E;
+            nb_real_roots = 4;
+        }
+    }
+    return nb_real_roots;
+}
+
+// cyclic Jacobi on a symmetric 4x4 (upper triangle of A used and destroyed): eigenvalues D, eigenvectors in the columns of U
+PNP_HD bool eigen_sym4(double* A, double* D, double* U) {
+    double B[4], Z[4];
+    for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int i = 0; i < 4; i++) {
+        B[i] = A[5 * i];
+        D[i] = B[i];
+        Z[i] = 0;
+    }
+    for (int iter = 0; iter < 50; iter++) {
+        const double sum = fabs(A[1]) + fabs(A[2]) + fabs(A[3]) + fabs(A[6]) + fabs(A[7]) + fabs(A[11]);
+        if (sum == 0.0) return true;
+        const double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+        for (int i = 0; i < 3; i++)
+            for (int j = i + 1; j < 4; j++) {
+                const double Aij = A[4 * i + j];
+                const double eps_machine = 100.0 * fabs(Aij);
+                if (iter > 3 && fabs(D[i]) + eps_machine == fabs(D[i]) && fabs(D[j]) + eps_machine == fabs(D[j])) {
+                    A[4 * i + j] = 0.0;
+                } else if (fabs(Aij) > tresh) {
+                    double hh = D[j] - D[i], t;
+                    if (fabs(hh) + eps_machine == fabs(hh)) t = Aij / hh;
+                    else {
+                        const double theta = 0.5 * hh / Aij;
+                        t = 1.0 / (fabs(theta) + sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    hh = t * Aij;
+                    Z[i] -= hh;
+                    Z[j] += hh;
+                    D[i] -= hh;
+                    D[j] += hh;
+                    A[4 * i + j] = 0.0;
+                    const double c = 1.0 / sqrt(1 + t * t);
+                    const double s = t * c;
+                    const double tau = s / (1.0 + c);
+                    for (int k = 0; k <= i - 1; k++) {
+                        const double g = A[k * 4 + i], h = A[k * 4 + j];
+                        A[k * 4 + i] = g - s * (h + g * tau);
+                        A[k * 4 + j] = h + s * (g - h * tau);
+                    }
+                    for (int k = i + 1; k <= j - 1; k++) {
+                        const double g = A[i * 4 + k], h = A[k * 4 + j];
+                        A[i * 4 + k] = g - s * (h + g * tau);
+                        A[k * 4 + j] = h + s * (g - h * tau);
+                    }
+                    for (int k = j + 1; k < 4; k++) {
+                        const double g = A[i * 4 + k], h = A[j * 4 + k];
+                        A[i * 4 + k] = g - s * (h + g * tau);
+                        A[j * 4 + k] = h + s * (g - h * tau);
+                    }
+                    for (int k = 0; k < 4; k++) {
+                        const double g = U[k * 4 + i], h = U[k * 4 + j];
+                        U[k * 4 + i] = g - s * (h + g * tau);
+                        U[k * 4 + j] = h + s * (g - h * tau);
+                    }
+                }
+            }
+        for (int i = 0; i < 4; i++) {
+            B[i] += Z[i];
+            D[i] = B[i];
+            Z[i] = 0;
+        }
+    }
+    return false;
+}
+
+// Horn: rotation + translation taking the three object points P0..P2 onto the camera-frame points M (rows)
+PNP_HD void p3p_align(const double* M /*3x3*/, const double* P0, const double* P1, const double* P2, double* R /*9*/, double* T /*3*/) {
+    double C_start[3], C_end[3];
+    for (int i = 0; i < 3; i++) C_end[i] = (M[i] + M[3 + i] + M[6 + i]) / 3;
+    C_start[0] = (P0[0] + P1[0] + P2[0]) / 3;
+    C_start[1] = (P0[1] + P1[1] + P2[1]) / 3;
+    C_start[2] = (P0[2] + P1[2] + P2[2]) / 3;
+    double s[9];
+    for (int j = 0; j < 3; j++) {
+        s[0 * 3 + j] = (P0[0] * M[j] + P1[0] * M[3 + j] + P2[0] * M[6 + j]) / 3 - C_end[j] * C_start[0];
+        s[1 * 3 + j] = (P0[1] * M[j] + P1[1] * M[3 + j] + P2[1] * M[6 + j]) / 3 - C_end[j] * C_start[1];
+        s[2 * 3 + j] = (P0[2] * M[j] + P1[2] * M[3 + j] + P2[2] * M[6 + j]) / 3 - C_end[j] * C_start[2];
+    }
+    double Qs[16], evs[4], U[16];
+    Qs[0 * 4 + 0] = s[0 * 3 + 0] + s[1 * 3 + 1] + s[2 * 3 + 2];
+    Qs[1 * 4 + 1] = s[0 * 3 + 0] - s[1 * 3 + 1] - s[2 * 3 + 2];
+    Qs[2 * 4 + 2] = s[1 * 3 + 1] - s[2 * 3 + 2] - s[0 * 3 + 0];
+    Qs[3 * 4 + 3] = s[2 * 3 + 2] - s[0 * 3 + 0] - s[1 * 3 + 1];
+    Qs[1 * 4 + 0] = Qs[0 * 4 + 1] = s[1 * 3 + 2] - s[2 * 3 + 1];
+    Qs[2 * 4 + 0] = Qs[0 * 4 + 2] = s[2 * 3 + 0] - s[0 * 3 + 2];
+    Qs[3 * 4 + 0] = Qs[0 * 4 + 3] = s[0 * 3 + 1] - s[1 * 3 + 0];
+    Qs[2 * 4 + 1] = Qs[1 * 4 + 2] = s[1 * 3 + 0] + s[0 * 3 + 1];
+    Qs[3 * 4 + 1] = Qs[1 * 4 + 3] = s[2 * 3 + 0] + s[0 * 3 + 2];
+    Qs[3 * 4 + 2] = Qs[2 * 4 + 3] = s[2 * 3 + 1] + s[1 * 3 + 2];
+    eigen_sym4(Qs, evs, U);
+    int i_ev = 0;
+    double ev_max = evs[0];
+    for (int i = 1; i < 4; i++)
+        if (evs[i] > ev_max) {
+            i_ev = i;
+            ev_max = evs[i];
+        }
+    const double q0 = U[0 * 4 + i_ev], q1 = U[1 * 4 + i_ev], q2 = U[2 * 4 + i_ev], q3 = U[3 * 4 + i_ev];
+    const double q02 = q0 * q0, q12 = q1 * q1, q22 = q2 * q2, q32 = q3 * q3;
+    const double q0_1 = q0 * q1, q0_2 = q0 * q2, q0_3 = q0 * q3;
+    const double q1_2 = q1 * q2, q1_3 = q1 * q3;
+    const double q2_3 = q2 * q3;
+    R[0] = q02 + q12 - q22 - q32;
+    R[1] = 2. * (q1_2 - q0_3);
+    R[2] = 2. * (q1_3 + q0_2);
+    R[3] = 2. * (q1_2 + q0_3);
+    R[4] = q02 + q22 - q12 - q32;
+    R[5] = 2. * (q2_3 - q0_1);
+    R[6] = 2. * (q1_3 - q0_2);
+    R[7] = 2. * (q2_3 + q0_1);
+    R[8] = q02 + q32 - q12 - q22;
+    for (int i = 0; i < 3; i++) T[i] = C_end[i] - (R[3 * i] * C_start[0] + R[3 * i + 1] * C_start[1] + R[3 * i + 2] * C_start[2]);
+}
+
+// the camera-to-point distances: lengths[k] = (X, Y, Z) for solution k; returns the number of solutions (<= 4)
+PNP_HD int p3p_lengths(double lengths[4][3], const double* distances, const double* cosines) {
+    const double p = cosines[0] * 2, q = cosines[1] * 2, r = cosines[2] * 2;
+    const double inv_d22 = 1. / (distances[2] * distances[2]);
+    const double a = inv_d22 * (distances[0] * distances[0]);
+    const double b = inv_d22 * (distances[1] * distances[1]);
+    const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
+    const double pr = p * r, pqr = q * pr;
+    if (p2 + q2 + r2 - pqr - 1 == 0) return 0;
+    const double ab = a * b, a_2 = 2 * a;
+    const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+    if (A == 0) return 0;
+    const double a_4 = 4 * a;
+    const double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+    const double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+    const double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+    const double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+    const double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+    const double b0 = b * temp * temp;
+    if (b0 == 0) return 0;
+    double roots[4];
+    const int n = poly_deg4(A, B, C, D, E, roots[0], roots[1], roots[2], roots[3]);
+    if (n == 0) return 0;
+    int nb_solutions = 0;
+    const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
+    const double inv_b0 = 1. / b0;
+    for (int i = 0; i < n; i++) {
+        const double x = roots[i];
+        if (x <= 0) continue;
+        const double x2 = x * x;
+        const double b1 =
+            ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+            (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+              (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+             (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+              pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+             2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+             p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+        if (b1 <= 0) continue;
+        const double y = inv_b0 * b1;
+        const double v = x2 + y * y - x * y * r;
+        if (v <= 0) continue;
+        const double Z = distances[2] / sqrt(v);
+        lengths[nb_solutions][0] = x * Z;
+        lengths[nb_solutions][1] = y * Z;
+        lengths[nb_solutions][2] = Z;
+        nb_solutions++;
+    }
+    return nb_solutions;
+}
+
+// solvePnP(SOLVEPNP_P3P) on four correspondences: mu/mv pixel coordinates (already through undistortPoints), P object points.
+// Writes the first pose of OpenCV's list sorted by the fourth point's error.
+PNP_HD bool p3p_best_pose(const Camera& cam, const double* mu_in, const double* mv_in, const double* P /*4x3*/, double* Rbest /*9*/, double* tbest /*3*/) {
+    const double inv_fx = 1. / cam.fu, inv_fy = 1. / cam.fv, cx_fx = cam.uc / cam.fu, cy_fy = cam.vc / cam.fv;
+    double mu[4], mv[4], mk[3];
+    for (int i = 0; i < 3; i++) {
+        mu[i] = inv_fx * mu_in[i] - cx_fx;
+        mv[i] = inv_fy * mv_in[i] - cy_fy;
+        const double norm = sqrt(mu[i] * mu[i] + mv[i] * mv[i] + 1);
+        mk[i] = 1. / norm;
+        mu[i] *= mk[i];
+        mv[i] *= mk[i];
+    }
+    mu[3] = inv_fx * mu_in[3] - cx_fx;
+    mv[3] = inv_fy * mv_in[3] - cy_fy;
+    const double* P0 = P;
+    const double* P1 = P + 3;
+    const double* P2 = P + 6;
+    const double* P3 = P + 9;
+    double distances[3], cosines[3];
+    distances[0] = sqrt((P1[0] - P2[0]) * (P1[0] - P2[0]) + (P1[1] - P2[1]) * (P1[1] - P2[1]) + (P1[2] - P2[2]) * (P1[2] - P2[2]));
+    distances[1] = sqrt((P0[0] - P2[0]) * (P0[0] - P2[0]) + (P0[1] - P2[1]) * (P0[1] - P2[1]) + (P0[2] - P2[2]) * (P0[2] - P2[2]));
+    distances[2] = sqrt((P0[0] - P1[0]) * (P0[0] - P1[0]) + (P0[1] - P1[1]) * (P0[1] - P1[1]) + (P0[2] - P1[2]) * (P0[2] - P1[2]));
+    cosines[0] = mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2];
+    cosines[1] = mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2];
+    cosines[2] = mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1];
+    double lengths[4][3];
+    const int n = p3p_lengths(lengths, distances, cosines);
+    double Rs[4][9], ts[4][3], errs[4];
+    int order[4] = {0, 1, 2, 3};
+    for (int i = 0; i < n; i++) {
+        double M[9];
+        for (int j = 0; j < 3; j++) {
+            M[3 * j] = lengths[i][j] * mu[j];
+            M[3 * j + 1] = lengths[i][j] * mv[j];
+            M[3 * j + 2] = lengths[i][j] * mk[j];
+        }
+        p3p_align(M, P0, P1, P2, Rs[i], ts[i]);
+        const double X3p = Rs[i][0] * P3[0] + Rs[i][1] * P3[1] + Rs[i][2] * P3[2] + ts[i][0];
+        const double Y3p = Rs[i][3] * P3[0] + Rs[i][4] * P3[1] + Rs[i][5] * P3[2] + ts[i][1];
+        const double Z3p = Rs[i][6] * P3[0] + Rs[i][7] * P3[1] + Rs[i][8] * P3[2] + ts[i][2];
+        const double mu3p = X3p / Z3p, mv3p = Y3p / Z3p;
+        errs[i] = (mu3p - mu[3]) * (mu3p - mu[3]) + (mv3p - mv[3]) * (mv3p - mv[3]);
+    }
+    // OpenCV's insertion sort by the fourth point's error (a NaN neither moves nor lets anything pass it); the head is returned
+    for (int i = 1; i < n; i++)
+        for (int j = i; j > 0 && errs[j - 1] > errs[j]; j--) {
+            const double e = errs[j];
+            errs[j] = errs[j - 1];
+            errs[j - 1] = e;
+            const int o = order[j];
+            order[j] = order[j - 1];
+            order[j - 1] = o;
+        }
+    if (n <= 0) return false;
+    // (a switch keeps Rs / ts in registers on the device: no dynamically indexed copy)
+    const int h = order[0];
+    for (int k = 0; k < 9; k++) Rbest[k] = h == 0 ? Rs[0][k] : (h == 1 ? Rs[1][k] : (h == 2 ? Rs[2][k] : Rs[3][k]));
+    for (int k = 0; k < 3; k++) tbest[k] = h == 0 ? ts[0][k] : (h == 1 ? ts[1][k] : (h == 2 ? ts[2][k] : ts[3][k]));
+    return true;
+}
+
 }  // namespace pnp
 }  // namespace apds

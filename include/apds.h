@@ -131,8 +131,10 @@ int apds_warp_perspective(const uint8_t* src, int rows, int cols, int channels, 
  * confidence, dist_coeffs, method) -> Result<Option<PNPRANSACSolution>, MatError>: cv::solvePnPRansac with useExtrinsicGuess = false and
  * distCoeffs = zeros(4,1) (mod.rs:344 shadows the dist_coeffs argument with zeros, so it never reaches OpenCV and is not part of this ABI).
  * obj_xyz: n Point3d (ImgObjCorrespondence::obj_point, mod.rs:53-65), img_xy: n Point2d, camera_intrinsic: 3x3 f64 row major.
- * method: cv::SolvePnPMethod; the shim passes method.unwrap_or(SOLVEPNP_EPNP) (mod.rs:360). Only APDS_SOLVEPNP_EPNP is built; P3P / AP3P
- * and n == 4 (which OpenCV routes through P3P) return APDS_ERR_NOT_IMPLEMENTED. n < 4 -> APDS_ERR_ASSERT (mod.rs:627-638).
+ * method: cv::SolvePnPMethod; the shim passes method.unwrap_or(SOLVEPNP_EPNP) (mod.rs:360). Built: APDS_SOLVEPNP_EPNP (RANSAC kernel
+ * EPnP on 5 points) and APDS_SOLVEPNP_P3P (Gao's P3P on 4 points; also the kernel OpenCV switches to when n == 4); the final pose
+ * over the inliers is EPnP in both cases, as in OpenCV. AP3P / ITERATIVE / ... return APDS_ERR_NOT_IMPLEMENTED.
+ * n < 4 -> APDS_ERR_ASSERT (mod.rs:627-638).
  * *found = 1: rvec[3], tvec[3], inliers[0..*n_inliers) filled (inliers: caller allocated, n ints); *found = 0: Ok(None). */
 #define APDS_SOLVEPNP_ITERATIVE 0
 #define APDS_SOLVEPNP_EPNP 1
@@ -221,9 +223,10 @@ int apds_thread_release(void);
  * (which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet as f32 w*h; 7 keypoint mask after cross-level suppression as u8 w*h; 8 contrast factor, 1 float). */
 int apds_akaze_debug_plane(const uint8_t* img, int rows, int cols, int channels, size_t stride_bytes, int level, int which, void* out_plane);
 
-/* Test hook: EPnP pose (rvec, tvec: 6 doubles per sample) of n_samples explicit 5-correspondence samples, as the RANSAC kernel computes them. */
-int apds_pnp_hypotheses(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, const int32_t* idx5, int n_samples,
-                        double* models);
+/* Test hook: the pose (rvec, tvec: 6 doubles per sample) of n_samples explicit samples as the RANSAC kernels compute them:
+ * model_points 5 = EPnP on 5 correspondences, 4 = P3P on 4 (three solve, the fourth ranks; NaNs when there is no pose). */
+int apds_pnp_hypotheses(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, const int32_t* samples, int n_samples,
+                        int model_points, double* models);
 
 /* Measurement helpers used by bench.py (not part of the reference surface). */
 /* Register-only xor+popcount loop: returns measured lane-ops/s (32-bit xor + bcnt counted as 2 ops). */

@@ -76,6 +76,10 @@ def lib():
         L.oracle_pnp_ransac_samples.argtypes = [C.c_int, C.c_int, C.c_void_p]
         L.oracle_pnp_hypothesis.restype = C.c_int
         L.oracle_pnp_hypothesis.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_pnp_ransac_samples4.restype = C.c_int
+        L.oracle_pnp_ransac_samples4.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.oracle_pnp_p3p_hypothesis.restype = C.c_int
+        L.oracle_pnp_p3p_hypothesis.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_rodrigues.restype = None
         L.oracle_rodrigues.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.oracle_det_acos.restype = None
@@ -377,3 +381,20 @@ def world_coordinates(xy, dataset_gt, elevation_gt=None, elevation=None):
         el = np.ascontiguousarray(elevation, np.float64)
         rc = lib().oracle_world_coordinates(_ptr(xy), len(xy), _ptr(dgt), _ptr(egt), _ptr(el), el.shape[1], el.shape[0], _ptr(out))
     return rc, out
+
+
+def pnp_ransac_samples4(n, iters):
+    idx = np.zeros((iters, 4), np.int32)
+    lib().oracle_pnp_ransac_samples4(n, iters, _ptr(idx))
+    return idx
+
+
+def pnp_p3p_hypothesis(obj, img, idx4, K):
+    """Returns (found, rvec, tvec) of solvePnP(P3P) on the four correspondences idx4 (converted to float as in the RANSAC loop)."""
+    obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+    idx4 = np.ascontiguousarray(idx4, np.int32)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    ok = lib().oracle_pnp_p3p_hypothesis(_ptr(obj), _ptr(img), _ptr(idx4), _ptr(K), _ptr(rvec), _ptr(tvec))
+    return ok == 1, rvec, tvec

@@ -726,6 +726,371 @@ void pnp_errors(const float* obj, const float* img, int n, const double* K, cons
     }
 }
 
+// ---- p3p.cpp (Gao, Hou, Tang, Cheng 2003) + polynom_solver.cpp --------------------------------------------------------
+// cube root with a fixed evaluation order (OpenCV calls pow(x, 1/3.)): bit-level first guess + 6 Newton steps, x > 0
+double det_cbrt(double x) {
+    uint64_t i;
+    std::memcpy(&i, &x, 8);
+    i = i / 3 + 0x2A9F7893782DA1CEull;
+    double y;
+    std::memcpy(&y, &i, 8);
+    for (int k = 0; k < 6; k++) y = y - (y * y * y - x) / (3.0 * (y * y));
+    return y;
+}
+double det_cos(double a) {   // a in [0, 2 pi]
+    double s, c;
+    det_sincos(a, s, c);
+    return c;
+}
+
+int solve_deg2(double a, double b, double c, double& x1, double& x2) {
+    const double delta = b * b - 4 * a * c;
+    if (delta < 0) return 0;
+    const double inv_2a = 0.5 / a;
+    if (delta == 0) {
+        x1 = -b * inv_2a;
+        x2 = x1;
+        return 1;
+    }
+    const double sqrt_delta = std::sqrt(delta);
+    x1 = (-b + sqrt_delta) * inv_2a;
+    x2 = (-b - sqrt_delta) * inv_2a;
+    return 2;
+}
+
+int solve_deg3(double a, double b, double c, double d, double& x0, double& x1, double& x2) {
+    if (a == 0) {
+        if (b == 0) {
+            if (c == 0) return 0;
+            x0 = -d / c;
+            return 1;
+        }
+        x2 = 0;
+        return solve_deg2(b, c, d, x0, x1);
+    }
+    const double inv_a = 1. / a;
+    const double b_a = inv_a * b, b_a2 = b_a * b_a;
+    const double c_a = inv_a * c;
+    const double d_a = inv_a * d;
+    const double Q = (3 * c_a - b_a2) / 9;
+    const double R = (9 * b_a * c_a - 27 * d_a - 2 * b_a * b_a2) / 54;
+    const double Q3 = Q * Q * Q;
+    const double D = Q3 + R * R;
+    const double b_a_3 = (1. / 3.) * b_a;
+    if (Q == 0) {
+        if (R == 0) {
+            x0 = x1 = x2 = -b_a_3;
+            return 3;
+        }
+        x0 = (2 * R > 0 ? det_cbrt(2 * R) : std::nan("")) - b_a_3;   // pow(negative, 1/3.) is NaN
+        return 1;
+    }
+    if (D <= 0) {
+        const double theta = det_acos(R / std::sqrt(-Q3));
+        const double sqrt_Q = std::sqrt(-Q);
+        x0 = 2 * sqrt_Q * det_cos(theta / 3.0) - b_a_3;
+        x1 = 2 * sqrt_Q * det_cos((theta + 2 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+        x2 = 2 * sqrt_Q * det_cos((theta + 4 * 3.1415926535897932384626433832795) / 3.0) - b_a_3;
+        return 3;
+    }
+    const double AD = det_cbrt(std::fabs(R) + std::sqrt(D)) * (R > 0 ? 1 : (R < 0 ? -1 : 0));
+    const double BD = (AD == 0) ? 0 : -Q / AD;
+    x0 = AD + BD - b_a_3;
+    return 1;
+}
+
+int solve_deg4(double a, double b, double c, double d, double e, double& x0, double& x1, double& x2, double& x3) {
+    if (a == 0) {
+        x3 = 0;
+        return solve_deg3(b, c, d, e, x0, x1, x2);
+    }
+    const double inv_a = 1. / a;
+    b *= inv_a;
+    c *= inv_a;
+    d *= inv_a;
+    e *= inv_a;
+    const double b2 = b * b, bc = b * c, b3 = b2 * b;
+    double r0, r1, r2;
+    const int n = solve_deg3(1, -c, d * b - 4 * e, 4 * c * e - d * d - b2 * e, r0, r1, r2);
+    if (n == 0) return 0;
+    const double R2 = 0.25 * b2 - c + r0;
+    if (R2 < 0) return 0;
+    const double R = std::sqrt(R2);
+    const double inv_R = 1. / R;
+    int nb_real_roots = 0;
+    double D2, E2;
+    if (R < 10E-12) {
+        const double temp = r0 * r0 - 4 * e;
+        if (temp < 0) D2 = E2 = -1;
+        else {
+            const double sqrt_temp = std::sqrt(temp);
+            D2 = 0.75 * b2 - 2 * c + 2 * sqrt_temp;
+            E2 = D2 - 4 * sqrt_temp;
+        }
+    } else {
+        const double u = 0.75 * b2 - 2 * c - R2, v = 0.25 * inv_R * (4 * bc - 8 * d - b3);
+        D2 = u + v;
+        E2 = u - v;
+    }
+    const double b_4 = 0.25 * b, R_2 = 0.5 * R;
+    if (D2 >= 0) {
+        const double D = std::sqrt(D2);
+        nb_real_roots = 2;
+        const double D_2 = 0.5 * D;
+        x0 = R_2 + D_2 - b_4;
+        x1 = x0 - D;
+    }
+    if (E2 >= 0) {
+        const double E = std::sqrt(E2);
+        const double E_2 = 0.5 * E;
+        if (nb_real_roots == 0) {
+            x0 = -R_2 + E_2 - b_4;
+            x1 = x0 - E;
+            nb_real_roots = 2;
+        } else {
+            x2 = -R_2 + E_2 - b_4;
+            x3 = x2 - E;
+            nb_real_roots = 4;
+        }
+    }
+    return nb_real_roots;
+}
+
+bool jacobi_4x4(double* A, double* D, double* U) {
+    double B[4], Z[4];
+    for (int i = 0; i < 16; i++) U[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    B[0] = A[0];
+    B[1] = A[5];
+    B[2] = A[10];
+    B[3] = A[15];
+    std::memcpy(D, B, sizeof B);
+    std::memset(Z, 0, sizeof Z);
+    for (int iter = 0; iter < 50; iter++) {
+        const double sum = std::fabs(A[1]) + std::fabs(A[2]) + std::fabs(A[3]) + std::fabs(A[6]) + std::fabs(A[7]) + std::fabs(A[11]);
+        if (sum == 0.0) return true;
+        const double tresh = (iter < 3) ? 0.2 * sum / 16. : 0.0;
+        for (int i = 0; i < 3; i++) {
+            double* pAij = A + 5 * i + 1;
+            for (int j = i + 1; j < 4; j++) {
+                const double Aij = *pAij;
+                const double eps_machine = 100.0 * std::fabs(Aij);
+                if (iter > 3 && std::fabs(D[i]) + eps_machine == std::fabs(D[i]) && std::fabs(D[j]) + eps_machine == std::fabs(D[j])) {
+                    *pAij = 0.0;
+                } else if (std::fabs(Aij) > tresh) {
+                    double hh = D[j] - D[i], t;
+                    if (std::fabs(hh) + eps_machine == std::fabs(hh)) t = Aij / hh;
+                    else {
+                        const double theta = 0.5 * hh / Aij;
+                        t = 1.0 / (std::fabs(theta) + std::sqrt(1.0 + theta * theta));
+                        if (theta < 0.0) t = -t;
+                    }
+                    hh = t * Aij;
+                    Z[i] -= hh;
+                    Z[j] += hh;
+                    D[i] -= hh;
+                    D[j] += hh;
+                    *pAij = 0.0;
+                    const double c = 1.0 / std::sqrt(1 + t * t);
+                    const double s = t * c;
+                    const double tau = s / (1.0 + c);
+                    for (int k = 0; k <= i - 1; k++) {
+                        const double g = A[k * 4 + i], h = A[k * 4 + j];
+                        A[k * 4 + i] = g - s * (h + g * tau);
+                        A[k * 4 + j] = h + s * (g - h * tau);
+                    }
+                    for (int k = i + 1; k <= j - 1; k++) {
+                        const double g = A[i * 4 + k], h = A[k * 4 + j];
+                        A[i * 4 + k] = g - s * (h + g * tau);
+                        A[k * 4 + j] = h + s * (g - h * tau);
+                    }
+                    for (int k = j + 1; k < 4; k++) {
+                        const double g = A[i * 4 + k], h = A[j * 4 + k];
+                        A[i * 4 + k] = g - s * (h + g * tau);
+                        A[j * 4 + k] = h + s * (g - h * tau);
+                    }
+                    for (int k = 0; k < 4; k++) {
+                        const double g = U[k * 4 + i], h = U[k * 4 + j];
+                        U[k * 4 + i] = g - s * (h + g * tau);
+                        U[k * 4 + j] = h + s * (g - h * tau);
+                    }
+                }
+                pAij++;
+            }
+        }
+        for (int i = 0; i < 4; i++) B[i] += Z[i];
+        std::memcpy(D, B, sizeof B);
+        std::memset(Z, 0, sizeof Z);
+    }
+    return false;
+}
+
+bool p3p_align(double M_end[3][3], const double* P0, const double* P1, const double* P2, double R[3][3], double T[3]) {
+    double C_start[3], C_end[3];
+    for (int i = 0; i < 3; i++) C_end[i] = (M_end[0][i] + M_end[1][i] + M_end[2][i]) / 3;
+    C_start[0] = (P0[0] + P1[0] + P2[0]) / 3;
+    C_start[1] = (P0[1] + P1[1] + P2[1]) / 3;
+    C_start[2] = (P0[2] + P1[2] + P2[2]) / 3;
+    double s[9];
+    for (int j = 0; j < 3; j++) {
+        s[0 * 3 + j] = (P0[0] * M_end[0][j] + P1[0] * M_end[1][j] + P2[0] * M_end[2][j]) / 3 - C_end[j] * C_start[0];
+        s[1 * 3 + j] = (P0[1] * M_end[0][j] + P1[1] * M_end[1][j] + P2[1] * M_end[2][j]) / 3 - C_end[j] * C_start[1];
+        s[2 * 3 + j] = (P0[2] * M_end[0][j] + P1[2] * M_end[1][j] + P2[2] * M_end[2][j]) / 3 - C_end[j] * C_start[2];
+    }
+    double Qs[16], evs[4], U[16];
+    Qs[0 * 4 + 0] = s[0 * 3 + 0] + s[1 * 3 + 1] + s[2 * 3 + 2];
+    Qs[1 * 4 + 1] = s[0 * 3 + 0] - s[1 * 3 + 1] - s[2 * 3 + 2];
+    Qs[2 * 4 + 2] = s[1 * 3 + 1] - s[2 * 3 + 2] - s[0 * 3 + 0];
+    Qs[3 * 4 + 3] = s[2 * 3 + 2] - s[0 * 3 + 0] - s[1 * 3 + 1];
+    Qs[1 * 4 + 0] = Qs[0 * 4 + 1] = s[1 * 3 + 2] - s[2 * 3 + 1];
+    Qs[2 * 4 + 0] = Qs[0 * 4 + 2] = s[2 * 3 + 0] - s[0 * 3 + 2];
+    Qs[3 * 4 + 0] = Qs[0 * 4 + 3] = s[0 * 3 + 1] - s[1 * 3 + 0];
+    Qs[2 * 4 + 1] = Qs[1 * 4 + 2] = s[1 * 3 + 0] + s[0 * 3 + 1];
+    Qs[3 * 4 + 1] = Qs[1 * 4 + 3] = s[2 * 3 + 0] + s[0 * 3 + 2];
+    Qs[3 * 4 + 2] = Qs[2 * 4 + 3] = s[2 * 3 + 1] + s[1 * 3 + 2];
+    jacobi_4x4(Qs, evs, U);
+    int i_ev = 0;
+    double ev_max = evs[i_ev];
+    for (int i = 1; i < 4; i++)
+        if (evs[i] > ev_max) ev_max = evs[i_ev = i];
+    double q[4];
+    for (int i = 0; i < 4; i++) q[i] = U[i * 4 + i_ev];
+    const double q02 = q[0] * q[0], q12 = q[1] * q[1], q22 = q[2] * q[2], q32 = q[3] * q[3];
+    const double q0_1 = q[0] * q[1], q0_2 = q[0] * q[2], q0_3 = q[0] * q[3];
+    const double q1_2 = q[1] * q[2], q1_3 = q[1] * q[3];
+    const double q2_3 = q[2] * q[3];
+    R[0][0] = q02 + q12 - q22 - q32;
+    R[0][1] = 2. * (q1_2 - q0_3);
+    R[0][2] = 2. * (q1_3 + q0_2);
+    R[1][0] = 2. * (q1_2 + q0_3);
+    R[1][1] = q02 + q22 - q12 - q32;
+    R[1][2] = 2. * (q2_3 - q0_1);
+    R[2][0] = 2. * (q1_3 - q0_2);
+    R[2][1] = 2. * (q2_3 + q0_1);
+    R[2][2] = q02 + q32 - q12 - q22;
+    for (int i = 0; i < 3; i++) T[i] = C_end[i] - (R[i][0] * C_start[0] + R[i][1] * C_start[1] + R[i][2] * C_start[2]);
+    return true;
+}
+
+int p3p_solve_for_lengths(double lengths[4][3], const double distances[3], const double cosines[3]) {
+    const double p = cosines[0] * 2, q = cosines[1] * 2, r = cosines[2] * 2;
+    const double inv_d22 = 1. / (distances[2] * distances[2]);
+    const double a = inv_d22 * (distances[0] * distances[0]);
+    const double b = inv_d22 * (distances[1] * distances[1]);
+    const double a2 = a * a, b2 = b * b, p2 = p * p, q2 = q * q, r2 = r * r;
+    const double pr = p * r, pqr = q * pr;
+    if (p2 + q2 + r2 - pqr - 1 == 0) return 0;   // reality condition (the four points are coplanar with the centre)
+    const double ab = a * b, a_2 = 2 * a;
+    const double A = -2 * b + b2 + a2 + 1 + ab * (2 - r2) - a_2;
+    if (A == 0) return 0;
+    const double a_4 = 4 * a;
+    const double B = q * (-2 * (ab + a2 + 1 - b) + r2 * ab + a_4) + pr * (b - b2 + ab);
+    const double C = q2 + b2 * (r2 + p2 - 2) - b * (p2 + pqr) - ab * (r2 + pqr) + (a2 - a_2) * (2 + q2) + 2;
+    const double D = pr * (ab - b2 + b) + q * ((p2 - 2) * b + 2 * (ab - a2) + a_4 - 2);
+    const double E = 1 + 2 * (b - a - ab) + b2 - b * p2 + a2;
+    const double temp = (p2 * (a - 1 + b) + r2 * (a - 1 - b) + pqr - a * pqr);
+    const double b0 = b * temp * temp;
+    if (b0 == 0) return 0;
+    double real_roots[4];
+    const int n = solve_deg4(A, B, C, D, E, real_roots[0], real_roots[1], real_roots[2], real_roots[3]);
+    if (n == 0) return 0;
+    int nb_solutions = 0;
+    const double r3 = r2 * r, pr2 = p * r2, r3q = r3 * q;
+    const double inv_b0 = 1. / b0;
+    for (int i = 0; i < n; i++) {
+        const double x = real_roots[i];
+        if (x <= 0) continue;
+        const double x2 = x * x;
+        const double b1 =
+            ((1 - a - b) * x2 + (q * a - q) * x + 1 - a + b) *
+            (((r3 * (a2 + ab * (2 - r2) - a_2 + b2 - 2 * b + 1)) * x +
+              (r3q * (2 * (b - a2) + a_4 + ab * (r2 - 2) - 2) + pr2 * (1 + a2 + 2 * (ab - a - b) + r2 * (b - b2) + b2))) * x2 +
+             (r3 * (q2 * (1 - 2 * a + a2) + r2 * (b2 - ab) - a_4 + 2 * (a2 - b2) + 2) + r * p2 * (b2 + 2 * (ab - b - a) + 1 + a2) +
+              pr2 * q * (a_4 + 2 * (b - ab - a2) - 2 - r2 * b)) * x +
+             2 * r3q * (a_2 - b - a2 + ab - 1) + pr2 * (q2 - a_4 + 2 * (a2 - b2) + r2 * b + q2 * (a2 - a_2) + 2) +
+             p2 * (p * (2 * (ab - a - b) + a2 + b2 + 1) + 2 * q * r * (b + a_2 - a2 - ab - 1)));
+        if (b1 <= 0) continue;
+        const double y = inv_b0 * b1;
+        const double v = x2 + y * y - x * y * r;
+        if (v <= 0) continue;
+        const double Z = distances[2] / std::sqrt(v);
+        lengths[nb_solutions][0] = x * Z;
+        lengths[nb_solutions][1] = y * Z;
+        lengths[nb_solutions][2] = Z;
+        nb_solutions++;
+    }
+    return nb_solutions;
+}
+
+// p3p::solve for four correspondences (pixel coordinates mu/mv, object X/Y/Z): up to four poses from the first three points,
+// sorted by the squared normalised reprojection error of the fourth. Returns the number of poses.
+int p3p_solve(const Camera& cam, const double* mu_in, const double* mv_in, const double P[4][3], double R[4][3][3], double t[4][3]) {
+    const double inv_fx = 1. / cam.fu, inv_fy = 1. / cam.fv, cx_fx = cam.uc / cam.fu, cy_fy = cam.vc / cam.fv;
+    double mu[4], mv[4], mk[3];
+    for (int i = 0; i < 3; i++) {
+        mu[i] = inv_fx * mu_in[i] - cx_fx;
+        mv[i] = inv_fy * mv_in[i] - cy_fy;
+        const double norm = std::sqrt(mu[i] * mu[i] + mv[i] * mv[i] + 1);
+        mk[i] = 1. / norm;
+        mu[i] *= mk[i];
+        mv[i] *= mk[i];
+    }
+    mu[3] = inv_fx * mu_in[3] - cx_fx;
+    mv[3] = inv_fy * mv_in[3] - cy_fy;
+    double distances[3];
+    distances[0] = std::sqrt((P[1][0] - P[2][0]) * (P[1][0] - P[2][0]) + (P[1][1] - P[2][1]) * (P[1][1] - P[2][1]) + (P[1][2] - P[2][2]) * (P[1][2] - P[2][2]));
+    distances[1] = std::sqrt((P[0][0] - P[2][0]) * (P[0][0] - P[2][0]) + (P[0][1] - P[2][1]) * (P[0][1] - P[2][1]) + (P[0][2] - P[2][2]) * (P[0][2] - P[2][2]));
+    distances[2] = std::sqrt((P[0][0] - P[1][0]) * (P[0][0] - P[1][0]) + (P[0][1] - P[1][1]) * (P[0][1] - P[1][1]) + (P[0][2] - P[1][2]) * (P[0][2] - P[1][2]));
+    double cosines[3];
+    cosines[0] = mu[1] * mu[2] + mv[1] * mv[2] + mk[1] * mk[2];
+    cosines[1] = mu[0] * mu[2] + mv[0] * mv[2] + mk[0] * mk[2];
+    cosines[2] = mu[0] * mu[1] + mv[0] * mv[1] + mk[0] * mk[1];
+    double lengths[4][3] = {};
+    const int n = p3p_solve_for_lengths(lengths, distances, cosines);
+    int nb = 0;
+    double reproj_errors[4];
+    for (int i = 0; i < n; i++) {
+        double M_orig[3][3];
+        for (int j = 0; j < 3; j++) {
+            M_orig[j][0] = lengths[i][j] * mu[j];
+            M_orig[j][1] = lengths[i][j] * mv[j];
+            M_orig[j][2] = lengths[i][j] * mk[j];
+        }
+        if (!p3p_align(M_orig, P[0], P[1], P[2], R[nb], t[nb])) continue;
+        const double X3p = R[nb][0][0] * P[3][0] + R[nb][0][1] * P[3][1] + R[nb][0][2] * P[3][2] + t[nb][0];
+        const double Y3p = R[nb][1][0] * P[3][0] + R[nb][1][1] * P[3][1] + R[nb][1][2] * P[3][2] + t[nb][1];
+        const double Z3p = R[nb][2][0] * P[3][0] + R[nb][2][1] * P[3][1] + R[nb][2][2] * P[3][2] + t[nb][2];
+        const double mu3p = X3p / Z3p, mv3p = Y3p / Z3p;
+        reproj_errors[nb] = (mu3p - mu[3]) * (mu3p - mu[3]) + (mv3p - mv[3]) * (mv3p - mv[3]);
+        nb++;
+    }
+    for (int i = 1; i < nb; i++)
+        for (int j = i; j > 0 && reproj_errors[j - 1] > reproj_errors[j]; j--) {
+            std::swap(reproj_errors[j], reproj_errors[j - 1]);
+            for (int k = 0; k < 9; k++) std::swap((&R[j][0][0])[k], (&R[j - 1][0][0])[k]);
+            for (int k = 0; k < 3; k++) std::swap(t[j][k], t[j - 1][k]);
+        }
+    return nb;
+}
+
+// solvePnP(4 points, SOLVEPNP_P3P): undistortPoints(k = 0, P = cameraMatrix) -> pixel coordinates (stored as T) -> best pose
+template <typename T>
+bool solve_pnp_p3p(const T* obj, const T* img, const double* K, double* rvec, double* tvec) {
+    const Camera cam{K[0], K[4], K[2], K[5]};
+    const double ifx = 1. / K[0], ify = 1. / K[4];
+    double mu[4], mv[4], P[4][3];
+    for (int i = 0; i < 4; i++) {
+        const double xn = ((double)img[2 * i] - K[2]) * ifx, yn = ((double)img[2 * i + 1] - K[5]) * ify;
+        mu[i] = (T)(K[0] * xn + K[2]);
+        mv[i] = (T)(K[4] * yn + K[5]);
+        for (int c = 0; c < 3; c++) P[i][c] = obj[3 * i + c];
+    }
+    double R[4][3][3], t[4][3];
+    if (p3p_solve(cam, mu, mv, P, R, t) <= 0) return false;
+    rodrigues_to_vector(&R[0][0][0], rvec);
+    for (int i = 0; i < 3; i++) tvec[i] = t[0][i];
+    return true;
+}
+
 int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     p = std::max(p, 0.);
     p = std::min(p, 1.);
@@ -739,8 +1104,7 @@ int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : (int)lrint(num / denom);
 }
 
-bool next_subset(int count, int* idx, RNG& rng) {   // getSubset with the default checkSubset (always true)
-    const int modelPoints = 5;
+bool next_subset(int count, int* idx, RNG& rng, int modelPoints = 5) {   // getSubset with the default checkSubset (always true)
     for (int i = 0; i < modelPoints; ++i) {
         int idx_i;
         for (idx_i = rng.uniform(0, count); std::find(idx, idx + i, idx_i) != idx + i; idx_i = rng.uniform(0, count)) {
@@ -789,22 +1153,47 @@ int oracle_pnp_hypothesis(const double* obj_xyz, const double* img_xy, const int
     return 1;
 }
 
+int oracle_pnp_p3p_hypothesis(const double* obj_xyz, const double* img_xy, const int32_t* idx4, const double* K, double* rvec, double* tvec) {
+    float o[12], m[8];
+    for (int j = 0; j < 4; j++) {
+        for (int c = 0; c < 3; c++) o[3 * j + c] = (float)obj_xyz[3 * idx4[j] + c];
+        for (int c = 0; c < 2; c++) m[2 * j + c] = (float)img_xy[2 * idx4[j] + c];
+    }
+    return solve_pnp_p3p<float>(o, m, K, rvec, tvec) ? 1 : 0;
+}
+
+int oracle_pnp_ransac_samples4(int n, int iters, int32_t* idx4) {
+    RNG rng((uint64_t)-1);
+    for (int it = 0; it < iters; it++) {
+        int idx[4];
+        next_subset(n, idx, rng, 4);
+        for (int j = 0; j < 4; j++) idx4[it * 4 + j] = idx[j];
+    }
+    return iters;
+}
+
 int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, const double* K, int iterations, float reproj_thr,
                             double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers) {
     *n_inliers = 0;
     if (n < 4 || !obj_xyz || !img_xy || !K) return -215;          // CV_Assert(npoints >= 4 && ...)
-    if (method != 1 /* SOLVEPNP_EPNP */ || n == 4) return -213;    // P3P / AP3P kernels (and the n == 4 shortcut through P3P): not restated
+    if (method != 1 /* SOLVEPNP_EPNP */ && method != 2 /* SOLVEPNP_P3P */) return -213;   // AP3P, ITERATIVE, ...: not restated
+    // kernel choice of solvePnPRansac: P3P on 4 points when asked for, or when there are only 4 points; EPnP on 5 otherwise
+    const bool p3p = method == 2 || n == 4;
+    const int modelPoints = p3p ? 4 : 5;
     // Point3d / Point2d -> CV_32F (solvePnPRansac converts CV_64F inputs to float)
     std::vector<float> op(3 * (size_t)n), ip(2 * (size_t)n);
     for (size_t i = 0; i < op.size(); i++) op[i] = (float)obj_xyz[i];
     for (size_t i = 0; i < ip.size(); i++) ip[i] = (float)img_xy[i];
-    const int modelPoints = 5;
     std::vector<uint8_t> mask(n), bestMask(n);
     std::vector<float> err(n);
     double best_r[3] = {0, 0, 0}, best_t[3] = {0, 0, 0};
     int maxGoodCount = 0;
-    if (n == modelPoints) {
-        solve_pnp_epnp<float>(op.data(), ip.data(), n, K, rvec, tvec);
+    if (n == modelPoints) {   // one direct solve, every point an inlier
+        if (p3p) {
+            if (!solve_pnp_p3p<float>(op.data(), ip.data(), K, rvec, tvec)) return 0;
+        } else {
+            solve_pnp_epnp<float>(op.data(), ip.data(), n, K, rvec, tvec);
+        }
         for (int i = 0; i < n; i++) inliers[i] = i;
         *n_inliers = n;
         return 1;
@@ -814,14 +1203,18 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
     const float t = (float)((double)reproj_thr * (double)reproj_thr);
     for (int iter = 0; iter < niters; iter++) {
         int idx[5];
-        next_subset(n, idx, rng);
+        next_subset(n, idx, rng, modelPoints);
         float o[15], m[10];
-        for (int j = 0; j < 5; j++) {
+        for (int j = 0; j < modelPoints; j++) {
             std::memcpy(&o[3 * j], &op[3 * (size_t)idx[j]], 12);
             std::memcpy(&m[2 * j], &ip[2 * (size_t)idx[j]], 8);
         }
         double r[3], tv[3];
-        solve_pnp_epnp<float>(o, m, 5, K, r, tv);
+        if (p3p) {
+            if (!solve_pnp_p3p<float>(o, m, K, r, tv)) continue;   // runKernel returned 0 models
+        } else {
+            solve_pnp_epnp<float>(o, m, 5, K, r, tv);
+        }
         pnp_errors(op.data(), ip.data(), n, K, r, tv, err.data());
         int goodCount = 0;
         for (int i = 0; i < n; i++) {
@@ -838,7 +1231,7 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
         }
     }
     if (maxGoodCount <= 0) return 0;
-    // final EPnP over the inliers, as doubles converted back from the float copies
+    // final pose: EPnP over the inliers (also when the RANSAC kernel was P3P), as doubles converted back from the float copies
     std::vector<double> oi, ii;
     int cnt = 0;
     for (int i = 0; i < n; i++)

@@ -186,13 +186,27 @@ def test_pnp_fewer_than_4_points_is_an_error_kat(oracle_mod):
     assert rc == -215 and len(inl) == 0
 
 
+def test_p3p_exact_on_noise_free_points(oracle_mod, pkg):
+    # every admissible 4-point sample of exact projections gives the planted pose (to the float rounding of the inputs)
+    obj, img, K, rvec, tvec, _ = pkg.synth.make_pnp_set(500, seed=77, inlier_frac=1.1, noise=0.0)
+    idx = oracle_mod.pnp_ransac_samples4(len(obj), 200)
+    errs = []
+    for i in range(len(idx)):
+        found, r, t = oracle_mod.pnp_p3p_hypothesis(obj, img, idx[i], K)
+        if found:
+            errs.append(max(np.abs(r - rvec).max(), np.abs(t - tvec).max() / 100))
+    assert len(errs) > 190 and np.median(errs) < 1e-4
+
+
 def test_pnp_ignored_reference_case_finds_a_pose(oracle_mod):
-    # mod.rs:640-682 (#[ignore]d upstream, P3P requested there; EPnP here): 5 correspondences, no assertion on values upstream.
+    # mod.rs:640-682 (#[ignore]d upstream): 5 correspondences, SOLVEPNP_P3P requested, no assertion on values upstream.
     obj = np.array([[0, 5, 1], [5, 0, 0], [5, 5, 1.5], [0, 0, 1], [2, 8, -2]], np.float64)
     img = np.array([[-1.48, 0.39], [2.14, -1.92], [1.74, 0.56], [-2, -1.62], [-0.16, 0.3]], np.float64)
     K = np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1]])
     rc, rvec, tvec, inl = oracle_mod.solve_pnp_ransac(obj, img, K, 10000, 100.0, 0.5)
     assert rc == 1 and list(inl) == [0, 1, 2, 3, 4] and np.isfinite(rvec).all() and np.isfinite(tvec).all()
+    rc, rvec, tvec, inl = oracle_mod.solve_pnp_ransac(obj, img, K, 10000, 100.0, 0.5, method=2)      # as upstream asks for it
+    assert rc in (0, 1) and (rc == 0 or (len(inl) >= 4 and np.isfinite(rvec).all()))
 
 
 def test_pnp_fixed_elementary_functions(oracle_mod):
@@ -228,9 +242,16 @@ def test_pnp_ransac_recovers_planted_pose(oracle_mod, pkg):
     assert (got & inl).sum() > 0.97 * inl.sum()            # nearly every true inlier (0.5 px noise, 3 px gate)
     assert (got & ~inl).sum() <= 0.002 * len(obj) + 2      # chance hits of uniformly random outliers only
     assert np.allclose(r, rvec, atol=2e-3) and np.allclose(t, tvec, rtol=2e-3, atol=0.5)
-    # n == 4 and the P3P family are not restated
-    assert oracle_mod.solve_pnp_ransac(obj[:4], img[:4], K)[0] == -213
-    assert oracle_mod.solve_pnp_ransac(obj, img, K, method=2)[0] == -213
+    # SOLVEPNP_P3P: the RANSAC kernel is Gao's P3P on 4 points, the final pose EPnP over the inliers
+    rc3, r3, t3, idx3 = oracle_mod.solve_pnp_ransac(obj, img, K, 1000, 3.0, 0.99, method=2)
+    got3 = np.zeros(len(obj), bool)
+    got3[idx3] = True
+    assert rc3 == 1 and (got3 & inl).sum() > 0.97 * inl.sum() and (got3 & ~inl).sum() <= 0.002 * len(obj) + 2
+    assert np.allclose(r3, rvec, atol=2e-3) and np.allclose(t3, tvec, rtol=2e-3, atol=0.5)
+    # n == 4 goes through P3P directly (all four are inliers); AP3P / ITERATIVE are not restated
+    rc4, r4, t4, idx4 = oracle_mod.solve_pnp_ransac(obj[inl][:4], img[inl][:4], K)
+    assert rc4 == 1 and list(idx4) == [0, 1, 2, 3] and np.isfinite(r4).all()
+    assert oracle_mod.solve_pnp_ransac(obj, img, K, method=5)[0] == -213 and oracle_mod.solve_pnp_ransac(obj, img, K, method=0)[0] == -213
     # all outliers: no model gathers more than the 4 points that define it ... or only by chance; the call must not fail
     rc2, _, _, idx2 = oracle_mod.solve_pnp_ransac(obj[~inl][:200], img[~inl][:200], K, 200, 1.0, 0.99)
     assert rc2 in (0, 1) and (rc2 == 0) == (len(idx2) == 0)

@@ -12,7 +12,8 @@ def _hyp(pkg, obj, img, K, idx):
     idx = np.ascontiguousarray(idx, np.int32)
     out = np.zeros((len(idx), 6))
     K = np.ascontiguousarray(K, np.float64)
-    rc = pkg.lib().apds_pnp_hypotheses(pkg._lib.ptr(obj), pkg._lib.ptr(img), len(obj), pkg._lib.ptr(K), pkg._lib.ptr(idx), len(idx), pkg._lib.ptr(out))
+    rc = pkg.lib().apds_pnp_hypotheses(pkg._lib.ptr(obj), pkg._lib.ptr(img), len(obj), pkg._lib.ptr(K), pkg._lib.ptr(idx), len(idx), idx.shape[1],
+                                       pkg._lib.ptr(out))
     assert rc == 0, pkg.lib().apds_last_error()
     return out
 
@@ -56,16 +57,49 @@ def test_ransac_matches_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, thr, 
     assert np.allclose(r, rvec, atol=3e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.0)
 
 
-def test_unbuilt_methods_and_no_solution(gpu_pkg, oracle_mod):
+def test_p3p_hypotheses_bit_identical_to_oracle(gpu_pkg, oracle_mod):
+    obj, img, K, _, _, _ = gpu_pkg.synth.make_pnp_set(2000, inlier_frac=0.6, noise=0.5)
+    idx = oracle_mod.pnp_ransac_samples4(len(obj), 400)
+    got = _hyp(gpu_pkg, obj, img, K, idx)
+    n_found = 0
+    for b in range(len(idx)):
+        found, r, t = oracle_mod.pnp_p3p_hypothesis(obj, img, idx[b], K)
+        if found:
+            n_found += 1
+            assert np.array_equal(got[b], np.concatenate([r, t]), equal_nan=True), (b, got[b], r, t)
+        else:
+            assert np.isnan(got[b]).all()
+    assert n_found > 300
+
+
+@pytest.mark.parametrize("n,frac,noise,iters,thr,conf", [(2000, 0.6, 0.5, 1000, 3.0, 0.99), (50000, 0.4, 0.5, 2000, 2.0, 0.995),
+                                                        (300, 0.9, 0.2, 100, 8.0, 0.99), (5, 1.1, 0.0, 50, 2.0, 0.99)])
+def test_p3p_ransac_matches_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, thr, conf):
+    hg = gpu_pkg.homographier
+    obj, img, K, rvec, tvec, inl = gpu_pkg.synth.make_pnp_set(n, seed=17 + n, inlier_frac=frac, noise=noise)
+    sol = _solve(gpu_pkg, obj, img, K, iters, thr, conf, hg.SolvePnPMethod.SOLVEPNP_P3P)
+    rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, iters, thr, conf, method=2)
+    assert (sol is not None) == (rc == 1) and rc == 1
+    assert np.array_equal(sol.inliers.mat.ravel(), idx)
+    assert np.array_equal(sol.rvec.mat.ravel(), r) and np.array_equal(sol.tvec.mat.ravel(), t)
+    assert np.allclose(r, rvec, atol=3e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.0)
+
+
+def test_four_points_and_unbuilt_methods(gpu_pkg, oracle_mod):
     hg = gpu_pkg.homographier
     obj, img, K, _, _, inl = gpu_pkg.synth.make_pnp_set(400, inlier_frac=0.5, noise=0.5)
-    for method in (hg.SolvePnPMethod.SOLVEPNP_P3P, hg.SolvePnPMethod.SOLVEPNP_AP3P, hg.SolvePnPMethod.SOLVEPNP_ITERATIVE):
+    for method in (hg.SolvePnPMethod.SOLVEPNP_AP3P, hg.SolvePnPMethod.SOLVEPNP_ITERATIVE):
         with pytest.raises(hg.MatError) as e:
             _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, method)
         assert e.value.inner.code == -213
-    with pytest.raises(hg.MatError) as e:
-        _solve(gpu_pkg, obj[:4], img[:4], K, 100, 3.0, 0.99)
-    assert e.value.inner.code == -213
+    # exactly four correspondences: one direct P3P solve, whatever the method (OpenCV switches kernels)
+    o4, i4 = obj[inl][:4], img[inl][:4]
+    for method in (None, hg.SolvePnPMethod.SOLVEPNP_P3P):
+        sol = _solve(gpu_pkg, o4, i4, K, 100, 3.0, 0.99, method)
+        rc, r, t, idx = oracle_mod.solve_pnp_ransac(o4, i4, K, 100, 3.0, 0.99, method=2 if method else 1)
+        assert (sol is not None) == (rc == 1)
+        if sol is not None:
+            assert list(sol.inliers.mat.ravel()) == [0, 1, 2, 3] and np.array_equal(sol.rvec.mat.ravel(), r) and np.array_equal(sol.tvec.mat.ravel(), t)
     # outliers only: same outcome (usually Ok(None)) as the oracle
     o, i = obj[~inl][:150], img[~inl][:150]
     sol = _solve(gpu_pkg, o, i, K, 150, 0.5, 0.99)

@@ -33,3 +33,13 @@ for n, frac, iters, conf in ((50000, 0.4, 4096, 0.9999999), (50000, 0.4, 2000, 0
     to = time.perf_counter() - t0
     print(f"n={n} iters={iters} conf={conf}: hip {tg*1e3:.2f} ms  oracle {to*1e3:.2f} ms  inliers {ni.value}/{len(idx)} equal={np.array_equal(inliers[:ni.value], idx)} "
           f"pose_equal={np.array_equal(rv, r) and np.array_equal(tv, t)}")
+    t0 = time.perf_counter()
+    for _ in range(3):
+        rc = pkg.lib().apds_pnp_solver_ransac(pkg._lib.ptr(o), pkg._lib.ptr(i2), n, pkg._lib.ptr(K), iters, 3.0, conf, 2, pkg._lib.ptr(rv), pkg._lib.ptr(tv),
+                                              pkg._lib.ptr(inliers), C.byref(ni), C.byref(found))
+    tg = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    rc2, r, t, idx = oracle.solve_pnp_ransac(obj, img, K, iters, 3.0, conf, method=2)
+    to = time.perf_counter() - t0
+    print(f"   P3P kernel: hip {tg*1e3:.2f} ms  oracle {to*1e3:.2f} ms  inliers {ni.value}/{len(idx)} equal={np.array_equal(inliers[:ni.value], idx)} "
+          f"pose_equal={np.array_equal(rv, r) and np.array_equal(tv, t)}")
