@@ -246,6 +246,273 @@ __global__ __launch_bounds__(HYP_THREADS) void hypothesis_kernel(const P2* __res
 }
 static constexpr size_t HYP_LDS_BYTES = (size_t)171 * HYP_THREADS * sizeof(double) + (size_t)18 * HYP_THREADS * sizeof(int);
 
+// Cooperative form of the same computation: 16 lanes per 4-point sample (four samples per wave). The matrices stay in LDS, but
+// the work inside one Jacobi rotation -- the row/column updates, the eigenvector update, the four pivot-index rescans -- is
+// spread over the lanes, and every lane evaluates the (cheap, uniform) pivot scan and rotation parameters itself. Each
+// element goes through exactly the operations of jacobi_eigen<9> in the same order, so the result is bit-identical to the
+// one-thread-per-sample kernel above (and to the host refit). What it cannot change is the rotation COUNT: the stopping rule
+// is |pivot| <= DBL_EPSILON in absolute terms, which the rounding noise of a 9x9 system with O(10) entries rarely reaches, so
+// most samples run the full 9*9*30 = 2430 rotations (as they do in OpenCV); a rotation costs ~0.2 us here against ~0.3 us.
+static constexpr int COOP_LANES = 16, COOP_PER_BLOCK = 16;
+
+struct CoopSlot {
+    double A[81], V[81], W[9];
+    int indR[9], indC[9];
+    int pad[2];
+};
+
+__device__ __forceinline__ double coop_l_entry(int row, int j, double x, double y, double X, double Y) {
+    // row 0: Lx = {X, Y, 1, 0, 0, 0, -x*X, -x*Y, -x}; row 1: Ly = {0, 0, 0, X, Y, 1, -y*X, -y*Y, -y}
+    const double u = row == 0 ? x : y;
+    const int jj = row == 0 ? j : j - 3;
+    if (j >= 6) return j == 6 ? -u * X : (j == 7 ? -u * Y : -u);
+    if (jj < 0 || jj > 2) return 0.0;
+    return jj == 0 ? X : (jj == 1 ? Y : 1.0);
+}
+
+__global__ __launch_bounds__(COOP_LANES* COOP_PER_BLOCK) void hypothesis_coop_kernel(const P2* __restrict__ M, const P2* __restrict__ m,
+                                                                                    const int* __restrict__ idx4, int B, double* __restrict__ models,
+                                                                                    uint8_t* __restrict__ valid) {
+    APDS_RAISE_WAVE_PRIORITY();
+    __shared__ CoopSlot s_slot[COOP_PER_BLOCK];
+    const int g = threadIdx.x / COOP_LANES, li = threadIdx.x % COOP_LANES;
+    const int h = blockIdx.x * COOP_PER_BLOCK + g;
+    const bool live = h < B;
+    volatile double* A = s_slot[g].A;
+    volatile double* V = s_slot[g].V;
+    volatile double* W = s_slot[g].W;
+    volatile int* indR = s_slot[g].indR;
+    volatile int* indC = s_slot[g].indC;
+    constexpr int N = 9;
+    const double eps = 2.2204460492503131e-16;
+    // every lane of the group reads the four correspondences and normalises them (uniform work, identical results)
+    P2 ms1[4], ms2[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int id = live ? idx4[h * 4 + j] : 0;
+        ms1[j] = M[id];
+        ms2[j] = m[id];
+    }
+    double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        cmx += ms2[i].x; cmy += ms2[i].y;
+        cMx += ms1[i].x; cMy += ms1[i].y;
+    }
+    cmx /= 4; cmy /= 4; cMx /= 4; cMy /= 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        smx += fabs(ms2[i].x - cmx); smy += fabs(ms2[i].y - cmy);
+        sMx += fabs(ms1[i].x - cMx); sMy += fabs(ms1[i].y - cMy);
+    }
+    const bool ok = live && !(fabs(smx) < eps || fabs(smy) < eps || fabs(sMx) < eps || fabs(sMy) < eps);
+    smx = 4 / smx; smy = 4 / smy;
+    sMx = 4 / sMx; sMy = 4 / sMy;
+    // normal equations: 45 upper-triangle entries over 16 lanes, each summed over the points in order
+    for (int e = li; e < 45; e += COOP_LANES) {
+        int j = 0, rem = e;
+        while (rem >= N - j) {
+            rem -= N - j;
+            j++;
+        }
+        const int k = j + rem;
+        double acc = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const double x = (ms2[i].x - cmx) * smx, y = (ms2[i].y - cmy) * smy;
+            const double X = (ms1[i].x - cMx) * sMx, Y = (ms1[i].y - cMy) * sMy;
+            acc += coop_l_entry(0, j, x, y, X, Y) * coop_l_entry(0, k, x, y, X, Y) + coop_l_entry(1, j, x, y, X, Y) * coop_l_entry(1, k, x, y, X, Y);
+        }
+        A[j * N + k] = acc;
+        A[k * N + j] = acc;
+    }
+    for (int e = li; e < 81; e += COOP_LANES) V[e] = (e % 10 == 0) ? 1.0 : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    if (li < N) {   // initial eigenvalues and pivot indices, one row / column per lane
+        const int k = li;
+        W[k] = A[(N + 1) * k];
+        if (k < N - 1) {
+            int mi = k + 1;
+            double mv = fabs(A[N * k + mi]);
+            for (int i = k + 2; i < N; i++) {
+                const double val = fabs(A[N * k + i]);
+                if (mv < val) mv = val, mi = i;
+            }
+            indR[k] = mi;
+        }
+        if (k > 0) {
+            int mi = 0;
+            double mv = fabs(A[k]);
+            for (int i = 1; i < k; i++) {
+                const double val = fabs(A[N * i + k]);
+                if (mv < val) mv = val, mi = i;
+            }
+            indC[k] = mi;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    bool done = !ok;
+    for (int iters = 0; iters < N * N * 30; iters++) {
+        if (!__any(!done)) break;   // wave-uniform exit: every group of this wave has converged
+        if (!done) {
+            // pivot: the sequential scan of jacobi_eigen, evaluated by every lane (broadcast LDS reads). All loads of a level
+            // are issued before the first compare, so the scan costs two LDS latencies instead of sixteen.
+            int ir[N - 1], ic[N];
+            double vr[N - 1], vc[N];
+#pragma unroll
+            for (int i = 0; i < N - 1; i++) ir[i] = indR[i];
+#pragma unroll
+            for (int i = 1; i < N; i++) ic[i] = indC[i];
+#pragma unroll
+            for (int i = 0; i < N - 1; i++) vr[i] = A[N * i + ir[i]];
+#pragma unroll
+            for (int i = 1; i < N; i++) vc[i] = A[N * ic[i] + i];
+            int k = 0;
+            double mv = fabs(vr[0]);
+#pragma unroll
+            for (int i = 1; i < N - 1; i++) {
+                const double val = fabs(vr[i]);
+                if (mv < val) mv = val, k = i;
+            }
+            int l = 0;
+#pragma unroll
+            for (int i = 0; i < N - 1; i++)
+                if (i == k) l = ir[i];
+#pragma unroll
+            for (int i = 1; i < N; i++) {
+                const double val = fabs(vc[i]);
+                if (mv < val) mv = val, k = ic[i], l = i;
+            }
+            const double p = A[N * k + l];
+            if (fabs(p) <= eps) {
+                done = true;
+            } else {
+                const double y = (W[l] - W[k]) * 0.5;
+                double t = fabs(y) + hypot_cv(p, y);
+                double sn = hypot_cv(p, t);
+                const double c = t / sn;
+                sn = p / sn;
+                t = (p / t) * p;
+                if (y < 0) sn = -sn, t = -t;
+                __builtin_amdgcn_wave_barrier();   // all lanes have read the pivot data before anything is modified
+                if (li == 0) {
+                    A[N * k + l] = 0;
+                    W[k] = W[k] - t;
+                    W[l] = W[l] + t;
+                }
+                if (li < N) {
+                    const int i = li;
+                    double a0, b0;
+                    if (i < k) {
+                        a0 = A[N * i + k], b0 = A[N * i + l];
+                        A[N * i + k] = a0 * c - b0 * sn;
+                        A[N * i + l] = a0 * sn + b0 * c;
+                    } else if (i > k && i < l) {
+                        a0 = A[N * k + i], b0 = A[N * i + l];
+                        A[N * k + i] = a0 * c - b0 * sn;
+                        A[N * i + l] = a0 * sn + b0 * c;
+                    } else if (i > l) {
+                        a0 = A[N * k + i], b0 = A[N * l + i];
+                        A[N * k + i] = a0 * c - b0 * sn;
+                        A[N * l + i] = a0 * sn + b0 * c;
+                    }
+                    a0 = V[N * k + i], b0 = V[N * l + i];
+                    V[N * k + i] = a0 * c - b0 * sn;
+                    V[N * l + i] = a0 * sn + b0 * c;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (li < 4) {   // lanes 0..3: indR[k], indC[k], indR[l], indC[l]; loads first, then the scan in registers
+                    const int idx = li < 2 ? k : l;
+                    const bool rows = (li & 1) == 0;
+                    double v[N - 1];
+#pragma unroll
+                    for (int q = 0; q < N - 1; q++) {
+                        // row scan: elements (idx, q + 1) with q + 1 > idx; column scan: elements (q, idx) with q < idx
+                        const int e = rows ? N * idx + min(max(q + 1, idx + 1), N - 1) : N * min(q, max(idx - 1, 0)) + idx;
+                        v[q] = A[e];
+                    }
+                    if (rows) {
+                        if (idx < N - 1) {
+                            int mi = idx + 1;
+                            double mv2 = 0;
+                            bool first = true;
+#pragma unroll
+                            for (int q = 0; q < N - 1; q++) {
+                                const int i = q + 1;
+                                if (i > idx) {
+                                    const double val = fabs(v[q]);
+                                    if (first) mv2 = val, mi = i, first = false;
+                                    else if (mv2 < val) mv2 = val, mi = i;
+                                }
+                            }
+                            indR[idx] = mi;
+                        }
+                    } else if (idx > 0) {
+                        int mi = 0;
+                        double mv2 = fabs(v[0]);
+#pragma unroll
+                        for (int q = 1; q < N - 1; q++) {
+                            if (q < idx) {
+                                const double val = fabs(v[q]);
+                                if (mv2 < val) mv2 = val, mi = q;
+                            }
+                        }
+                        indC[idx] = mi;
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // eigenvalues descending: selection sort, the row swaps of V spread over the lanes
+    if (ok) {
+        for (int k = 0; k < N - 1; k++) {
+            int mi = k;
+            for (int i = k + 1; i < N; i++)
+                if (W[mi] < W[i]) mi = i;
+            __builtin_amdgcn_wave_barrier();
+            if (k != mi) {
+                if (li == 0) {
+                    const double tw = W[mi];
+                    W[mi] = W[k];
+                    W[k] = tw;
+                }
+                if (li < N) {
+                    const double tv = V[N * mi + li];
+                    V[N * mi + li] = V[N * k + li];
+                    V[N * k + li] = tv;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (!live) return;
+    double H[9];
+    if (ok) {
+        double H0[9];
+        for (int i = 0; i < 9; i++) H0[i] = V[72 + i];
+        const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+        const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+        double Ht[9], Hd[9];
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++) {
+                double sacc = 0;
+                for (int kk = 0; kk < 3; kk++) sacc += invHnorm[r * 3 + kk] * H0[kk * 3 + cc];
+                Ht[r * 3 + cc] = sacc;
+            }
+        for (int r = 0; r < 3; r++)
+            for (int cc = 0; cc < 3; cc++) {
+                double sacc = 0;
+                for (int kk = 0; kk < 3; kk++) sacc += Ht[r * 3 + kk] * Hnorm2[kk * 3 + cc];
+                Hd[r * 3 + cc] = sacc;
+            }
+        const double sc = 1. / Hd[8];
+        for (int i = 0; i < 9; i++) H[i] = Hd[i] * sc;
+    }
+    if (li == 0) valid[h] = ok ? 1 : 0;
+    if (li < 9) models[(size_t)h * 9 + li] = ok ? H[li] : 0.0;
+}
+
 __device__ __forceinline__ float reproj_err(const float (&Hf)[8], float Mx, float My, float mx, float my) {
     const float ww = 1.f / (Hf[6] * Mx + Hf[7] * My + 1.f);
     const float dx = (Hf[0] * Mx + Hf[1] * My + Hf[2]) * ww - mx;
@@ -462,6 +729,15 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const P2* __restric
 
 // ---- host side ----------------------------------------------------------------------------------------------------
 namespace {
+
+void launch_hypotheses(const P2* M, const P2* m, const int* idx_dev, int B, double* models_dev, uint8_t* valid_dev, hipStream_t s) {
+    static const bool coop = !(getenv("APDS_RANSAC_COOP") && atoi(getenv("APDS_RANSAC_COOP")) == 0);
+    if (coop)
+        hipLaunchKernelGGL(hypothesis_coop_kernel, dim3(ceil_div(B, COOP_PER_BLOCK)), dim3(COOP_LANES * COOP_PER_BLOCK), 0, s, M, m, idx_dev, B, models_dev,
+                           valid_dev);
+    else
+        hipLaunchKernelGGL(hypothesis_kernel, dim3(ceil_div(B, HYP_THREADS)), dim3(HYP_THREADS), HYP_LDS_BYTES, s, M, m, idx_dev, B, models_dev, valid_dev);
+}
 
 struct RNG {
     uint64_t state;
@@ -754,7 +1030,7 @@ int find_homography_device(const float* src, const float* dst, int n, int method
                 if (B > 0) {
                     HIP_CHECK(hipMemcpyAsync(idx_dev, idx.data(), (size_t)B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
                     HIP_CHECK(hipMemsetAsync(good_dev, 0, (size_t)B * sizeof(int), s));
-                    hipLaunchKernelGGL(hypothesis_kernel, dim3(ceil_div(B, HYP_THREADS)), dim3(HYP_THREADS), HYP_LDS_BYTES, s, M, m, (const int*)idx_dev, B, models_dev, valid_dev);
+                    launch_hypotheses(M, m, idx_dev, B, models_dev, valid_dev, s);
                     {
                         KernelTimer timer("ransac_score", s);
                         const int parts = std::max(1, std::min(64, ceil_div(256 * 8, ceil_div(B, HT))));
@@ -798,7 +1074,7 @@ int find_homography_device(const float* src, const float* dst, int n, int method
                 float* err_dev = c.alloc_n<float>((size_t)B * n);
                 float* med_dev = c.alloc_n<float>(B);
                 HIP_CHECK(hipMemcpyAsync(idx_dev, idx.data(), (size_t)B * 4 * sizeof(int), hipMemcpyHostToDevice, s));
-                hipLaunchKernelGGL(hypothesis_kernel, dim3(ceil_div(B, HYP_THREADS)), dim3(HYP_THREADS), HYP_LDS_BYTES, s, M, m, (const int*)idx_dev, B, models_dev, valid_dev);
+                launch_hypotheses(M, m, idx_dev, B, models_dev, valid_dev, s);
                 hipLaunchKernelGGL(errors_kernel, dim3(std::min(64, ceil_div(n, 256)), B), dim3(256), 0, s, M, m, n, (const double*)models_dev, err_dev);
                 hipLaunchKernelGGL(kth_select_kernel, dim3(B), dim3(1024), 0, s, (const float*)err_dev, n, n / 2, med_dev);
                 std::vector<float> med(B);
