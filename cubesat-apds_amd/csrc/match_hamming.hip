@@ -26,10 +26,20 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 static constexpr uint64_t EMPTY_KEY = ~0ull;
 static constexpr int INF_THR = 1 << 20;          // > any Hamming distance of a 512-bit row
 static constexpr uint32_t NO_INDEX = 0xFFFFFFFFu;
-// Per-chunk candidate lists are written as 32-bit keys: distance (<= 512, 10 bits) << 22 | row offset inside the chunk
-// (chunks hold at most 2^22 rows). Same order as the 64-bit (distance << 32 | global row) keys they expand to in the merge.
+// Per-chunk candidate lists. A work item (one wave: 64*T queries x one row chunk) leaves one RECORD: T*K 64-bit presence masks
+// (bit = lane; slot s = t*K + k) followed by the present keys only, slot-major, lanes ascending. After the threshold pre-pass
+// ~5 of 6 slots are empty (the chunk held nothing better than the query's starting threshold), so records are mostly header:
+// the lists cost ~0.8 bytes per slot instead of 4 (and instead of 8 as 64-bit keys). Keys are 32 bits: distance (<= 512,
+// 10 bits) << 22 | row offset inside the chunk (chunks hold at most 2^22 rows); same order as the 64-bit
+// (distance << 32 | global row) keys they expand to in the merge. Records sit at a fixed pitch (capacity for all slots
+// present); untouched bytes cost no traffic.
 static constexpr int PART_ROW_BITS = 22;
-static constexpr uint32_t EMPTY_PART = 0xFFFFFFFFu;
+template <int T, int K>
+struct PartRecord {
+    static constexpr int SLOTS = T * K;
+    static constexpr int HEADER = 2 * SLOTS;             // u32 words of masks
+    static constexpr int PITCH = HEADER + 64 * SLOTS;    // u32 words per record
+};
 
 // acc + popcount(x) in ONE VALU op. hipcc otherwise splits the accumulate into v_bcnt(x,0) + v_add3 (5 ops per
 // two dwords instead of 4), so the accumulate form is spelled out.
@@ -171,15 +181,25 @@ __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ tra
         for (int t = 0; t < T; t++) nthr[t] = -bd[t][K - 1];
     }
 
+    // one record per (chunk, wave tile): presence masks + the present keys, compacted with ballot / popcount prefix sums
+    using Rec = PartRecord<T, K>;
+    const int n_wtiles = (nq + 64 * T - 1) / (64 * T);
+    uint32_t* rec = out + ((size_t)chunk * n_wtiles + (qblock * 4 + wave)) * Rec::PITCH;
+    const uint64_t lt = (1ull << lane) - 1;
+    int base = 0;
 #pragma unroll
     for (int t = 0; t < T; t++) {
         const int qi = qbase + t * 64 + lane;
-        if (qi < nq) {
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                out[((size_t)chunk * nq + qi) * K + k] =
-                    bi[t][k] == NO_INDEX ? EMPTY_PART : ((uint32_t)bd[t][k] << PART_ROW_BITS) | (bi[t][k] - (uint32_t)row0);
+        for (int k = 0; k < K; k++) {
+            const bool present = qi < nq && bi[t][k] != NO_INDEX;
+            const uint64_t m = __ballot(present);
+            if (present) rec[Rec::HEADER + base + __popcll(m & lt)] = ((uint32_t)bd[t][k] << PART_ROW_BITS) | (bi[t][k] - (uint32_t)row0);
+            if (lane == 0) {
+                rec[2 * (t * K + k)] = (uint32_t)m;
+                rec[2 * (t * K + k) + 1] = (uint32_t)(m >> 32);
             }
+            base += __popcll(m);
         }
     }
 }
@@ -273,54 +293,70 @@ __global__ void merge_topk_kernel(const uint64_t* __restrict__ parts_keys, int p
     for (int k = 0; k < K; k++) out[(size_t)qi * K + k] = best[k];
 }
 
-// Same merge over the 32-bit per-chunk lists of hamming_topk_kernel: chunk p's keys expand to (distance << 32 | row offset + p *
-// rows_per_chunk + row_base); `extra` (nq x K 64-bit keys, may be null) is one more already-expanded list (the sample pass).
-template <int K>
-__global__ void merge_parts_kernel(const uint32_t* __restrict__ parts_keys, int parts, int rows_per_chunk, uint32_t row_base,
-                                   const uint64_t* __restrict__ extra, int nq, uint64_t* __restrict__ out) {
+// Merge of the per-chunk records of hamming_topk_kernel: one wave per query tile (lane = the T queries it owned in the match
+// kernel) walks the chunks; a present key expands to (distance << 32 | row offset + p * rows_per_chunk + row_base). `extra`
+// (nq x K 64-bit keys, may be null) is one more already-expanded sorted list (the sample pass).
+template <int T, int K>
+__global__ __launch_bounds__(256) void merge_records_kernel(const uint32_t* __restrict__ recs, int parts, int rows_per_chunk, uint32_t row_base,
+                                                            const uint64_t* __restrict__ extra, int nq, uint64_t* __restrict__ out) {
     APDS_RAISE_WAVE_PRIORITY();
-    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-    if (qi >= nq) return;
-    uint64_t best[K];
+    using Rec = PartRecord<T, K>;
+    const int lane = threadIdx.x & 63;
+    const int n_wtiles = (nq + 64 * T - 1) / (64 * T);
+    const int wtile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wtile >= n_wtiles) return;
+    uint64_t best[T][K];
 #pragma unroll
-    for (int k = 0; k < K; k++) best[k] = extra ? extra[(size_t)qi * K + k] : EMPTY_KEY;   // a sorted list: a valid start
-    auto push = [&](uint32_t part, int p) {
-        if (part == EMPTY_PART) return;
-        const uint64_t key = ((uint64_t)(part >> PART_ROW_BITS) << 32) |
-                             (uint64_t)(uint32_t)((part & ((1u << PART_ROW_BITS) - 1)) + (uint32_t)p * (uint32_t)rows_per_chunk + row_base);
-        if (key < best[K - 1]) {
-            bool placed = false;
+    for (int t = 0; t < T; t++) {
+        const int qi = wtile * 64 * T + t * 64 + lane;
 #pragma unroll
-            for (int j = K - 1; j > 0; j--) {
-                if (!placed) {
-                    if (best[j - 1] > key) best[j] = best[j - 1];
-                    else {
-                        best[j] = key;
-                        placed = true;
+        for (int k = 0; k < K; k++) best[t][k] = (extra && qi < nq) ? extra[(size_t)qi * K + k] : EMPTY_KEY;   // a sorted list: a valid start
+    }
+    const uint64_t lt = (1ull << lane) - 1;
+    for (int p = 0; p < parts; p++) {
+        const uint32_t* rec = recs + ((size_t)p * n_wtiles + wtile) * Rec::PITCH;
+        uint64_t masks[Rec::SLOTS];
+#pragma unroll
+        for (int s = 0; s < Rec::SLOTS; s++) masks[s] = (uint64_t)rec[2 * s] | ((uint64_t)rec[2 * s + 1] << 32);   // wave-uniform
+        uint32_t keys[Rec::SLOTS];
+        int base = 0;
+#pragma unroll
+        for (int s = 0; s < Rec::SLOTS; s++) {   // all loads of the record first, then the insertions
+            const bool present = (masks[s] >> lane) & 1;
+            keys[s] = present ? rec[Rec::HEADER + base + __popcll(masks[s] & lt)] : 0xFFFFFFFFu;
+            base += __popcll(masks[s]);
+        }
+        const uint32_t chunk_base = (uint32_t)p * (uint32_t)rows_per_chunk + row_base;
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const uint32_t part = keys[t * K + k];
+                if (part == 0xFFFFFFFFu) continue;   // distance 1023 cannot occur: "absent"
+                const uint64_t key = ((uint64_t)(part >> PART_ROW_BITS) << 32) | (uint64_t)(uint32_t)((part & ((1u << PART_ROW_BITS) - 1)) + chunk_base);
+                if (key < best[t][K - 1]) {
+                    bool placed = false;
+#pragma unroll
+                    for (int j = K - 1; j > 0; j--) {
+                        if (!placed) {
+                            if (best[t][j - 1] > key) best[t][j] = best[t][j - 1];
+                            else {
+                                best[t][j] = key;
+                                placed = true;
+                            }
+                        }
                     }
+                    if (!placed) best[t][0] = key;
                 }
             }
-            if (!placed) best[0] = key;
-        }
-    };
-    constexpr int U = K <= 2 ? 8 : 2;   // independent loads in flight per lane
-    int p = 0;
-    for (; p + U <= parts; p += U) {
-        uint32_t v[U][K];
-#pragma unroll
-        for (int u = 0; u < U; u++)
-#pragma unroll
-            for (int k = 0; k < K; k++) v[u][k] = parts_keys[((size_t)(p + u) * nq + qi) * K + k];
-#pragma unroll
-        for (int u = 0; u < U; u++)
-#pragma unroll
-            for (int k = 0; k < K; k++) push(v[u][k], p + u);
     }
-    for (; p < parts; p++)
 #pragma unroll
-        for (int k = 0; k < K; k++) push(parts_keys[((size_t)p * nq + qi) * K + k], p);
+    for (int t = 0; t < T; t++) {
+        const int qi = wtile * 64 * T + t * 64 + lane;
+        if (qi < nq)
 #pragma unroll
-    for (int k = 0; k < K; k++) out[(size_t)qi * K + k] = best[k];
+            for (int k = 0; k < K; k++) out[(size_t)qi * K + k] = best[t][k];
+    }
 }
 
 __global__ void take_first_columns_kernel(const uint64_t* __restrict__ in, int nq, int kin, int kout, uint64_t* __restrict__ out) {
@@ -566,9 +602,20 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, cons
 }
 
 template <int K>
-static void merge_parts_launch(const uint32_t* parts, int nparts, int rows_per_chunk, uint32_t row_base, const uint64_t* extra, int nq, uint64_t* out,
-                               hipStream_t s) {
-    hipLaunchKernelGGL((merge_parts_kernel<K>), dim3(ceil_div(nq, 256)), dim3(256), 0, s, parts, nparts, rows_per_chunk, row_base, extra, nq, out);
+static size_t record_words(int nq, const ChunkPlan& p) {   // u32 words of the record buffer of one launch
+    const size_t wtiles = (size_t)ceil_div(nq, 64 * p.T);
+    const size_t pitch = p.T == 4 ? PartRecord<4, K>::PITCH : (p.T == 2 ? PartRecord<2, K>::PITCH : PartRecord<1, K>::PITCH);
+    return (size_t)p.chunks * wtiles * pitch;
+}
+
+template <int K>
+static void merge_records_launch(const uint32_t* recs, const ChunkPlan& p, uint32_t row_base, const uint64_t* extra, int nq, uint64_t* out, hipStream_t s) {
+    const dim3 grid(ceil_div(ceil_div(nq, 64 * p.T), 4)), block(256);
+    switch (p.T) {
+        case 4: hipLaunchKernelGGL((merge_records_kernel<4, K>), grid, block, 0, s, recs, p.chunks, p.rows_per_chunk, row_base, extra, nq, out); break;
+        case 2: hipLaunchKernelGGL((merge_records_kernel<2, K>), grid, block, 0, s, recs, p.chunks, p.rows_per_chunk, row_base, extra, nq, out); break;
+        default: hipLaunchKernelGGL((merge_records_kernel<1, K>), grid, block, 0, s, recs, p.chunks, p.rows_per_chunk, row_base, extra, nq, out); break;
+    }
 }
 
 template <int K>
@@ -590,10 +637,10 @@ static void topk_device_k(const void* q, int nq, const void* t, long long nt, ui
     uint64_t* sample_keys = nullptr;
     if (sample) {
         ChunkPlan sp = plan_chunks(nq, sample, true, K > 2);
-        uint32_t* sparts = c.alloc_n<uint32_t>((size_t)sp.chunks * nq * K);
+        uint32_t* sparts = c.alloc_n<uint32_t>(record_words<K>(nq, sp));
         sample_keys = c.alloc_n<uint64_t>((size_t)nq * K);
         launch_topk<K>(q, nq, t, sample, nullptr, sparts, sp, s, "hamming_topk_sample");
-        merge_parts_launch<K>(sparts, sp.chunks, sp.rows_per_chunk, index_base, nullptr, nq, sample_keys, s);
+        merge_records_launch<K>(sparts, sp, index_base, nullptr, nq, sample_keys, s);
         int* thr_buf = c.alloc_n<int>(nq);
         hipLaunchKernelGGL(thr_from_keys_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, sample_keys, nq, K, thr_buf);
         thr = thr_buf;
@@ -601,10 +648,10 @@ static void topk_device_k(const void* q, int nq, const void* t, long long nt, ui
     const char* rest = static_cast<const char*>(t) + (size_t)sample * 64;
     const long long nrest = nt - sample;
     ChunkPlan p = plan_chunks(nq, nrest, false, K > 2);
-    uint32_t* parts = c.alloc_n<uint32_t>((size_t)p.chunks * nq * K);   // [chunks][nq][K] 32-bit keys
+    uint32_t* parts = c.alloc_n<uint32_t>(record_words<K>(nq, p));   // [chunks][wave tiles] records
     launch_topk<K>(q, nq, rest, nrest, thr, parts, p, s);
     // the sample pass's result joins the merge as one more (already expanded) list
-    merge_parts_launch<K>(parts, p.chunks, p.rows_per_chunk, index_base + (uint32_t)sample, sample_keys, nq, out, s);
+    merge_records_launch<K>(parts, p, index_base + (uint32_t)sample, sample_keys, nq, out, s);
     HIP_CHECK(hipGetLastError());
 }
 
