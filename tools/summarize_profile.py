@@ -32,11 +32,18 @@ for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
 print("== PMC (per-dispatch sums over hamming_topk_kernel<4, 2>, the main match launch) ==")
 print(res)
 if res["FETCH_SIZE"][1]:
-    # rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB; MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports half the bytes
-    # of a wide coalesced stream -> doubled here; WRITE_SIZE is exact.
-    fetch_b = res["FETCH_SIZE"][0] * 1024 * 2 / res["FETCH_SIZE"][1]
+    # rocprofv3 FETCH_SIZE / WRITE_SIZE are in KiB. MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE counts requests at 64 B each, so
+    # it reports half the bytes of a wide coalesced VECTOR stream (16 B/lane = 128-byte requests) and must be doubled for those;
+    # WRITE_SIZE is exact. This kernel reads its train rows with s_load_dwordx16, i.e. 64-byte requests that the counter tallies
+    # exactly; only the query tiles (64 B per query per work item, mostly L2 hits) are vector loads. `traffic` therefore takes the
+    # raw fetch figure, and the doubled figure is kept beside it as the upper bound the blanket correction would give.
+    fetch_raw = res["FETCH_SIZE"][0] * 1024 / res["FETCH_SIZE"][1]
     write_b = res["WRITE_SIZE"][0] * 1024 / max(res["WRITE_SIZE"][1], 1)
-    t = {"hamming_topk_hbm_bytes_per_launch": fetch_b + write_b, "fetch_bytes_per_launch_corrected_x2": fetch_b, "write_bytes_per_launch": write_b,
-         "launches_sampled": res["FETCH_SIZE"][1], "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --serial --steps 2 --warmup 1 (serial: the counters are device-wide)"}
+    t = {"hamming_topk_hbm_bytes_per_launch": fetch_raw + write_b, "fetch_bytes_per_launch": fetch_raw,
+         "fetch_bytes_per_launch_if_all_requests_were_128B": 2 * fetch_raw, "write_bytes_per_launch": write_b,
+         "launches_sampled": res["FETCH_SIZE"][1],
+         "note": "reads are 64-byte scalar-cache line requests (s_load_dwordx16): FETCH_SIZE (requests x 64 B) is exact for them; the x2 gfx950 "
+                 "correction of MI355X_MICROARCH.md applies to 128-byte vector requests only",
+         "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --serial --steps 2 --warmup 1 (serial: the counters are device-wide)"}
     print(json.dumps(t))
     json.dump(t, open(os.path.join(out, "traffic.json"), "w"), indent=1)
