@@ -850,31 +850,92 @@ void eig_solve8(const double* Asym, const double* b, int nb, double* x) {
     }
 }
 
+// Sums over the selected points. Large selections: two-stage parallel f64 reductions on the device (reduce_kernel). Small
+// ones (<= HOST_REFIT_MAX points, where the refit is poorly conditioned and every rounding shows): a plain loop on the host
+// over the compressed points in index order, with the associations of the sequential algorithm (J^T J and |r|^2 accumulate
+// row by row, i.e. the x and y residual of a point in two steps), which makes the result bit-identical to the CPU restatement.
+constexpr int HOST_REFIT_MAX = 256;
+
 struct Refit {
     const P2 *M, *m;
     const uint8_t* mask;
     int n;
     double *pd, *ph;
     hipStream_t s;
+    bool host = false;
+    std::vector<P2> selM, selm;   // host: the selected (inlier) pairs, compressed, index order
+
+    void sums(const RedParams& P, int K, double* r) {
+        if (!host) {
+            run_reduce(M, m, mask, n, P, K, r, pd, ph, s);
+            return;
+        }
+        for (int k = 0; k < 46; k++) r[k] = 0;
+        double rinf = 0;
+        const double* h = P.p;
+        for (size_t i = 0; i < selM.size(); i++) {
+            const P2 Mi = selM[i], mi = selm[i];
+            if (P.kind == 0) {
+                r[0] += mi.x; r[1] += mi.y; r[2] += Mi.x; r[3] += Mi.y; r[4] += 1.0;
+            } else if (P.kind == 1) {
+                r[0] += std::fabs(mi.x - P.p[0]); r[1] += std::fabs(mi.y - P.p[1]);
+                r[2] += std::fabs(Mi.x - P.p[2]); r[3] += std::fabs(Mi.y - P.p[3]);
+            } else if (P.kind == 2) {
+                const double x = (mi.x - P.p[0]) * P.p[4], y = (mi.y - P.p[1]) * P.p[5];
+                const double X = (Mi.x - P.p[2]) * P.p[6], Y = (Mi.y - P.p[3]) * P.p[7];
+                const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+                const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+                int q = 0;
+                for (int j = 0; j < 9; j++)
+                    for (int k = j; k < 9; k++) r[q++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+            } else {
+                const double Mx = Mi.x, My = Mi.y;
+                double ww = h[6] * Mx + h[7] * My + 1.;
+                ww = std::fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+                const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+                const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+                const double r0 = xi - mi.x, r1 = yi - mi.y;
+                r[44] += r0 * r0;
+                r[44] += r1 * r1;
+                rinf = std::max(rinf, std::max(std::fabs(r0), std::fabs(r1)));
+                if (P.kind == 3) {
+                    const double J0[8] = {Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi};
+                    const double J1[8] = {0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi};
+                    int q = 0;
+                    for (int a = 0; a < 8; a++)
+                        for (int b = a; b < 8; b++) {
+                            r[q] += J0[a] * J0[b];
+                            r[q] += J1[a] * J1[b];
+                            q++;
+                        }
+                    for (int a = 0; a < 8; a++) {
+                        r[36 + a] += J0[a] * r0;
+                        r[36 + a] += J1[a] * r1;
+                    }
+                }
+            }
+        }
+        r[45] = rinf;
+    }
 
     // runKernel over the masked points: returns 0 when degenerate
     int run_kernel(double* H) {
         RedParams P{};
         double r[46];
         P.kind = 0;
-        run_reduce(M, m, mask, n, P, 5, r, pd, ph, s);
+        sums(P, 5, r);
         const double count = r[4];
         if (count < 1) return 0;
         const double cmx = r[0] / count, cmy = r[1] / count, cMx = r[2] / count, cMy = r[3] / count;
         P.kind = 1;
         P.p[0] = cmx; P.p[1] = cmy; P.p[2] = cMx; P.p[3] = cMy;
-        run_reduce(M, m, mask, n, P, 4, r, pd, ph, s);
+        sums(P, 4, r);
         double smx = r[0], smy = r[1], sMx = r[2], sMy = r[3];
         if (std::fabs(smx) < DBL_EPSILON || std::fabs(smy) < DBL_EPSILON || std::fabs(sMx) < DBL_EPSILON || std::fabs(sMy) < DBL_EPSILON) return 0;
         smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
         P.kind = 2;
         P.p[4] = smx; P.p[5] = smy; P.p[6] = sMx; P.p[7] = sMy;
-        run_reduce(M, m, mask, n, P, 45, r, pd, ph, s);
+        sums(P, 45, r);
         double LtL[81];
         int q = 0;
         for (int j = 0; j < 9; j++)
@@ -894,7 +955,7 @@ struct Refit {
         P.kind = need_J ? 3 : 4;
         for (int i = 0; i < 8; i++) P.p[i] = h[i];
         double r[46];
-        run_reduce(M, m, mask, n, P, 45, r, pd, ph, s);
+        sums(P, 45, r);
         S = r[44];
         rinf_last = r[45];
         if (need_J) {
@@ -986,16 +1047,29 @@ int find_homography_device(const float* src, const float* dst, int n, int method
     std::vector<double> partials_host((size_t)RED_BLOCKS * RED_MAXK);
     Refit refit{M, m, nullptr, n, partials_dev, partials_host.data(), s};
     bool result = false;
-
-    if (method == 0 || n == 4) {
-        HIP_CHECK(hipMemsetAsync(mask, 1, n, s));
-        result = refit.run_kernel(H_host) > 0;
-    } else {
-        // host copy of the points drives the cv::RNG sample stream (subset checks need the coordinates)
-        std::vector<P2> hM(n), hm(n);
+    // host copy of the points: drives the cv::RNG sample stream (subset checks need the coordinates) and small refits
+    std::vector<P2> hM, hm;
+    auto fetch_points = [&]() {
+        if (!hM.empty()) return;
+        hM.resize(n);
+        hm.resize(n);
         HIP_CHECK(hipMemcpyAsync(hM.data(), M, (size_t)n * sizeof(P2), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipMemcpyAsync(hm.data(), m, (size_t)n * sizeof(P2), hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
+    };
+    int selected = n;   // points the final refit runs over (inliers), when known
+
+    if (method == 0 || n == 4) {
+        HIP_CHECK(hipMemsetAsync(mask, 1, n, s));
+        if (n <= HOST_REFIT_MAX) {
+            fetch_points();
+            refit.host = true;
+            refit.selM = hM;
+            refit.selm = hm;
+        }
+        result = refit.run_kernel(H_host) > 0;
+    } else {
+        fetch_points();
         RNG rng((uint64_t)-1);
         static const int batch_env = getenv("APDS_RANSAC_BATCH") ? atoi(getenv("APDS_RANSAC_BATCH")) : 512;
         double best_model[9] = {0};
@@ -1058,6 +1132,7 @@ int find_homography_device(const float* src, const float* dst, int n, int method
                 hipLaunchKernelGGL(inlier_mask_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, s, M, m, n, (const double*)models_dev, t, mask);
                 std::memcpy(H_host, best_model, sizeof(best_model));
                 result = true;
+                selected = maxGood;
             }
         } else {   // LMEDS
             const double outlierRatio = 0.45;
@@ -1105,6 +1180,7 @@ int find_homography_device(const float* src, const float* dst, int n, int method
                     run_reduce(M, m, mask, n, P, 5, r, partials_dev, partials_host.data(), s);
                     std::memcpy(H_host, best_model, sizeof(best_model));
                     result = r[4] >= 4;
+                    selected = (int)r[4];
                 }
             }
         }
@@ -1113,6 +1189,20 @@ int find_homography_device(const float* src, const float* dst, int n, int method
 
     if (result && n > 4) {
         refit.mask = mask;
+        if (!refit.host && selected <= HOST_REFIT_MAX) {   // few inliers: refit on the host in index order
+            fetch_points();
+            std::vector<uint8_t> hmask(n);
+            HIP_CHECK(hipMemcpyAsync(hmask.data(), mask, n, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+            refit.host = true;
+            refit.selM.clear();
+            refit.selm.clear();
+            for (int i = 0; i < n; i++)
+                if (hmask[i]) {
+                    refit.selM.push_back(hM[i]);
+                    refit.selm.push_back(hm[i]);
+                }
+        }
         if (method == APDS_HOMOGRAPHY_RANSAC || method == APDS_HOMOGRAPHY_LMEDS) refit.run_kernel(H_host);
         refit.lm_refine(H_host, 10);
     }
