@@ -93,3 +93,31 @@ def test_pnp_random_sets(gpu_pkg, oracle_mod):
         if sol is not None:
             assert np.array_equal(sol.inliers.mat.ravel(), idx), (case, n, method)
             assert np.array_equal(sol.rvec.mat.ravel(), r, equal_nan=True) and np.array_equal(sol.tvec.mat.ravel(), t, equal_nan=True), (case, n, method)
+
+
+def test_ingest_and_warp_random(gpu_pkg, oracle_mod):
+    rng = np.random.default_rng(99)
+    ge, hg = gpu_pkg.geotiff_extractor, gpu_pkg.homographier
+    for case in range(40):
+        n = int(rng.integers(1, 50000))
+        bands = [(rng.normal(rng.uniform(-5, 5), rng.uniform(0.01, 50), n)).astype(np.float32) for _ in range(3)]
+        for b in bands:
+            b[rng.random(n) < 0.02] = np.nan
+            b[rng.random(n) < 0.005] = np.inf
+            b[rng.random(n) < 0.005] = -np.inf
+        lo = [float(np.nanmin(np.where(np.isfinite(b), b, np.nan))) if np.isfinite(b).any() else 0.0 for b in bands]
+        hi = [float(np.nanmax(np.where(np.isfinite(b), b, np.nan))) if np.isfinite(b).any() else 1.0 for b in bands]
+        if case % 7 == 3:
+            hi[1] = lo[1]                                            # degenerate range: division by zero -> None -> 0
+        mm = ge.BandsMinMax(lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+        assert np.array_equal(ge.band_merger(bands, mm), oracle_mod.band_merger(*bands, mm.as_array())), case
+    for case in range(40):
+        h, w = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+        img = hg.Cmat(rng.integers(0, 256, (h, w, 4), dtype=np.uint8), np.uint8, 4)
+        M = np.eye(3) + rng.normal(0, 0.15, (3, 3)) * np.array([[1, 1, 40], [1, 1, 40], [1e-3, 1e-3, 0.2]])
+        if case % 9 == 4:
+            M[2] = [0.01, -0.02, 0.0]                                # rows where W crosses zero
+        size = None if case % 3 else (int(rng.integers(1, 350)), int(rng.integers(1, 350)))
+        got = hg.warp_image_perspective(img, hg.Cmat(M, np.float64), size).mat
+        want = oracle_mod.warp_perspective(img.mat, M, size)
+        assert np.array_equal(got, want), (case, h, w, size)
