@@ -522,12 +522,16 @@ constexpr MldbLut make_mldb_lut() {
 }
 __constant__ MldbLut c_mldb = make_mldb_lut();
 
-// One wave per keypoint. Per grid (2x2, 3x3, 4x4 cells of 10^2, 7^2, 5^2 samples): all 64 lanes gather the samples
-// (Lt, rotated Lx/Ly) into LDS, then one lane per cell adds its samples in the reference's order (k-major, l-minor;
-// float sums are order dependent), and the 486 comparisons are done 32 per lane.
+// One wave per keypoint. The three grids (2x2, 3x3, 4x4 cells of 10^2, 7^2, 5^2 samples) take their samples from the same
+// lattice of offsets (k, l) in [-10, 11)^2 around the keypoint -- the 2x2 and 4x4 grids use its [-10, 10)^2 part, the 3x3 grid
+// all of it -- and a sample depends on (k, l) only. So the 441 lattice samples (Lt, rotated Lx/Ly) are gathered ONCE into LDS
+// by all 64 lanes (they were gathered 1241 times, once per grid), then 29 lanes, one per cell of any grid, add their cell's
+// samples in the reference's order (k-major, l-minor; float sums are order dependent), and the 486 comparisons are done 32
+// per lane.
 __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, int n, uint32_t* __restrict__ desc64) {
     APDS_RAISE_WAVE_PRIORITY();
-    __shared__ float4 s_samp[4][448];   // (ri, rrx, rry, valid) of one grid: at most 9 * 49 = 441 samples
+    constexpr int LW = 21;                     // lattice width: offsets -10 .. 10
+    __shared__ float4 s_samp[4][LW * LW + 7];   // (ri, rrx, rry, valid) per lattice point
     __shared__ int s_val[4][88];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ki = blockIdx.x * 4 + wv;
@@ -544,38 +548,36 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
     double sd, cd;
     det_sincos((double)angle, sd, cd);
     const float co = (float)cd, si = (float)sd;
-    int base = 0;
-#pragma unroll
-    for (int g = 0; g < 3; g++) {
+    for (int sidx = lane; sidx < LW * LW; sidx += 64) {
+        const int k = -10 + sidx / LW, l = -10 + sidx % LW;
+        const float sample_y = yf + (l * co * scale + k * si * scale);
+        const float sample_x = xf + (-l * si * scale + k * co * scale);
+        const int y1 = __float2int_rn(sample_y), x1 = __float2int_rn(sample_x);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (!(y1 < 0 || y1 >= h || x1 < 0 || x1 >= w)) {
+            const size_t o = (size_t)y1 * w + x1;
+            const float2 d = Lxy[o];
+            const float rx = d.x, ry = d.y;
+            v.x = Lt[o];
+            v.y = -rx * si + ry * co;   // rrx
+            v.z = rx * co + ry * si;    // rry
+            v.w = 1.0f;
+        }
+        s_samp[wv][sidx] = v;
+    }
+    __syncthreads();
+    if (lane < 29) {   // lanes 0..3: the 2x2 grid, 4..12: 3x3, 13..28: 4x4; values land at s_val[3 * lane ..]
+        const int g = lane < 4 ? 0 : (lane < 13 ? 1 : 2);
+        const int cell = lane - (g == 0 ? 0 : (g == 1 ? 4 : 13));
         const int side = g + 2;
         const int step = g == 0 ? 10 : (g == 1 ? 7 : 5);
-        const int per_cell = step * step, ncells = side * side, nsamp = ncells * per_cell;
-        for (int sidx = lane; sidx < nsamp; sidx += 64) {
-            const int cell = sidx / per_cell, within = sidx - cell * per_cell;
-            const int k = -10 + (cell / side) * step + within / step;
-            const int l = -10 + (cell % side) * step + within % step;
-            const float sample_y = yf + (l * co * scale + k * si * scale);
-            const float sample_x = xf + (-l * si * scale + k * co * scale);
-            const int y1 = __float2int_rn(sample_y), x1 = __float2int_rn(sample_x);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!(y1 < 0 || y1 >= h || x1 < 0 || x1 >= w)) {
-                const size_t o = (size_t)y1 * w + x1;
-                const float2 d = Lxy[o];
-                const float rx = d.x, ry = d.y;
-                v.x = Lt[o];
-                v.y = -rx * si + ry * co;   // rrx
-                v.z = rx * co + ry * si;    // rry
-                v.w = 1.0f;
-            }
-            s_samp[wv][sidx] = v;
-        }
-        __syncthreads();
-        if (lane < ncells) {
-            float di = 0.0f, dx = 0.0f, dy = 0.0f;
-            int nsamples = 0;
-            const float4* p = &s_samp[wv][lane * per_cell];
-            for (int i = 0; i < per_cell; i++) {
-                const float4 v = p[i];
+        const int k0 = (cell / side) * step, l0 = (cell % side) * step;
+        float di = 0.0f, dx = 0.0f, dy = 0.0f;
+        int nsamples = 0;
+        for (int a = 0; a < step; a++) {
+            const float4* p = &s_samp[wv][(k0 + a) * LW + l0];
+            for (int b = 0; b < step; b++) {
+                const float4 v = p[b];
                 if (v.w != 0.0f) {
                     di += v.x;
                     dx += v.y;
@@ -583,20 +585,19 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
                     nsamples++;
                 }
             }
-            if (nsamples > 0) {
-                const float inv = 1.0f / nsamples;
-                di *= inv;
-                dx *= inv;
-                dy *= inv;
-            }
-            const int v0 = __float_as_int(di), v1 = __float_as_int(dx), v2 = __float_as_int(dy);
-            s_val[wv][base + 3 * lane + 0] = v0 ^ (v0 < 0 ? 0x7fffffff : 0);   // CV_TOGGLE_FLT: int order == float order
-            s_val[wv][base + 3 * lane + 1] = v1 ^ (v1 < 0 ? 0x7fffffff : 0);
-            s_val[wv][base + 3 * lane + 2] = v2 ^ (v2 < 0 ? 0x7fffffff : 0);
         }
-        __syncthreads();
-        base += 3 * ncells;
+        if (nsamples > 0) {
+            const float inv = 1.0f / nsamples;
+            di *= inv;
+            dx *= inv;
+            dy *= inv;
+        }
+        const int v0 = __float_as_int(di), v1 = __float_as_int(dx), v2 = __float_as_int(dy);
+        s_val[wv][3 * lane + 0] = v0 ^ (v0 < 0 ? 0x7fffffff : 0);   // CV_TOGGLE_FLT: int order == float order
+        s_val[wv][3 * lane + 1] = v1 ^ (v1 < 0 ? 0x7fffffff : 0);
+        s_val[wv][3 * lane + 2] = v2 ^ (v2 < 0 ? 0x7fffffff : 0);
     }
+    __syncthreads();
     if (live && lane < 16) {
         uint32_t word = 0;
 #pragma unroll 4
