@@ -47,7 +47,8 @@ void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int 
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s);
 void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, const int* xofs, const float* xw, const int* xcnt, const int* yofs,
                         const float* yw, const int* ycnt, hipStream_t s);
-void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s);
+void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
+                      uint32_t* list, int* list_count, hipStream_t s);
 
 // Test hook: when armed (per thread) the next akaze_extract_device copies one intermediate plane to the host.
 // which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet (f32), 7 keypoint mask after cross-level suppression (u8), 8 kcontrast (1 float)

@@ -369,29 +369,38 @@ __global__ void area_resize_kernel(const float* __restrict__ src, int sw, float*
     dst[(size_t)y * dw + x] = sum;
 }
 
-// ---- a1.5 fused: Lsmooth -> Lx, Ly (dilated Scharr pair at scale s) -> Lxx, Lxy, Lyy -> Ldet, one pass -------------
+// ---- a1.5 + a1.6 fused: Lsmooth -> Lx, Ly (dilated Scharr pair at scale s) -> Lxx, Lxy, Lyy -> Ldet -> 3x3 extrema, one pass ----
 // The reference applies sepFilter2D twice (derivatives of derivatives), each with BORDER_REFLECT_101 on ITS input. Fused,
 // that means: the Lx/Ly values a tile needs within s pixels beyond the image are the values AT the reflected positions
-// (Lx(reflect(p)), not a stencil evaluated on a reflected Lsmooth). So: Lsmooth tile with a 2s halo (reflect on load),
-// then Lx/Ly on the tile + s ring evaluated at the reflected coordinate of every ring position, then the second
-// derivatives on the tile. Lsmooth is read once (24 -> ~19 B/pixel incl. halo) and one launch per level disappears.
-static constexpr int DW = 128, DH = 32;   // wide tiles: the 2s halo costs 1.33x instead of 1.9x at s = 4
+// (Lx(reflect(p)), not a stencil evaluated on a reflected Lsmooth). So: Lsmooth tile with a 2s+1 halo (reflect on load),
+// then Lx/Ly on the tile + (s+1) ring evaluated at the reflected coordinate of every ring position, then the second
+// derivatives and the determinant on the tile + 1 ring (kept in LDS), then the strict 3x3 maxima of the tile above the
+// threshold and inside the level's border -> keypoint mask + candidate list (block-aggregated append). Lsmooth is read once,
+// Ldet is not read back for the extrema test, and two launches per level disappear.
+static constexpr int DW = 128, DH = 32;   // wide tiles: the halo costs ~1.4x instead of ~2x at s = 4
 #ifndef APDS_DOH_THREADS
 #define APDS_DOH_THREADS 1024
 #endif
 static constexpr int DNT = APDS_DOH_THREADS;
+static constexpr int DCAND = 1024;        // strict 3x3 maxima are never adjacent: at most a quarter of the 4096 tile pixels
 
 __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict__ Lsmooth, float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h,
-                                                        int s, float kside, float kmid, float sq) {
+                                                        int s, float kside, float kmid, float sq, int border, float thr, uint8_t* __restrict__ mask,
+                                                        uint32_t* __restrict__ list, int* __restrict__ list_count) {
     APDS_RAISE_WAVE_PRIORITY();
     extern __shared__ float smem[];
-    const int SW = DW + 4 * s, SH = DH + 4 * s;      // Lsmooth tile, halo 2s
-    const int MW = DW + 2 * s, MH = DH + 2 * s;      // first derivatives, halo s
+    __shared__ int s_n, s_base;
+    const int SW = DW + 4 * s + 2, SH = DH + 4 * s + 2;   // Lsmooth tile, halo 2s + 1
+    const int MW = DW + 2 * s + 2, MH = DH + 2 * s + 2;   // first derivatives, halo s + 1
+    constexpr int EW = DW + 2, EH = DH + 2;               // determinant, halo 1
     float* s_src = smem;
     float* s_mx = s_src + SW * SH;
     float* s_my = s_mx + MW * MH;
+    float* s_det = s_src;                                 // reuses the Lsmooth tile once the first derivatives exist
+    uint32_t* s_cand = reinterpret_cast<uint32_t*>(s_src + EW * EH);
     const int x0 = blockIdx.x * DW, y0 = blockIdx.y * DH;
-    const int ox = x0 - 2 * s, oy = y0 - 2 * s;      // global coordinate of s_src[0]
+    const int ox = x0 - 2 * s - 1, oy = y0 - 2 * s - 1;   // global coordinate of s_src[0]
+    if (threadIdx.x == 0) s_n = 0;
     for (int i = threadIdx.x; i < SW * SH; i += DNT) {
         const int ly = i / SW, lx = i - ly * SW;
         s_src[i] = Lsmooth[(size_t)reflect101(oy + ly, h) * w + reflect101(ox + lx, w)];
@@ -400,7 +409,7 @@ __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < MW * MH; i += DNT) {
         const int my = i / MW, mx = i - my * MW;
         // the first-derivative value this ring position stands for lives at the reflected coordinate
-        const int cx = reflect101(x0 - s + mx, w) - ox, cy = reflect101(y0 - s + my, h) - oy;
+        const int cx = reflect101(x0 - s - 1 + mx, w) - ox, cy = reflect101(y0 - s - 1 + my, h) - oy;
         const float* r0 = &s_src[(cy - s) * SW + cx];
         const float* r1 = &s_src[cy * SW + cx];
         const float* r2 = &s_src[(cy + s) * SW + cx];
@@ -415,11 +424,11 @@ __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict_
         s_my[i] = rs2 - rs0;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < DW * DH; i += DNT) {
-        const int ly = i / DW, lx = i - ly * DW;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx >= w || gy >= h) continue;
-        const int c = (ly + s) * MW + lx + s;
+    for (int i = threadIdx.x; i < EW * EH; i += DNT) {
+        const int ey = i / EW, ex = i - ey * EW;
+        const int gx = x0 - 1 + ex, gy = y0 - 1 + ey;
+        if (gx < 0 || gy < 0 || gx >= w || gy >= h) continue;   // never compared: tested pixels are >= border away from the edge
+        const int c = (ey + s) * MW + ex + s;
         const float* x0r = &s_mx[c - s * MW];
         const float* x1r = &s_mx[c];
         const float* x2r = &s_mx[c + s * MW];
@@ -438,10 +447,33 @@ __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict_
         float rsy2 = kmid * y2r[0];
         rsy2 += kside * (y2r[-s] + y2r[s]);
         const float lyy = rsy2 - rsy0;
-        const size_t o = (size_t)gy * w + gx;
-        Lxy[o] = make_float2(s_mx[c], s_my[c]);   // interleaved: orientation and M-LDB gather both with one 8-byte load
-        Ldet[o] = (lxx * lyy - lxy * lxy) * sq;
+        const float det = (lxx * lyy - lxy * lxy) * sq;
+        s_det[i] = det;
+        if (ex >= 1 && ex <= DW && ey >= 1 && ey <= DH) {   // the tile itself
+            const size_t o = (size_t)gy * w + gx;
+            Lxy[o] = make_float2(s_mx[c], s_my[c]);   // interleaved: orientation and M-LDB gather both with one 8-byte load
+            Ldet[o] = det;
+        }
     }
+    __syncthreads();
+    if (border < 0) return;   // level too small for any extremum (block-uniform)
+    for (int i = threadIdx.x; i < DW * DH; i += DNT) {
+        const int ly = i / DW, lx = i - ly * DW;
+        const int gx = x0 + lx, gy = y0 + ly;
+        if (gx < border || gx >= w - border || gy < border || gy >= h - border) continue;
+        const float* p = &s_det[(ly + 1) * EW + lx + 1];
+        const float v = p[0];
+        if (v <= thr || v <= p[-EW] || v <= p[EW] || v <= p[-1] || v <= p[1]) continue;
+        if (v <= p[-EW - 1] || v <= p[-EW + 1] || v <= p[EW - 1] || v <= p[EW + 1]) continue;
+        mask[(size_t)gy * w + gx] = 1;
+        s_cand[atomicAdd(&s_n, 1)] = (uint32_t)gx | ((uint32_t)gy << 16);
+    }
+    __syncthreads();
+    const int n = s_n;
+    if (n == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(list_count, n);   // list order is irrelevant (only used to enumerate candidates)
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += DNT) list[s_base + i] = s_cand[i];
 }
 
 // ---- host launchers -------------------------------------------------------------------------------------
@@ -507,12 +539,16 @@ void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, co
                         const float* yw, const int* ycnt, hipStream_t s) {
     hipLaunchKernelGGL(area_resize_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, src, sw, dst, dw, dh, xofs, xw, xcnt, yofs, yw, ycnt);
 }
-void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, hipStream_t s) {
-    const size_t lds = (size_t)((DW + 4 * sc) * (DH + 4 * sc) + 2 * (DW + 2 * sc) * (DH + 2 * sc)) * sizeof(float);
+void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
+                      uint32_t* list, int* list_count, hipStream_t s) {
+    const size_t lds = (size_t)((DW + 4 * sc + 2) * (DH + 4 * sc + 2) + 2 * (DW + 2 * sc + 2) * (DH + 2 * sc + 2)) * sizeof(float);
+    APDS_REQUIRE((size_t)(DW + 2) * (DH + 2) + DCAND <= (size_t)(DW + 4 * sc + 2) * (DH + 4 * sc + 2), APDS_ERR_INTERNAL, "doh_fused: LDS aliasing needs sigma_size >= 2");
     if (lds > 64 * 1024)   // above the default dynamic-LDS limit: opt in (idempotent)
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&doh_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    // the extrema test of a level that is too small for its border is skipped (border < 0 in the kernel)
+    const bool none = border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0;
     hipLaunchKernelGGL(doh_fused_kernel, dim3(ceil_div(w, DW), ceil_div(h, DH)), dim3(DNT), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
-                       (float)(sc * sc * sc * sc));
+                       (float)(sc * sc * sc * sc), none ? -1 : border, thr, mask, list, list_count);
 }
 
 }  // namespace apds

@@ -18,49 +18,6 @@ namespace apds {
 
 __device__ __forceinline__ int clampi2(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
-// ---- a1.6 extrema: 3x3 strict maxima above the threshold, inside the level's border ----------------------
-__global__ __launch_bounds__(256) void extrema_kernel(const float* __restrict__ Ldet, int w, int h, int border, float thr, uint8_t* __restrict__ mask,
-                                                      uint32_t* __restrict__ list, int* __restrict__ list_count) {
-    APDS_RAISE_WAVE_PRIORITY();
-    // candidates of the block are collected in LDS and appended with ONE global atomic per block (a per-candidate
-    // atomic on the shared counter serialises: it was 1 ms per frame)
-    __shared__ uint32_t s_cand[256 * 8];   // strict 3x3 maxima are never adjacent: at most 8 per column of 16 rows
-    __shared__ int s_n, s_base;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const int x = border + blockIdx.x * 256 + threadIdx.x;
-    const int y0 = border + blockIdx.y * 16, y1 = min(y0 + 16, h - border);
-    if (x < w - border) {
-        // the thread's own column for rows y0-1 .. y1: 18 independent loads in flight, then the (rare) row neighbours
-        float col[18];
-#pragma unroll
-        for (int r = 0; r < 18; r++) {
-            const int y = min(y0 - 1 + r, h - 1);
-            col[r] = Ldet[(size_t)y * w + x];
-        }
-#pragma unroll
-        for (int r = 1; r <= 16; r++) {
-            const int y = y0 - 1 + r;
-            const float v = col[r];
-            if (y >= y1 || v <= thr || v <= col[r - 1] || v <= col[r + 1]) continue;
-            const float* curr = Ldet + (size_t)y * w;
-            const float* prev = curr - w;
-            const float* next = curr + w;
-            if (v <= curr[x - 1] || v <= curr[x + 1]) continue;
-            if (v <= prev[x - 1] || v <= prev[x + 1]) continue;
-            if (v <= next[x - 1] || v <= next[x + 1]) continue;
-            mask[(size_t)y * w + x] = 1;
-            s_cand[atomicAdd(&s_n, 1)] = (uint32_t)x | ((uint32_t)y << 16);
-        }
-    }
-    __syncthreads();
-    const int n = s_n;
-    if (n == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(list_count, n);   // list order is irrelevant (only used to enumerate candidates)
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) list[s_base + i] = s_cand[i];
-}
-
 // ---- cross-level suppression -------------------------------------------------------------------------------
 static constexpr uint8_t ST_PENDING = 255, ST_DONE_OLD = 254;
 
@@ -610,11 +567,6 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------
-static void launch_extrema_level(const float* Ldet, int w, int h, int border, float thr, uint8_t* mask, uint32_t* list, int* list_count, hipStream_t s) {
-    if (border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0) return;
-    hipLaunchKernelGGL(extrema_kernel, dim3(ceil_div(w - 2 * border, 256), ceil_div(h - 2 * border, 16)), dim3(256), 0, s, Ldet, w, h, border, thr, mask, list, list_count);
-}
-
 namespace {
 
 bool fed_is_prime(int n) {
@@ -844,6 +796,13 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     float* k_oct = c.alloc_n<float>(8);
     int* list_count = c.alloc_n<int>(AKAZE_MAX_LEVELS);
 
+    // candidate lists and keypoint masks are filled by the determinant kernel of each level: allocate / clear them first
+    std::vector<uint32_t*> lists(L);
+    for (int i = 0; i < L; i++) lists[i] = c.alloc_n<uint32_t>((size_t)((ev[i].w + 1) / 2) * ((ev[i].h + 1) / 2));   // strict 3x3 maxima are never adjacent
+    HIP_CHECK(hipMemsetAsync(mask_all, 0, (size_t)total_pix, s));
+    HIP_CHECK(hipMemsetAsync(status_all, 0, (size_t)total_pix, s));
+    HIP_CHECK(hipMemsetAsync(list_count, 0, AKAZE_MAX_LEVELS * sizeof(int), s));
+
     // ---- a1.1 / a1.2 / a1.3
     launch_gray(img, H, W, channels, stride, gray, s);
     const GaussTaps g16 = gauss_taps(9, (double)soffset), g10 = gauss_taps(5, 1.0);
@@ -913,15 +872,15 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         }
         float kside, kmid;
         deriv_weights(e.sigma_size, kside, kmid);
-        launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, s);
+        // a1.5 + a1.6: first / second derivatives, determinant, and the level's 3x3 extrema (mask + candidate list)
+        launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i, s);
     }
     HIP_CHECK(hipGetLastError());
 
-    // ---- a1.6 extrema + candidate lists
+    // ---- level tables for the keypoint kernels
     LevelTable T{};
     SuppressArgs A{};
     T.n = A.n_levels = L;
-    std::vector<uint32_t*> lists(L);
     for (int i = 0; i < L; i++) {
         const LevelDesc& e = ev[i];
         T.w[i] = A.w[i] = e.w;
@@ -938,7 +897,6 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         T.Ldet[i] = A.Ldet[i] = e.Ldet;
         T.mask[i] = A.mask[i] = mask_all + e.pix_offset;
         A.status[i] = status_all + e.pix_offset;
-        lists[i] = c.alloc_n<uint32_t>((size_t)((e.w + 1) / 2) * ((e.h + 1) / 2));   // strict 3x3 maxima are never adjacent
         A.list[i] = lists[i];
         A.pend_cap[i] = ((e.w + 1) / 2) * ((e.h + 1) / 2);
         A.pend[i] = c.alloc_n<uint32_t>((size_t)3 * A.pend_cap[i]);
@@ -947,11 +905,6 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     A.pend_count = pend_count;
     T.pix_offset[L] = total_pix;
     A.list_count = list_count;
-    HIP_CHECK(hipMemsetAsync(mask_all, 0, (size_t)total_pix, s));
-    HIP_CHECK(hipMemsetAsync(status_all, 0, (size_t)total_pix, s));
-    HIP_CHECK(hipMemsetAsync(list_count, 0, AKAZE_MAX_LEVELS * sizeof(int), s));
-    for (int i = 0; i < L; i++)
-        launch_extrema_level(ev[i].Ldet, ev[i].w, ev[i].h, ev[i].border, dthreshold, T.mask[i], lists[i], list_count + i, s);
 
     // ---- cross-level suppression: phase 0 (vs previous level), then phase 1 (vs next level)
     if (L > 1) {
