@@ -197,10 +197,18 @@ class StreamedFramePipeline:
     synchronises with the host (single GPU), so match kernels of consecutive frames queue back to back. Stages hand
     over through HIP events; results come back in frame order."""
 
-    def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=5, reserve_cus=0,
-                 n_cus=256, meta_group=None):
+    def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=6, reserve_cus=0,
+                 n_cus=256, meta_group=None, extract_workers=None):
+        import os
         import queue
         self.queue = queue
+        # Extraction is ~100 short launches and ~8 count read-backs per frame: 3 ms of GPU work whose WALL time, once the
+        # match kernel owns every CU, is set by dispatch and host round-trip latency (measured 8-33 ms depending on the
+        # box). Two workers extract alternate frames on two streams, so a frame may take up to two match periods of wall
+        # time before extraction paces the pipeline. Each worker owns its share of the slots (a shared pool would let one
+        # worker run ahead with every slot while the ordering thread waits for the other's frame).
+        self.extract_workers = max(1, int(extract_workers if extract_workers is not None else os.environ.get("APDS_EXTRACT_WORKERS", "2")))
+        slots = max(slots, 2 * self.extract_workers)
         self.dev = torch.device(device)
         self.matcher = ShardedMatcher(db_rows64, index_base, group, meta_group=meta_group)
         self.n_db = db_xy.shape[0]
@@ -217,7 +225,8 @@ class StreamedFramePipeline:
                      p2=torch.empty((self.cap, 2), dtype=torch.float32, device=self.dev),
                      mask=torch.empty(self.cap, dtype=torch.uint8, device=self.dev),
                      keys=torch.empty((self.cap, 2), dtype=torch.int64, device=self.dev), keys_view=None,
-                     ev_extract=torch.cuda.Event(), ev_match=torch.cuda.Event(), K=0, M=0, index=0)
+                     ev_extract=torch.cuda.Event(), ev_match=torch.cuda.Event(), K=0, M=0, index=0,
+                     owner=len(self.slots) % self.extract_workers)
             self.slots.append(s)
         # the match kernel alone fills every CU for ~30 ms; the short extraction / homography kernels get the high-priority
         # queues so that their blocks are dispatched as soon as match workgroups retire
@@ -226,7 +235,7 @@ class StreamedFramePipeline:
         # poorly filled phases of one frame's match (threshold pre-pass, merges, grid tail) run under the other frame's
         # main kernel: +1 % frames/s, but per-launch kernel times then overlap and no longer read as kernel efficiency,
         # so the default is one worker. With a sharded DB the collectives must be issued in frame order by one thread.
-        import os
+        self.extract_streams = [self.streams[0]] + [torch.cuda.Stream(self.dev, priority=-1) for _ in range(self.extract_workers - 1)]
         self.match_workers = 2 if (group is None and os.environ.get("APDS_MATCH_WORKERS", "1") == "2") else 1
         self.match_streams = [self.streams[1]] + [torch.cuda.Stream(self.dev, priority=0) for _ in range(self.match_workers - 1)]
         if reserve_cus > 0:
@@ -257,9 +266,12 @@ class StreamedFramePipeline:
         """Push `count` frames (cycled from `frames`) through the three stages. Returns (results in frame order, timers)."""
         import threading
         L = lib()
-        q_free, q1, q2 = self.queue.Queue(), self.queue.Queue(), self.queue.Queue()
+        q1, q2 = self.queue.Queue(), self.queue.Queue()
+        E = self.extract_workers
+        q_free = [self.queue.Queue() for _ in range(E)]      # per extraction worker: its own slots
+        q_ext = [self.queue.Queue() for _ in range(E)]       # per extraction worker: its finished frames, in its order
         for s in self.slots:
-            q_free.put(s)
+            q_free[s["owner"]].put(s)
         results = [None] * count
         timers, errors = {}, []
         dev_index = self.dev.index or 0
@@ -275,6 +287,8 @@ class StreamedFramePipeline:
                     errors.append(e)
                     q1.put(None)
                     q2.put(None)
+                    for q in q_ext + q_free:
+                        q.put(None)
                 finally:
                     try:
                         L.apds_dev_timing_enable(0)
@@ -292,21 +306,41 @@ class StreamedFramePipeline:
                     ms, k = _lib.kernel_ms(n)
                     timers[n] = (ms, k)
 
-        def extract_worker():
-            with torch.cuda.stream(self.streams[0]):
-                for i in range(count):
-                    s = q_free.get()
-                    f = frames[i % len(frames)]
-                    ch = 1 if f.dim() == 2 else f.shape[2]
-                    n = C.c_int(0)
-                    check(L.apds_dev_akaze_extract(f.data_ptr(), f.shape[0], f.shape[1], ch, f.stride(0), self.cap, s["kps"].data_ptr(),
-                                                   s["desc"].data_ptr(), self.cap, C.byref(n), torch_stream()))
-                    s["K"], s["index"] = n.value, i
-                    s["counts"] = self.matcher.exchange_counts(n.value)   # host-side, keeps the match thread free of syncs
-                    s["ev_extract"].record(self.streams[0])
-                    q1.put(s)
-                q1.put(None)
-                collect(["akaze_extract"])
+        timer_lock = threading.Lock()
+
+        def make_extract_worker(e):
+            def extract_worker():
+                stream = self.extract_streams[e]
+                with torch.cuda.stream(stream):
+                    for i in range(e, count, E):
+                        s = q_free[e].get()
+                        if s is None:
+                            return
+                        f = frames[i % len(frames)]
+                        ch = 1 if f.dim() == 2 else f.shape[2]
+                        n = C.c_int(0)
+                        check(L.apds_dev_akaze_extract(f.data_ptr(), f.shape[0], f.shape[1], ch, f.stride(0), self.cap, s["kps"].data_ptr(),
+                                                       s["desc"].data_ptr(), self.cap, C.byref(n), torch_stream()))
+                        s["K"], s["index"] = n.value, i
+                        s["ev_extract"].record(stream)
+                        q_ext[e].put(s)
+                    if timing:
+                        ms, k = _lib.kernel_ms("akaze_extract")
+                        with timer_lock:
+                            old = timers.get("akaze_extract", (0.0, 0))
+                            timers["akaze_extract"] = (old[0] + ms, old[1] + k)
+            return extract_worker
+
+        def order_worker():
+            # frames back into order; the host-side count exchange of a sharded DB (one gloo collective per frame, which
+            # every rank must issue in the same order) happens here, so the match thread stays free of host synchronisation
+            for i in range(count):
+                s = q_ext[i % E].get()
+                if s is None:
+                    return
+                s["counts"] = self.matcher.exchange_counts(s["K"])
+                q1.put(s)
+            q1.put(None)
 
         done_lock = threading.Lock()
         alive = [self.match_workers]
@@ -362,10 +396,10 @@ class StreamedFramePipeline:
                         elif rc != _lib.ERR_EMPTY:
                             check(rc)
                     results[s["index"]] = out
-                    q_free.put(s)
+                    q_free[s["owner"]].put(s)
                 collect(["ransac_score"])
 
-        workers = [extract_worker] + [make_match_worker(st) for st in self.match_streams] + [homography_worker]
+        workers = [make_extract_worker(e) for e in range(E)] + [order_worker] + [make_match_worker(st) for st in self.match_streams] + [homography_worker]
         threads = [threading.Thread(target=guarded(f), daemon=True) for f in workers]
         for t in threads:
             t.start()
