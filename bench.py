@@ -235,7 +235,10 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hamming_topk_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                # the PMC profile was taken on the default workload on one GPU: it says nothing about other DB / tile sizes
+                if (tj.get("db_rows_per_gpu", 1_000_000), tj.get("tile", 4096)) == (rows_local, args.tile):
+                    traffic = tj.get("hamming_topk_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         bytes_per_launch = match_bytes / max(launches_per_step, 1e-9)

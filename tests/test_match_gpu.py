@@ -156,3 +156,26 @@ def test_full_size_properties_1m_rows(gpu_pkg, oracle_mod):
     sel = np.arange(0, len(q), 64)
     oi, od = oracle_mod.knn_hamming(q[sel], db, 2)
     assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od)
+
+
+def test_config5_db_size_10m_rows(gpu_pkg, oracle_mod):
+    """BASELINE config 5's DB size (10 M rows, 640 MB resident) on one GPU: row indices pass 2^22 (the width of the in-chunk row
+    offset of the packed partial keys), so the scan splits into more chunks. Properties: exact copies found at distance 0 anywhere in
+    the index range (including the last row), duplicated rows resolve to the lower index, planted neighbours recovered, and a bounded
+    sample of the queries equals the oracle exactly."""
+    n = 10_000_000
+    db = gpu_pkg.synth.make_descriptor_db(n)
+    db[9_000_001] = db[4_194_303]                           # duplicate across the 2^22 boundary region: the lower index must win
+    q, src = gpu_pkg.synth.make_queries(db, 1024)
+    q[0], q[1], q[2], q[3] = db[4_194_303], db[n - 1], db[4_194_304], db[0]
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q, db, 2)
+    assert tuple(idx[0]) == (4_194_303, 9_000_001) and tuple(dist[0]) == (0, 0)
+    assert idx[1, 0] == n - 1 and dist[1, 0] == 0 and idx[2, 0] == 4_194_304 and dist[2, 0] == 0 and idx[3, 0] == 0 and dist[3, 0] == 0
+    planted = np.nonzero(src >= 0)[0]
+    planted = planted[planted > 3]
+    assert len(planted) > 200 and np.array_equal(idx[planted, 0], src[planted])
+    assert (np.diff(dist.astype(np.int64), axis=1) >= 0).all()
+    oracle_mod.set_threads(8)
+    sel = np.arange(0, len(q), 32)
+    oi, od = oracle_mod.knn_hamming(q[sel], db, 2)
+    assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od)

@@ -41,7 +41,7 @@ if res["FETCH_SIZE"][1]:
     write_b = res["WRITE_SIZE"][0] * 1024 / max(res["WRITE_SIZE"][1], 1)
     t = {"hamming_topk_hbm_bytes_per_launch": fetch_raw + write_b, "fetch_bytes_per_launch": fetch_raw,
          "fetch_bytes_per_launch_if_all_requests_were_128B": 2 * fetch_raw, "write_bytes_per_launch": write_b,
-         "launches_sampled": res["FETCH_SIZE"][1],
+         "launches_sampled": res["FETCH_SIZE"][1], "db_rows_per_gpu": 1000000, "tile": 4096,
          "note": "reads are 64-byte scalar-cache line requests (s_load_dwordx16): FETCH_SIZE (requests x 64 B) is exact for them; the x2 gfx950 "
                  "correction of MI355X_MICROARCH.md applies to 128-byte vector requests only",
          "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --serial --steps 2 --warmup 1 (serial: the counters are device-wide)"}
