@@ -159,63 +159,105 @@ __global__ __launch_bounds__(256) void deriv_pair_kernel(const float* __restrict
 // position outside the image is, under reflect-101, an in-image position at most one pixel inside the border, i.e. part of
 // the same region, so the gradient stencil simply indexes it through the reflected coordinate. Arithmetic per value is
 // that of gauss_kernel<2> followed by deriv_pair_kernel<1>.
-static constexpr int FW = 64, FH = 32, FNT = 1024;
+#ifndef APDS_SF_THREADS
+#define APDS_SF_THREADS 1024
+#endif
+static constexpr int FW = 64, FH = 32, FNT = APDS_SF_THREADS;
 
+// Persistent blocks: each block walks a strided list of tiles of its XCD's band and issues the loads of its NEXT tile (into
+// registers) before it computes the current one, so the HBM latency of a tile hides behind the three LDS passes of the previous
+// tile instead of being paid once per tile per block.
 __global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow, int w, int h,
-                                                          GaussTaps taps, const float* __restrict__ kptr) {
+                                                          GaussTaps taps, const float* __restrict__ kptr, int tiles_x, int ntiles) {
     APDS_RAISE_WAVE_PRIORITY();
     constexpr int SW = FW + 6, SH = FH + 6;      // start image, halo 3 (= ring 1 + Gaussian radius 2), replicate on load
     constexpr int TWD = FW + 2;                  // row-pass / Lsmooth width: tile + ring 1
     constexpr int MH = FH + 2;
+    constexpr int NL = (SW * SH + FNT - 1) / FNT;
     __shared__ float s_src[SH * SW];
     __shared__ float s_tmp[SH * TWD];
     __shared__ float s_sm[MH * TWD];
-    const int x0 = blockIdx.x * FW, y0 = blockIdx.y * FH;
-    for (int i = threadIdx.x; i < SW * SH; i += FNT) {
-        const int ly = i / SW, lx = i - ly * SW;
-        s_src[i] = src[(size_t)clampi(y0 - 3 + ly, h) * w + clampi(x0 - 3 + lx, w)];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < SH * TWD; i += FNT) {
-        const int ly = i / TWD, lx = i - ly * TWD;
-        const float* p = &s_src[ly * SW + lx + 2];
-        float acc = taps.k[0] * p[0];
-        acc += taps.k[1] * (p[-1] + p[1]);
-        acc += taps.k[2] * (p[-2] + p[2]);
-        s_tmp[i] = acc;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < MH * TWD; i += FNT) {
-        const int ly = i / TWD, lx = i - ly * TWD;
-        const float* p = &s_tmp[(ly + 2) * TWD + lx];
-        float acc = taps.k[0] * p[0];
-        acc += taps.k[1] * (p[-TWD] + p[TWD]);
-        acc += taps.k[2] * (p[-2 * TWD] + p[2 * TWD]);
-        s_sm[i] = acc;
-        const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-        if (lx >= 1 && lx <= FW && ly >= 1 && ly <= FH && gx < w && gy < h) smooth[(size_t)gy * w + gx] = acc;
-    }
-    __syncthreads();
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;          // gridDim.x is a multiple of 8: blocks go round-robin over the XCDs
+    const int band = (ntiles + 7) >> 3;
+    const int t_end = min(ntiles, (xcd + 1) * band);
+    int t = xcd * band + (blockIdx.x >> 3);
+    float v[NL];
+    auto issue_loads = [&](int tile) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int x0 = tx * FW, y0 = ty * FH;
+        const bool inside = x0 >= 3 && y0 >= 3 && x0 + FW + 3 <= w && y0 + FH + 3 <= h;
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = min((int)threadIdx.x + k * FNT, SW * SH - 1);
+            const int ly = i / SW, lx = i - ly * SW;
+            v[k] = inside ? src[(size_t)(y0 - 3 + ly) * w + (x0 - 3 + lx)] : src[(size_t)clampi(y0 - 3 + ly, h) * w + clampi(x0 - 3 + lx, w)];
+        }
+    };
+    if (t < t_end) issue_loads(t);
     const float k = *kptr;
     const float k2inv = 1.0f / (k * k);
     const float kside = 3.0f, kmid = 10.0f;      // unnormalised Scharr, as launch_flow passes them
-    for (int i = threadIdx.x; i < FW * FH; i += FNT) {
-        const int ly = i / FW, lx = i - ly * FW;
-        const int gx = x0 + lx, gy = y0 + ly;
-        if (gx >= w || gy >= h) continue;
-        const int cx = lx + 1, cxm = reflect101(gx - 1, w) - (x0 - 1), cxp = reflect101(gx + 1, w) - (x0 - 1);
-        const float* r0 = &s_sm[(reflect101(gy - 1, h) - (y0 - 1)) * TWD];
-        const float* r1 = &s_sm[(ly + 1) * TWD];
-        const float* r2 = &s_sm[(reflect101(gy + 1, h) - (y0 - 1)) * TWD];
-        const float rd0 = r0[cxp] - r0[cxm], rd1 = r1[cxp] - r1[cxm], rd2 = r2[cxp] - r2[cxm];
-        float ax = kmid * rd1;
-        ax += kside * (rd0 + rd2);
-        float rs0 = kmid * r0[cx];
-        rs0 += kside * (r0[cxm] + r0[cxp]);
-        float rs2 = kmid * r2[cx];
-        rs2 += kside * (r2[cxm] + r2[cxp]);
-        const float ay = rs2 - rs0;
-        flow[(size_t)gy * w + gx] = 1.0f / (1.0f + ((ax * ax + ay * ay) * k2inv));
+    for (; t < t_end; t += per) {
+        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+        const int x0 = tx * FW, y0 = ty * FH;
+        // the tile and its halo inside the image (all but the outermost tiles): no bounds tests, no reflected coordinates
+        const bool inside = x0 >= 3 && y0 >= 3 && x0 + FW + 3 <= w && y0 + FH + 3 <= h;
+#pragma unroll
+        for (int kk = 0; kk < NL; kk++) {
+            const int i = threadIdx.x + kk * FNT;
+            if (i < SW * SH) s_src[i] = v[kk];
+        }
+        __syncthreads();
+        if (t + per < t_end) issue_loads(t + per);
+        for (int i = threadIdx.x; i < SH * TWD; i += FNT) {
+            const int ly = i / TWD, lx = i - ly * TWD;
+            const float* p = &s_src[ly * SW + lx + 2];
+            float acc = taps.k[0] * p[0];
+            acc += taps.k[1] * (p[-1] + p[1]);
+            acc += taps.k[2] * (p[-2] + p[2]);
+            s_tmp[i] = acc;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < MH * TWD; i += FNT) {
+            const int ly = i / TWD, lx = i - ly * TWD;
+            const float* p = &s_tmp[(ly + 2) * TWD + lx];
+            float acc = taps.k[0] * p[0];
+            acc += taps.k[1] * (p[-TWD] + p[TWD]);
+            acc += taps.k[2] * (p[-2 * TWD] + p[2 * TWD]);
+            s_sm[i] = acc;
+            const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+            if (lx >= 1 && lx <= FW && ly >= 1 && ly <= FH && (inside || (gx < w && gy < h))) smooth[(size_t)gy * w + gx] = acc;
+        }
+        __syncthreads();
+        auto flow_point = [&](const float* r0, const float* r1, const float* r2, int cxm, int cx, int cxp) {
+            const float rd0 = r0[cxp] - r0[cxm], rd1 = r1[cxp] - r1[cxm], rd2 = r2[cxp] - r2[cxm];
+            float ax = kmid * rd1;
+            ax += kside * (rd0 + rd2);
+            float rs0 = kmid * r0[cx];
+            rs0 += kside * (r0[cxm] + r0[cxp]);
+            float rs2 = kmid * r2[cx];
+            rs2 += kside * (r2[cxm] + r2[cxp]);
+            const float ay = rs2 - rs0;
+            return 1.0f / (1.0f + ((ax * ax + ay * ay) * k2inv));
+        };
+        if (inside) {
+            for (int i = threadIdx.x; i < FW * FH; i += FNT) {
+                const int ly = i / FW, lx = i - ly * FW;
+                const float* r1 = &s_sm[(ly + 1) * TWD];
+                flow[(size_t)(y0 + ly) * w + (x0 + lx)] = flow_point(r1 - TWD, r1, r1 + TWD, lx, lx + 1, lx + 2);
+            }
+        } else {
+            for (int i = threadIdx.x; i < FW * FH; i += FNT) {
+                const int ly = i / FW, lx = i - ly * FW;
+                const int gx = x0 + lx, gy = y0 + ly;
+                if (gx >= w || gy >= h) continue;
+                const int cxm = reflect101(gx - 1, w) - (x0 - 1), cxp = reflect101(gx + 1, w) - (x0 - 1);
+                flow[(size_t)gy * w + gx] = flow_point(&s_sm[(reflect101(gy - 1, h) - (y0 - 1)) * TWD], &s_sm[(ly + 1) * TWD],
+                                                       &s_sm[(reflect101(gy + 1, h) - (y0 - 1)) * TWD], cxm, lx + 1, cxp);
+            }
+        }
+        // the next iteration's s_src stores are ordered after this iteration's row pass by the two barriers above; its row pass
+        // (s_tmp) and column pass (s_sm) are each a barrier away from this iteration's readers of those planes
     }
 }
 
@@ -299,20 +341,41 @@ struct NldSteps {
     float v[8];
 };
 
-template <int S, int NT>
-__global__ __launch_bounds__(NT) void nld_multi_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
-                                                        NldSteps steps) {
-    APDS_RAISE_WAVE_PRIORITY();
+// a point with all four neighbours inside the image: nld_point without the border cases (same expression, same order)
+__device__ __forceinline__ float nld_point_interior(const float* __restrict__ st, const float* __restrict__ sf, int c, int pitch, float step_size) {
+    const float tc = st[c], fc = sf[c];
+    const float xp = (fc + sf[c + 1]) * (st[c + 1] - tc);
+    const float xm = (fc + sf[c - 1]) * (st[c - 1] - tc);
+    const float yp = (fc + sf[c + pitch]) * (st[c + pitch] - tc);
+    const float ym = (fc + sf[c - pitch]) * (st[c - pitch] - tc);
+    return tc + (xp + xm + yp + ym) * step_size;
+}
+
+// INTERIOR: the tile with its halo lies inside the image and touches no image border (block-uniform; all but the outermost
+// tiles): no clamping, no in-image tests, no border cases — a third of the instructions of the general path.
+template <int S, int NT, bool INTERIOR>
+__device__ __forceinline__ void nld_multi_tile(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
+                                               const NldSteps& steps, float* s_f, float* s_a, float* s_b, int x0, int y0) {
     constexpr int SW = T2W + 2 * S, SH = T2H + 2 * S;
-    __shared__ float s_f[SH * SW];
-    __shared__ float s_a[SH * SW];
-    __shared__ float s_b[SH * SW];
-    const int x0 = blockIdx.x * T2W - S, y0 = blockIdx.y * T2H - S;   // global coordinate of local (0, 0)
-    for (int i = threadIdx.x; i < SW * SH; i += NT) {
-        const int ly = i / SW, lx = i - ly * SW;
-        const size_t o = (size_t)clampi(y0 + ly, h) * w + clampi(x0 + lx, w);
-        s_a[i] = Lt[o];
-        s_f[i] = Lf[o];
+    {
+        constexpr int NL = (SW * SH + NT - 1) / NT;
+        float va[NL], vf[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {   // every load of both tiles in flight before the first LDS store
+            const int i = min((int)threadIdx.x + k * NT, SW * SH - 1);
+            const int ly = i / SW, lx = i - ly * SW;
+            const size_t o = INTERIOR ? (size_t)(y0 + ly) * w + (x0 + lx) : (size_t)clampi(y0 + ly, h) * w + clampi(x0 + lx, w);
+            va[k] = Lt[o];
+            vf[k] = Lf[o];
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = threadIdx.x + k * NT;
+            if (i < SW * SH) {
+                s_a[i] = va[k];
+                s_f[i] = vf[k];
+            }
+        }
     }
     __syncthreads();
     const float* src = s_a;
@@ -323,8 +386,12 @@ __global__ __launch_bounds__(NT) void nld_multi_kernel(const float* __restrict__
         for (int i = threadIdx.x; i < rw * rh; i += NT) {
             const int ry = i / rw, rx = i - ry * rw;
             const int lx = rx + j, ly = ry + j;
-            const int gx = x0 + lx, gy = y0 + ly;
-            if (gx >= 0 && gx < w && gy >= 0 && gy < h) dst[ly * SW + lx] = nld_point(src, s_f, ly * SW + lx, SW, gx, gy, w, h, steps.v[j - 1]);
+            if constexpr (INTERIOR) {
+                dst[ly * SW + lx] = nld_point_interior(src, s_f, ly * SW + lx, SW, steps.v[j - 1]);
+            } else {
+                const int gx = x0 + lx, gy = y0 + ly;
+                if (gx >= 0 && gx < w && gy >= 0 && gy < h) dst[ly * SW + lx] = nld_point(src, s_f, ly * SW + lx, SW, gx, gy, w, h, steps.v[j - 1]);
+            }
         }
         __syncthreads();
         const float* t = src;
@@ -334,8 +401,26 @@ __global__ __launch_bounds__(NT) void nld_multi_kernel(const float* __restrict__
     for (int i = threadIdx.x; i < T2W * T2H; i += NT) {
         const int ly = i / T2W, lx = i - ly * T2W;
         const int gx = x0 + S + lx, gy = y0 + S + ly;
-        if (gx < w && gy < h) Lnew[(size_t)gy * w + gx] = nld_point(src, s_f, (ly + S) * SW + lx + S, SW, gx, gy, w, h, steps.v[S - 1]);
+        if constexpr (INTERIOR) {
+            Lnew[(size_t)gy * w + gx] = nld_point_interior(src, s_f, (ly + S) * SW + lx + S, SW, steps.v[S - 1]);
+        } else {
+            if (gx < w && gy < h) Lnew[(size_t)gy * w + gx] = nld_point(src, s_f, (ly + S) * SW + lx + S, SW, gx, gy, w, h, steps.v[S - 1]);
+        }
     }
+}
+
+template <int S, int NT>
+__global__ __launch_bounds__(NT) void nld_multi_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
+                                                        NldSteps steps) {
+    APDS_RAISE_WAVE_PRIORITY();
+    constexpr int SW = T2W + 2 * S, SH = T2H + 2 * S;
+    __shared__ float s_f[SH * SW];
+    __shared__ float s_a[SH * SW];
+    __shared__ float s_b[SH * SW];
+    const int x0 = blockIdx.x * T2W - S, y0 = blockIdx.y * T2H - S;   // global coordinate of local (0, 0)
+    // every evaluated point (local [1, SW-1) x [1, SH-1) at the first step) has its four neighbours inside the image
+    if (x0 >= 0 && y0 >= 0 && x0 + SW <= w && y0 + SH <= h) nld_multi_tile<S, NT, true>(Lt, Lf, Lnew, w, h, steps, s_f, s_a, s_b, x0, y0);
+    else nld_multi_tile<S, NT, false>(Lt, Lf, Lnew, w, h, steps, s_f, s_a, s_b, x0, y0);
 }
 
 // ---- resize(INTER_AREA) by exactly 2: mean of 2x2 ---------------------------------------------------------
@@ -384,12 +469,16 @@ static constexpr int DW = 128, DH = 32;   // wide tiles: the halo costs ~1.4x in
 static constexpr int DNT = APDS_DOH_THREADS;
 static constexpr int DCAND = 1024;        // strict 3x3 maxima are never adjacent: at most a quarter of the 4096 tile pixels
 
+// S = sigma_size as a compile-time constant (2, 3, 4 are all the reference's AKAZE parameters produce): constant LDS strides turn
+// the index divisions into multiplies and let the tile loads be issued together; S = 0 takes it at run time.
+template <int S>
 __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict__ Lsmooth, float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h,
-                                                        int s, float kside, float kmid, float sq, int border, float thr, uint8_t* __restrict__ mask,
+                                                        int s_rt, float kside, float kmid, float sq, int border, float thr, uint8_t* __restrict__ mask,
                                                         uint32_t* __restrict__ list, int* __restrict__ list_count) {
     APDS_RAISE_WAVE_PRIORITY();
     extern __shared__ float smem[];
     __shared__ int s_n, s_base;
+    const int s = S ? S : s_rt;
     const int SW = DW + 4 * s + 2, SH = DH + 4 * s + 2;   // Lsmooth tile, halo 2s + 1
     const int MW = DW + 2 * s + 2, MH = DH + 2 * s + 2;   // first derivatives, halo s + 1
     constexpr int EW = DW + 2, EH = DH + 2;               // determinant, halo 1
@@ -401,15 +490,33 @@ __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict_
     const int x0 = blockIdx.x * DW, y0 = blockIdx.y * DH;
     const int ox = x0 - 2 * s - 1, oy = y0 - 2 * s - 1;   // global coordinate of s_src[0]
     if (threadIdx.x == 0) s_n = 0;
-    for (int i = threadIdx.x; i < SW * SH; i += DNT) {
-        const int ly = i / SW, lx = i - ly * SW;
-        s_src[i] = Lsmooth[(size_t)reflect101(oy + ly, h) * w + reflect101(ox + lx, w)];
+    // the tile with its 2s+1 halo inside the image (all but the outermost tiles, block-uniform): no reflected coordinates, no tests
+    const bool inside = ox >= 0 && oy >= 0 && ox + SW <= w && oy + SH <= h;
+    if constexpr (S > 0) {
+        constexpr int CSW = DW + 4 * S + 2, CSH = DH + 4 * S + 2, NL = (CSW * CSH + DNT - 1) / DNT;
+        float v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {   // all of the tile's loads in flight before the first LDS store
+            const int i = min((int)threadIdx.x + k * DNT, CSW * CSH - 1);
+            const int ly = i / CSW, lx = i - ly * CSW;
+            v[k] = inside ? Lsmooth[(size_t)(oy + ly) * w + (ox + lx)] : Lsmooth[(size_t)reflect101(oy + ly, h) * w + reflect101(ox + lx, w)];
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = threadIdx.x + k * DNT;
+            if (i < CSW * CSH) s_src[i] = v[k];
+        }
+    } else {
+        for (int i = threadIdx.x; i < SW * SH; i += DNT) {
+            const int ly = i / SW, lx = i - ly * SW;
+            s_src[i] = Lsmooth[(size_t)reflect101(oy + ly, h) * w + reflect101(ox + lx, w)];
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < MW * MH; i += DNT) {
         const int my = i / MW, mx = i - my * MW;
         // the first-derivative value this ring position stands for lives at the reflected coordinate
-        const int cx = reflect101(x0 - s - 1 + mx, w) - ox, cy = reflect101(y0 - s - 1 + my, h) - oy;
+        const int cx = inside ? mx + s : reflect101(x0 - s - 1 + mx, w) - ox, cy = inside ? my + s : reflect101(y0 - s - 1 + my, h) - oy;
         const float* r0 = &s_src[(cy - s) * SW + cx];
         const float* r1 = &s_src[cy * SW + cx];
         const float* r2 = &s_src[(cy + s) * SW + cx];
@@ -427,7 +534,7 @@ __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < EW * EH; i += DNT) {
         const int ey = i / EW, ex = i - ey * EW;
         const int gx = x0 - 1 + ex, gy = y0 - 1 + ey;
-        if (gx < 0 || gy < 0 || gx >= w || gy >= h) continue;   // never compared: tested pixels are >= border away from the edge
+        if (!inside && (gx < 0 || gy < 0 || gx >= w || gy >= h)) continue;   // never compared: tested pixels are >= border away from the edge
         const int c = (ey + s) * MW + ex + s;
         const float* x0r = &s_mx[c - s * MW];
         const float* x1r = &s_mx[c];
@@ -477,6 +584,11 @@ __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict_
 }
 
 // ---- host launchers -------------------------------------------------------------------------------------
+// grid of a persistent tile kernel with two 1024-thread blocks per CU: a multiple of 8 (one slice per XCD), at most 2 x 256 blocks
+static int persistent_grid(int ntiles) {
+    static const int cap = getenv("APDS_PERSISTENT_BLOCKS") ? atoi(getenv("APDS_PERSISTENT_BLOCKS")) : 512;
+    return std::min((ntiles + 7) & ~7, std::max(8, cap & ~7));
+}
 void launch_gray(const void* img, int rows, int cols, int channels, size_t stride, float* out, hipStream_t s) {
     hipLaunchKernelGGL(gray_kernel, dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, static_cast<const uint8_t*>(img), rows, cols, channels, stride, out);
 }
@@ -498,7 +610,8 @@ void launch_flow(const float* src, float* flow, int w, int h, const float* kptr,
                        3.0f, 10.0f, kptr, (unsigned int*)nullptr);
 }
 void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int h, const GaussTaps& taps, const float* kptr, hipStream_t s) {
-    hipLaunchKernelGGL(smooth_flow_kernel, dim3(ceil_div(w, FW), ceil_div(h, FH)), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr);
+    const int tiles_x = ceil_div(w, FW), ntiles = tiles_x * ceil_div(h, FH);
+    hipLaunchKernelGGL(smooth_flow_kernel, dim3(persistent_grid(ntiles)), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr, tiles_x, ntiles);
 }
 void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s) {
     HIP_CHECK(hipMemsetAsync(hmax_bits, 0, sizeof(unsigned int), s));
@@ -543,12 +656,20 @@ void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int
                       uint32_t* list, int* list_count, hipStream_t s) {
     const size_t lds = (size_t)((DW + 4 * sc + 2) * (DH + 4 * sc + 2) + 2 * (DW + 2 * sc + 2) * (DH + 2 * sc + 2)) * sizeof(float);
     APDS_REQUIRE((size_t)(DW + 2) * (DH + 2) + DCAND <= (size_t)(DW + 4 * sc + 2) * (DH + 4 * sc + 2), APDS_ERR_INTERNAL, "doh_fused: LDS aliasing needs sigma_size >= 2");
-    if (lds > 64 * 1024)   // above the default dynamic-LDS limit: opt in (idempotent)
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&doh_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     // the extrema test of a level that is too small for its border is skipped (border < 0 in the kernel)
     const bool none = border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0;
-    hipLaunchKernelGGL(doh_fused_kernel, dim3(ceil_div(w, DW), ceil_div(h, DH)), dim3(DNT), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
-                       (float)(sc * sc * sc * sc), none ? -1 : border, thr, mask, list, list_count);
+    auto go = [&](auto kernel) {
+        if (lds > 64 * 1024)   // above the default dynamic-LDS limit: opt in (idempotent)
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(w, DW), ceil_div(h, DH)), dim3(DNT), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
+                           (float)(sc * sc * sc * sc), none ? -1 : border, thr, mask, list, list_count);
+    };
+    switch (sc) {
+        case 2: go(&doh_fused_kernel<2>); break;
+        case 3: go(&doh_fused_kernel<3>); break;
+        case 4: go(&doh_fused_kernel<4>); break;
+        default: go(&doh_fused_kernel<0>); break;
+    }
 }
 
 }  // namespace apds
