@@ -71,6 +71,28 @@ def akaze_keypoint_descriptor_extraction_def(img, max_points=None):
     return ExtractedKeyPoint(k, d)
 
 
+def tile_keypoint_descriptor_extraction(red, green, blue, min_max, max_points=None):
+    """One preprocessor tile (preprocessor/src/main.rs:258-277): to_rgb's band_merger, raster_to_mat and the extraction above in one
+    library call — red/green/blue are equal-shape 2-D float32 views (row-strided views into the mosaic are taken as they are), the
+    RGBA/BGRA image exists on the device only. Same result as the three separate calls."""
+    bands = [np.asarray(b) for b in (red, green, blue)]
+    h, w = bands[0].shape
+    if any(b.dtype != np.float32 or b.ndim != 2 or b.shape != (h, w) for b in bands) or h == 0 or w == 0:
+        raise ApdsError(_lib.ERR_ASSERT, "bands must be equal, non-empty 2-D float32 arrays")
+    stride = bands[0].strides[0]
+    if any(b.strides[1] != 4 or b.strides[0] != stride or stride % 4 for b in bands):
+        bands = [np.ascontiguousarray(b) for b in bands]
+        stride = w * 4
+    mm = min_max.as_array()
+    kps, desc = C.c_void_p(), C.c_void_p()
+    n, nb = C.c_int(0), C.c_int(0)
+    check(lib().apds_tile_extract(bands[0].ctypes.data, bands[1].ctypes.data, bands[2].ctypes.data, h, w, stride // 4, ptr(mm),
+                                  MAX_POINTS if max_points is None else int(max_points), C.byref(kps), C.byref(desc), C.byref(n), C.byref(nb)))
+    k = take(kps, n.value, KEYPOINT_DTYPE)
+    d = take(desc, n.value * nb.value, np.uint8).reshape(n.value, nb.value)
+    return ExtractedKeyPoint(k, d)
+
+
 def _desc(a):
     a = np.ascontiguousarray(a, np.uint8)
     if a.ndim != 2:

@@ -166,9 +166,20 @@ class MosaicedDataset:
         W, H = self.raster_size()
         if x0 < 0 or y0 < 0 or ww <= 0 or wh <= 0 or x0 + ww > W or y0 + wh > H or ow <= 0 or oh <= 0:
             raise _lib.ApdsError(_lib.ERR_OUT_OF_RANGE, "window outside the raster")
+        win = self.window(window, window_size, size)
+        return band_merger([np.ascontiguousarray(win[i]).ravel() for i in range(3)], self.datasets_min_max())
+
+    def window(self, window, window_size, size):
+        """The three f32 band windows `to_rgb` merges ([3, size_h, size_w]; a strided view of the mosaic when no resampling is needed)."""
+        x0, y0 = int(window[0]), int(window[1])
+        ww, wh = int(window_size[0]), int(window_size[1])
+        ow, oh = int(size[0]), int(size[1])
+        W, H = self.raster_size()
+        if x0 < 0 or y0 < 0 or ww <= 0 or wh <= 0 or x0 + ww > W or y0 + wh > H or ow <= 0 or oh <= 0:
+            raise _lib.ApdsError(_lib.ERR_OUT_OF_RANGE, "window outside the raster")
         win = self.bands[:3, y0:y0 + wh, x0:x0 + ww]
         if (ow, oh) != (ww, wh):
             ys = np.minimum(((np.arange(oh) + 0.5) * (wh / oh)).astype(np.int64), wh - 1)
             xs = np.minimum(((np.arange(ow) + 0.5) * (ww / ow)).astype(np.int64), ww - 1)
             win = win[:, ys][:, :, xs]
-        return band_merger([np.ascontiguousarray(win[i]).ravel() for i in range(3)], self.datasets_min_max())
+        return win

@@ -26,12 +26,22 @@ def tile_grid(image_resolution, amount_lod, lod):
     return tile_size, columns, rows
 
 
-def feature_extraction_to_database(table, images, dataset, tile_size, column, row, lod):
-    """main.rs:248-327 — one tile: read, convert, extract, insert the image row and its keypoints. Returns (image_id, n_keypoints)."""
+def extract_tile(dataset, tile_size, column, row, lod, fused=True):
+    """main.rs:258-277 — the part of one tile that does not touch the database: read, convert, extract. Thread-safe (the C ABI
+    gives every calling thread its own stream and workspace, as the reference's rayon workers each own their OpenCV objects)."""
     span = (tile_size[0] * 2 ** lod, tile_size[1] * 2 ** lod)
+    if fused:
+        # the same three steps inside the library: the band windows go to the GPU once and the 8-bit image never comes back
+        win = dataset.window((column * span[0], row * span[1]), span, tile_size)
+        return feature_extraction.tile_keypoint_descriptor_extraction(win[0], win[1], win[2], dataset.datasets_min_max(), None)
     tile = dataset.to_rgb((column * span[0], row * span[1]), span, tile_size)                     # main.rs:258-272
     tile_mat = homographier.raster_to_mat(tile, tile_size[0], tile_size[1])                       # main.rs:274
-    keypoints = feature_extraction.akaze_keypoint_descriptor_extraction_def(tile_mat.mat, None)   # main.rs:277
+    return feature_extraction.akaze_keypoint_descriptor_extraction_def(tile_mat.mat, None)        # main.rs:277
+
+
+def store_tile(table, images, keypoints, tile_size, column, row, lod):
+    """main.rs:280-324 — the image row and its keypoints. Returns (image_id, n_keypoints)."""
+    span = (tile_size[0] * 2 ** lod, tile_size[1] * 2 ** lod)
     image_id = images.create_image(lod, column * span[0], column * span[0] + span[0] - 1,          # main.rs:280-293
                                    row * span[1], row * span[1] + span[1] - 1)
     # main.rs:296-324: x = x * 2^lod + column * tile_w * 2^lod (same for y), one multi-row INSERT
@@ -39,17 +49,53 @@ def feature_extraction_to_database(table, images, dataset, tile_size, column, ro
     return image_id, len(keypoints.keypoints)
 
 
-def downscale_from_lod(table, images, dataset, amount_lod, lod):
-    """main.rs:197-246 — every tile of one level, row-major (the reference spawns them on a thread pool: order is not part of
-    the result, image ids are)."""
+def feature_extraction_to_database(table, images, dataset, tile_size, column, row, lod, fused=True):
+    """main.rs:248-327 — one tile: read, convert, extract, insert the image row and its keypoints. Returns (image_id, n_keypoints)."""
+    return store_tile(table, images, extract_tile(dataset, tile_size, column, row, lod, fused), tile_size, column, row, lod)
+
+
+def downscale_from_lod(table, images, dataset, amount_lod, lod, workers=1, fused=True):
+    """main.rs:197-246 — every tile of one level. The reference spawns the tiles on a rayon pool (main.rs:233-243) and image ids
+    follow whatever order the inserts reach Postgres in; here `workers` threads extract tiles concurrently (small tiles are
+    launch-latency-bound on the GPU: concurrent streams fill it) and the rows are stored in row-major tile order, so ids and
+    table contents do not depend on `workers`."""
     tile_size, columns, rows = tile_grid(dataset.raster_size(), amount_lod, lod)
+    cells = [(j, i) for i in range(rows) for j in range(columns)]
+    if workers <= 1:
+        return [feature_extraction_to_database(table, images, dataset, tile_size, j, i, lod, fused) for j, i in cells]
+    from concurrent.futures import ThreadPoolExecutor
+    import threading
+    from ._lib import lib
+
+    def work(cell):
+        return extract_tile(dataset, tile_size, cell[0], cell[1], lod, fused)
+
+    # every pool thread gives its stream + device workspace back before the pool goes away: the barrier makes each of the
+    # `workers` threads take exactly one release task
+    barrier = threading.Barrier(workers)
+
+    def release():
+        barrier.wait(timeout=60)
+        lib().apds_thread_release()
+
     out = []
-    for i in range(rows):
-        for j in range(columns):
-            out.append(feature_extraction_to_database(table, images, dataset, tile_size, j, i, lod))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        try:
+            # bounded look-ahead: at most 2 x workers extracted tiles wait for their turn to be stored
+            pending, it = [], iter(cells)
+            for cell in it:
+                pending.append((cell, pool.submit(work, cell)))
+                if len(pending) >= 2 * workers:
+                    (j, i), fut = pending.pop(0)
+                    out.append(store_tile(table, images, fut.result(), tile_size, j, i, lod))
+            for (j, i), fut in pending:
+                out.append(store_tile(table, images, fut.result(), tile_size, j, i, lod))
+        finally:
+            for f in [pool.submit(release) for _ in range(workers)]:
+                f.result()
     return out
 
 
-def process_lod_from_mosaic(table, images, dataset, lod):
+def process_lod_from_mosaic(table, images, dataset, lod, workers=1, fused=True):
     """main.rs:175-194 — all levels 0 .. lod-1."""
-    return [downscale_from_lod(table, images, dataset, lod, i) for i in range(lod)]
+    return [downscale_from_lod(table, images, dataset, lod, i, workers, fused) for i in range(lod)]

@@ -122,6 +122,12 @@ int apds_raster_to_mat(const uint8_t* rgba, size_t n_pixels, int w, int h, uint8
  * BGRA8 (bgra = 1: raster_to_mat, mod.rs:183-220, fused). NaN / out-of-range -> 0; alpha 0 only if all three bands are NaN. */
 int apds_band_merger(const float* red, const float* green, const float* blue, size_t n, const double* minmax6, int bgra, uint8_t* out);
 int apds_dev_band_merger(const void* red, const void* green, const void* blue, size_t n, const double* minmax6, int bgra, void* out, void* stream);
+/* One preprocessor tile in one call: `to_rgb` of an equal-size window (geotiff_extractor/src/image_extractor/mod.rs:241-269, band_merger
+ * :346-378) -> `raster_to_mat` (homographier/src/homographier/mod.rs:183-197) -> `akaze_keypoint_descriptor_extraction_def`
+ * (feature_extraction/src/lib.rs:61-92), as preprocessor/src/main.rs:258-277 chains them. red/green/blue: rows x cols f32 windows with
+ * `row_stride` elements between rows (they may point into the mosaic); the RGBA / BGRA image exists on the device only. Outputs as apds_akaze_extract. */
+int apds_tile_extract(const float* red, const float* green, const float* blue, int rows, int cols, size_t row_stride, const double* minmax6,
+                      int max_points, apds_keypoint** kps, uint8_t** desc, int* n, int* desc_bytes);
 
 /* homographier/src/homographier/mod.rs:271-300 warp_image_perspective: warpPerspective(src, M, size, INTER_LINEAR, BORDER_CONSTANT,
  * Scalar(1,1,1,1)). M (9 doubles) maps source to destination coordinates. channels must be 4 (Vec4b). */

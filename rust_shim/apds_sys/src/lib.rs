@@ -42,6 +42,10 @@ extern "C" {
     pub fn apds_find_homography(input_xy: *const f32, reference_xy: *const f32, n: c_int, method: c_int, reproj_threshold: c_double,
                                 h: *mut f64, mask: *mut u8) -> c_int;
     pub fn apds_raster_to_mat(rgba: *const u8, n_pixels: usize, w: c_int, h: c_int, bgra: *mut u8) -> c_int;
+    /// to_rgb (equal-size window) + raster_to_mat + AKAZE of one preprocessor tile in one call (include/apds.h).
+    pub fn apds_tile_extract(red: *const f32, green: *const f32, blue: *const f32, rows: c_int, cols: c_int, row_stride: usize,
+                             minmax6: *const f64, max_points: c_int, kps: *mut *mut apds_keypoint, desc: *mut *mut u8, n: *mut c_int,
+                             desc_bytes: *mut c_int) -> c_int;
     pub fn apds_get_world_coordinates(xy: *const f64, n: c_int, dataset_gt: *const f64, elevation_gt: *const f64, elevation: *const f64,
                                       ew: c_int, eh: c_int, xyz: *mut f64) -> c_int;
     pub fn apds_thread_release() -> c_int;

@@ -52,3 +52,23 @@ def test_process_lod_from_mosaic(gpu_pkg, oracle_mod, tmp_path):
     lod0 = table.read_keypoints_from_lod(0)
     assert len(lod0) == sum(n for _, n in out[0]) and lod0.keypoints["x"].max() > 512
     table.close()
+
+
+def test_concurrent_tile_workers_give_the_same_tables(gpu_pkg):
+    """The reference extracts tiles on a rayon pool (main.rs:233-243): with `workers` threads calling the C ABI concurrently the image
+    ids, row order and every stored value must equal the serial run's."""
+    ge, pp, fd = gpu_pkg.geotiff_extractor, gpu_pkg.preprocessor, gpu_pkg.feature_database
+    ds = ge.MosaicedDataset(_mosaic(gpu_pkg, 2048))
+    runs = []
+    for workers, fused in ((1, False), (4, True), (1, True)):      # fused: band_merger -> BGRA -> AKAZE inside one library call
+        table, images = fd.KeypointTable(400000), pp.ImageTable()
+        out = pp.process_lod_from_mosaic(table, images, ds, 3, workers=workers, fused=fused)     # 16 + 4 + 1 tiles of 512
+        assert [len(level) for level in out] == [16, 4, 1]
+        allk = table.read_keypoints_from_lod(0), table.read_keypoints_from_lod(1), table.read_keypoints_from_lod(2)
+        runs.append((out, images.rows, [(k.keypoints.copy(), k.descriptors.copy(), k.image_ids.copy()) for k in allk]))
+        table.close()
+    for other in runs[1:]:
+        assert runs[0][0] == other[0] and runs[0][1] == other[1]
+        for a, b in zip(runs[0][2], other[2]):
+            assert len(a[0]) > 100
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
