@@ -351,6 +351,19 @@ __device__ __forceinline__ float nld_point_interior(const float* __restrict__ st
     return tc + (xp + xm + yp + ym) * step_size;
 }
 
+// two horizontally adjacent interior points at once: the same IEEE operations per point, issued as packed-f32 instructions
+// (v_pk_add_f32 / v_pk_mul_f32 work on register pairs), so the per-item index arithmetic is also paid once per two points
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 lds_pair(const float* p) { return f32x2{p[0], p[1]}; }
+__device__ __forceinline__ f32x2 nld_pair_interior(const float* __restrict__ st, const float* __restrict__ sf, int c, int pitch, float step_size) {
+    const f32x2 t = lds_pair(st + c), f = lds_pair(sf + c);
+    const f32x2 xp = (f + lds_pair(sf + c + 1)) * (lds_pair(st + c + 1) - t);
+    const f32x2 xm = (f + lds_pair(sf + c - 1)) * (lds_pair(st + c - 1) - t);
+    const f32x2 yp = (f + lds_pair(sf + c + pitch)) * (lds_pair(st + c + pitch) - t);
+    const f32x2 ym = (f + lds_pair(sf + c - pitch)) * (lds_pair(st + c - pitch) - t);
+    return t + (xp + xm + yp + ym) * step_size;
+}
+
 // INTERIOR: the tile with its halo lies inside the image and touches no image border (block-uniform; all but the outermost
 // tiles): no clamping, no in-image tests, no border cases — a third of the instructions of the general path.
 template <int S, int NT, bool INTERIOR>
@@ -383,12 +396,19 @@ __device__ __forceinline__ void nld_multi_tile(const float* __restrict__ Lt, con
 #pragma unroll
     for (int j = 1; j < S; j++) {
         const int rw = SW - 2 * j, rh = SH - 2 * j;   // region of this step: local [j, SW - j) x [j, SH - j)
-        for (int i = threadIdx.x; i < rw * rh; i += NT) {
-            const int ry = i / rw, rx = i - ry * rw;
-            const int lx = rx + j, ly = ry + j;
-            if constexpr (INTERIOR) {
-                dst[ly * SW + lx] = nld_point_interior(src, s_f, ly * SW + lx, SW, steps.v[j - 1]);
-            } else {
+        if constexpr (INTERIOR) {
+            const int hw = rw / 2;   // the region's width is even: two points per item
+            for (int i = threadIdx.x; i < hw * rh; i += NT) {
+                const int ry = i / hw, rx = i - ry * hw;
+                const int c = (ry + j) * SW + 2 * rx + j;
+                const f32x2 v = nld_pair_interior(src, s_f, c, SW, steps.v[j - 1]);
+                dst[c] = v.x;
+                dst[c + 1] = v.y;
+            }
+        } else {
+            for (int i = threadIdx.x; i < rw * rh; i += NT) {
+                const int ry = i / rw, rx = i - ry * rw;
+                const int lx = rx + j, ly = ry + j;
                 const int gx = x0 + lx, gy = y0 + ly;
                 if (gx >= 0 && gx < w && gy >= 0 && gy < h) dst[ly * SW + lx] = nld_point(src, s_f, ly * SW + lx, SW, gx, gy, w, h, steps.v[j - 1]);
             }
@@ -398,12 +418,18 @@ __device__ __forceinline__ void nld_multi_tile(const float* __restrict__ Lt, con
         src = dst;
         dst = const_cast<float*>(t);
     }
-    for (int i = threadIdx.x; i < T2W * T2H; i += NT) {
-        const int ly = i / T2W, lx = i - ly * T2W;
-        const int gx = x0 + S + lx, gy = y0 + S + ly;
-        if constexpr (INTERIOR) {
-            Lnew[(size_t)gy * w + gx] = nld_point_interior(src, s_f, (ly + S) * SW + lx + S, SW, steps.v[S - 1]);
-        } else {
+    if constexpr (INTERIOR) {
+        for (int i = threadIdx.x; i < (T2W / 2) * T2H; i += NT) {
+            const int ly = i / (T2W / 2), lx = 2 * (i - ly * (T2W / 2));
+            const f32x2 v = nld_pair_interior(src, s_f, (ly + S) * SW + lx + S, SW, steps.v[S - 1]);
+            float* o = &Lnew[(size_t)(y0 + S + ly) * w + (x0 + S + lx)];
+            o[0] = v.x;
+            o[1] = v.y;
+        }
+    } else {
+        for (int i = threadIdx.x; i < T2W * T2H; i += NT) {
+            const int ly = i / T2W, lx = i - ly * T2W;
+            const int gx = x0 + S + lx, gy = y0 + S + ly;
             if (gx < w && gy < h) Lnew[(size_t)gy * w + gx] = nld_point(src, s_f, (ly + S) * SW + lx + S, SW, gx, gy, w, h, steps.v[S - 1]);
         }
     }
