@@ -1,0 +1,42 @@
+"""Aggregate extraction throughput with N host threads calling the C ABI concurrently (each thread: own stream + workspace)."""
+import ctypes as C
+import importlib
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("cubesat-apds_amd")
+L = pkg._lib.lib()
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+imgs = [np.ascontiguousarray(pkg.synth.make_tile(T, T, frame_index=i)) for i in range(4)]
+reps = 24
+
+
+def worker(k, out):
+    for r in range(reps + 2):
+        if r == 2:
+            barrier.wait()
+            out[k] = time.perf_counter()
+        img = imgs[(k + r) % 4]
+        kps, desc, n, nb = C.c_void_p(), C.c_void_p(), C.c_int(0), C.c_int(0)
+        pkg._lib.check(L.apds_akaze_extract(img.ctypes.data, T, T, 4, img.strides[0], 0, C.byref(kps), C.byref(desc), C.byref(n), C.byref(nb)))
+        L.apds_free(kps)
+        L.apds_free(desc)
+    L.apds_thread_release()
+
+
+for nthreads in (1, 2, 4, 8):
+    barrier = threading.Barrier(nthreads)
+    starts = [0.0] * nthreads
+    ts = [threading.Thread(target=worker, args=(k, starts)) for k in range(nthreads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - min(starts)
+    print(f"tile {T}^2, {nthreads} threads: {nthreads * reps / dt:8.1f} extractions/s ({dt / reps * 1e3:.3f} ms per extraction per thread)", flush=True)
