@@ -356,18 +356,36 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
     const int x0 = __float2int_rn(kp.x / ratio), y0 = __float2int_rn(kp.y / ratio);
     const float2* __restrict__ Lxy = T.Lxy[lvl];
     const float rad = (float)(3.14159265358979323846 / 180);
-    for (int k = lane; k < 109; k += 64) {
-        const int i = c_orient.dy[k], j = c_orient.dx[k];
-        const float wgt = c_gauss25[i < 0 ? -i : i][j < 0 ? -j : j];
-        const int y = clampi2(y0 + i * scale, h), x = clampi2(x0 + j * scale, w);
-        const float2 d = Lxy[(size_t)y * w + x];
-        const float rx = wgt * d.x, ry = wgt * d.y;
-        const float ang = fast_atan2_deg(ry, rx) * rad;
-        int b = (int)(ang / ang_step);
-        if (b < 0 || b >= nkeys) b = 0;
-        s_x[wv][k] = rx;
-        s_y[wv][k] = ry;
-        s_bin[wv][k] = (uint8_t)b;
+    {
+        // both of a lane's samples: table entries, then the two gathers, are in flight together (one round trip each)
+        int si[2], sj[2];
+        float wgt[2];
+        float2 d[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int k = min(lane + 64 * u, 108);
+            si[u] = c_orient.dy[k];
+            sj[u] = c_orient.dx[k];
+            wgt[u] = c_gauss25[si[u] < 0 ? -si[u] : si[u]][sj[u] < 0 ? -sj[u] : sj[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int y = clampi2(y0 + si[u] * scale, h), x = clampi2(x0 + sj[u] * scale, w);
+            d[u] = Lxy[(size_t)y * w + x];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int k = lane + 64 * u;
+            if (k < 109) {
+                const float rx = wgt[u] * d[u].x, ry = wgt[u] * d[u].y;
+                const float ang = fast_atan2_deg(ry, rx) * rad;
+                int b = (int)(ang / ang_step);
+                if (b < 0 || b >= nkeys) b = 0;
+                s_x[wv][k] = rx;
+                s_y[wv][k] = ry;
+                s_bin[wv][k] = (uint8_t)b;
+            }
+        }
     }
     __syncthreads();
     // counting sort, identical to idx[--cum[b]] = i for ascending i: within a bin the larger sample index comes first
@@ -490,6 +508,7 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
     constexpr int LW = 21;                     // lattice width: offsets -10 .. 10
     __shared__ float4 s_samp[4][LW * LW + 7];   // (ri, rrx, rry, valid) per lattice point
     __shared__ int s_val[4][88];
+    __shared__ uint8_t s_lut[976];              // c_mldb: a[488] then b[488]
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int ki = blockIdx.x * 4 + wv;
     const bool live = ki < n;
@@ -505,22 +524,41 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
     double sd, cd;
     det_sincos((double)angle, sd, cd);
     const float co = (float)cd, si = (float)sd;
-    for (int sidx = lane; sidx < LW * LW; sidx += 64) {
-        const int k = -10 + sidx / LW, l = -10 + sidx % LW;
-        const float sample_y = yf + (l * co * scale + k * si * scale);
-        const float sample_x = xf + (-l * si * scale + k * co * scale);
-        const int y1 = __float2int_rn(sample_y), x1 = __float2int_rn(sample_x);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (!(y1 < 0 || y1 >= h || x1 < 0 || x1 >= w)) {
-            const size_t o = (size_t)y1 * w + x1;
-            const float2 d = Lxy[o];
-            const float rx = d.x, ry = d.y;
-            v.x = Lt[o];
-            v.y = -rx * si + ry * co;   // rrx
-            v.z = rx * co + ry * si;    // rry
-            v.w = 1.0f;
+    // the comparison table goes to LDS once per block (lane-indexed reads of __constant__ data are global loads)
+    for (int i = threadIdx.x; i < 244; i += 256) reinterpret_cast<uint32_t*>(s_lut)[i] = reinterpret_cast<const uint32_t*>(&c_mldb)[i];
+    {
+        // all of a lane's lattice gathers are issued before the first LDS store: one memory round trip per keypoint, not seven
+        constexpr int NS = (LW * LW + 63) / 64;
+        float2 d[NS];
+        float li[NS];
+        bool ok[NS];
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const int sidx = min(lane + 64 * j, LW * LW - 1);
+            const int k = -10 + sidx / LW, l = -10 + sidx % LW;
+            const float sample_y = yf + (l * co * scale + k * si * scale);
+            const float sample_x = xf + (-l * si * scale + k * co * scale);
+            const int y1 = __float2int_rn(sample_y), x1 = __float2int_rn(sample_x);
+            ok[j] = !(y1 < 0 || y1 >= h || x1 < 0 || x1 >= w);
+            const size_t o = ok[j] ? (size_t)y1 * w + x1 : 0;
+            d[j] = Lxy[o];
+            li[j] = Lt[o];
         }
-        s_samp[wv][sidx] = v;
+#pragma unroll
+        for (int j = 0; j < NS; j++) {
+            const int sidx = lane + 64 * j;
+            if (sidx < LW * LW) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[j]) {
+                    const float rx = d[j].x, ry = d[j].y;
+                    v.x = li[j];
+                    v.y = -rx * si + ry * co;   // rrx
+                    v.z = rx * co + ry * si;    // rry
+                    v.w = 1.0f;
+                }
+                s_samp[wv][sidx] = v;
+            }
+        }
     }
     __syncthreads();
     if (lane < 29) {   // lanes 0..3: the 2x2 grid, 4..12: 3x3, 13..28: 4x4; values land at s_val[3 * lane ..]
@@ -560,7 +598,7 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
 #pragma unroll 4
         for (int b = 0; b < 32; b++) {
             const int pos = lane * 32 + b;
-            if (pos < 486 && s_val[wv][c_mldb.a[pos]] > s_val[wv][c_mldb.b[pos]]) word |= 1u << b;
+            if (pos < 486 && s_val[wv][s_lut[pos]] > s_val[wv][s_lut[488 + pos]]) word |= 1u << b;
         }
         desc64[(size_t)ki * 16 + lane] = word;   // 61 payload bytes + 3 zero bytes per 64-byte row
     }
