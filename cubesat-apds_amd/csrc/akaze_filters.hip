@@ -449,6 +449,99 @@ __global__ __launch_bounds__(NT) void nld_multi_kernel(const float* __restrict__
     else nld_multi_tile<S, NT, false>(Lt, Lf, Lnew, w, h, steps, s_f, s_a, s_b, x0, y0);
 }
 
+// ---- FED steps on register strips (the large levels) -------------------------------------------------------------
+// One wave owns a strip of 64 columns x (RB + 2S) rows of Lt and of the conductivity, one column per lane, all rows in registers
+// (fully unrolled, static register indices): no LDS, no barriers. Horizontal neighbours come through DPP wave shifts. With
+//   P[x] = (f[x] + f[x+1]) * (t[x+1] - t[x])        Q[r] = (f[r] + f[r+1]) * (t[r+1] - t[r])
+// the four flux terms of nld_point are xp = P[x], xm = -P[x-1], yp = Q[r], ym = -Q[r-1] EXACTLY: float addition commutes,
+// a - b == -(b - a) and (-a) * b == -(a * b) in IEEE arithmetic, and x + (-y) is x - y. So a step costs one P and one Q per point
+// (11 instructions) instead of four products. Step j is valid on rows [j, R - j) and lanes [j, 64 - j): the same shrinking halo as
+// the LDS kernel. Border handling (BORDER waves only): a flux across the image edge is forced to +0 — exactly the reference's
+// dropped term, because the sum's first operand is never -0 (a difference of equal floats is +0 and conductivities are positive),
+// so adding +-0 changes nothing — and the four corner pixels, whose step is 0 in the reference, keep their value.
+__device__ __forceinline__ float dpp_from_next_lane(float v) {   // lane i <- lane i + 1 (lane 63: unspecified, a halo lane)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));   // wave_shl:1
+}
+__device__ __forceinline__ float dpp_from_prev_lane(float v) {   // lane i <- lane i - 1 (lane 0: unspecified, a halo lane)
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));   // wave_shr:1
+}
+
+template <int S, int RB, bool BORDER>
+__device__ __forceinline__ void nld_strip(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
+                                          const NldSteps& steps, int gx0, int y0) {
+    constexpr int R = RB + 2 * S;
+    const int lane = threadIdx.x & 63;
+    const int gx = gx0 + lane;
+    const int ys = y0 - S;                      // image row of strip row 0
+    float t[R], f[R];
+    {
+        // buffer loads: (descriptor, one lane-offset VGPR shared by every row, the row's byte offset in a scalar register) — plain
+        // global loads would keep a 64-bit address pair per row in vector registers
+        const int plane_bytes = w * h * 4;
+        const __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lt), 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Lf), 0, plane_bytes, 0x00020000);
+        const int cx4 = 4 * (BORDER ? clampi(gx, w) : gx);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int row4 = (BORDER ? clampi(ys + r, h) : ys + r) * w * 4;
+            t[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rt, cx4, row4, 0));
+            f[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rf, cx4, row4, 0));
+        }
+    }
+    const bool flux_x_inside = gx >= 0 && gx + 1 <= w - 1;   // the edge between columns gx and gx + 1
+    const bool edge_col = gx == 0 || gx == w - 1;
+#pragma unroll
+    for (int j = 1; j <= S; j++) {
+        const float tau = steps.v[j - 1];
+        float qprev = (f[j - 1] + f[j]) * (t[j] - t[j - 1]);
+        if (BORDER && !(ys + j - 1 >= 0 && ys + j <= h - 1)) qprev = 0.0f;
+#pragma unroll
+        for (int r = j; r < R - j; r++) {
+            const float tc = t[r];
+            const float d = dpp_from_next_lane(tc) - tc;
+            float P = (f[r] + dpp_from_next_lane(f[r])) * d;
+            if (BORDER && !flux_x_inside) P = 0.0f;
+            float q = (f[r] + f[r + 1]) * (t[r + 1] - tc);   // t[r + 1] is still this step's input
+            if (BORDER && !(ys + r >= 0 && ys + r + 1 <= h - 1)) q = 0.0f;
+            float sr = P - dpp_from_prev_lane(P);             // xp + xm
+            sr = sr + q;                                      // + yp
+            sr = sr - qprev;                                  // + ym
+            float out = tc + sr * tau;
+            if (BORDER && edge_col && (ys + r == 0 || ys + r == h - 1)) out = tc;
+            qprev = q;
+            t[r] = out;
+        }
+    }
+    if (lane >= S && lane < 64 - S && gx < w) {
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(Lnew, 0, w * h * 4, 0x00020000);
+#pragma unroll
+        for (int r = S; r < S + RB; r++)
+            if (!BORDER || ys + r < h) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t[r]), rn, 4 * gx, (ys + r) * w * 4, 0);
+    }
+}
+
+template <int S, int RB>
+#ifndef APDS_STRIP_WAVES
+#define APDS_STRIP_WAVES 4
+#endif
+#ifndef APDS_STRIP_RB
+#define APDS_STRIP_RB 16
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_WAVES, 8))) void nld_strip_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
+                                                         NldSteps steps, int strips, int nwaves) {
+    APDS_RAISE_WAVE_PRIORITY();
+    constexpr int VW = 64 - 2 * S;              // columns a wave finishes
+    // wave-uniform by construction; readfirstlane tells the compiler, so that row bases and row conditions live in scalar registers
+    const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (id >= nwaves) return;                   // the kernel has no barriers
+    const int band = __builtin_amdgcn_readfirstlane(id / strips);   // (the division itself runs on the vector ALU)
+    const int strip = id - band * strips;
+    const int gx0 = strip * VW - S, y0 = band * RB;
+    const bool border = gx0 < 0 || gx0 + 64 > w || y0 - S < 0 || y0 + RB + S > h;
+    if (border) nld_strip<S, RB, true>(Lt, Lf, Lnew, w, h, steps, gx0, y0);
+    else nld_strip<S, RB, false>(Lt, Lf, Lnew, w, h, steps, gx0, y0);
+}
+
 // ---- resize(INTER_AREA) by exactly 2: mean of 2x2 ---------------------------------------------------------
 __global__ void half_sample_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh) {
     APDS_RAISE_WAVE_PRIORITY();
@@ -656,9 +749,26 @@ static void nld_multi_launch(const float* Lt, const float* Lf, float* Lnew, int 
     else if (nt == 512) hipLaunchKernelGGL((nld_multi_kernel<S, 512>), grid, dim3(512), 0, s, Lt, Lf, Lnew, w, h, st);
     else hipLaunchKernelGGL((nld_multi_kernel<S, 1024>), grid, dim3(1024), 0, s, Lt, Lf, Lnew, w, h, st);
 }
+template <int S>
+static void nld_strip_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s) {
+    constexpr int RB = APDS_STRIP_RB;
+    const int strips = ceil_div(w, 64 - 2 * S), nwaves = strips * ceil_div(h, RB);
+    hipLaunchKernelGGL((nld_strip_kernel<S, RB>), dim3(ceil_div(nwaves, 4)), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves);
+}
 void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s) {
     NldSteps st{};
     for (int i = 0; i < nsteps; i++) st.v[i] = step_sizes[i];
+    // register strips for the throughput-bound launches (up to 4 steps on levels of at least 1 Mpx); the LDS tiles keep the
+    // deeply fused launches of the small, latency-bound octaves (their unrolled strip code would not fit the instruction cache)
+    static const int strip_mode = getenv("APDS_NLD_STRIP") ? atoi(getenv("APDS_NLD_STRIP")) : 1;
+    if (strip_mode && nsteps <= 4 && ((size_t)w * h >= ((size_t)1 << 20) || strip_mode == 2) && (size_t)w * h < ((size_t)1 << 29)) {   // 32-bit byte offsets
+        switch (nsteps) {
+            case 1: nld_strip_launch<1>(Lt, Lf, Lnew, w, h, st, s); return;
+            case 2: nld_strip_launch<2>(Lt, Lf, Lnew, w, h, st, s); return;
+            case 3: nld_strip_launch<3>(Lt, Lf, Lnew, w, h, st, s); return;
+            default: nld_strip_launch<4>(Lt, Lf, Lnew, w, h, st, s); return;
+        }
+    }
     switch (nsteps) {
         case 1: nld_multi_launch<1>(Lt, Lf, Lnew, w, h, st, s); break;
         case 2: nld_multi_launch<2>(Lt, Lf, Lnew, w, h, st, s); break;
