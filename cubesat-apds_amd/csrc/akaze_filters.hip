@@ -168,7 +168,7 @@ static constexpr int FW = 64, FH = 32, FNT = APDS_SF_THREADS;
 // registers) before it computes the current one, so the HBM latency of a tile hides behind the three LDS passes of the previous
 // tile instead of being paid once per tile per block.
 __global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow, int w, int h,
-                                                          GaussTaps taps, const float* __restrict__ kptr, int tiles_x, int ntiles) {
+                                                          GaussTaps taps, const float* __restrict__ kptr, int tiles_x, int ntiles, int txi, int tyi) {
     APDS_RAISE_WAVE_PRIORITY();
     constexpr int SW = FW + 6, SH = FH + 6;      // start image, halo 3 (= ring 1 + Gaussian radius 2), replicate on load
     constexpr int TWD = FW + 2;                  // row-pass / Lsmooth width: tile + ring 1
@@ -177,12 +177,30 @@ __global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restric
     __shared__ float s_src[SH * SW];
     __shared__ float s_tmp[SH * TWD];
     __shared__ float s_sm[MH * TWD];
-    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;          // gridDim.x is a multiple of 8: blocks go round-robin over the XCDs
+    // Item i of this block -> tile. Whole level: blocks go round-robin over the XCDs (gridDim.x is a multiple of 8) and each XCD
+    // walks its own band of tiles. Frame only (txi > 0: tiles [1, txi) x [1, tyi) belong to smooth_flow_strip_kernel): the frame's
+    // tiles are enumerated compactly — top rows, then (left column + right columns) of the middle rows, then the bottom rows — and
+    // dealt out one per block, so that no block gets a whole column of them.
+    const int tiles_y = ntiles / tiles_x;
+    const int n_top = tiles_x, per_mid = 1 + (tiles_x - txi), n_mid = (tyi - 1) * per_mid;
+    const int n_frame = n_top + n_mid + (tiles_y - tyi) * tiles_x;
+    const int xcd = blockIdx.x & 7, per = txi > 0 ? (int)gridDim.x : (int)(gridDim.x >> 3);
     const int band = (ntiles + 7) >> 3;
-    const int t_end = min(ntiles, (xcd + 1) * band);
-    int t = xcd * band + (blockIdx.x >> 3);
+    const int t_end = txi > 0 ? n_frame : min(ntiles, (xcd + 1) * band);
+    int t = txi > 0 ? (int)blockIdx.x : xcd * band + (int)(blockIdx.x >> 3);
+    auto tile_of = [&](int i) {
+        if (txi <= 0) return i;
+        if (i < n_top) return i;
+        i -= n_top;
+        if (i < n_mid) {
+            const int row = i / per_mid, c = i - row * per_mid;
+            return (1 + row) * tiles_x + (c == 0 ? 0 : txi + c - 1);
+        }
+        return tyi * tiles_x + (i - n_mid);
+    };
     float v[NL];
-    auto issue_loads = [&](int tile) {
+    auto issue_loads = [&](int item) {
+        const int tile = tile_of(item);
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int x0 = tx * FW, y0 = ty * FH;
         const bool inside = x0 >= 3 && y0 >= 3 && x0 + FW + 3 <= w && y0 + FH + 3 <= h;
@@ -197,8 +215,10 @@ __global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restric
     const float k = *kptr;
     const float k2inv = 1.0f / (k * k);
     const float kside = 3.0f, kmid = 10.0f;      // unnormalised Scharr, as launch_flow passes them
-    for (; t < t_end; t += per) {
-        const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    for (int tn; t < t_end; t = tn) {
+        tn = t + per;
+        const int tile = tile_of(t);
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int x0 = tx * FW, y0 = ty * FH;
         // the tile and its halo inside the image (all but the outermost tiles): no bounds tests, no reflected coordinates
         const bool inside = x0 >= 3 && y0 >= 3 && x0 + FW + 3 <= w && y0 + FH + 3 <= h;
@@ -208,7 +228,7 @@ __global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restric
             if (i < SW * SH) s_src[i] = v[kk];
         }
         __syncthreads();
-        if (t + per < t_end) issue_loads(t + per);
+        if (tn < t_end) issue_loads(tn);
         for (int i = threadIdx.x; i < SH * TWD; i += FNT) {
             const int ly = i / TWD, lx = i - ly * TWD;
             const float* p = &s_src[ly * SW + lx + 2];
@@ -258,6 +278,85 @@ __global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restric
         }
         // the next iteration's s_src stores are ordered after this iteration's row pass by the two barriers above; its row pass
         // (s_tmp) and column pass (s_sm) are each a barrier away from this iteration's readers of those planes
+    }
+}
+
+// The same pass on register strips, for the tiles that lie inside the image together with their halo (no clamping, no reflection):
+// a wave owns 64 columns x (RB + 6) rows, one column per lane; the 5-tap row pass takes its neighbours through DPP wave shifts, the
+// column pass and the Scharr rows come out of the lane's own registers. Every value is produced by the same operations in the same
+// order as in smooth_flow_kernel. Lanes [3, 61) and strip rows [3, 3 + RB) are final.
+__device__ __forceinline__ float dpp_next(float v) {   // lane i <- lane i + 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_prev(float v) {   // lane i <- lane i - 1
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+static constexpr int SF_RB = 16, SF_VW = 58;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+void smooth_flow_strip_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow, int w, int h, GaussTaps taps,
+                              const float* __restrict__ kptr, int rx0, int ry0, int rx1, int ry1, int strips, int nwaves) {
+    APDS_RAISE_WAVE_PRIORITY();
+    constexpr int RB = SF_RB, R = RB + 6;
+    const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (id >= nwaves) return;                   // wave-uniform; no barriers in this kernel
+    const int band = __builtin_amdgcn_readfirstlane(id / strips);
+    const int strip = id - band * strips;
+    const int lane = threadIdx.x & 63;
+    const int gx = rx0 + strip * SF_VW - 3 + lane;
+    const int y0 = ry0 + band * RB, ys = y0 - 3;
+    const int plane_bytes = w * h * 4;
+    const __amdgpu_buffer_rsrc_t rs_src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, plane_bytes, 0x00020000);
+    float s[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) s[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_src, 4 * gx, (ys + r) * w * 4, 0));
+    const float k = *kptr;
+    const float k2inv = 1.0f / (k * k);
+    const float kside = 3.0f, kmid = 10.0f;
+#pragma unroll
+    for (int r = 0; r < R; r++) {               // row pass, in place
+        const float v = s[r];
+        const float l1 = dpp_prev(v), r1 = dpp_next(v);
+        const float l2 = dpp_prev(l1), r2 = dpp_next(r1);
+        float acc = taps.k[0] * v;
+        acc += taps.k[1] * (l1 + r1);
+        acc += taps.k[2] * (l2 + r2);
+        s[r] = acc;
+    }
+    float sm[RB + 2];                           // Lsmooth rows y0 - 1 .. y0 + RB
+#pragma unroll
+    for (int q = 0; q < RB + 2; q++) {
+        const int r = q + 2;
+        float acc = taps.k[0] * s[r];
+        acc += taps.k[1] * (s[r - 1] + s[r + 1]);
+        acc += taps.k[2] * (s[r - 2] + s[r + 2]);
+        sm[q] = acc;
+    }
+    const bool mine = lane >= 3 && lane < 61 && gx < rx1;
+    float rd[RB + 2], rs[RB + 2];
+#pragma unroll
+    for (int q = 0; q < RB + 2; q++) {
+        const float l = dpp_prev(sm[q]), r = dpp_next(sm[q]);
+        rd[q] = r - l;
+        float a = kmid * sm[q];
+        a += kside * (l + r);
+        rs[q] = a;
+    }
+    if (mine) {
+        const __amdgpu_buffer_rsrc_t rs_sm = __builtin_amdgcn_make_buffer_rsrc(smooth, 0, plane_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_fl = __builtin_amdgcn_make_buffer_rsrc(flow, 0, plane_bytes, 0x00020000);
+#pragma unroll
+        for (int q = 1; q <= RB; q++) {
+            const int gy = y0 + q - 1;
+            if (gy < ry1) {
+                float ax = kmid * rd[q];
+                ax += kside * (rd[q - 1] + rd[q + 1]);
+                const float ay = rs[q + 1] - rs[q - 1];
+                const float fl = 1.0f / (1.0f + ((ax * ax + ay * ay) * k2inv));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, sm[q]), rs_sm, 4 * gx, gy * w * 4, 0);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, fl), rs_fl, 4 * gx, gy * w * 4, 0);
+            }
+        }
     }
 }
 
@@ -729,8 +828,23 @@ void launch_flow(const float* src, float* flow, int w, int h, const float* kptr,
                        3.0f, 10.0f, kptr, (unsigned int*)nullptr);
 }
 void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int h, const GaussTaps& taps, const float* kptr, hipStream_t s) {
-    const int tiles_x = ceil_div(w, FW), ntiles = tiles_x * ceil_div(h, FH);
-    hipLaunchKernelGGL(smooth_flow_kernel, dim3(persistent_grid(ntiles)), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr, tiles_x, ntiles);
+    const int tiles_x = ceil_div(w, FW), tiles_y = ceil_div(h, FH), ntiles = tiles_x * tiles_y;
+    // tiles [1, txi) x [1, tyi) lie inside the image with their 3-pixel halo: register strips; the frame around them: LDS tiles
+    static const int strip_mode = getenv("APDS_SF_STRIP") ? atoi(getenv("APDS_SF_STRIP")) : 1;
+    const int txi = w >= FW + 67 ? (w - 67) / FW + 1 : 1, tyi = h >= FH + 35 ? (h - 35) / FH + 1 : 1;
+    const bool strips_on = strip_mode && txi > 1 && tyi > 1 && (size_t)w * h < ((size_t)1 << 29) && ((size_t)w * h >= ((size_t)1 << 21) || strip_mode == 2);
+    if (strips_on) {
+        const int rx0 = FW, ry0 = FH, rx1 = txi * FW, ry1 = tyi * FH;
+        const int strips = ceil_div(rx1 - rx0, SF_VW), nwaves = strips * ceil_div(ry1 - ry0, SF_RB);
+        hipLaunchKernelGGL(smooth_flow_strip_kernel, dim3(ceil_div(nwaves, 4)), dim3(256), 0, s, src, smooth, flow, w, h, taps, kptr, rx0, ry0, rx1, ry1, strips,
+                           nwaves);
+    }
+    if (strips_on) {   // the frame: one tile per block
+        const int n_frame = tiles_x + (tyi - 1) * (1 + tiles_x - txi) + (tiles_y - tyi) * tiles_x;
+        hipLaunchKernelGGL(smooth_flow_kernel, dim3(n_frame), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr, tiles_x, ntiles, txi, tyi);
+    } else {
+        hipLaunchKernelGGL(smooth_flow_kernel, dim3(persistent_grid(ntiles)), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr, tiles_x, ntiles, 0, 0);
+    }
 }
 void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s) {
     HIP_CHECK(hipMemsetAsync(hmax_bits, 0, sizeof(unsigned int), s));
