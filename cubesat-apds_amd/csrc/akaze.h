@@ -42,7 +42,10 @@ void launch_gauss(const float* src, float* dst, int w, int h, const GaussTaps& t
 void launch_deriv_pair(const float* src, float* outA, float* outB, int w, int h, int sc, float kside, float kmid, hipStream_t s);
 void launch_flow(const float* src, float* flow, int w, int h, const float* kptr, hipStream_t s);
 void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int h, const GaussTaps& taps, const float* kptr, hipStream_t s);
-void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s);
+void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s,
+                      bool gradient_done = false);
+bool launch_base_strips(const void* img, int rows, int cols, int channels, size_t stride, const GaussTaps& g16, const GaussTaps& g10, float* Lt0, float* modg,
+                        unsigned int* hmax_bits, bool want_modg, hipStream_t s);
 void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s);
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s);
 void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, const int* xofs, const float* xw, const int* xcnt, const int* yofs,

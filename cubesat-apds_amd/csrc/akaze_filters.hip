@@ -360,6 +360,142 @@ void smooth_flow_strip_kernel(const float* __restrict__ src, float* __restrict__
     }
 }
 
+// ---- a1.1 + a1.2 + the gradient pass of a1.3 on register strips (large images) ---------------------------------------------------
+// image -> gray (registers) -> { 9-tap Gaussian -> Lt[0] } and { 5-tap Gaussian -> unnormalised Scharr -> |grad| + its maximum over
+// the interior }: one read of the image instead of gray_kernel, gauss_kernel<4>, gauss_kernel<2> and deriv_pair_kernel<2> with
+// their three f32 round trips. A wave owns 64 columns x (RB + 8) rows, one column per lane; x +- 1 .. 4 come through chained DPP
+// wave shifts (the same shifted values serve both Gaussians). Borders: both Gaussians replicate THE GRAY IMAGE, which clamped
+// loads give for free; the Scharr pass reflects (101) its input, the 5-tap result, so at the image edge the missing neighbour is
+// the opposite one (lane x + 1 for x - 1 at x = 0, row 1 for row -1, ...): selects in the BORDER waves only. Same operations in
+// the same order as the four kernels it replaces. Lanes [4, 60) and strip rows [4, 4 + RB) are final.
+#ifndef APDS_BS_RB
+#define APDS_BS_RB 8
+#endif
+#ifndef APDS_BS_WAVES
+#define APDS_BS_WAVES 4
+#endif
+static constexpr int BS_RB = APDS_BS_RB, BS_VW = 56;
+
+template <int CH, bool BORDER>
+__device__ __forceinline__ void base_strip(const uint8_t* __restrict__ img, int w, int h, int stride, const GaussTaps& g16, const GaussTaps& g10,
+                                           float* __restrict__ Lt0, float* __restrict__ modg, unsigned int* __restrict__ hmax_bits, int want_modg, int gx0,
+                                           int y0) {
+    constexpr int RB = BS_RB, R = RB + 8;
+    const int lane = threadIdx.x & 63;
+    const int gx = gx0 + lane, ys = y0 - 4;
+    const int cx = BORDER ? clampi(gx, w) : gx;
+    const __amdgpu_buffer_rsrc_t r_img = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, h * stride, 0x00020000);
+    float h9[R], h5[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int row = (BORDER ? clampi(ys + r, h) : ys + r) * stride;   // scalar
+        int gi;
+        if (CH == 4) {
+            const uint32_t v = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(r_img, 4 * cx, row, 0);   // B,G,R,A little endian
+            gi = (int)((v & 0xFF) * 3735u + ((v >> 8) & 0xFF) * 19235u + ((v >> 16) & 0xFF) * 9798u + (1u << 14)) >> 15;
+        } else if (CH == 3) {
+            const int b = __builtin_amdgcn_raw_buffer_load_b8(r_img, 3 * cx, row, 0), g = __builtin_amdgcn_raw_buffer_load_b8(r_img, 3 * cx + 1, row, 0),
+                      rr = __builtin_amdgcn_raw_buffer_load_b8(r_img, 3 * cx + 2, row, 0);
+            gi = (b * 3735 + g * 19235 + rr * 9798 + (1 << 14)) >> 15;
+        } else {
+            gi = __builtin_amdgcn_raw_buffer_load_b8(r_img, cx, row, 0);
+        }
+        const float v = (float)gi * (float)(1.0 / 255.0);
+        const float l1 = dpp_prev(v), r1 = dpp_next(v);
+        const float l2 = dpp_prev(l1), r2 = dpp_next(r1);
+        const float l3 = dpp_prev(l2), r3 = dpp_next(r2);
+        const float l4 = dpp_prev(l3), r4 = dpp_next(r3);
+        const float p1 = l1 + r1, p2 = l2 + r2;
+        float a = g16.k[0] * v;
+        a += g16.k[1] * p1;
+        a += g16.k[2] * p2;
+        a += g16.k[3] * (l3 + r3);
+        a += g16.k[4] * (l4 + r4);
+        h9[r] = a;
+        float b5 = g10.k[0] * v;
+        b5 += g10.k[1] * p1;
+        b5 += g10.k[2] * p2;
+        h5[r] = b5;
+    }
+    const bool mine = lane >= 4 && lane < 60 && gx < w;
+    const int plane_bytes = w * h * 4;
+    {
+        const __amdgpu_buffer_rsrc_t r_lt = __builtin_amdgcn_make_buffer_rsrc(Lt0, 0, plane_bytes, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < RB; q++) {
+            const int r = q + 4;
+            float a = g16.k[0] * h9[r];
+#pragma unroll
+            for (int j = 1; j <= 4; j++) a += g16.k[j] * (h9[r - j] + h9[r + j]);
+            if (mine && (!BORDER || y0 + q < h)) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, a), r_lt, 4 * gx, (y0 + q) * w * 4, 0);
+        }
+    }
+    if (!want_modg) return;                     // uniform
+    float rd[RB + 2], rs[RB + 2];               // image rows y0 - 1 .. y0 + RB
+    const float kside = 3.0f, kmid = 10.0f;     // unnormalised Scharr, as launch_kcontrast passes them
+#pragma unroll
+    for (int q = 0; q < RB + 2; q++) {
+        const int r = q + 3;
+        float sm = g10.k[0] * h5[r];
+        sm += g10.k[1] * (h5[r - 1] + h5[r + 1]);
+        sm += g10.k[2] * (h5[r - 2] + h5[r + 2]);
+        float lo = dpp_prev(sm), hi = dpp_next(sm);
+        if (BORDER) {
+            const float lo0 = lo;
+            if (gx == 0) lo = hi;               // reflect-101 of the Gaussian's output
+            if (gx == w - 1) hi = lo0;
+        }
+        rd[q] = hi - lo;
+        float a = kmid * sm;
+        a += kside * (lo + hi);
+        rs[q] = a;
+    }
+    float local_max = 0.f;
+    const __amdgpu_buffer_rsrc_t r_mg = __builtin_amdgcn_make_buffer_rsrc(modg, 0, plane_bytes, 0x00020000);
+#pragma unroll
+    for (int q = 1; q <= RB; q++) {
+        const int gy = y0 + q - 1;
+        float rd_up = rd[q - 1], rd_dn = rd[q + 1], rs_up = rs[q - 1], rs_dn = rs[q + 1];
+        if (BORDER) {
+            if (gy == 0) {
+                rd_up = rd[q + 1];
+                rs_up = rs[q + 1];
+            }
+            if (gy == h - 1) {
+                rd_dn = rd[q - 1];
+                rs_dn = rs[q - 1];
+            }
+        }
+        float ax = kmid * rd[q];
+        ax += kside * (rd_up + rd_dn);
+        const float ay = rs_dn - rs_up;
+        const float m = sqrtf(ax * ax + ay * ay);
+        if (mine && (!BORDER || gy < h)) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, m), r_mg, 4 * gx, gy * w * 4, 0);
+            if (!BORDER || (gx >= 1 && gx < w - 1 && gy >= 1 && gy < h - 1)) local_max = fmaxf(local_max, m);
+        }
+    }
+    // non-negative floats order like their bit patterns; one atomic per wave, and only if it can raise the maximum
+    unsigned int bits = __float_as_uint(local_max);
+    for (int off = 32; off > 0; off >>= 1) bits = max(bits, (unsigned int)__shfl_xor((int)bits, off));
+    if (lane == 0 && bits > *reinterpret_cast<volatile unsigned int*>(hmax_bits)) atomicMax(hmax_bits, bits);
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_BS_WAVES, 8)))
+void base_strip_kernel(const uint8_t* __restrict__ img, int w, int h, int stride, GaussTaps g16, GaussTaps g10, float* __restrict__ Lt0,
+                       float* __restrict__ modg, unsigned int* __restrict__ hmax_bits, int want_modg, int strips, int nwaves) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (id >= nwaves) return;                   // wave-uniform; no barriers in this kernel
+    const int band = __builtin_amdgcn_readfirstlane(id / strips);
+    const int strip = id - band * strips;
+    const int gx0 = strip * BS_VW - 4, y0 = band * BS_RB;
+    const bool border = gx0 < 0 || gx0 + 64 > w || y0 - 4 < 0 || y0 + BS_RB + 4 > h;
+    if (border) base_strip<CH, true>(img, w, h, stride, g16, g10, Lt0, modg, hmax_bits, want_modg, gx0, y0);
+    else base_strip<CH, false>(img, w, h, stride, g16, g10, Lt0, modg, hmax_bits, want_modg, gx0, y0);
+}
+
 // ---- contrast factor: 300-bin histogram of |grad|/hmax over interior pixels, 70th percentile -----------
 __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __restrict__ modg, int w, int h, const unsigned int* __restrict__ hmax_bits,
                                                               int* __restrict__ hist) {
@@ -846,13 +982,35 @@ void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int
         hipLaunchKernelGGL(smooth_flow_kernel, dim3(persistent_grid(ntiles)), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr, tiles_x, ntiles, 0, 0);
     }
 }
-void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s) {
-    HIP_CHECK(hipMemsetAsync(hmax_bits, 0, sizeof(unsigned int), s));
+void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s,
+                      bool gradient_done) {
+    if (!gradient_done) {   // otherwise launch_base_strips has written |grad| to modg_tmp and its maximum to hmax_bits
+        HIP_CHECK(hipMemsetAsync(hmax_bits, 0, sizeof(unsigned int), s));
+        hipLaunchKernelGGL((deriv_pair_kernel<2>), dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), deriv_lds_bytes(1), s, smooth, modg_tmp, (float*)nullptr,
+                           w, h, 1, 3.0f, 10.0f, (const float*)nullptr, hmax_bits);
+    }
     HIP_CHECK(hipMemsetAsync(hist, 0, 300 * sizeof(int), s));
-    hipLaunchKernelGGL((deriv_pair_kernel<2>), dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), deriv_lds_bytes(1), s, smooth, modg_tmp, (float*)nullptr, w,
-                       h, 1, 3.0f, 10.0f, (const float*)nullptr, hmax_bits);
     hipLaunchKernelGGL(kcontrast_hist_kernel, dim3(1024), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist);
     hipLaunchKernelGGL(kcontrast_finish_kernel, dim3(1), dim3(64), 0, s, hist, hmax_bits, w, h, k_oct, n_oct);
+}
+// image -> Lt[0] (and, if want_modg, |grad| of the sigma = 1 image + its interior maximum) in one pass on register strips. Returns
+// false when the image is too small to pay (the launch-bound small tiles keep the separate kernels) or does not fit 32-bit offsets.
+bool launch_base_strips(const void* img, int rows, int cols, int channels, size_t stride, const GaussTaps& g16, const GaussTaps& g10, float* Lt0, float* modg,
+                        unsigned int* hmax_bits, bool want_modg, hipStream_t s) {
+    static const int strip_mode = getenv("APDS_BASE_STRIP") ? atoi(getenv("APDS_BASE_STRIP")) : 1;
+    const size_t px = (size_t)rows * cols;
+    if (!strip_mode || (px < ((size_t)1 << 21) && strip_mode != 2) || px >= ((size_t)1 << 29) || (size_t)rows * stride >= ((size_t)1 << 31)) return false;
+    if (channels == 4 && ((reinterpret_cast<uintptr_t>(img) | stride) & 3)) return false;   // dword loads of the BGRA pixels
+    if (want_modg) HIP_CHECK(hipMemsetAsync(hmax_bits, 0, sizeof(unsigned int), s));
+    const int strips = ceil_div(cols, BS_VW), nwaves = strips * ceil_div(rows, BS_RB);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(nwaves, 4)), dim3(256), 0, s, static_cast<const uint8_t*>(img), cols, rows, (int)stride, g16, g10, Lt0, modg,
+                           hmax_bits, want_modg ? 1 : 0, strips, nwaves);
+    };
+    if (channels == 4) go(&base_strip_kernel<4>);
+    else if (channels == 3) go(&base_strip_kernel<3>);
+    else go(&base_strip_kernel<1>);
+    return true;
 }
 template <int S>
 static void nld_multi_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s) {

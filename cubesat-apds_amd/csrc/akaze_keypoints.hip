@@ -842,12 +842,16 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     HIP_CHECK(hipMemsetAsync(list_count, 0, AKAZE_MAX_LEVELS * sizeof(int), s));
 
     // ---- a1.1 / a1.2 / a1.3
-    launch_gray(img, H, W, channels, stride, gray, s);
     const GaussTaps g16 = gauss_taps(9, (double)soffset), g10 = gauss_taps(5, 1.0);
-    launch_gauss(gray, ev[0].Lt, W, H, g16, 4, s);   // Lt[0] == Lsmooth[0]
-    if (L > 1) {
-        launch_gauss(gray, tmpS, W, H, g10, 2, s);
-        launch_kcontrast(tmpS, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s);
+    if (launch_base_strips(img, H, W, channels, stride, g16, g10, ev[0].Lt, tmpF, hmax_bits, L > 1, s)) {   // large images: one fused pass
+        if (L > 1) launch_kcontrast(nullptr, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s, /*gradient_done=*/true);
+    } else {
+        launch_gray(img, H, W, channels, stride, gray, s);
+        launch_gauss(gray, ev[0].Lt, W, H, g16, 4, s);   // Lt[0] == Lsmooth[0]
+        if (L > 1) {
+            launch_gauss(gray, tmpS, W, H, g10, 2, s);
+            launch_kcontrast(tmpS, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s);
+        }
     }
     auto deriv_weights = [](int sc, float& kside, float& kmid) {
         if (sc == 1) {
