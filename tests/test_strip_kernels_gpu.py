@@ -1,5 +1,5 @@
 """GPU: the register-strip kernels (FED steps, smoothing + conductivity, the fused base stage) serve the large levels only; the LDS
-tile kernels serve the rest. This runs the whole AKAZE parity file again in a child process with the strips forced on for EVERY
+tile kernels serve the rest. This runs the whole AKAZE parity file and the random-shape AKAZE fuzz again in a child process with the strips forced on for EVERY
 level size (APDS_*_STRIP=2; the switches are read once per process), so their border variants meet the small, odd-sized, strided
 and 1/3/4-channel images of those tests and must reproduce the oracle bit for bit there too."""
 import os
@@ -15,7 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_akaze_parity_with_strips_forced_on_every_level(gpu_pkg):
     env = dict(os.environ, APDS_NLD_STRIP="2", APDS_SF_STRIP="2", APDS_BASE_STRIP="2")
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_akaze_gpu.py"), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"],
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_akaze_gpu.py"),
+                        os.path.join("tests", "test_fuzz_gpu.py") + "::test_akaze_random_shapes", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
     assert " passed" in r.stdout and "failed" not in r.stdout
