@@ -252,6 +252,8 @@ def main():
             "config": {"workload": f"frame{T}x{T}_bgra_detect+describe -> hamming_top2 vs db{NDB} (sharded/{world}) -> ratio{args.filter_strength} -> ransac_homography",
                        "tile": T, "db_rows": NDB, "db_rows_per_gpu": rows_local, "frames_per_step": world, "parallelism": f"frame-dp{world}+db-shard{world}",
                        "stage_overlap": "none (serial)" if args.serial else "extract (2 workers, alternate frames) | match | homography on their own streams, software-pipelined over frames",
+                       "match_occupancy_cap": ({"lds_bytes": 55000, "set_at": pipe.cap_events[0]} if getattr(pipe, "cap_events", None) else
+                                               {"lds_bytes": int(os.environ.get("APDS_MATCH_LDS_CAP", "0") or 0)}),
                        "keypoints_per_frame": K, "matches_per_frame": float(np.mean([s["n_matches"] for s in stats])),
                        "inliers_per_frame": float(np.mean([s["n_inliers"] for s in stats])), "homography_found": all(s["H"] is not None for s in stats)},
             "mmatches_per_s": world * K * args.steps / elapsed / 1e6,

@@ -864,6 +864,14 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
             kmid = wgt * norm;
         }
     };
+    // The Hessian / extrema kernel of a level hangs off the main chain (it only needs the level's Lsmooth and nothing waits for it
+    // before the suppression): it goes to a second stream, so the latency-bound launches of the small octaves overlap the
+    // smoothing and diffusion launches of the levels that follow. Lsmooth then needs a plane per level instead of a shared one.
+    static const bool fork_doh = !(getenv("APDS_AKAZE_FORK") && atoi(getenv("APDS_AKAZE_FORK")) == 0);
+    std::vector<float*> lsm(L, tmpS);
+    if (fork_doh)
+        for (int i = 1; i < L; i++) lsm[i] = c.alloc_n<float>((size_t)ev[i].w * ev[i].h);
+    hipStream_t s_doh = fork_doh ? c.side_stream() : s;
     // ---- a1.4 / a1.5 per level: Lsmooth -> (Lx, Ly, Ldet) and flow; FED steps ping-pong into Lt[i]
     for (int i = 0; i < L; i++) {
         LevelDesc& e = ev[i];
@@ -896,8 +904,12 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
             } else {
                 P = p.Lt;
             }
-            launch_smooth_flow(P, tmpS, tmpF, e.w, e.h, g10, k_oct + e.octave, s);   // Lsmooth and the conductivity in one pass
-            smooth = tmpS;
+            launch_smooth_flow(P, lsm[i], tmpF, e.w, e.h, g10, k_oct + e.octave, s);   // Lsmooth and the conductivity in one pass
+            smooth = lsm[i];
+            if (fork_doh) {   // Lsmooth of this level exists from here on
+                HIP_CHECK(hipEventRecord(c.fork_event(i), s));
+                HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(i), 0));
+            }
             const float* in = P;
             int pass = 0;
             for (int k = 0; k < e.nsteps; pass++) {
@@ -915,7 +927,17 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         float kside, kmid;
         deriv_weights(e.sigma_size, kside, kmid);
         // a1.5 + a1.6: first / second derivatives, determinant, and the level's 3x3 extrema (mask + candidate list)
-        launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i, s);
+        if (fork_doh && i == 0) {   // level 0: Lsmooth is Lt[0], ready after the base stage
+            HIP_CHECK(hipEventRecord(c.fork_event(0), s));
+            HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
+        }
+        launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i,
+                         s_doh);
+    }
+    if (fork_doh) {   // join: everything after this point reads what the Hessian kernels wrote
+        if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, hipEventDisableTiming));
+        HIP_CHECK(hipEventRecord(c.join_event, s_doh));
+        HIP_CHECK(hipStreamWaitEvent(s, c.join_event, 0));
     }
     HIP_CHECK(hipGetLastError());
 

@@ -185,6 +185,14 @@ int apds_dev_hamming_topk(const void* q, int nq, const void* t, int64_t nt, uint
     });
 }
 
+int apds_dev_match_lds_cap(int bytes, int* previous) {
+    return guarded([&] {
+        APDS_REQUIRE(bytes >= 0 && bytes <= 64 * 1024, APDS_ERR_BAD_ARG, "cap must be 0 .. 65536 bytes");
+        const int old = match_lds_cap().exchange(bytes);
+        if (previous) *previous = old;
+    });
+}
+
 int apds_dev_merge_topk(const void* parts, int nparts, int nq, int k, void* out_keys, void* stream) {
     return guarded([&] { merge_topk_device(static_cast<const uint64_t*>(parts), nparts, nq, k, static_cast<uint64_t*>(out_keys), pick_stream(stream)); });
 }

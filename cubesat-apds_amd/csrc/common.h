@@ -59,6 +59,12 @@ struct ThreadCtx {
         hipStream_t s;
     };
     std::map<std::string, std::vector<Ev>> events;
+    // fork / join inside one call: a second stream for work that hangs off the main chain (akaze: the per-level Hessian kernels)
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> fork_events;
+    hipEvent_t join_event = nullptr;
+    hipStream_t side_stream();                  // created on first use
+    hipEvent_t fork_event(size_t i);            // i-th reusable event (no timing)
 
     void ensure();
     void* alloc(size_t bytes);   // valid until the next ws_reset()

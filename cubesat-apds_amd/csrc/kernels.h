@@ -1,5 +1,6 @@
 // csrc/kernels.h — host-callable launchers implemented in the .hip files.
 #pragma once
+#include <atomic>
 #include "common.h"
 
 namespace apds {
@@ -21,6 +22,7 @@ void points_from_matches_device(const apds_keypoint* kp1, int n1, const apds_key
 void rgba_to_bgra_device(const uint8_t* rgba, size_t n_pixels, uint8_t* bgra, hipStream_t s);
 
 // ingest.hip
+std::atomic<int>& match_lds_cap();   // match_hamming.hip: occupancy cap of the main Hamming scan
 void band_merger_device(const float* r, const float* g, const float* b, size_t n, const double* mm, int bgra, uint8_t* out, hipStream_t s);
 void warp_perspective_device(const uint8_t* src, int rows, int cols, const double* M, int dst_rows, int dst_cols, uint8_t* dst, hipStream_t s);
 

@@ -14,6 +14,7 @@
 // the rare groups that contain a hit. Train rows are split into chunks over blockIdx.y so the grid fills
 // 256 CUs; per-chunk candidates are merged by a second tiny kernel. Keys are (distance << 32 | index):
 // unsigned 64-bit min reproduces BFMatcher's order (distance, then lower train index).
+#include <atomic>
 #include <cstdlib>
 
 #include "common.h"
@@ -525,6 +526,13 @@ static int env_int(const char* name, int dflt) {
     return v && *v ? atoi(v) : dflt;
 }
 
+// Occupancy cap of the main scan (bytes of unused dynamic LDS per workgroup; 0 = none), process-wide: APDS_MATCH_LDS_CAP at first
+// use, then apds_dev_match_lds_cap(). See launch_topk.
+std::atomic<int>& match_lds_cap() {
+    static std::atomic<int> cap{env_int("APDS_MATCH_LDS_CAP", 0)};
+    return cap;
+}
+
 // Work items are (64*T queries) x (rows_per_chunk train rows) per wave. Items are kept small enough that the
 // grid is many dispatch rounds deep (the block scheduler then balances the tail), but not so small that the
 // per-chunk candidate lists dominate the merge.
@@ -591,7 +599,7 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, cons
     // workgroups resident per CU (160 KB / cap). Two waves per SIMD already issue at full VALU rate; capping there leaves
     // registers, wave slots and the rest of the LDS free, so the short kernels of the other pipeline stages are dispatched
     // at once instead of waiting for a match wave to retire.
-    static const int cap = env_int("APDS_MATCH_LDS_CAP", 0);
+    const int cap = match_lds_cap().load(std::memory_order_relaxed);
     KernelTimer timer(timer_name, s);
     switch (p.T) {
         case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, (size_t)cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;

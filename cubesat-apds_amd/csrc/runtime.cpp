@@ -29,6 +29,20 @@ void ThreadCtx::ensure() {
     ready = true;
 }
 
+hipStream_t ThreadCtx::side_stream() {
+    if (!side) HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, -1));
+    return side;
+}
+
+hipEvent_t ThreadCtx::fork_event(size_t i) {
+    while (fork_events.size() <= i) {
+        hipEvent_t e = nullptr;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        fork_events.push_back(e);
+    }
+    return fork_events[i];
+}
+
 void* ThreadCtx::alloc(size_t bytes) {
     bytes = (bytes + 255) & ~size_t(255);
     if (bytes == 0) bytes = 256;
@@ -139,6 +153,15 @@ int apds_thread_release(void) {
                 (void)hipEventDestroy(ev.b);
             }
         c.events.clear();
+        if (c.side) {
+            (void)hipStreamSynchronize(c.side);
+            (void)hipStreamDestroy(c.side);
+            c.side = nullptr;
+        }
+        for (hipEvent_t e : c.fork_events) (void)hipEventDestroy(e);
+        c.fork_events.clear();
+        if (c.join_event) (void)hipEventDestroy(c.join_event);
+        c.join_event = nullptr;
         for (auto& s : c.slabs) (void)hipFree(s.first);
         c.slabs.clear();
         c.slab_used = 0;

@@ -15,6 +15,7 @@ Multi-GPU (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROC
 torch is used for device buffers, streams and the collectives only; every compute step is a libapds_hip kernel.
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -226,6 +227,7 @@ class StreamedFramePipeline:
                      mask=torch.empty(self.cap, dtype=torch.uint8, device=self.dev),
                      keys=torch.empty((self.cap, 2), dtype=torch.int64, device=self.dev), keys_view=None,
                      ev_extract=torch.cuda.Event(), ev_match=torch.cuda.Event(), K=0, M=0, index=0,
+                     ev_mstart=torch.cuda.Event(enable_timing=True), ev_mend=torch.cuda.Event(enable_timing=True),
                      owner=len(self.slots) % self.extract_workers)
             self.slots.append(s)
         # the match kernel alone fills every CU for ~30 ms; the short extraction / homography kernels get the high-priority
@@ -236,6 +238,10 @@ class StreamedFramePipeline:
         # main kernel: +1 % frames/s, but per-launch kernel times then overlap and no longer read as kernel efficiency,
         # so the default is one worker. With a sharded DB the collectives must be issued in frame order by one thread.
         self.extract_streams = [self.streams[0]] + [torch.cuda.Stream(self.dev, priority=-1) for _ in range(self.extract_workers - 1)]
+        # 1: cap the match kernel's occupancy when the match stream is seen starving (see match_worker); APDS_ADAPTIVE_CAP=0 turns it off
+        self.adaptive_cap = os.environ.get("APDS_ADAPTIVE_CAP", "1") != "0"
+        self.cap_events = []
+        self.debug_extract_delay = float(os.environ.get("APDS_DEBUG_EXTRACT_DELAY_MS", "0")) * 1e-3
         self.match_workers = 2 if (group is None and os.environ.get("APDS_MATCH_WORKERS", "1") == "2") else 1
         self.match_streams = [self.streams[1]] + [torch.cuda.Stream(self.dev, priority=0) for _ in range(self.match_workers - 1)]
         if reserve_cus > 0:
@@ -323,6 +329,8 @@ class StreamedFramePipeline:
                                                        s["desc"].data_ptr(), self.cap, C.byref(n), torch_stream()))
                         s["K"], s["index"] = n.value, i
                         s["ev_extract"].record(stream)
+                        if self.debug_extract_delay > 0:       # test hook: emulate a box on which extraction cannot keep up
+                            time.sleep(self.debug_extract_delay)
                         q_ext[e].put(s)
                     if timing:
                         ms, k = _lib.kernel_ms("akaze_extract")
@@ -347,6 +355,14 @@ class StreamedFramePipeline:
 
         def make_match_worker(stream):
             def match_worker():
+                # Starvation watch (single match worker): the match stream should never wait for a frame. On some boxes the short
+                # extraction kernels are dispatched so late under the match kernel, which owns every wave slot, that extraction
+                # paces the pipeline (36 ms per frame instead of 30, seen on about one box in eight). The gap on the match stream
+                # between one frame's last match kernel and the next frame's first is measured with events; if it stays above
+                # 1.5 ms the match kernel's occupancy is capped at two workgroups per CU (apds_dev_match_lds_cap), which leaves
+                # wave slots free for the other stages at ~1.5 % of match throughput.
+                watch = self.adaptive_cap and self.match_workers == 1
+                pending, gaps, prev = [], [], None
                 with torch.cuda.stream(stream):
                     while True:
                         s = q1.get()
@@ -354,8 +370,28 @@ class StreamedFramePipeline:
                             q1.put(None)            # let the other match worker see the end marker too
                             break
                         stream.wait_event(s["ev_extract"])
+                        if watch:
+                            s["ev_mstart"].record(stream)
                         s["keys_view"] = self.matcher.knn(s["desc"][:s["K"]], 2, out=s["keys"], counts=s["counts"])
                         s["ev_match"].record(stream)
+                        if watch:
+                            s["ev_mend"].record(stream)
+                            if prev is not None and s["index"] >= 2:
+                                pending.append((prev["ev_mend"], s["ev_mstart"]))
+                            prev = s
+                            while pending and pending[0][1].query():       # both recorded before it, both complete
+                                a, b = pending.pop(0)
+                                try:
+                                    g = a.elapsed_time(b)
+                                except RuntimeError:                        # an event was re-recorded in the meantime: skip the sample
+                                    continue
+                                if 0.0 <= g < 1000.0:
+                                    gaps.append(g)
+                            if len(gaps) >= 3 and sorted(gaps[-3:])[1] > 1.5:
+                                old = C.c_int(0)
+                                check(L.apds_dev_match_lds_cap(55000, C.byref(old)))
+                                self.cap_events.append(dict(frame=s["index"], gaps_ms=[round(g, 2) for g in gaps[-3:]], previous=old.value))
+                                watch = False
                         q2.put(s)
                     with done_lock:
                         alive[0] -= 1

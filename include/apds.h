@@ -196,6 +196,11 @@ int apds_dev_hamming_topk(const void* query_rows64, int n_query, const void* tra
                           uint32_t index_base, int k, void* out_keys, void* stream);
 /* Merge `parts` candidate lists (each n_query*k keys, e.g. gathered from DB shards) into the global top-k. */
 int apds_dev_merge_topk(const void* keys_parts, int parts, int n_query, int k, void* out_keys, void* stream);
+/* Occupancy cap of the main Hamming scan, process-wide: the kernel requests `bytes` of (unused) dynamic LDS per workgroup, which bounds
+ * the workgroups resident per CU (160 KB / bytes; 55000 -> two). A pipeline that overlaps the scan with short kernels of other stages
+ * sets it when those kernels cannot get onto the GPU (the scan alone is ~1.5 % slower with the cap). 0 = none (default, or
+ * APDS_MATCH_LDS_CAP). *previous (may be NULL) receives the old value. */
+int apds_dev_match_lds_cap(int bytes, int* previous);
 /* Lowe ratio filter on merged keys (k >= 2): writes compacted matches in query order, count to *n_matches (host). */
 int apds_dev_ratio_filter(const void* keys, int n_query, int k, float filter_strength, void* out_matches, int* n_matches, void* stream);
 /* Cross-check: given for every train row its best query key (from apds_dev_hamming_topk with roles swapped, k=1),

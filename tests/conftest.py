@@ -29,6 +29,11 @@ def oracle_mod():
 @pytest.fixture(scope="session")
 def gpu_pkg(pkg):
     """The product package with the HIP library loaded and a device present; GPU tests fail (not skip) without it."""
+    # torch first: its wheel brings its own HIP runtime, and a process in which libapds_hip.so has already initialised the system
+    # one leaves torch without devices ("No HIP GPUs are available"); loaded in this order both use the same runtime, as in bench.py
+    import torch
+    assert torch.cuda.is_available(), "no HIP device: -m gpu tests must run on the GPU box"
+    torch.cuda.init()
     pkg.lib()
     assert pkg.lib().apds_device_count() > 0, "no HIP device: -m gpu tests must run on the GPU box"
     return pkg

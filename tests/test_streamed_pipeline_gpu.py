@@ -1,0 +1,70 @@
+"""GPU: StreamedFramePipeline (bench.py's default path: extract | match | homography on their own threads and streams, two extraction
+workers, ordering thread) must give, frame by frame, what the one-frame-at-a-time FramePipeline gives; and its starvation watch must
+cap the match kernel's occupancy when extraction is made artificially late."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(pkg, T=768, ndb=60000, nframes=3):
+    import torch
+    from importlib import import_module
+    pl = import_module(pkg.__name__ + ".pipeline")
+    L, check, synth = pkg.lib(), pkg._lib.check, pkg.synth
+    dev = torch.device("cuda:0")
+    frames_np = [synth.make_tile(T, T, frame_index=40 + i) for i in range(nframes)]
+    frames = [torch.from_numpy(f).to(dev) for f in frames_np]
+    cap = pkg.feature_extraction.MAX_POINTS
+    kps = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.empty((cap, 64), dtype=torch.uint8, device=dev)
+    rows, xy = [], []
+    with torch.cuda.stream(torch.cuda.Stream(dev)):       # extraction and the torch copies of its output in one stream
+        for f in frames_np:                               # DB: descriptors of a shifted copy of every frame + random rows
+            rolled = torch.from_numpy(np.roll(f, (19, 23), axis=(0, 1)).copy()).to(dev)
+            n = C.c_int(0)
+            check(L.apds_dev_akaze_extract(rolled.data_ptr(), T, T, 4, rolled.stride(0), cap, kps.data_ptr(), desc.data_ptr(), cap, C.byref(n),
+                                           pl.torch_stream()))
+            rows.append(desc[:n.value].clone())
+            xy.append(kps[:n.value, 0:2].clone())
+            torch.cuda.synchronize()
+    rows, xy = torch.cat(rows), torch.cat(xy)
+    P = rows.shape[0]
+    pad = np.zeros((ndb - P, 64), np.uint8)
+    pad[:, :61] = synth.make_descriptor_db(ndb - P)
+    db = torch.cat([rows, torch.from_numpy(pad).to(dev)]).contiguous()
+    db_xy = torch.zeros((ndb, 2), dtype=torch.float32, device=dev)
+    db_xy[:P] = xy
+    torch.cuda.synchronize()
+    return pl, frames, db, db_xy
+
+
+def test_streamed_results_equal_the_serial_pipeline(gpu_pkg):
+    pl, frames, db, db_xy = _setup(gpu_pkg)
+    serial = pl.FramePipeline(db, db_xy)
+    want = [serial.step(frames[i % len(frames)], filter_strength=0.3) for i in range(7)]
+    streamed = pl.StreamedFramePipeline(db, db_xy)
+    got, _ = streamed.run(frames, 7, filter_strength=0.3)
+    assert len(got) == 7
+    for a, b in zip(want, got):
+        assert a["n_keypoints"] == b["n_keypoints"] > 500 and a["n_matches"] == b["n_matches"] > 100 and a["n_inliers"] == b["n_inliers"] > 50
+        assert a["H"] is not None and np.array_equal(a["H"], b["H"])
+        assert abs(a["H"][0, 2] - 23) < 0.5 and abs(a["H"][1, 2] - 19) < 0.5      # the planted translation
+
+
+def test_starvation_watch_caps_the_match_kernel(gpu_pkg):
+    pl, frames, db, db_xy = _setup(gpu_pkg)
+    L, check = gpu_pkg.lib(), gpu_pkg._lib.check
+    streamed = pl.StreamedFramePipeline(db, db_xy)
+    streamed.debug_extract_delay = 0.012                  # every frame reaches the match 12 ms late: its stream sits idle
+    old = C.c_int(-1)
+    try:
+        got, _ = streamed.run(frames, 10, filter_strength=0.3)
+        assert all(r is not None and r["H"] is not None for r in got)
+        assert streamed.cap_events and streamed.cap_events[0]["previous"] == 0 and sorted(streamed.cap_events[0]["gaps_ms"])[1] > 1.5
+        check(L.apds_dev_match_lds_cap(0, C.byref(old)))
+        assert old.value == 55000
+    finally:
+        check(L.apds_dev_match_lds_cap(0, None))
