@@ -2,6 +2,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace apds {
@@ -43,6 +45,37 @@ hipEvent_t ThreadCtx::fork_event(size_t i) {
     return fork_events[i];
 }
 
+// Device slabs that released threads leave behind, per device. A pipeline that starts fresh worker threads for every run would
+// otherwise pay hipMalloc / hipFree (gigabytes, with an implicit device-wide synchronisation) at the start of every run; that showed
+// up as sporadic stalls of 0.1 - 0.5 s inside timed regions. A new slab request is served from here first, largest slab first (the
+// first threads to ask are the extraction workers, which are also the ones that grew the largest workspaces).
+namespace {
+struct SlabCache {
+    std::mutex m;
+    std::vector<std::pair<int, std::pair<char*, size_t>>> free;   // (device, (pointer, bytes))
+};
+SlabCache& slab_cache() {
+    static SlabCache c;
+    return c;
+}
+bool take_cached_slab(int device, size_t want, std::pair<char*, size_t>& out) {
+    SlabCache& c = slab_cache();
+    std::lock_guard<std::mutex> g(c.m);
+    int best = -1;
+    for (int i = 0; i < (int)c.free.size(); i++)
+        if (c.free[i].first == device && c.free[i].second.second >= want && (best < 0 || c.free[i].second.second > c.free[best].second.second)) best = i;
+    if (best < 0) return false;
+    out = c.free[best].second;
+    c.free.erase(c.free.begin() + best);
+    return true;
+}
+void cache_slab(int device, std::pair<char*, size_t> s) {
+    SlabCache& c = slab_cache();
+    std::lock_guard<std::mutex> g(c.m);
+    c.free.emplace_back(device, s);
+}
+}  // namespace
+
 void* ThreadCtx::alloc(size_t bytes) {
     bytes = (bytes + 255) & ~size_t(255);
     if (bytes == 0) bytes = 256;
@@ -50,9 +83,14 @@ void* ThreadCtx::alloc(size_t bytes) {
         size_t want = bytes;
         if (!slabs.empty()) want = std::max(want, slabs.back().second * 2);
         want = std::max(want, size_t(1) << 22);
-        char* p = nullptr;
-        HIP_CHECK(hipMalloc(&p, want));
-        slabs.emplace_back(p, want);
+        std::pair<char*, size_t> got;
+        if (take_cached_slab(device, want, got)) {
+            slabs.push_back(got);
+        } else {
+            char* p = nullptr;
+            HIP_CHECK(hipMalloc(&p, want));
+            slabs.emplace_back(p, want);
+        }
         slab_used = 0;
     }
     void* r = slabs.back().first + slab_used;
@@ -141,6 +179,18 @@ int apds_dev_timing_enable(int on) {
     return guarded([&] { ctx().timing = on != 0; });
 }
 
+int apds_release_cached_memory(void) {
+    return guarded([&] {
+        SlabCache& c = slab_cache();
+        std::lock_guard<std::mutex> g(c.m);
+        for (auto& e : c.free) {
+            (void)hipSetDevice(e.first);
+            (void)hipFree(e.second.first);
+        }
+        c.free.clear();
+    });
+}
+
 int apds_thread_release(void) {
     return guarded([&] {
         ThreadCtx& c = g_ctx;
@@ -162,7 +212,7 @@ int apds_thread_release(void) {
         c.fork_events.clear();
         if (c.join_event) (void)hipEventDestroy(c.join_event);
         c.join_event = nullptr;
-        for (auto& s : c.slabs) (void)hipFree(s.first);
+        for (auto& s : c.slabs) cache_slab(c.device, s);   // the stream(s) were synchronised above: nothing uses them any more
         c.slabs.clear();
         c.slab_used = 0;
         (void)hipStreamDestroy(c.stream);

@@ -241,6 +241,7 @@ class StreamedFramePipeline:
         # 1: cap the match kernel's occupancy when the match stream is seen starving (see match_worker); APDS_ADAPTIVE_CAP=0 turns it off
         self.adaptive_cap = os.environ.get("APDS_ADAPTIVE_CAP", "1") != "0"
         self.cap_events = []
+        self.gap_log = []                 # idle time of the match stream before each frame's match (ms), for diagnosis
         self.debug_extract_delay = float(os.environ.get("APDS_DEBUG_EXTRACT_DELAY_MS", "0")) * 1e-3
         self.match_workers = 2 if (group is None and os.environ.get("APDS_MATCH_WORKERS", "1") == "2") else 1
         self.match_streams = [self.streams[1]] + [torch.cuda.Stream(self.dev, priority=0) for _ in range(self.match_workers - 1)]
@@ -358,8 +359,8 @@ class StreamedFramePipeline:
                 # Starvation watch (single match worker): the match stream should never wait for a frame. On some boxes the short
                 # extraction kernels are dispatched so late under the match kernel, which owns every wave slot, that extraction
                 # paces the pipeline (36 ms per frame instead of 30, seen on about one box in eight). The gap on the match stream
-                # between one frame's last match kernel and the next frame's first is measured with events; if it stays above
-                # 1.5 ms the match kernel's occupancy is capped at two workgroups per CU (apds_dev_match_lds_cap), which leaves
+                # between one frame's last match kernel and the next frame's first is measured with events; if at least three of
+                # six consecutive gaps exceed 2 ms the match kernel's occupancy is capped at two workgroups per CU (apds_dev_match_lds_cap), which leaves
                 # wave slots free for the other stages at ~1.5 % of match throughput.
                 watch = self.adaptive_cap and self.match_workers == 1
                 pending, gaps, prev = [], [], None
@@ -376,7 +377,7 @@ class StreamedFramePipeline:
                         s["ev_match"].record(stream)
                         if watch:
                             s["ev_mend"].record(stream)
-                            if prev is not None and s["index"] >= 2:
+                            if prev is not None and s["index"] >= 4:           # the first frames are the pipeline filling up
                                 pending.append((prev["ev_mend"], s["ev_mstart"]))
                             prev = s
                             while pending and pending[0][1].query():       # both recorded before it, both complete
@@ -387,10 +388,13 @@ class StreamedFramePipeline:
                                     continue
                                 if 0.0 <= g < 1000.0:
                                     gaps.append(g)
-                            if len(gaps) >= 3 and sorted(gaps[-3:])[1] > 1.5:
+                                    self.gap_log.append(g)
+                            # with two extraction workers late frames arrive in pairs (gaps alternate long / short), and one long
+                            # stall (an allocation, a page fault storm) is not starvation: at least three of the last six gaps
+                            if len(gaps) >= 6 and sum(1 for g in gaps[-6:] if g > 2.0) >= 3:
                                 old = C.c_int(0)
                                 check(L.apds_dev_match_lds_cap(55000, C.byref(old)))
-                                self.cap_events.append(dict(frame=s["index"], gaps_ms=[round(g, 2) for g in gaps[-3:]], previous=old.value))
+                                self.cap_events.append(dict(frame=s["index"], gaps_ms=[round(g, 2) for g in gaps[-6:]], previous=old.value))
                                 watch = False
                         q2.put(s)
                     with done_lock:

@@ -229,6 +229,9 @@ int apds_stream_destroy(void* stream);
  * otherwise live as long as the thread; nothing is freed from thread-exit destructors, which may run after the HIP runtime has
  * shut down). Call it before a worker thread that used the library exits; the thread may use the library again afterwards. */
 int apds_thread_release(void);
+/* apds_thread_release keeps the thread's device workspace in a process-wide cache (a later thread reuses it instead of allocating);
+ * this frees everything in that cache. */
+int apds_release_cached_memory(void);
 
 /* Test hook: run apds_akaze_extract and copy one intermediate plane of evolution level `level` to out_plane
  * (which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet as f32 w*h; 7 keypoint mask after cross-level suppression as u8 w*h; 8 contrast factor, 1 float). */
