@@ -872,6 +872,10 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     if (fork_doh)
         for (int i = 1; i < L; i++) lsm[i] = c.alloc_n<float>((size_t)ev[i].w * ev[i].h);
     hipStream_t s_doh = fork_doh ? c.side_stream() : s;
+    if (fork_doh && c.fork_open) {   // an earlier call failed between fork and join: its side-stream kernels may still use the workspace
+        HIP_CHECK(hipStreamSynchronize(s_doh));
+        c.fork_open = false;
+    }
     // ---- a1.4 / a1.5 per level: Lsmooth -> (Lx, Ly, Ldet) and flow; FED steps ping-pong into Lt[i]
     for (int i = 0; i < L; i++) {
         LevelDesc& e = ev[i];
@@ -928,6 +932,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         deriv_weights(e.sigma_size, kside, kmid);
         // a1.5 + a1.6: first / second derivatives, determinant, and the level's 3x3 extrema (mask + candidate list)
         if (fork_doh && i == 0) {   // level 0: Lsmooth is Lt[0], ready after the base stage
+            c.fork_open = true;
             HIP_CHECK(hipEventRecord(c.fork_event(0), s));
             HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
         }
@@ -938,6 +943,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, hipEventDisableTiming));
         HIP_CHECK(hipEventRecord(c.join_event, s_doh));
         HIP_CHECK(hipStreamWaitEvent(s, c.join_event, 0));
+        c.fork_open = false;
     }
     HIP_CHECK(hipGetLastError());
 

@@ -63,6 +63,7 @@ struct ThreadCtx {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork_events;
     hipEvent_t join_event = nullptr;
+    bool fork_open = false;                     // side-stream work was issued and not yet joined (only after an error in between)
     hipStream_t side_stream();                  // created on first use
     hipEvent_t fork_event(size_t i);            // i-th reusable event (no timing)
 
