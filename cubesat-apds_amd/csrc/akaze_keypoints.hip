@@ -993,9 +993,13 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
                 fprintf(stderr, "\n");
             }
             HIP_CHECK(hipMemsetAsync(pend_count, 0, 3 * AKAZE_MAX_LEVELS * PEND_PITCH * sizeof(int), s));
-            // rounds are cheap once only the still-pending candidates are visited, a host check costs a stream sync: run 8
-            // rounds before the first look, then 4 at a time (a typical frame needs ~6 rounds in phase 0 and ~16 in phase 1)
-            for (int batch = 8;; batch = 4) {
+            // rounds are cheap once only the still-pending candidates are visited, a host check costs a stream sync: the first
+            // batch is as long as this thread's previous image needed in this phase (8 at first; a typical frame needs ~6
+            // rounds in phase 0 and ~15 in phase 1), then 4 at a time. Rounds after convergence change nothing.
+            int& first_batch = c.akaze_first_batch[phase];
+            const int fb = std::min(32, std::max(4, first_batch));
+            bool first = true;
+            for (int batch = fb;; batch = 4) {
                 for (int b = 0; b < batch; b++) {
                     const uint8_t stamp = (uint8_t)(round % 253 + 1);
                     // after a few rounds only a handful of candidates are left: a small grid keeps the launch itself short
@@ -1015,7 +1019,19 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
                 HIP_CHECK(hipMemcpyAsync(pc, pend_count + ((round - 1) % 3) * AKAZE_MAX_LEVELS * PEND_PITCH, sizeof(pc), hipMemcpyDeviceToHost, s));
                 HIP_CHECK(hipStreamSynchronize(s));
                 for (int i = 0; i < L; i++) pending += pc[i * PEND_PITCH];
-                if (pending == 0) break;
+                if (pending == 0) {
+                    // converged within the first batch: after eight such images in a row try one round less; otherwise start from
+                    // what this image took
+                    if (!first) {
+                        first_batch = round;
+                        c.akaze_batch_streak[phase] = 0;
+                    } else if (++c.akaze_batch_streak[phase] >= 8) {
+                        first_batch = std::max(4, fb - 1);
+                        c.akaze_batch_streak[phase] = 0;
+                    }
+                    break;
+                }
+                first = false;
                 APDS_REQUIRE(round < 1000000, APDS_ERR_INTERNAL, "cross-level suppression did not converge");
             }
         }

@@ -63,6 +63,8 @@ struct ThreadCtx {
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> fork_events;
     hipEvent_t join_event = nullptr;
+    int akaze_first_batch[2] = {8, 8};          // suppression rounds to launch before the first host check, per phase (adaptive)
+    int akaze_batch_streak[2] = {0, 0};
     bool fork_open = false;                     // side-stream work was issued and not yet joined (only after an error in between)
     hipStream_t side_stream();                  // created on first use
     hipEvent_t fork_event(size_t i);            // i-th reusable event (no timing)
