@@ -294,63 +294,96 @@ __global__ void merge_topk_kernel(const uint64_t* __restrict__ parts_keys, int p
     for (int k = 0; k < K; k++) out[(size_t)qi * K + k] = best[k];
 }
 
-// Merge of the per-chunk records of hamming_topk_kernel: one wave per query tile (lane = the T queries it owned in the match
-// kernel) walks the chunks; a present key expands to (distance << 32 | row offset + p * rows_per_chunk + row_base). `extra`
-// (nq x K 64-bit keys, may be null) is one more already-expanded sorted list (the sample pass).
+// Merge of the per-chunk records of hamming_topk_kernel. One BLOCK per query tile (lane = the T queries it owned in the match
+// kernel): its four waves take every fourth chunk each, four chunks per trip with all of a trip's loads issued before the first
+// insertion (a wave walking all chunks one by one was a chain of 360 dependent memory round trips: 0.23 ms for 138 waves on an
+// otherwise idle GPU), then wave 0 folds the other waves' lists into its own through LDS. A present key expands to
+// (distance << 32 | row offset + p * rows_per_chunk + row_base); keys are unique, so the K smallest do not depend on the order of
+// insertion. `extra` (nq x K 64-bit keys, may be null) is one more already-expanded sorted list (the sample pass).
+template <int K>
+__device__ __forceinline__ void topk_insert(uint64_t (&best)[K], uint64_t key) {
+    if (key < best[K - 1]) {
+        bool placed = false;
+#pragma unroll
+        for (int j = K - 1; j > 0; j--) {
+            if (!placed) {
+                if (best[j - 1] > key) best[j] = best[j - 1];
+                else {
+                    best[j] = key;
+                    placed = true;
+                }
+            }
+        }
+        if (!placed) best[0] = key;
+    }
+}
+
 template <int T, int K>
 __global__ __launch_bounds__(256) void merge_records_kernel(const uint32_t* __restrict__ recs, int parts, int rows_per_chunk, uint32_t row_base,
                                                             const uint64_t* __restrict__ extra, int nq, uint64_t* __restrict__ out) {
     APDS_RAISE_WAVE_PRIORITY();
     using Rec = PartRecord<T, K>;
+    constexpr int G = T * K <= 8 ? 4 : 1;       // chunks per trip (the wide records of large k: one)
+    __shared__ uint64_t s_best[3][T * K][64];   // lists of waves 1..3
     const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_wtiles = (nq + 64 * T - 1) / (64 * T);
-    const int wtile = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (wtile >= n_wtiles) return;
+    const int wtile = blockIdx.x;
     uint64_t best[T][K];
 #pragma unroll
     for (int t = 0; t < T; t++) {
         const int qi = wtile * 64 * T + t * 64 + lane;
 #pragma unroll
-        for (int k = 0; k < K; k++) best[t][k] = (extra && qi < nq) ? extra[(size_t)qi * K + k] : EMPTY_KEY;   // a sorted list: a valid start
+        for (int k = 0; k < K; k++) best[t][k] = (wave == 0 && extra && qi < nq) ? extra[(size_t)qi * K + k] : EMPTY_KEY;   // a sorted list: a valid start
     }
     const uint64_t lt = (1ull << lane) - 1;
-    for (int p = 0; p < parts; p++) {
-        const uint32_t* rec = recs + ((size_t)p * n_wtiles + wtile) * Rec::PITCH;
-        uint64_t masks[Rec::SLOTS];
+    for (int p0 = wave; p0 < parts; p0 += 4 * G) {
+        uint32_t keys[G][Rec::SLOTS];
 #pragma unroll
-        for (int s = 0; s < Rec::SLOTS; s++) masks[s] = (uint64_t)rec[2 * s] | ((uint64_t)rec[2 * s + 1] << 32);   // wave-uniform
-        uint32_t keys[Rec::SLOTS];
-        int base = 0;
+        for (int g = 0; g < G; g++) {           // all loads of the trip first
+            const int p = p0 + 4 * g;
+            const bool live = p < parts;        // wave-uniform
+            const uint32_t* rec = recs + ((size_t)(live ? p : p0) * n_wtiles + wtile) * Rec::PITCH;
+            int base = 0;
 #pragma unroll
-        for (int s = 0; s < Rec::SLOTS; s++) {   // all loads of the record first, then the insertions
-            const bool present = (masks[s] >> lane) & 1;
-            keys[s] = present ? rec[Rec::HEADER + base + __popcll(masks[s] & lt)] : 0xFFFFFFFFu;
-            base += __popcll(masks[s]);
+            for (int s = 0; s < Rec::SLOTS; s++) {
+                const uint64_t m = live ? ((uint64_t)rec[2 * s] | ((uint64_t)rec[2 * s + 1] << 32)) : 0ull;   // wave-uniform
+                const bool present = (m >> lane) & 1;
+                keys[g][s] = present ? rec[Rec::HEADER + base + __popcll(m & lt)] : 0xFFFFFFFFu;
+                base += __popcll(m);
+            }
         }
-        const uint32_t chunk_base = (uint32_t)p * (uint32_t)rows_per_chunk + row_base;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const uint32_t chunk_base = (uint32_t)(p0 + 4 * g) * (uint32_t)rows_per_chunk + row_base;
+#pragma unroll
+            for (int t = 0; t < T; t++)
+#pragma unroll
+                for (int k = 0; k < K; k++) {
+                    const uint32_t part = keys[g][t * K + k];
+                    if (part == 0xFFFFFFFFu) continue;   // distance 1023 cannot occur: "absent"
+                    topk_insert<K>(best[t], ((uint64_t)(part >> PART_ROW_BITS) << 32) |
+                                                (uint64_t)(uint32_t)((part & ((1u << PART_ROW_BITS) - 1)) + chunk_base));
+                }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < T; t++)
+#pragma unroll
+            for (int k = 0; k < K; k++) s_best[wave - 1][t * K + k][lane] = best[t][k];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; w++)
 #pragma unroll
         for (int t = 0; t < T; t++)
 #pragma unroll
             for (int k = 0; k < K; k++) {
-                const uint32_t part = keys[t * K + k];
-                if (part == 0xFFFFFFFFu) continue;   // distance 1023 cannot occur: "absent"
-                const uint64_t key = ((uint64_t)(part >> PART_ROW_BITS) << 32) | (uint64_t)(uint32_t)((part & ((1u << PART_ROW_BITS) - 1)) + chunk_base);
-                if (key < best[t][K - 1]) {
-                    bool placed = false;
-#pragma unroll
-                    for (int j = K - 1; j > 0; j--) {
-                        if (!placed) {
-                            if (best[t][j - 1] > key) best[t][j] = best[t][j - 1];
-                            else {
-                                best[t][j] = key;
-                                placed = true;
-                            }
-                        }
-                    }
-                    if (!placed) best[t][0] = key;
-                }
+                const uint64_t key = s_best[w][t * K + k][lane];
+                if (key != EMPTY_KEY) topk_insert<K>(best[t], key);
             }
-    }
 #pragma unroll
     for (int t = 0; t < T; t++) {
         const int qi = wtile * 64 * T + t * 64 + lane;
@@ -539,7 +572,7 @@ std::atomic<int>& match_lds_cap() {
 static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false, bool one_query_per_lane = false) {
     ChunkPlan p;
     static const int forced_t = env_int("APDS_MATCH_T", 0);
-    static const int target_waves = env_int("APDS_MATCH_TARGET_WAVES", 256 * 4 * 4 * 12);
+    static const int target_waves = env_int("APDS_MATCH_TARGET_WAVES", 256 * 4 * 4 * 24);
     static const int min_rows_main = env_int("APDS_MATCH_MIN_ROWS", 1024);
     static const int min_rows_sample = env_int("APDS_MATCH_SAMPLE_MIN_ROWS", 256);
     static const int sample_t = env_int("APDS_MATCH_SAMPLE_T", 1);
@@ -618,7 +651,7 @@ static size_t record_words(int nq, const ChunkPlan& p) {   // u32 words of the r
 
 template <int K>
 static void merge_records_launch(const uint32_t* recs, const ChunkPlan& p, uint32_t row_base, const uint64_t* extra, int nq, uint64_t* out, hipStream_t s) {
-    const dim3 grid(ceil_div(ceil_div(nq, 64 * p.T), 4)), block(256);
+    const dim3 grid(ceil_div(nq, 64 * p.T)), block(256);   // one block per query tile
     switch (p.T) {
         case 4: hipLaunchKernelGGL((merge_records_kernel<4, K>), grid, block, 0, s, recs, p.chunks, p.rows_per_chunk, row_base, extra, nq, out); break;
         case 2: hipLaunchKernelGGL((merge_records_kernel<2, K>), grid, block, 0, s, recs, p.chunks, p.rows_per_chunk, row_base, extra, nq, out); break;

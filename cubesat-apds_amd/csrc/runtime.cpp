@@ -212,7 +212,19 @@ int apds_thread_release(void) {
         c.fork_events.clear();
         if (c.join_event) (void)hipEventDestroy(c.join_event);
         c.join_event = nullptr;
-        for (auto& s : c.slabs) cache_slab(c.device, s);   // the stream(s) were synchronised above: nothing uses them any more
+        // the stream(s) were synchronised above: nothing uses the slabs any more. A thread that ends before its second call still
+        // holds the chain of doubling slabs of its first one: hand ONE slab of the total size to the cache (the next thread would
+        // otherwise start from a fragment, grow and consolidate inside somebody's timed region, with a device-wide sync).
+        if (c.slabs.size() > 1) {
+            size_t total = 0;
+            for (auto& s : c.slabs) total += s.second;
+            for (auto& s : c.slabs) (void)hipFree(s.first);
+            c.slabs.clear();
+            char* p = nullptr;
+            if (hipMalloc(&p, total) == hipSuccess) c.slabs.emplace_back(p, total);
+            else (void)hipGetLastError();
+        }
+        for (auto& s : c.slabs) cache_slab(c.device, s);
         c.slabs.clear();
         c.slab_used = 0;
         (void)hipStreamDestroy(c.stream);

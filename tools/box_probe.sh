@@ -1,11 +1,11 @@
 #!/bin/bash
-# Streamed bench repeated on whatever box this lands on (looking for sporadic stalls).
+# Streamed bench with 2 / 3 extraction workers, interleaved, on whatever box this lands on.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for w in 1 2 3 4 5 6; do
-  python3 $R/bench.py --no-cpu-baseline > /tmp/bp.json 2>/dev/null
+for w in 2 3 2 3; do
+  APDS_EXTRACT_WORKERS=$w python3 $R/bench.py --no-cpu-baseline > /tmp/bp.json 2>/dev/null
   python3 - $w <<'PY'
 import json, sys
 j = json.load(open("/tmp/bp.json"))
-print("run", sys.argv[1], round(j["value"], 3), "fps", round(j["ms_per_step"], 3), "ms", {k: round(v, 2) for k, v in j["stages_ms_per_step"].items()}, j["config"]["match_occupancy_cap"], "gap", j["config"].get("match_stream_gap_ms"), flush=True)
+print("workers", sys.argv[1], round(j["value"], 3), "fps", round(j["ms_per_step"], 3), "ms", {k: round(v, 2) for k, v in j["stages_ms_per_step"].items()}, j["config"]["match_occupancy_cap"], "gap", j["config"].get("match_stream_gap_ms"), flush=True)
 PY
 done
