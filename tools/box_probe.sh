@@ -1,11 +1,12 @@
 #!/bin/bash
-# Streamed bench with 2 / 3 extraction workers, interleaved, on whatever box this lands on.
+# Streamed bench under a few settings, interleaved, on whatever box this lands on.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-for w in 2 3 2 3; do
-  APDS_EXTRACT_WORKERS=$w python3 $R/bench.py --no-cpu-baseline > /tmp/bp.json 2>/dev/null
-  python3 - $w <<'PY'
+for cfg in "0 2" "40000 2" "33000 2" "0 2" "40000 2"; do
+  set -- $cfg
+  APDS_MATCH_LDS_CAP=$1 APDS_EXTRACT_WORKERS=$2 python3 $R/bench.py --no-cpu-baseline > /tmp/bp.json 2>/dev/null
+  python3 - $1 $2 <<'PY'
 import json, sys
 j = json.load(open("/tmp/bp.json"))
-print("workers", sys.argv[1], round(j["value"], 3), "fps", round(j["ms_per_step"], 3), "ms", {k: round(v, 2) for k, v in j["stages_ms_per_step"].items()}, j["config"]["match_occupancy_cap"], "gap", j["config"].get("match_stream_gap_ms"), flush=True)
+print("cap", sys.argv[1], "workers", sys.argv[2], round(j["value"], 3), "fps", round(j["ms_per_step"], 3), "ms", {k: round(v, 2) for k, v in j["stages_ms_per_step"].items()}, "gap", j["config"].get("match_stream_gap_ms"), flush=True)
 PY
 done
