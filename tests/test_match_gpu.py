@@ -10,7 +10,8 @@ def _bits(a, b):
 
 
 @pytest.mark.parametrize("nq,nt,k", [(1, 2, 2), (3, 5, 2), (64, 64, 2), (65, 4097, 2), (1000, 10000, 2), (257, 33333, 1),
-                                     (5000, 20000, 2), (20000, 3001, 2)])
+                                     (5000, 20000, 2), (20000, 3001, 2),
+                                     (9000, 70000, 2), (20000, 50000, 2)])   # 2 / 4 queries per lane with a threshold pass and many chunks
 def test_knn_match_equals_oracle(gpu_pkg, oracle_mod, nq, nt, k):
     db = gpu_pkg.synth.make_descriptor_db(nt, seed=0x44420001 + nt)
     q, _ = gpu_pkg.synth.make_queries(db, nq, seed=0x51550001 + nq)
