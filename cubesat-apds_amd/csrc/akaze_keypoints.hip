@@ -105,10 +105,36 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
         const int x = e & 0xFFFF, y = e >> 16;
         const size_t p = (size_t)y * w + x;
         if (status[p] != ST_PENDING) continue;   // wave-uniform
+        // The first trip of BOTH windows (four 64-element slabs each) and the candidate's own response are loaded before anything is
+        // evaluated: the neighbour search of the other level does not depend on the readiness test, so its memory round trip overlaps
+        // the readiness one instead of following it (a round is bound by one candidate's chain of dependent loads). A blocked
+        // candidate discards the search; a ready candidate's search window cannot be touched by another candidate of the same round
+        // (that is what "ready" means), so reading it early sees the same bytes.
+        const int px = A.phase == 0 ? x * diff : x / diff, py = A.phase == 0 ? y * diff : y / diff;
+        uint8_t sv[4], mv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = u * 64 + lane;
+            sv[u] = 0;
+            if (idx < total) {
+                const int ry = idx / W, rx = idx - ry * W;
+                const int yy = y - D + ry, xx = x - D + rx;
+                if (yy >= 0 && xx >= 0 && xx < w && (yy < y || xx < x)) sv[u] = status[(size_t)yy * w + xx];
+            }
+            mv[u] = 0;
+            if (idx < total2) {
+                const int iy = idx / side, ix = idx - iy * side;
+                const int ii = py - radius + iy, jj = px - radius + ix;
+                if (ii >= 0 && ii < oh && jj >= 0 && jj < ow) mv[u] = omask[(size_t)ii * ow + jj];
+            }
+        }
+        const float own_response = A.Ldet[lvl][p];
         // ready iff no EARLIER (row-major) keypoint of this level within D is pending or finished only in this round
-        // (four 64-element slabs per trip: the loads of a trip are independent, so their latencies overlap)
-        bool blocked = false;
-        for (int base = 0; base < total && !blocked; base += 256) {
+        bool hit0 = false;
+#pragma unroll
+        for (int u = 0; u < 4; u++) hit0 |= sv[u] == ST_PENDING || sv[u] == stamp;
+        bool blocked = __any(hit0);
+        for (int base = 256; base < total && !blocked; base += 256) {
             bool hit = false;
 #pragma unroll
             for (int u = 0; u < 4; u++) {
@@ -124,6 +150,49 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
             }
             blocked = __any(hit);
         }
+        int found = -1;
+        if (!blocked) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) {   // first hit in row-major order: lowest slab, lowest lane
+                const int idx = u * 64 + lane;
+                bool ok = false;
+                if (mv[u]) {
+                    const int iy = idx / side, ix = idx - iy * side;
+                    const int dx = ix - radius, dy = iy - radius;
+                    ok = dx * dx + dy * dy <= radius * radius;
+                }
+                const unsigned long long bb = __ballot(ok);
+                if (found < 0 && bb) {
+                    const int first = u * 64 + __ffsll((long long)bb) - 1;
+                    const int iy = first / side, ix = first - iy * side;
+                    found = (py - radius + iy) * ow + (px - radius + ix);
+                }
+            }
+            for (int base = 256; base < total2 && found < 0; base += 256) {   // (windows wider than 16 x 16: none with AKAZE's parameters)
+                unsigned long long b[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int idx = base + u * 64 + lane;
+                    bool ok = false;
+                    if (idx < total2) {
+                        const int iy = idx / side, ix = idx - iy * side;
+                        const int ii = py - radius + iy, jj = px - radius + ix;
+                        if (ii >= 0 && ii < oh && jj >= 0 && jj < ow && omask[(size_t)ii * ow + jj]) {
+                            const int dx = jj - px, dy = ii - py;
+                            ok = dx * dx + dy * dy <= radius * radius;
+                        }
+                    }
+                    b[u] = __ballot(ok);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (found < 0 && b[u]) {
+                        const int first = base + u * 64 + __ffsll((long long)b[u]) - 1;
+                        const int iy = first / side, ix = first - iy * side;
+                        found = (py - radius + iy) * ow + (px - radius + ix);
+                    }
+            }
+        }
         if (blocked) {
             if (lane == 0) {
                 const int slot = atomicAdd(&s_n, 1);
@@ -132,34 +201,8 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
             }
             continue;
         }
-        const int px = A.phase == 0 ? x * diff : x / diff, py = A.phase == 0 ? y * diff : y / diff;
-        int found = -1;
-        for (int base = 0; base < total2 && found < 0; base += 256) {
-            unsigned long long b[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const int idx = base + u * 64 + lane;
-                bool ok = false;
-                if (idx < total2) {
-                    const int iy = idx / side, ix = idx - iy * side;
-                    const int ii = py - radius + iy, jj = px - radius + ix;
-                    if (ii >= 0 && ii < oh && jj >= 0 && jj < ow && omask[(size_t)ii * ow + jj]) {
-                        const int dx = jj - px, dy = ii - py;
-                        ok = dx * dx + dy * dy <= radius * radius;
-                    }
-                }
-                b[u] = __ballot(ok);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-                if (found < 0 && b[u]) {   // first hit in row-major order: lowest slab, lowest lane
-                    const int first = base + u * 64 + __ffsll((long long)b[u]) - 1;
-                    const int iy = first / side, ix = first - iy * side;
-                    found = (py - radius + iy) * ow + (px - radius + ix);
-                }
-        }
         if (lane == 0) {
-            if (found >= 0 && A.Ldet[lvl][p] > A.Ldet[other][found]) A.mask[other][found] = 0;
+            if (found >= 0 && own_response > A.Ldet[other][found]) A.mask[other][found] = 0;
             status[p] = stamp;
         }
     }
