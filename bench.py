@@ -255,6 +255,7 @@ def main():
                        "match_occupancy_cap": ({"lds_bytes": 55000, "set_at": pipe.cap_events[0]} if getattr(pipe, "cap_events", None) else
                                                {"lds_bytes": int(os.environ.get("APDS_MATCH_LDS_CAP", "0") or 0)}),
                        "match_stream_gap_ms": (round(float(np.mean(pipe.gap_log)), 3) if getattr(pipe, "gap_log", None) else None),
+                       "match_stream_gaps_ms_first16": ([round(float(g), 2) for g in pipe.gap_log[:16]] if getattr(pipe, "gap_log", None) else None),
                        "keypoints_per_frame": K, "matches_per_frame": float(np.mean([s["n_matches"] for s in stats])),
                        "inliers_per_frame": float(np.mean([s["n_inliers"] for s in stats])), "homography_found": all(s["H"] is not None for s in stats)},
             "mmatches_per_s": world * K * args.steps / elapsed / 1e6,
