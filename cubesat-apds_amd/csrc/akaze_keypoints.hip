@@ -431,18 +431,25 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
         }
     }
     __syncthreads();
-    // counting sort, identical to idx[--cum[b]] = i for ascending i: within a bin the larger sample index comes first
-    if (lane < 43) {
-        int cnt = 0;   // samples in bins < lane  -> start of bin `lane` (lane == 42 gives the total)
-        for (int k = 0; k < 109; k++) cnt += s_bin[wv][k] < lane;
-        s_start[wv][lane] = cnt;
-    }
-    __syncthreads();
-    for (int k = lane; k < 109; k += 64) {
-        const int b = s_bin[wv][k];
-        int later = 0;   // samples of the same bin with a larger index precede this one
-        for (int k2 = k + 1; k2 < 109; k2++) later += s_bin[wv][k2] == b;
-        s_sorted[wv][s_start[wv][b] + later] = (uint8_t)k;
+    // counting sort, identical to idx[--cum[b]] = i for ascending i: within a bin the larger sample index comes first. Every lane
+    // holds the bins of its samples lane and lane + 64; one ballot per bin gives the bin's population (prefix -> its start) and,
+    // masked to the higher lanes, how many same-bin samples with a larger index precede a sample (the 218 dependent LDS reads per lane
+    // that the two counting loops used to make were most of this kernel's time).
+    {
+        const int bin0 = s_bin[wv][lane];
+        const int bin1 = lane + 64 < 109 ? (int)s_bin[wv][lane + 64] : -1;
+        const unsigned long long higher = ~((2ull << lane) - 1);   // lanes above this one (none for lane 63)
+        int acc = 0, st_mine = 0, pos0 = 0, pos1 = 0;
+        for (int b = 0; b < 43; b++) {                              // b == 42: no sample, st_mine becomes the total
+            const unsigned long long m0 = __ballot(bin0 == b), m1 = __ballot(bin1 == b);
+            if (lane == b) st_mine = acc;
+            if (bin0 == b) pos0 = acc + __popcll(m0 & higher) + __popcll(m1);   // every sample lane' + 64 has a larger index
+            if (bin1 == b) pos1 = acc + __popcll(m1 & higher);
+            acc += __popcll(m0) + __popcll(m1);
+        }
+        if (lane < 43) s_start[wv][lane] = st_mine;
+        s_sorted[wv][pos0] = (uint8_t)lane;
+        if (bin1 >= 0) s_sorted[wv][pos1] = (uint8_t)(lane + 64);
     }
     __syncthreads();
     float sumX = 0.0f, sumY = 0.0f, norm = -1.0f;
