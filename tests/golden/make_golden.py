@@ -7,6 +7,8 @@ akaze_256.npz      : synthetic 256x256 BGRA tile (frame 5) -> keypoints (cv::Key
 hamming_1k_4k.npz  : 1000 queries x 4000 train rows (seeded) -> top-2 indices and distances, ratio(0.3) and cross-check matches
 homography_200.npz : 200 point pairs (40 % inliers) -> H (RANSAC, thr 3) and inlier mask
 ingest.npz         : band_merger / warp_perspective expected bytes for seeded inputs
+pnp_400.npz        : 400 3D-2D correspondences (60 % inliers) -> solvePnPRansac pose + inlier indices, EPnP and P3P
+world_coordinates.npz : 500 mosaic pixels -> ECEF through two geotransforms and a seeded elevation raster
 """
 import os
 import sys
@@ -51,5 +53,33 @@ def main():
     np.savez_compressed(os.path.join(HERE, "ingest.npz"), rgba=oracle.band_merger(*bands, mm), warped=oracle.warp_perspective(img, M))
 
 
+def pnp_inputs():
+    obj, img, K, _, _, _ = synth.make_pnp_set(400, seed=0x504E5000 + 400, inlier_frac=0.6, noise=0.5)
+    return obj, img, K
+
+
+def world_inputs():
+    rng = np.random.default_rng(20261004)
+    dgt = [9.0, 1e-4, 0.0, 57.0, 0.0, -1e-4]
+    egt = [8.99, 3e-4, 1e-7, 57.01, 2e-7, -3e-4]
+    yy, xx = np.mgrid[0:300, 0:400]
+    elevation = 80 + 60 * np.sin(xx / 37.0) * np.cos(yy / 23.0) + rng.uniform(0, 3, (300, 400))
+    xy = rng.uniform(0, 700, (500, 2))
+    return xy, dgt, egt, elevation
+
+
+def main_extra():
+    obj, img, K = pnp_inputs()
+    out = {}
+    for name, method in (("epnp", 1), ("p3p", 2)):
+        rc, r, t, idx = oracle.solve_pnp_ransac(obj, img, K, 500, 3.0, 0.99, method)
+        out.update({name + "_rc": rc, name + "_rvec": r, name + "_tvec": t, name + "_inliers": idx})
+    np.savez_compressed(os.path.join(HERE, "pnp_400.npz"), **out)
+    xy, dgt, egt, elevation = world_inputs()
+    rc, xyz = oracle.world_coordinates(xy, dgt, egt, elevation)
+    np.savez_compressed(os.path.join(HERE, "world_coordinates.npz"), rc=rc, xyz=xyz)
+
+
 if __name__ == "__main__":
     main()
+    main_extra()
