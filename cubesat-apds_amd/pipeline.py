@@ -360,7 +360,7 @@ class StreamedFramePipeline:
                 # extraction kernels are dispatched so late under the match kernel, which owns every wave slot, that extraction
                 # paces the pipeline (36 ms per frame instead of 30, seen on about one box in eight). The gap on the match stream
                 # between one frame's last match kernel and the next frame's first is measured with events; if at least three of
-                # six consecutive gaps exceed 2 ms the match kernel's occupancy is capped at two workgroups per CU (apds_dev_match_lds_cap), which leaves
+                # six consecutive gaps exceed 4 ms (the healthy pattern is 0.01 / 1.2 ms alternating) the match kernel's occupancy is capped at two workgroups per CU (apds_dev_match_lds_cap), which leaves
                 # wave slots free for the other stages at ~1.5 % of match throughput.
                 watch = self.adaptive_cap and self.match_workers == 1
                 pending, gaps, prev = [], [], None
@@ -391,7 +391,7 @@ class StreamedFramePipeline:
                                     self.gap_log.append(g)
                             # with two extraction workers late frames arrive in pairs (gaps alternate long / short), and one long
                             # stall (an allocation, a page fault storm) is not starvation: at least three of the last six gaps
-                            if len(gaps) >= 6 and sum(1 for g in gaps[-6:] if g > 2.0) >= 3:
+                            if len(gaps) >= 6 and sum(1 for g in gaps[-6:] if g > 4.0) >= 3:
                                 old = C.c_int(0)
                                 check(L.apds_dev_match_lds_cap(55000, C.byref(old)))
                                 self.cap_events.append(dict(frame=s["index"], gaps_ms=[round(g, 2) for g in gaps[-6:]], previous=old.value))
