@@ -277,6 +277,7 @@ class StreamedFramePipeline:
         E = self.extract_workers
         q_free = [self.queue.Queue() for _ in range(E)]      # per extraction worker: its own slots
         q_ext = [self.queue.Queue() for _ in range(E)]       # per extraction worker: its finished frames, in its order
+        q_any = self.queue.Queue()                           # tokens: which worker finished a frame (arrival order)
         for s in self.slots:
             q_free[s["owner"]].put(s)
         results = [None] * count
@@ -294,7 +295,7 @@ class StreamedFramePipeline:
                     errors.append(e)
                     q1.put(None)
                     q2.put(None)
-                    for q in q_ext + q_free:
+                    for q in q_ext + q_free + [q_any]:
                         q.put(None)
                 finally:
                     try:
@@ -333,6 +334,7 @@ class StreamedFramePipeline:
                         if self.debug_extract_delay > 0:       # test hook: emulate a box on which extraction cannot keep up
                             time.sleep(self.debug_extract_delay)
                         q_ext[e].put(s)
+                        q_any.put(e)
                     if timing:
                         ms, k = _lib.kernel_ms("akaze_extract")
                         with timer_lock:
@@ -341,13 +343,29 @@ class StreamedFramePipeline:
             return extract_worker
 
         def order_worker():
-            # frames back into order; the host-side count exchange of a sharded DB (one gloo collective per frame, which
-            # every rank must issue in the same order) happens here, so the match thread stays free of host synchronisation
-            for i in range(count):
-                s = q_ext[i % E].get()
+            # Sharded DB: frames back into order; the host-side count exchange (one gloo collective per frame, which every rank
+            # must issue in the same order) happens here, so the match thread stays free of host synchronisation.
+            # One GPU: no collective, so nothing requires frame order on the match stream (results are stored by frame index):
+            # frames go to the match first come, first served. One of the two extraction workers tends to finish just after
+            # a match ends (its last kernels only run freely once the match kernel is gone); in frame order the match stream then
+            # waited ~1.2 ms for every second frame, now it takes the other worker's next frame, which is already there.
+            if self.matcher.world > 1:
+                for i in range(count):
+                    s = q_ext[i % E].get()
+                    if s is None:
+                        return
+                    s["counts"] = self.matcher.exchange_counts(s["K"])
+                    q1.put(s)
+                q1.put(None)
+                return
+            for _ in range(count):
+                e = q_any.get()            # a worker's token: its next finished frame is in q_ext[e]
+                if e is None:
+                    return
+                s = q_ext[e].get()
                 if s is None:
                     return
-                s["counts"] = self.matcher.exchange_counts(s["K"])
+                s["counts"] = [int(s["K"])]
                 q1.put(s)
             q1.put(None)
 
