@@ -22,9 +22,9 @@ SYMBOLS = [
     "apds_last_error", "apds_free", "apds_device_count", "apds_set_device", "apds_build_info", "apds_thread_release", "apds_release_cached_memory",
     "apds_akaze_extract", "apds_tile_extract", "apds_get_knn_matches", "apds_get_bruteforce_matches", "apds_knn_match",
     "apds_get_points_from_matches", "apds_find_homography", "apds_find_homography_ex", "apds_raster_to_mat",
-    "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_match_lds_cap", "apds_dev_ratio_filter",
+    "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_match_lds_cap", "apds_dev_match_last_launch_lds", "apds_dev_ratio_filter",
     "apds_dev_cross_check", "apds_dev_akaze_extract", "apds_dev_points_from_matches", "apds_dev_find_homography",
-    "apds_dev_valu_popcount_peak", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane", "apds_stream_create", "apds_stream_destroy",
+    "apds_dev_valu_popcount_peak", "apds_dev_valu_peak", "apds_dev_valu_peak_modes", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane", "apds_stream_create", "apds_stream_destroy",
     "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective", "apds_pnp_solver_ransac", "apds_pnp_hypotheses", "apds_get_world_coordinates", "apds_l2_knn_match", "apds_dev_l2_topk",
     "apds_db_create", "apds_db_destroy", "apds_db_rows", "apds_db_insert_image", "apds_db_select", "apds_db_view", "apds_db_view_download", "apds_db_knn_match",
 ]
@@ -77,12 +77,15 @@ def lib():
             "apds_dev_hamming_topk": (i, [vp, i, vp, i64, u32, i, vp, vp]),
             "apds_dev_merge_topk": (i, [vp, i, i, i, vp, vp]),
             "apds_dev_match_lds_cap": (i, [i, ip]),
+            "apds_dev_match_last_launch_lds": (i, [ip]),
             "apds_dev_ratio_filter": (i, [vp, i, i, f, vp, ip, vp]),
             "apds_dev_cross_check": (i, [vp, i64, i, vp, ip, vp]),
             "apds_dev_akaze_extract": (i, [vp, i, i, i, sz, i, vp, vp, i, ip, vp]),
             "apds_dev_points_from_matches": (i, [vp, i, vp, i, vp, i, i, vp, vp, vp]),
             "apds_dev_find_homography": (i, [vp, vp, i, i, d, i, d, vp, vp, vp]),
             "apds_dev_valu_popcount_peak": (i, [C.POINTER(d)]),
+            "apds_dev_valu_peak": (i, [i, i, C.POINTER(d), C.POINTER(d), C.POINTER(C.c_char_p)]),
+            "apds_dev_valu_peak_modes": (i, []),
             "apds_dev_last_kernel_ms": (i, [C.c_char_p, C.POINTER(f), ip]),
             "apds_dev_timing_enable": (i, [i]),
             "apds_akaze_debug_plane": (i, [vp, i, i, i, sz, i, i, vp]),

@@ -193,6 +193,13 @@ int apds_dev_match_lds_cap(int bytes, int* previous) {
     });
 }
 
+int apds_dev_match_last_launch_lds(int* bytes) {
+    return guarded([&] {
+        APDS_REQUIRE(bytes, APDS_ERR_BAD_ARG, "null output");
+        *bytes = last_scan_launch_lds().load();
+    });
+}
+
 int apds_dev_merge_topk(const void* parts, int nparts, int nq, int k, void* out_keys, void* stream) {
     return guarded([&] { merge_topk_device(static_cast<const uint64_t*>(parts), nparts, nq, k, static_cast<uint64_t*>(out_keys), pick_stream(stream)); });
 }
@@ -239,5 +246,17 @@ int apds_dev_valu_popcount_peak(double* lane_ops_per_s) {
         *lane_ops_per_s = valu_popcount_peak_device();
     });
 }
+
+int apds_dev_valu_peak(int mode, int waves_per_simd, double* lane_ops_per_s, double* cycles_per_inst, const char** name) {
+    return guarded([&] {
+        APDS_REQUIRE(mode >= 0 && mode < valu_peak_modes(), APDS_ERR_BAD_ARG, "mode out of range");
+        APDS_REQUIRE(waves_per_simd >= 1 && waves_per_simd <= 8, APDS_ERR_BAD_ARG, "1 <= waves_per_simd <= 8");
+        ctx().ws_reset();
+        if (name) *name = valu_peak_mode_name(mode);
+        valu_peak_device(mode, waves_per_simd, lane_ops_per_s, cycles_per_inst);
+    });
+}
+
+int apds_dev_valu_peak_modes(void) { return valu_peak_modes(); }
 
 }  // extern "C"

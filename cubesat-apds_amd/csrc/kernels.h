@@ -13,6 +13,9 @@ int* scan_flags_device(const uint8_t* flags, int n, int** total_dev, hipStream_t
 int ratio_filter_device(const uint64_t* keys, int nq, int k, float fs, apds_dmatch* out, hipStream_t s);
 int cross_check_device(const uint64_t* train_best, long long n_train, int nq, apds_dmatch* out, hipStream_t s);
 double valu_popcount_peak_device();
+int valu_peak_modes();
+const char* valu_peak_mode_name(int mode);
+void valu_peak_device(int mode, int waves_per_simd, double* lane_ops_per_s, double* cycles_per_inst);
 
 // akaze.hip
 int akaze_extract_device(const void* img, int rows, int cols, int channels, size_t stride, int max_points, apds_keypoint* kps,
@@ -23,6 +26,7 @@ void rgba_to_bgra_device(const uint8_t* rgba, size_t n_pixels, uint8_t* bgra, hi
 
 // ingest.hip
 std::atomic<int>& match_lds_cap();   // match_hamming.hip: occupancy cap of the main Hamming scan
+std::atomic<int>& last_scan_launch_lds();
 void band_merger_device(const float* r, const float* g, const float* b, size_t n, const double* mm, int bgra, uint8_t* out, hipStream_t s);
 void warp_perspective_device(const uint8_t* src, int rows, int cols, const double* M, int dst_rows, int dst_cols, uint8_t* dst, hipStream_t s);
 

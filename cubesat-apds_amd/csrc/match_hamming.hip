@@ -16,6 +16,7 @@
 // unsigned 64-bit min reproduces BFMatcher's order (distance, then lower train index).
 #include <atomic>
 #include <cstdlib>
+#include <vector>
 
 #include "common.h"
 
@@ -54,13 +55,34 @@ __device__ __forceinline__ int bcnt_acc(uint32_t x, int acc) {
 // on top of start[t] = -threshold. M-LDB uses 486 bits, so dword 15 holds at most 6 set bits of the XOR: if the bound
 // is already >= threshold the pair cannot be a hit, and dword 15 is only looked at in the rare hit path.
 // 30 VALU ops per pair instead of 32.
+//
+// Issue order (measured, profiles/r02/valu_calib.log): on a gfx950 SIMD a VOP2 v_xor_b32 takes 2 issue cycles and the VOP3
+// v_bcnt_u32_b32 takes 4, but one wave issues at most one VALU op per 4-cycle window, so an xor only costs 2 when the xor of
+// ANOTHER wave shares its window. With the waves of a SIMD running the plain stream xor, bcnt, xor, bcnt, ... in step that
+// pairing rarely happens (3.83 cycles per op, 38.5 T lane-ops/s chip-wide); an `s_nop 0` between each xor and the bcnt that
+// consumes it takes the wave out of step with its neighbours and the pairs settle at 2 + 4 cycles (2.9 per op, 50.7 T lane-ops/s,
+// 99 % of the 6-cycle pair). A nop after every op, or the xor issued one or two steps ahead, does not: only this placement.
+#ifndef APDS_PAIR_NOP
+#define APDS_PAIR_NOP 1
+#endif
 template <int T>
 __device__ __forceinline__ void row_distances(const u32x16 row, const uint32_t (&q)[T][16], const int (&start)[T], int (&acc)[T]) {
 #pragma unroll
     for (int t = 0; t < T; t++) {
         int a = start[t];
 #pragma unroll
-        for (int j = 0; j < 15; j++) a = bcnt_acc(q[t][j] ^ row[j], a);
+        for (int j = 0; j < 15; j++) {
+#if APDS_PAIR_NOP
+            const uint32_t x = q[t][j] ^ row[j];
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 0");
+            __builtin_amdgcn_sched_barrier(0);
+            a = bcnt_acc(x, a);
+            __builtin_amdgcn_sched_barrier(0);
+#else
+            a = bcnt_acc(q[t][j] ^ row[j], a);
+#endif
+        }
         acc[t] = a;
     }
 }
@@ -524,29 +546,164 @@ __global__ __launch_bounds__(SCAN_BLOCK) void emit_ratio_matches_kernel(const ui
 }
 
 // ---- register-only VALU microbenchmark (denominator of the popcount roofline) ---------------------------
-// MODE 0: the match kernel's inner pair (v_xor with an SGPR operand + accumulating v_bcnt); 1: v_xor only;
-// 2: v_bcnt only; 3: v_add_u32 only. All count one lane-op per instruction per lane.
+// One instruction kind per MODE, eight independent chains per lane, nothing but that instruction in the loop body (the loop
+// counter is scalar). Modes 0-3 and 8-10 are 32-bit integer ops, 4-7 and 11 are FP32 ops issued by the same waves on the same
+// SIMDs, so one run shows whether the integer ops the match kernel is made of issue at the FP32 rate or at half of it.
+//   0 v_xor_b32(sgpr, vgpr) + v_bcnt_u32_b32 accumulate: the match kernel's inner pair (two lane-ops per pair)
+//   1 v_xor_b32 (sgpr operand)   2 v_bcnt_u32_b32 accumulate   3 v_add_u32 (sgpr operand)
+//   4 v_fma_f32   5 v_add_f32   6 v_pk_fma_f32 (two FMAs per lane per instruction)   7 v_pk_add_f32 (two adds)
+//   8 v_xor_b32 (vgpr, vgpr)   9 v_bfi_b32 (VOP3, three vgprs)   10 v_and_b32 (vgpr, vgpr)   11 v_mul_f32
+// Modes 12-17 replay the ISSUE PATTERN of the match kernel's inner loop (one train row in 15 SGPRs against 4 queries of 15 dwords
+// in VGPRs = 60 xor + 60 bcnt per row) in different instruction orders, to find the order the SIMD issues fastest:
+//   12 query-sequential, one dependent chain per query (xor t,s_j,q_cj ; bcnt a_c,t,a_c for j = 0..14, then the next query): the
+//      order hipcc emits for row_distances()        13 dword-major (the four queries' chains interleaved round-robin)
+//   14 = 13 with the xor of step i+1 issued before the bcnt of step i (two temporaries)      15 = 13 with the row first copied to
+//   VGPRs (15 v_mov per row, not counted) so the xor has no SGPR operand      16 = 12 skewed like 14      17 = 13 with two xors
+//   ahead (three temporaries)
+// Every wave also leaves its s_memtime span, so the host can state cycles per wave-instruction per SIMD without assuming a clock.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static constexpr int VALU_MODES = 22;
+static constexpr int VALU_CHAINS = 8, VALU_UNROLL = 16;
+
 template <int MODE>
-__global__ __launch_bounds__(256) void valu_peak_kernel(uint32_t* __restrict__ sink, int iters) {
-    uint32_t q[16];
+__global__ __launch_bounds__(256) void valu_peak_kernel(uint32_t* __restrict__ sink, unsigned long long* __restrict__ spans, int iters,
+                                                        const u32x16* __restrict__ rowp) {
+    extern __shared__ uint32_t occupancy_pad[];   // dynamic LDS request only bounds the workgroups per CU
+    if (MODE >= 12) {
+        uint32_t q4[4][15];
+        int a[4];
 #pragma unroll
-    for (int j = 0; j < 16; j++) q[j] = threadIdx.x * 2654435761u + j * 40503u;
-    int acc[4] = {0, 1, 2, 3};
+        for (int c = 0; c < 4; c++) {
+            a[c] = c;
+#pragma unroll
+            for (int j = 0; j < 15; j++) q4[c][j] = threadIdx.x * 2654435761u + (c * 16 + j) * 40503u + 1u;
+        }
+        // the row is reloaded every iteration (wave-uniform address: s_load_dwordx16, as in the match kernel), one row ahead; the
+        // xor is plain C and the accumulate is bcnt_acc(), as in row_distances(); sched_barrier(0) pins the order under test
+        // (two adjacent inline-asm VALU ops make hipcc insert an s_nop between them, which the match kernel's loop does not have)
+        u32x16 row = rowp[blockIdx.x & 7];
+        const unsigned long long t0 = __builtin_readcyclecounter();
+        for (int it = 0; it < iters; it++) {
+            const u32x16 next = rowp[(blockIdx.x + it + 1) & 7];
+#define APDS_X(tmp, j, c) { tmp = row[j] ^ q4[c][j]; __builtin_amdgcn_sched_barrier(0); }
+#define APDS_XV(tmp, j, c) { tmp = rv[j] ^ q4[c][j]; __builtin_amdgcn_sched_barrier(0); }
+#define APDS_B(tmp, c) { a[c] = bcnt_acc(tmp, a[c]); __builtin_amdgcn_sched_barrier(0); }
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 12) {
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int j = 0; j < 15; j++) { uint32_t t; APDS_X(t, j, c); APDS_B(t, c); }
+            } else if (MODE == 18) {      // 12 with an s_nop between every xor and the bcnt that consumes it
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int j = 0; j < 15; j++) { uint32_t t; APDS_X(t, j, c); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0); APDS_B(t, c); }
+            } else if (MODE == 19) {      // 13 with the s_nop
+#pragma unroll
+                for (int j = 0; j < 15; j++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { uint32_t t; APDS_X(t, j, c); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0); APDS_B(t, c); }
+            } else if (MODE == 20) {      // 12 with an s_nop after EVERY instruction
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int j = 0; j < 15; j++) {
+                        uint32_t t;
+                        APDS_X(t, j, c); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0);
+                        APDS_B(t, c); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0);
+                    }
+            } else if (MODE == 21) {      // 12 with ONE SGPR for the whole row (row[0]) instead of fifteen
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int j = 0; j < 15; j++) { uint32_t t; t = row[0] ^ q4[c][j]; __builtin_amdgcn_sched_barrier(0); APDS_B(t, c); }
+            } else if (MODE == 13) {
+#pragma unroll
+                for (int j = 0; j < 15; j++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { uint32_t t; APDS_X(t, j, c); APDS_B(t, c); }
+            } else if (MODE == 14 || MODE == 17) {
+                constexpr int AHEAD = MODE == 17 ? 2 : 1;
+                uint32_t t[60];
+#pragma unroll
+                for (int i = 0; i < 60 + AHEAD; i++) {
+                    if (i < 60) APDS_X(t[i], i >> 2, i & 3);
+                    if (i >= AHEAD) APDS_B(t[i - AHEAD], (i - AHEAD) & 3);
+                }
+            } else if (MODE == 15) {
+                uint32_t rv[15];
+#pragma unroll
+                for (int j = 0; j < 15; j++) { asm volatile("v_mov_b32 %0, %1" : "=v"(rv[j]) : "s"(row[j])); }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 15; j++)
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { uint32_t t; APDS_XV(t, j, c); APDS_B(t, c); }
+            } else {   // 16: query-sequential, skewed by one
+                uint32_t t[60];
+#pragma unroll
+                for (int i = 0; i < 61; i++) {
+                    if (i < 60) APDS_X(t[i], i % 15, i / 15);
+                    if (i >= 1) APDS_B(t[i - 1], (i - 1) / 15);
+                }
+            }
+#undef APDS_X
+#undef APDS_XV
+#undef APDS_B
+            row = next;
+        }
+        const unsigned long long t1 = __builtin_readcyclecounter();
+        if ((a[0] + a[1] + a[2] + a[3]) == 0x7fffffff) sink[0] = 1;
+        if ((threadIdx.x & 63) == 0) spans[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+        return;
+    }
+    uint32_t q[VALU_UNROLL];
+#pragma unroll
+    for (int j = 0; j < VALU_UNROLL; j++) q[j] = threadIdx.x * 2654435761u + j * 40503u + 1u;
+    uint32_t acc[VALU_CHAINS];
+    float facc[VALU_CHAINS];
+    f32x2 pacc[VALU_CHAINS];
+#pragma unroll
+    for (int c = 0; c < VALU_CHAINS; c++) {
+        acc[c] = c + threadIdx.x;
+        facc[c] = 1.0f + 0.001f * (float)(c + (threadIdx.x & 7));
+        pacc[c] = f32x2{facc[c], facc[c] * 0.5f};
+    }
+    const float fm = 0.99999f, fa = 1e-6f;
+    const f32x2 pm = {0.99999f, 0.99998f}, pa = {1e-6f, 2e-6f};
     uint32_t s = blockIdx.x * 97u + 1u;
+    const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; it++) {
 #pragma unroll
-        for (int j = 0; j < 16; j++) {
+        for (int j = 0; j < VALU_UNROLL; j++) {
 #pragma unroll
-            for (int c = 0; c < 4; c++) {
-                if (MODE == 0) acc[c] = bcnt_acc(q[j] ^ (s + c), acc[c]);
-                else if (MODE == 1) { uint32_t r; asm volatile("v_xor_b32 %0, %1, %2" : "=v"(r) : "s"(s + c), "v"((uint32_t)acc[c])); acc[c] = (int)r; }
-                else if (MODE == 2) acc[c] = bcnt_acc(q[j], acc[c]);
-                else { uint32_t r; asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "s"(s + c), "v"((uint32_t)acc[c])); acc[c] = (int)r; }
+            for (int c = 0; c < VALU_CHAINS; c++) {
+                if (MODE == 0) {
+                    uint32_t x;
+                    asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "s"(s), "v"(q[j]));
+                    asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[c]) : "v"(x));
+                } else if (MODE == 1) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(acc[c]) : "s"(s));
+                else if (MODE == 2) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(acc[c]) : "v"(q[j]));
+                else if (MODE == 3) asm volatile("v_add_u32 %0, %1, %0" : "+v"(acc[c]) : "s"(s));
+                else if (MODE == 4) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(facc[c]) : "v"(fm), "v"(fa));
+                else if (MODE == 5) asm volatile("v_add_f32 %0, %1, %0" : "+v"(facc[c]) : "v"(fa));
+                else if (MODE == 6) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pacc[c]) : "v"(pm), "v"(pa));
+                else if (MODE == 7) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pacc[c]) : "v"(pa));
+                else if (MODE == 8) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(acc[c]) : "v"(q[j]));
+                else if (MODE == 9) asm volatile("v_bfi_b32 %0, %0, %1, %2" : "+v"(acc[c]) : "v"(q[j]), "v"(q[(j + 1) & (VALU_UNROLL - 1)]));
+                else if (MODE == 10) asm volatile("v_and_b32 %0, %1, %0" : "+v"(acc[c]) : "v"(q[j]));
+                else asm volatile("v_mul_f32 %0, %1, %0" : "+v"(facc[c]) : "v"(fm));
             }
         }
         s = s * 1664525u + 1013904223u;
     }
-    if ((acc[0] + acc[1] + acc[2] + acc[3]) == 0x7fffffff) sink[0] = 1;
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    uint32_t fold = 0;
+#pragma unroll
+    for (int c = 0; c < VALU_CHAINS; c++) fold += acc[c] + __float_as_uint(facc[c]) + __float_as_uint(pacc[c].x) + __float_as_uint(pacc[c].y);
+    if (fold == 0x7fffffffu) sink[0] = 1;
+    if ((threadIdx.x & 63) == 0) spans[(size_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
 // ---- host launchers -------------------------------------------------------------------------------------
@@ -561,6 +718,12 @@ static int env_int(const char* name, int dflt) {
 
 // Occupancy cap of the main scan (bytes of unused dynamic LDS per workgroup; 0 = none), process-wide: APDS_MATCH_LDS_CAP at first
 // use, then apds_dev_match_lds_cap(). See launch_topk.
+// dynamic-LDS bytes the most recent scan launch of the process was made with (test hook: the cap reaches every kernel variant)
+std::atomic<int>& last_scan_launch_lds() {
+    static std::atomic<int> v{-1};
+    return v;
+}
+
 std::atomic<int>& match_lds_cap() {
     static std::atomic<int> cap{env_int("APDS_MATCH_LDS_CAP", 0)};
     return cap;
@@ -606,10 +769,16 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, cons
     const u32x16* tr = static_cast<const u32x16*>(t);
     const u32x4* qq = static_cast<const u32x4*>(q);
     const int items = p.qtiles_blocks * p.chunks;
+    // Occupancy cap: the kernels use no LDS, so an (unused) dynamic LDS request of `cap` bytes per workgroup bounds the
+    // workgroups resident per CU (160 KB / cap). Two waves per SIMD already issue at full VALU rate; capping there leaves
+    // registers, wave slots and the rest of the LDS free, so the short kernels of the other pipeline stages are dispatched
+    // at once instead of waiting for a match wave to retire. Applies to every variant of the scan (all T, all K, persistent).
+    const size_t cap = (size_t)std::max(0, match_lds_cap().load(std::memory_order_relaxed));
+    last_scan_launch_lds().store((int)cap, std::memory_order_relaxed);
     if (K > 2) {   // larger k keeps K (distance, index) pairs per query in registers: one query per lane
         dim3 grid((unsigned)(ceil_div(p.chunks, 8) * 8 * p.qtiles_blocks)), block(256);
         KernelTimer timer(timer_name, s);
-        hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks,
+        hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks,
                            p.chunks, 0);
         HIP_CHECK(hipGetLastError());
         return;
@@ -620,24 +789,19 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, cons
         dim3 grid(256 * persist), block(256);
         KernelTimer timer(timer_name, s);
         switch (p.T) {
-            case 4: hipLaunchKernelGGL((hamming_topk_persistent_kernel<4, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
-            case 2: hipLaunchKernelGGL((hamming_topk_persistent_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
-            default: hipLaunchKernelGGL((hamming_topk_persistent_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
+            case 4: hipLaunchKernelGGL((hamming_topk_persistent_kernel<4, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
+            case 2: hipLaunchKernelGGL((hamming_topk_persistent_kernel<2, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
+            default: hipLaunchKernelGGL((hamming_topk_persistent_kernel<1, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
         }
         HIP_CHECK(hipGetLastError());
         return;
     }
     dim3 grid((unsigned)(ceil_div(p.chunks, 8) * 8 * p.qtiles_blocks)), block(256);
-    // Occupancy cap: the kernel uses no LDS, so an (unused) dynamic LDS request of `cap` bytes per workgroup bounds the
-    // workgroups resident per CU (160 KB / cap). Two waves per SIMD already issue at full VALU rate; capping there leaves
-    // registers, wave slots and the rest of the LDS free, so the short kernels of the other pipeline stages are dispatched
-    // at once instead of waiting for a match wave to retire.
-    const int cap = match_lds_cap().load(std::memory_order_relaxed);
     KernelTimer timer(timer_name, s);
     switch (p.T) {
-        case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, (size_t)cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;
-        case 2: hipLaunchKernelGGL((hamming_topk_kernel<2, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;
-        default: hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, 0, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;
+        case 4: hipLaunchKernelGGL((hamming_topk_kernel<4, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;
+        case 2: hipLaunchKernelGGL((hamming_topk_kernel<2, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;
+        default: hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, xcd); break;
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -789,39 +953,108 @@ int cross_check_device(const uint64_t* train_best, long long n_train, int nq, ap
     return total;
 }
 
+// One launch configuration of the microbenchmark: `waves_per_simd` workgroups of 256 threads resident per CU (one wave of each
+// on every SIMD; bounded through an unused dynamic-LDS request), a grid eight rounds deep.
+struct ValuPeak {
+    double lane_ops_per_s;      // wall clock (HIP events), lane-ops as defined per mode (a packed instruction counts two)
+    double cycles_per_inst;     // s_memtime cycles per wave-instruction per SIMD = mean wave span / (instructions per wave * waves per SIMD)
+};
+
 template <int MODE>
-static double run_valu_peak(uint32_t* sink, hipStream_t st) {
-    const int iters = 4096, blocks = 256 * 8;
+static ValuPeak run_valu_peak(int waves_per_simd, hipStream_t st) {
+    ThreadCtx& c = ctx();
+    const int w = std::min(std::max(waves_per_simd, 1), 8);
+    const int iters = 2048, cus = 256, blocks = cus * w * 8;
+    uint32_t* sink = c.alloc_n<uint32_t>(64);
+    unsigned long long* spans = c.alloc_n<unsigned long long>((size_t)blocks * 4);
+    // 160 KB of LDS per CU: a request of 160 KB / w (minus the granule) admits exactly w workgroups
+    const size_t lds = w >= 8 ? 0 : (size_t)(160 * 1024 / w) - (w == 1 ? 0 : 1024);
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&valu_peak_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a));
     HIP_CHECK(hipEventCreate(&b));
-    hipLaunchKernelGGL((valu_peak_kernel<MODE>), dim3(blocks), dim3(256), 0, st, sink, 64);
-    double best = 0;
-    for (int rep = 0; rep < 5; rep++) {
+    u32x16* rowp = reinterpret_cast<u32x16*>(c.alloc_n<uint32_t>(16 * 8));
+    {
+        uint32_t h[16 * 8];
+        for (int i = 0; i < 16 * 8; i++) h[i] = 0x9E3779B9u * (uint32_t)(i + 1);
+        HIP_CHECK(hipMemcpyAsync(rowp, h, sizeof(h), hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL((valu_peak_kernel<MODE>), dim3(blocks), dim3(256), lds, st, sink, spans, 32, rowp);
+    ValuPeak best{0, 0};
+    std::vector<unsigned long long> host((size_t)blocks * 4);
+    const double per_inst = MODE == 0 ? 1 : ((MODE == 6 || MODE == 7) ? 2 : 1);   // lane-ops per instruction per lane
+    const double insts_per_wave = MODE >= 12 ? (double)iters * 120 : (double)iters * VALU_UNROLL * VALU_CHAINS * (MODE == 0 ? 2 : 1);
+    for (int rep = 0; rep < 3; rep++) {
         HIP_CHECK(hipEventRecord(a, st));
-        hipLaunchKernelGGL((valu_peak_kernel<MODE>), dim3(blocks), dim3(256), 0, st, sink, iters);
+        hipLaunchKernelGGL((valu_peak_kernel<MODE>), dim3(blocks), dim3(256), lds, st, sink, spans, iters, rowp);
         HIP_CHECK(hipEventRecord(b, st));
         HIP_CHECK(hipEventSynchronize(b));
         float ms = 0;
         HIP_CHECK(hipEventElapsedTime(&ms, a, b));
-        const double ops = (double)blocks * 256 * (double)iters * 16 * 4 * (MODE == 0 ? 2 : 1);
-        best = std::max(best, ops / (ms * 1e-3));
+        const double ops = (double)blocks * 256 * insts_per_wave * per_inst;
+        if (ops / (ms * 1e-3) > best.lane_ops_per_s) {
+            HIP_CHECK(hipMemcpy(host.data(), spans, host.size() * 8, hipMemcpyDeviceToHost));
+            double sum = 0;
+            for (unsigned long long v : host) sum += (double)v;
+            best.lane_ops_per_s = ops / (ms * 1e-3);
+            best.cycles_per_inst = sum / (double)host.size() / (insts_per_wave * w);
+        }
     }
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     return best;
 }
 
-// lane-ops/s of the xor+bcnt pair; if APDS_VALU_PROBE is set also prints the single-instruction rates
-double valu_popcount_peak_device() {
-    ThreadCtx& c = ctx();
-    uint32_t* sink = c.alloc_n<uint32_t>(64);
-    const double pair = run_valu_peak<0>(sink, c.stream);
-    if (getenv("APDS_VALU_PROBE")) {
-        fprintf(stderr, "[apds] VALU lane-ops/s: xor+bcnt %.3e  xor %.3e  bcnt %.3e  add_u32 %.3e\n", pair, run_valu_peak<1>(sink, c.stream),
-                run_valu_peak<2>(sink, c.stream), run_valu_peak<3>(sink, c.stream));
+int valu_peak_modes() { return VALU_MODES; }
+
+const char* valu_peak_mode_name(int mode) {
+    static const char* names[VALU_MODES] = {"v_xor_b32(s,v)+v_bcnt_u32_b32", "v_xor_b32(s,v)", "v_bcnt_u32_b32", "v_add_u32(s,v)", "v_fma_f32", "v_add_f32",
+                                            "v_pk_fma_f32", "v_pk_add_f32", "v_xor_b32(v,v)", "v_bfi_b32", "v_and_b32(v,v)", "v_mul_f32",
+                                            "row x 4 queries: query-sequential", "row x 4 queries: dword-major", "dword-major, xor 1 ahead",
+                                            "dword-major, row in VGPRs", "query-sequential, xor 1 ahead", "dword-major, xor 2 ahead",
+                                            "query-sequential + s_nop before each bcnt", "dword-major + s_nop before each bcnt",
+                                            "query-sequential + s_nop after every op", "query-sequential, one SGPR"};
+    return mode >= 0 && mode < VALU_MODES ? names[mode] : "?";
+}
+
+void valu_peak_device(int mode, int waves_per_simd, double* lane_ops_per_s, double* cycles_per_inst) {
+    hipStream_t st = ctx().stream;
+    ValuPeak r{0, 0};
+    switch (mode) {
+        case 0: r = run_valu_peak<0>(waves_per_simd, st); break;
+        case 1: r = run_valu_peak<1>(waves_per_simd, st); break;
+        case 2: r = run_valu_peak<2>(waves_per_simd, st); break;
+        case 3: r = run_valu_peak<3>(waves_per_simd, st); break;
+        case 4: r = run_valu_peak<4>(waves_per_simd, st); break;
+        case 5: r = run_valu_peak<5>(waves_per_simd, st); break;
+        case 6: r = run_valu_peak<6>(waves_per_simd, st); break;
+        case 7: r = run_valu_peak<7>(waves_per_simd, st); break;
+        case 8: r = run_valu_peak<8>(waves_per_simd, st); break;
+        case 9: r = run_valu_peak<9>(waves_per_simd, st); break;
+        case 10: r = run_valu_peak<10>(waves_per_simd, st); break;
+        case 11: r = run_valu_peak<11>(waves_per_simd, st); break;
+        case 12: r = run_valu_peak<12>(waves_per_simd, st); break;
+        case 13: r = run_valu_peak<13>(waves_per_simd, st); break;
+        case 14: r = run_valu_peak<14>(waves_per_simd, st); break;
+        case 15: r = run_valu_peak<15>(waves_per_simd, st); break;
+        case 16: r = run_valu_peak<16>(waves_per_simd, st); break;
+        case 17: r = run_valu_peak<17>(waves_per_simd, st); break;
+        case 18: r = run_valu_peak<18>(waves_per_simd, st); break;
+        case 19: r = run_valu_peak<19>(waves_per_simd, st); break;
+        case 20: r = run_valu_peak<20>(waves_per_simd, st); break;
+        case 21: r = run_valu_peak<21>(waves_per_simd, st); break;
+        default: fail(APDS_ERR_BAD_ARG, "valu peak: mode out of range");
     }
-    return pair;
+    if (lane_ops_per_s) *lane_ops_per_s = r.lane_ops_per_s;
+    if (cycles_per_inst) *cycles_per_inst = r.cycles_per_inst;
+}
+
+// lane-ops/s of the xor+bcnt pair at full occupancy: the denominator bench.py divides the match kernel by
+double valu_popcount_peak_device() {
+    double v = 0;
+    valu_peak_device(0, 8, &v, nullptr);
+    return v;
 }
 
 }  // namespace apds

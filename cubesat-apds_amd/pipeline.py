@@ -46,10 +46,11 @@ class HipBackend:
         check(lib().apds_dev_hamming_topk(q_rows64.data_ptr(), nq, train_rows64.data_ptr(), nt, int(index_base), k, out.data_ptr(), torch_stream()))
         return out
 
-    def merge(self, parts, k):
-        """parts: [P, Q, k] int64 -> [Q, k]"""
+    def merge(self, parts, k, out=None):
+        """parts: [P, Q, k] int64 (contiguous) -> [Q, k]"""
         p, q = parts.shape[0], parts.shape[1]
-        out = torch.empty((q, k), dtype=torch.int64, device=parts.device)
+        if out is None:
+            out = torch.empty((q, k), dtype=torch.int64, device=parts.device)
         check(lib().apds_dev_merge_topk(parts.data_ptr(), p, q, k, out.data_ptr(), torch_stream()))
         return out
 
@@ -64,16 +65,57 @@ def _gather_into(dist, group, dst, src):
         dist.all_gather_into_tensor(dst.view(-1), src.view(-1), group=group)
 
 
-class ShardedMatcher:
-    """Hamming k-NN of per-rank query sets against a row-sharded resident DB."""
+def _all_to_all_into(dist, group, dst, src, out_splits, in_splits):
+    """all_to_all_single on flat tensors (gloo rehearsal with device tensors: staged through the host)."""
+    if dist.get_backend(group) == "gloo" and src.is_cuda:
+        d, s = torch.empty(dst.shape, dtype=dst.dtype), src.cpu()
+        dist.all_to_all_single(d, s, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        dst.copy_(d)
+    else:
+        dist.all_to_all_single(dst, src, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
 
-    def __init__(self, local_rows64, index_base, group=None, backend=None, pad_rows=32768, meta_group=None):
+
+class GatheredQueries:
+    """One frame's query exchange buffers (allocated once, reused every frame that goes through the same slot):
+    `mine` = this rank's rows padded to the common row count, `gathered` = every rank's padded rows, `all_q` = the ranks' rows
+    back to back without padding (what the local shard is scanned with), `local` = this shard's top-k of all of them,
+    `recv` = every shard's top-k of THIS rank's queries, `merged` = their u64-min merge."""
+
+    def __init__(self, world, pad, kmax, device):
+        self.world, self.pad, self.kmax = world, pad, kmax          # pad = capacity in rows per rank
+        self.mine = torch.zeros((pad, 64), dtype=torch.uint8, device=device)
+        self.gathered = torch.empty(world * pad * 64, dtype=torch.uint8, device=device)
+        self.all_q = torch.empty((world * pad, 64), dtype=torch.uint8, device=device)
+        self.local = torch.empty(world * pad * kmax, dtype=torch.int64, device=device)
+        self.recv = torch.empty(world * pad * kmax, dtype=torch.int64, device=device)
+        self.merged = torch.empty(pad * kmax, dtype=torch.int64, device=device)
+        self.counts, self.total, self.nq = None, 0, 0
+        self.event = torch.cuda.Event() if torch.device(device).type == "cuda" else None
+
+
+class ShardedMatcher:
+    """Hamming k-NN of per-rank query sets against a row-sharded resident DB.
+
+    Per frame: (1) all-gather of the ranks' query rows (fixed pad, so the message size never changes); (2) local top-k of ALL
+    queries against the local shard, keys carry global row indices; (3) all-to-all of the keys: rank r sends rank s the
+    [counts[s], k] block of s's queries and receives [counts[r], k] from every shard (1/world of what an all-gather of the
+    keys moves); (4) u64-min merge of the `world` candidate lists per query = the single-GPU result, lowest-index tie-break
+    included. The three steps are separate calls (gather_queries / scan_gathered / exchange_merge) so that a pipeline can issue
+    frame i+1's query gather on another stream BEFORE frame i's key exchange: it then runs under frame i's scan. All collectives
+    use ONE communicator and must be issued by ONE thread in the same order on every rank (torch serialises them on the process
+    group's internal stream; two communicators driven from two threads could be launched in different orders on different ranks
+    and dead-lock). No per-frame allocations."""
+
+    def __init__(self, local_rows64, index_base, group=None, backend=None, pad_rows=32768, meta_group=None, kmax=2):
         self.rows = local_rows64
         self.index_base = int(index_base)
         self.group = group
         self.meta_group = meta_group      # optional host-side (gloo) group for the per-frame query counts
         self.backend = backend or HipBackend()
-        self.pad_rows = pad_rows
+        self.pad_rows = pad_rows          # smallest buffer capacity (rows per rank)
+        self.msg_round = 1024             # the query all-gather's row count is the frame's largest count rounded up to this
+        self.kmax = kmax
+        self._own = None                  # buffers of the plain knn() form
         if group is not None:
             import torch.distributed as dist
             self.dist = dist
@@ -95,9 +137,57 @@ class ShardedMatcher:
         self.dist.all_gather_into_tensor(o, t, group=self.meta_group)
         return [int(v) for v in o.tolist()]
 
+    def make_buffers(self, max_queries=None, k=None):
+        """Exchange buffers for frames of at most `max_queries` queries per rank (one set per frame in flight)."""
+        pad = max(self.pad_rows, int(max_queries or 0))
+        return GatheredQueries(self.world, pad, k or self.kmax, self.rows.device)
+
+    def gather_queries(self, q_rows64, counts, buf):
+        """Step (1) on the CURRENT stream, into `buf`: after it `buf.all_q[:buf.total]` holds every rank's queries."""
+        nq = q_rows64.shape[0]
+        assert counts[self.rank] == nq and max(counts) <= buf.pad and buf.world == self.world
+        buf.counts, buf.total, buf.nq = list(counts), int(sum(counts)), nq
+        buf.mine[:nq].copy_(q_rows64)
+        # message size of this frame: the largest count, rounded up (the buffers are sized for the capacity, the wire is not)
+        rows = min(buf.pad, max(self.msg_round, -(-max(counts) // self.msg_round) * self.msg_round))
+        gathered = buf.gathered[:self.world * rows * 64].view(self.world, rows, 64)
+        _gather_into(self.dist, self.group, gathered, buf.mine[:rows])
+        off = 0
+        for r, c in enumerate(counts):          # drop the padding: `world` slice copies into the preallocated block
+            if c:
+                buf.all_q[off:off + c].copy_(gathered[r, :c])
+            off += c
+        if buf.event is not None:
+            buf.event.record()
+        return buf
+
+    def scan_gathered(self, buf, k=2):
+        """Step (2) on the CURRENT stream: this shard's top-k of every gathered query (no collective)."""
+        assert k <= buf.kmax
+        if buf.event is not None:
+            torch.cuda.current_stream().wait_event(buf.event)
+        if buf.total:
+            self.backend.topk(buf.all_q[:buf.total], self.rows, self.index_base, k, out=buf.local[:buf.total * k].view(buf.total, k))
+
+    def exchange_merge(self, buf, k=2, out=None):
+        """Steps (3)-(4) on the CURRENT stream (the one scan_gathered ran on): all-to-all of the keys, then the per-query merge."""
+        world, nq, total = self.world, buf.nq, buf.total
+        recv = buf.recv[:world * nq * k]
+        _all_to_all_into(self.dist, self.group, recv, buf.local[:total * k], [nq * k] * world, [c * k for c in buf.counts])
+        dst = out[:nq] if out is not None else buf.merged[:nq * k].view(nq, k)
+        if nq:
+            self.backend.merge(recv.view(world, nq, k), k, out=dst)
+        return dst
+
+    def match_gathered(self, buf, k=2, out=None):
+        """Steps (2)-(4) on the CURRENT stream for a frame whose queries gather_queries() has put into `buf`."""
+        self.scan_gathered(buf, k)
+        return self.exchange_merge(buf, k, out=out)
+
     def knn(self, q_rows64, k=2, out=None, counts=None):
         """q_rows64: this rank's queries [Q_r, 64] u8. Returns [Q_r, k] int64 keys over the WHOLE DB. `counts`: every rank's
-        query count (exchange_counts); without it the counts are gathered on the device, which costs a host synchronisation."""
+        query count (exchange_counts); without it the counts are gathered on the device, which costs a host synchronisation.
+        Without `out` the result is a view of an internal buffer, valid until the next call."""
         be = self.backend
         if self.world == 1:
             if out is not None:
@@ -109,24 +199,10 @@ class ShardedMatcher:
             cnt = torch.zeros(self.world, dtype=torch.int64, device=dev)
             _gather_into(dist, self.group, cnt, torch.tensor([nq], dtype=torch.int64, device=dev))
             counts = [int(c) for c in cnt.tolist()]
-        assert counts[self.rank] == nq
-        pad = max(self.pad_rows, max(counts))
-        mine = torch.zeros((pad, 64), dtype=torch.uint8, device=dev)
-        mine[:nq] = q_rows64
-        gathered = torch.empty((self.world, pad, 64), dtype=torch.uint8, device=dev)
-        _gather_into(dist, self.group, gathered, mine)
-        all_q = torch.cat([gathered[r, :counts[r]] for r in range(self.world)], 0).contiguous()
-        local = be.topk(all_q, self.rows, self.index_base, k)            # [sum Q, k] against the local shard
-        total = all_q.shape[0]
-        parts = torch.empty((self.world, total, k), dtype=torch.int64, device=dev)
-        _gather_into(dist, self.group, parts, local.contiguous())   # per-shard top-k of every query
-        off = sum(counts[:self.rank])
-        own = parts[:, off:off + nq, :].contiguous()
-        merged = be.merge(own, k)
-        if out is not None:
-            out[:nq].copy_(merged)
-            return out[:nq]
-        return merged
+        if self._own is None or self._own.pad < max(counts) or self._own.kmax < k:
+            self._own = self.make_buffers(max(counts), max(k, self.kmax))
+        self.gather_queries(q_rows64, counts, self._own)
+        return self.match_gathered(self._own, k, out=out)
 
 
 class FramePipeline:
@@ -212,6 +288,8 @@ class StreamedFramePipeline:
         slots = max(slots, 2 * self.extract_workers)
         self.dev = torch.device(device)
         self.matcher = ShardedMatcher(db_rows64, index_base, group, meta_group=meta_group)
+        self._masked_stream_handle = None
+        self.cap_bytes = 0                # occupancy cap this pipeline runs its scans with (set by the starvation watch)
         self.n_db = db_xy.shape[0]
         kp = torch.zeros((self.n_db, 7), dtype=torch.float32, device=self.dev)
         kp[:, 0:2] = db_xy
@@ -228,7 +306,8 @@ class StreamedFramePipeline:
                      keys=torch.empty((self.cap, 2), dtype=torch.int64, device=self.dev), keys_view=None,
                      ev_extract=torch.cuda.Event(), ev_match=torch.cuda.Event(), K=0, M=0, index=0,
                      ev_mstart=torch.cuda.Event(enable_timing=True), ev_mend=torch.cuda.Event(enable_timing=True),
-                     owner=len(self.slots) % self.extract_workers)
+                     owner=len(self.slots) % self.extract_workers,
+                     gq=self.matcher.make_buffers(self.cap) if self.matcher.world > 1 else None)
             self.slots.append(s)
         # the match kernel alone fills every CU for ~30 ms; the short extraction / homography kernels get the high-priority
         # queues so that their blocks are dispatched as soon as match workgroups retire
@@ -244,7 +323,7 @@ class StreamedFramePipeline:
         self.gap_log = []                 # idle time of the match stream before each frame's match (ms), for diagnosis
         self.debug_extract_delay = float(os.environ.get("APDS_DEBUG_EXTRACT_DELAY_MS", "0")) * 1e-3
         self.match_workers = 2 if (group is None and os.environ.get("APDS_MATCH_WORKERS", "1") == "2") else 1
-        self.match_streams = [self.streams[1]] + [torch.cuda.Stream(self.dev, priority=0) for _ in range(self.match_workers - 1)]
+        self.gather_stream = torch.cuda.Stream(self.dev, priority=-1) if self.matcher.world > 1 else None
         if reserve_cus > 0:
             # keep `reserve_cus` CUs (spread evenly over the CU index space) out of the MATCH stream only
             words = (n_cus + 31) // 32
@@ -267,7 +346,22 @@ class StreamedFramePipeline:
             check(lib().apds_stream_create(0, _lib.ptr(mask), words, C.byref(h)))
             self._masked_stream_handle = h
             self.streams[1] = torch.cuda.ExternalStream(h.value, device=self.dev)
+        # built AFTER the CU-mask block: the match workers launch on these, so the masked stream must already be in place
+        self.match_streams = [self.streams[1]] + [torch.cuda.Stream(self.dev, priority=0) for _ in range(self.match_workers - 1)]
         torch.cuda.synchronize()
+
+    def close(self):
+        """Destroy the CU-masked match stream (if any). The pipeline must be idle."""
+        h, self._masked_stream_handle = self._masked_stream_handle, None
+        if h is not None:
+            torch.cuda.synchronize()
+            lib().apds_stream_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def run(self, frames, count, filter_strength=0.8, reproj_thr=3.0, max_iters=2000, confidence=0.995, timing=False):
         """Push `count` frames (cycled from `frames`) through the three stages. Returns (results in frame order, timers)."""
@@ -283,6 +377,13 @@ class StreamedFramePipeline:
         results = [None] * count
         timers, errors = {}, []
         dev_index = self.dev.index or 0
+        # The occupancy cap of the scan is process-wide in the library; a pipeline that decided to cap (starvation watch) applies
+        # its cap for the duration of its own runs only and puts the previous value back when the run ends.
+        cap_restore = [None]
+        if self.cap_bytes:
+            old = C.c_int(0)
+            check(L.apds_dev_match_lds_cap(self.cap_bytes, C.byref(old)))
+            cap_restore[0] = old.value
 
         def guarded(fn):
             def wrap():
@@ -372,6 +473,39 @@ class StreamedFramePipeline:
         done_lock = threading.Lock()
         alive = [self.match_workers]
 
+        def sharded_match_worker():
+            # Sharded DB: this thread issues ALL collectives of the run, in the same order on every rank: gather(i+1) [its own
+            # stream, waits only for frame i+1's extraction] BEFORE exchange(i) [match stream, after scan(i)], so the query
+            # all-gather of the next frame travels under the current frame's scan. Frame i's scan is launched before the thread
+            # blocks on frame i+1, so the GPU never waits for the host here.
+            stream, m, prev = self.match_streams[0], self.matcher, None
+            with torch.cuda.stream(stream):
+                while True:
+                    s = q1.get()
+                    if s is not None and s["counts"] is not None:
+                        with torch.cuda.stream(self.gather_stream):
+                            self.gather_stream.wait_event(s["ev_extract"])
+                            m.gather_queries(s["desc"][:s["K"]], s["counts"], s["gq"])
+                    if prev is not None:
+                        prev["keys_view"] = m.exchange_merge(prev["gq"], 2, out=prev["keys"])
+                        prev["ev_match"].record(stream)
+                        q2.put(prev)
+                        prev = None
+                    if s is None:
+                        break
+                    if s["counts"] is None:      # no host-side count exchange available: one-call form (synchronises the stream)
+                        stream.wait_event(s["ev_extract"])
+                        s["keys_view"] = m.knn(s["desc"][:s["K"]], 2, out=s["keys"])
+                        s["ev_match"].record(stream)
+                        q2.put(s)
+                        continue
+                    m.scan_gathered(s["gq"], 2)
+                    prev = s
+                if timing:
+                    for n in ("hamming_topk", "hamming_topk_sample"):
+                        timers[n] = _lib.kernel_ms(n)
+                q2.put(None)
+
         def make_match_worker(stream):
             def match_worker():
                 # Starvation watch (single match worker): the match stream should never wait for a frame. On some boxes the short
@@ -380,7 +514,7 @@ class StreamedFramePipeline:
                 # between one frame's last match kernel and the next frame's first is measured with events; if at least three of
                 # six consecutive gaps exceed 4 ms (the healthy pattern is 0.01 / 1.2 ms alternating) the match kernel's occupancy is capped at two workgroups per CU (apds_dev_match_lds_cap), which leaves
                 # wave slots free for the other stages at ~1.5 % of match throughput.
-                watch = self.adaptive_cap and self.match_workers == 1
+                watch = self.adaptive_cap and self.match_workers == 1 and self.cap_bytes == 0
                 pending, gaps, prev = [], [], None
                 with torch.cuda.stream(stream):
                     while True:
@@ -412,6 +546,8 @@ class StreamedFramePipeline:
                             if len(gaps) >= 6 and sum(1 for g in gaps[-6:] if g > 4.0) >= 3:
                                 old = C.c_int(0)
                                 check(L.apds_dev_match_lds_cap(55000, C.byref(old)))
+                                self.cap_bytes = 55000                 # this pipeline's later runs start capped; run() restores the
+                                cap_restore[0] = old.value if cap_restore[0] is None else cap_restore[0]   # process-wide value when it ends
                                 self.cap_events.append(dict(frame=s["index"], gaps_ms=[round(g, 2) for g in gaps[-6:]], previous=old.value))
                                 watch = False
                         q2.put(s)
@@ -457,12 +593,15 @@ class StreamedFramePipeline:
                     q_free[s["owner"]].put(s)
                 collect(["ransac_score"])
 
-        workers = [make_extract_worker(e) for e in range(E)] + [order_worker] + [make_match_worker(st) for st in self.match_streams] + [homography_worker]
+        match_stage = [sharded_match_worker] if self.matcher.world > 1 else [make_match_worker(st) for st in self.match_streams]
+        workers = [make_extract_worker(e) for e in range(E)] + [order_worker] + match_stage + [homography_worker]
         threads = [threading.Thread(target=guarded(f), daemon=True) for f in workers]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
+        if cap_restore[0] is not None:
+            check(L.apds_dev_match_lds_cap(cap_restore[0], None))
         if errors:
             raise errors[0]
         return results, timers

@@ -199,8 +199,11 @@ int apds_dev_merge_topk(const void* keys_parts, int parts, int n_query, int k, v
 /* Occupancy cap of the main Hamming scan, process-wide: the kernel requests `bytes` of (unused) dynamic LDS per workgroup, which bounds
  * the workgroups resident per CU (160 KB / bytes; 55000 -> two). A pipeline that overlaps the scan with short kernels of other stages
  * sets it when those kernels cannot get onto the GPU (the scan alone is ~1.5 % slower with the cap). 0 = none (default, or
- * APDS_MATCH_LDS_CAP). *previous (may be NULL) receives the old value. */
+ * APDS_MATCH_LDS_CAP). The value is process-wide: a caller that sets it for its own launches restores *previous afterwards. *previous (may be NULL) receives the old value. */
 int apds_dev_match_lds_cap(int bytes, int* previous);
+/* Test hook: the dynamic-LDS request of the most recent scan launch of the process (-1 before the first); equals the cap in force for
+ * every kernel variant (all tile widths, all k, persistent grid). */
+int apds_dev_match_last_launch_lds(int* bytes);
 /* Lowe ratio filter on merged keys (k >= 2): writes compacted matches in query order, count to *n_matches (host). */
 int apds_dev_ratio_filter(const void* keys, int n_query, int k, float filter_strength, void* out_matches, int* n_matches, void* stream);
 /* Cross-check: given for every train row its best query key (from apds_dev_hamming_topk with roles swapped, k=1),
@@ -245,6 +248,11 @@ int apds_pnp_hypotheses(const double* obj_xyz, const double* img_xy, int n, cons
 /* Measurement helpers used by bench.py (not part of the reference surface). */
 /* Register-only xor+popcount loop: returns measured lane-ops/s (32-bit xor + bcnt counted as 2 ops). */
 int apds_dev_valu_popcount_peak(double* lane_ops_per_s);
+/* Calibration of that denominator: the same register-only loop with ONE instruction kind (`mode`, 0 <= mode < apds_dev_valu_peak_modes():
+ * integer xor / bcnt / add / and / xor3 and FP32 fma / add / mul / pk_fma / pk_add; *name = the mnemonic) at `waves_per_simd` (1..8) resident
+ * waves per SIMD. Returns wall-clock lane-ops/s (a packed instruction counts two) and s_memtime cycles per wave-instruction per SIMD. */
+int apds_dev_valu_peak(int mode, int waves_per_simd, double* lane_ops_per_s, double* cycles_per_inst, const char** name);
+int apds_dev_valu_peak_modes(void);
 /* Time of the last hamming_topk main kernel launched by this thread, measured with hipEvents on its stream (ms). */
 int apds_dev_last_kernel_ms(const char* which, float* ms, int* launches);
 int apds_dev_timing_enable(int on);

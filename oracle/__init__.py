@@ -28,10 +28,29 @@ def build(force=False):
     return so
 
 
+_NATIVE = False
+
+
+def use_native():
+    """Switch to liboracle_native.so (-O3 -march=native), built here and now on this host (bench.py's cpu_baseline
+    leg). Returns the flags string reported with the baseline; on any build/load failure keeps the portable library."""
+    global _LIB, _NATIVE
+    so = os.path.join(_HERE, "liboracle_native.so")
+    try:
+        if os.path.exists(so):
+            os.remove(so)             # never trust a copy built on another host
+        subprocess.check_call(["make", "-C", _HERE, "liboracle_native.so"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        C.CDLL(so)
+    except Exception:
+        return "-O2 (portable build; the -O3 -march=native build failed on this host)"
+    _LIB, _NATIVE = None, True
+    return "-O3 -march=native -fopenmp -ffp-contract=off"
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.path.join(_HERE, "liboracle_native.so" if _NATIVE else "liboracle.so")
         if not os.path.exists(so):
             so = build()
         L = C.CDLL(so)

@@ -59,12 +59,41 @@ def test_starvation_watch_caps_the_match_kernel(gpu_pkg):
     L, check = gpu_pkg.lib(), gpu_pkg._lib.check
     streamed = pl.StreamedFramePipeline(db, db_xy)
     streamed.debug_extract_delay = 0.012                  # every frame reaches the match 12 ms late: its stream sits idle
-    old = C.c_int(-1)
+    old, lds = C.c_int(-1), C.c_int(-1)
     try:
         got, _ = streamed.run(frames, 16, filter_strength=0.3)
         assert all(r is not None and r["H"] is not None for r in got)
         assert streamed.cap_events and streamed.cap_events[0]["previous"] == 0 and sum(1 for g in streamed.cap_events[0]["gaps_ms"] if g > 4.0) >= 3
+        # observable effect: the scans that followed were launched with the cap as their dynamic-LDS request (these 768^2 tiles
+        # take the one-query-per-lane kernel variants, not only the T = 4 one)
+        check(L.apds_dev_match_last_launch_lds(C.byref(lds)))
+        assert lds.value == 55000 and streamed.cap_bytes == 55000
+        # the cap is scoped to the pipeline's runs: the process-wide value is back to what it was
         check(L.apds_dev_match_lds_cap(0, C.byref(old)))
-        assert old.value == 55000
+        assert old.value == 0
+        # a second run of the same pipeline starts capped and restores again
+        streamed.debug_extract_delay = 0.0
+        streamed.run(frames, 3, filter_strength=0.3)
+        check(L.apds_dev_match_last_launch_lds(C.byref(lds)))
+        check(L.apds_dev_match_lds_cap(0, C.byref(old)))
+        assert lds.value == 55000 and old.value == 0
+        # and another matcher in the same process is not capped
+        pl.FramePipeline(db, db_xy).step(frames[0], filter_strength=0.3)
+        check(L.apds_dev_match_last_launch_lds(C.byref(lds)))
+        assert lds.value == 0
     finally:
         check(L.apds_dev_match_lds_cap(0, None))
+
+
+def test_reserved_cus_reach_the_match_stream(gpu_pkg):
+    """the CU-masked stream must be the one the match workers launch on."""
+    pl, frames, db, db_xy = _setup(gpu_pkg)
+    streamed = pl.StreamedFramePipeline(db, db_xy, reserve_cus=16)
+    try:
+        assert streamed._masked_stream_handle is not None
+        assert streamed.match_streams[0].cuda_stream == streamed._masked_stream_handle.value == streamed.streams[1].cuda_stream
+        got, _ = streamed.run(frames, 4, filter_strength=0.3)
+        assert all(r is not None and r["H"] is not None for r in got)
+    finally:
+        streamed.close()
+    assert streamed._masked_stream_handle is None
