@@ -27,7 +27,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 METRIC = "frames/sec (detect+match+homography) 4k×4k tile vs 1M-desc DB; Mmatches/sec"
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_INT_PEAK_SPEC = 256 * 64 * 2.4e9   # 32-bit integer VALU lane-ops/s (64 lanes/clk/CU)
+VALU_FP32_LANE_RATE_SPEC = 256 * 128 * 2.4e9   # MI355X_MICROARCH.md: SIMD-32 x 4, a wave64 VALU op per 2 cycles = 128 lanes/clk/CU
 
 
 def detect_algorithmic_bytes(w, h):
@@ -56,6 +56,9 @@ def main():
     ap.add_argument("--tile", type=int, default=4096)
     ap.add_argument("--db-rows", type=int, default=1_000_000, help="total descriptor DB rows (sharded over the ranks)")
     ap.add_argument("--frames", type=int, default=2, help="distinct frames per rank, cycled")
+    ap.add_argument("--db", choices=["mixed", "real"], default="mixed",
+                    help="mixed (default, SURVEY 8d): descriptors of a shifted copy of every frame + i.i.d. random rows. real: EVERY row is an AKAZE "
+                         "descriptor of some image (the frames' shifted copies + blended / flipped variants of them), rows shuffled (1 GPU)")
     ap.add_argument("--filter-strength", type=float, default=0.3, help="Lowe ratio (reference test: 0.3, lib.rs:222)")
     ap.add_argument("--workload", choices=["frame", "l2"], default="frame",
                     help="frame: the north-star pipeline (default). l2: BASELINE config 3, float-descriptor L2 match as an MFMA GEMM (1 GPU)")
@@ -140,12 +143,40 @@ def main():
     else:
         all_rows, all_xy = mine_rows, mine_xy
     P = min(all_rows.shape[0], NDB)
+    real_variants = 0
     # global DB = [P planted rows | NDB - P random rows]; this rank keeps rows [lo, hi)
     lo, hi = rank * NDB // world, (rank + 1) * NDB // world
     parts = []
     if lo < P:
         parts.append(all_rows[lo:min(hi, P)])
-    if hi > P:
+    if hi > P and args.db == "real":
+        # the rest of the DB = real AKAZE descriptors of OTHER images: blends of the frames with rolled / flipped copies of each other
+        # (new local structure, hence new descriptors; generated on the GPU, the CPU tile generator takes 15 s per 4096^2 tile)
+        assert world == 1, "--db real is a single-GPU configuration"
+        need, v = hi - max(lo, P), 0
+        base = [f.to(torch.float32) for f in frames]
+        while need > 0:
+            a, b = base[v % len(base)], base[(v + 1) % len(base)]
+            b = torch.roll(b, shifts=(137 * v + 50, 211 * v + 70), dims=(0, 1))
+            if v & 1:
+                b = torch.flip(b, dims=(0,))
+            if v & 2:
+                b = torch.flip(b, dims=(1,))
+            if v & 4:
+                a = torch.flip(a, dims=(0, 1))
+            w = 0.35 + 0.05 * (v % 7)
+            img = (a * w + b * (1.0 - w)).round().clamp(0, 255).to(torch.uint8).contiguous()
+            img[..., 3:] = 255
+            n = C.c_int(0)
+            check(L.apds_dev_akaze_extract(img.data_ptr(), T, T, img.shape[2], img.stride(0), cap, kps.data_ptr(), desc.data_ptr(), cap, C.byref(n),
+                                           pl.torch_stream()))
+            take = min(need, n.value)
+            parts.append(desc[:take].clone())
+            need -= take
+            v += 1
+            assert v < 4096 and n.value > 0, "variant images produce no keypoints"
+        real_variants = v
+    elif hi > P:
         r0 = max(lo, P)
         rnd = synth.make_descriptor_db(hi - r0, seed=synth.DB_SEED + r0)    # rows are a pure function of (seed, index block)
         pad = np.zeros((hi - r0, 64), np.uint8)
@@ -154,6 +185,11 @@ def main():
     db_local = torch.cat(parts).contiguous()
     db_xy = torch.zeros((NDB, 2), dtype=torch.float32, device=dev)
     db_xy[:P] = all_xy[:P]
+    if args.db == "real":     # shuffle: the threshold pre-pass's first 16384 rows are then a random sample of the whole DB, not the planted rows
+        gperm = torch.Generator(device=dev)
+        gperm.manual_seed(0x5245414C)
+        perm = torch.randperm(NDB, device=dev, generator=gperm)
+        db_local, db_xy = db_local[perm].contiguous(), db_xy[perm].contiguous()
     torch.cuda.synchronize()
     if args.serial:
         pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
@@ -237,20 +273,23 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 # the PMC profile was taken on the default workload on one GPU: it says nothing about other DB / tile sizes
-                if (tj.get("db_rows_per_gpu", 1_000_000), tj.get("tile", 4096)) == (rows_local, args.tile):
+                if (tj.get("db_rows_per_gpu", 1_000_000), tj.get("tile", 4096)) == (rows_local, args.tile) and args.db == "mixed":
                     traffic = tj.get("hamming_topk_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         bytes_per_launch = match_bytes / max(launches_per_step, 1e-9)
         avg_launch_ms = topk_ms / max(topk_n, 1)
         achieved_gbps = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if topk_n else 0.0
+        achieved_tops = match_ops / max(launches_per_step, 1e-9) / (avg_launch_ms * 1e-3) / 1e12 if topk_n else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": METRIC, "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/u32 popcount (match), f32 (AKAZE), f64 (homography solve)", "data": "synthetic",
             "config": {"workload": f"frame{T}x{T}_bgra_detect+describe -> hamming_top2 vs db{NDB} (sharded/{world}) -> ratio{args.filter_strength} -> ransac_homography",
-                       "tile": T, "db_rows": NDB, "db_rows_per_gpu": rows_local, "frames_per_step": world, "parallelism": f"frame-dp{world}+db-shard{world}",
+                       "tile": T, "db_rows": NDB, "db_rows_per_gpu": rows_local,
+                       "db_composition": ("all rows are AKAZE descriptors of images (shifted frames + %d blended variants), shuffled" % real_variants) if args.db == "real"
+                                         else f"{P} AKAZE descriptors of the frames' shifted copies + {NDB - P} i.i.d. random rows", "frames_per_step": world, "parallelism": f"frame-dp{world}+db-shard{world}",
                        "stage_overlap": "none (serial)" if args.serial else "extract (2 workers, alternate frames) | match | homography on their own streams, software-pipelined over frames",
                        "match_occupancy_cap": ({"lds_bytes": 55000, "set_at": pipe.cap_events[0]} if getattr(pipe, "cap_events", None) else
                                                {"lds_bytes": int(os.environ.get("APDS_MATCH_LDS_CAP", "0") or 0)}),
@@ -260,16 +299,20 @@ def main():
                        "inliers_per_frame": float(np.mean([s["n_inliers"] for s in stats])), "homography_found": all(s["H"] is not None for s in stats)},
             "mmatches_per_s": world * K * args.steps / elapsed / 1e6,
             "gpairs_per_s": world * Q_step * rows_local * args.steps / elapsed / 1e9,
-            "roofline": {"kernel": "hamming_topk_kernel<4,2>", "bound": "hbm", "achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved_gbps / HBM_PEAK_GBPS, "traffic": traffic, "launches_per_step": launches_per_step,
-                         "avg_launch_ms": avg_launch_ms, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "note": "north_star asks for the Hamming match as a fraction of HBM; the kernel is integer-VALU bound (32 lane-ops per pair), see valu"},
-            "valu": {"bound": "int32 VALU xor+popcount", "achieved_lane_ops_per_s": match_ops / (topk_ms_step * 1e-3) if topk_ms_step else 0.0,
-                     "peak_measured_lane_ops_per_s": peak.value, "peak_spec_lane_ops_per_s": VALU_INT_PEAK_SPEC,
-                     "frac_of_measured": match_ops / (topk_ms_step * 1e-3) / peak.value if topk_ms_step else 0.0,
-                     "frac_of_spec": match_ops / (topk_ms_step * 1e-3) / VALU_INT_PEAK_SPEC if topk_ms_step else 0.0,
-                     "tpairs_per_s": Q_step * rows_main / (topk_ms_step * 1e-3) / 1e12 if topk_ms_step else 0.0,
-                     "note": "algorithmic 32 lane-ops per pair (16 dword xor + 16 popcount); the fast path screens on 15 dwords = 30 ops, which is why the fraction can exceed the measured pair rate x 32"},
+            # The binding bound of the dominant kernel is integer-VALU issue, so that is what `roofline` carries:
+            # achieved = ALGORITHMIC lane-ops (32 per pair: 16 dword xor + 16 popcount-accumulate) / launch time;
+            # peak = the xor+bcnt pair rate measured on this GPU by the register-only microbenchmark in its best issue order
+            # (apds_dev_valu_popcount_peak; v_xor_b32 issues at the full FP32 rate, v_bcnt_u32_b32 at half of it:
+            # profiles/r02/valu_calib_*.log). north_star's "% of HBM" is the sub-object `hbm`.
+            "roofline": {"kernel": f"hamming_topk_kernel<{4 if Q_step >= 16384 else (2 if Q_step >= 8192 else 1)},2>", "bound": "int32-valu",
+                         "achieved": achieved_tops, "peak": peak.value / 1e12, "unit": "T lane-op/s", "frac": achieved_tops / (peak.value / 1e12) if peak.value else 0.0,
+                         "traffic": traffic, "launches_per_step": launches_per_step, "avg_launch_ms": avg_launch_ms,
+                         "algorithmic_lane_ops_per_launch": match_ops / max(launches_per_step, 1e-9), "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "tpairs_per_s": Q_step * rows_main / (topk_ms_step * 1e-3) / 1e12 if topk_ms_step else 0.0,
+                         "peak_spec_fp32_rate": VALU_FP32_LANE_RATE_SPEC,
+                         "hbm": {"achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS},
+                         "note": "32 algorithmic lane-ops per pair; the kernel screens on 15 of the 16 dwords (30.6 issued ops per pair), so frac can pass 1.0 slightly. "
+                                 "peak is measured (xor at the full VALU rate + bcnt at half rate = 6 issue cycles per dword pair); peak_spec_fp32_rate = 128 lanes/clk/CU x 256 CU x 2.4 GHz"},
             "stages_ms_per_step": {"akaze_extract": akaze_ms / max(args.steps, 1), "hamming_topk": topk_ms_step,
                                    "hamming_topk_sample": sample_ms / max(args.steps, 1), "ransac_score": score_ms / max(args.steps, 1)},
             "detect_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": detect_algorithmic_bytes(T, T),
@@ -325,42 +368,81 @@ def bench_l2(args, pkg, pl, torch, dev, world):
     print(json.dumps({
         "metric": "Mmatches/sec (L2 brute-force top-2, float descriptors 128-d, vs 1M-row DB)", "value": nq * args.steps / elapsed / 1e6, "unit": "Mmatches/s",
         "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32 (v_mfma_f32_32x32x2_f32, f32 accumulate)", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32 (v_mfma_f32_16x16x4_f32, f32 accumulate)", "data": "synthetic",
         "config": {"workload": f"l2_top2 q{nq}x{dim} vs db{nt}x{dim} (BASELINE config 3)", "planted_recovered": found / max(npl, 1)},
         "roofline": {"kernel": "l2_topk_kernel<2,true>", "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s", "frac": achieved / 157.3,
                      "traffic": None, "avg_launch_ms": ms / max(n, 1), "algorithmic_flops_per_launch": flops}}), flush=True)
 
 
 def cpu_baseline(pkg, frame, db_local, K, fs, db_xy, ref_stats):
-    """The oracle ("port") on the host cores, same frame and DB: full detect+describe, a bounded sample of the
-    query rows for the match (scaled to K), ratio test, RANSAC on that sample's matches."""
+    """The oracle ("port": this repo's scalar/OpenMP C++ restatement) on the host cores, same frame and DB, built
+    on this host with -O3 -march=native. Reported at ALL host cores (`value`, `cores`) and at ONE thread (`one_thread`). The match
+    runs the full query set when a probe says it fits in 60 s, otherwise a stated sample (`sampled_queries`, `scale`)."""
     import oracle
-    threads = max(1, min(os.cpu_count() or 1, 32))
-    oracle.set_threads(threads)
-    t0 = time.perf_counter()
-    ex = oracle.akaze(frame)
-    t_detect = time.perf_counter() - t0
+    flags = oracle.use_native()
+    threads, nproc = oracle.host_threads()
     db = db_local[:, :61].cpu().numpy()
-    # ~1e10 descriptor pairs: about 9 s on 32 host threads, so that the whole CPU sample is 10 - 30 s of work on the box's cores
-    nq_sample = max(1, min(len(ex.descriptors), max(256, int(1.0e10 / max(db.shape[0], 1)))))
+    xy = db_xy.cpu().numpy()
+
+    def leg(threads, budget_match_s, full_detect):
+        oracle.set_threads(threads)
+        if full_detect:
+            t0 = time.perf_counter()
+            ex = oracle.akaze(frame)
+            t_detect, detect_scale = time.perf_counter() - t0, 1.0
+        else:   # one thread: a quarter of the frame (its central half-size window), scaled by the pixel ratio
+            h, w = frame.shape[0] // 2, frame.shape[1] // 2
+            crop = np.ascontiguousarray(frame[h // 2:h // 2 + h, w // 2:w // 2 + w])
+            t0 = time.perf_counter()
+            oracle.akaze(crop)
+            t_detect, detect_scale = (time.perf_counter() - t0) * 4.0, 4.0
+            ex = None
+        return t_detect, detect_scale, ex
+
+    # ---- all cores
+    t_detect, _, ex = leg(threads, 60.0, True)
+    nq = len(ex.descriptors)
+    probe = min(nq, max(64, int(2.0e9 / max(db.shape[0], 1))))
+    t0 = time.perf_counter()
+    oracle.get_knn_matches(ex.descriptors[:probe], db, 2, fs)
+    t_probe = time.perf_counter() - t0
+    est_full = t_probe * nq / max(probe, 1)
+    nq_sample = nq if est_full <= 60.0 else max(probe, min(nq, int(nq * 20.0 / est_full)))
     t0 = time.perf_counter()
     m = oracle.get_knn_matches(ex.descriptors[:nq_sample], db, 2, fs)
     t_match_sample = time.perf_counter() - t0
-    t_match = t_match_sample * len(ex.descriptors) / nq_sample
+    scale = nq / max(nq_sample, 1)
+    t_match = t_match_sample * scale
     t_h = 0.0
     if len(m) >= 4:
-        xy = db_xy.cpu().numpy()
         p1 = np.stack([ex.keypoints["x"][m["query_idx"]], ex.keypoints["y"][m["query_idx"]]], 1)
         p2 = xy[m["train_idx"]]
         t0 = time.perf_counter()
         oracle.find_homography(p1, p2, 8, 3.0)
-        t_h = (time.perf_counter() - t0)
+        t_h = time.perf_counter() - t0
     total = t_detect + t_match + t_h
-    return {"value": 1.0 / total, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle on {threads} OpenMP threads: full {frame.shape[1]}x{frame.shape[0]} detect+describe ({t_detect:.2f}s, K={len(ex.keypoints)}), "
-                      f"match of {nq_sample} of the {len(ex.descriptors)} queries vs all {db.shape[0]} rows ({t_match_sample:.2f}s, scaled x{len(ex.descriptors) / nq_sample:.1f}), "
-                      f"RANSAC on the sample's matches ({t_h * 1e3:.1f} ms)",
-            "seconds_per_frame_estimated": total, "keypoints_equal_gpu": int(len(ex.keypoints)) == int(ref_stats["n_keypoints"])}
+    # ---- one thread, bounded: quarter-frame detect (x4), ~1e9 descriptor pairs of the match (scaled), the same RANSAC time
+    t1_detect, d_scale, _ = leg(1, 10.0, False)
+    nq1 = max(16, min(nq, int(1.0e9 / max(db.shape[0], 1))))
+    oracle.set_threads(1)
+    t0 = time.perf_counter()
+    oracle.get_knn_matches(ex.descriptors[:nq1], db, 2, fs)
+    t1_match_sample = time.perf_counter() - t0
+    t1_match = t1_match_sample * nq / nq1
+    total1 = t1_detect + t1_match + t_h
+    oracle.set_threads(threads)
+    return {"value": 1.0 / total, "unit": "frames/s", "cores": threads, "kind": "port", "nproc": nproc, "build_flags": flags,
+            "threads_note": f"nproc = {nproc}; {threads} OpenMP threads used (the fastest of 8/16/32/64/.../nproc on a small detect: the box's CPU share is below its affinity mask)",
+            "sample": f"oracle ({flags}) on {threads} OpenMP threads: full {frame.shape[1]}x{frame.shape[0]} detect+describe ({t_detect:.2f} s, K={nq}), "
+                      f"match of {nq_sample} of the {nq} queries vs all {db.shape[0]} rows ({t_match_sample:.2f} s, x{scale:.2f}), RANSAC on those matches ({t_h * 1e3:.1f} ms)",
+            "sampled_queries": nq_sample, "total_queries": nq, "scale": scale,
+            "seconds_per_frame": total, "seconds": {"detect": t_detect, "match": t_match, "homography": t_h},
+            "one_thread": {"value": 1.0 / total1, "unit": "frames/s", "cores": 1, "seconds_per_frame": total1,
+                           "seconds": {"detect": t1_detect, "match": t1_match, "homography": t_h},
+                           "sample": f"1 thread: detect+describe of the central {frame.shape[1] // 2}x{frame.shape[0] // 2} window x{d_scale:.0f}, "
+                                     f"match of {nq1} of the {nq} queries ({t1_match_sample:.2f} s, x{nq / nq1:.1f})",
+                           "sampled_queries": nq1, "scale": nq / nq1},
+            "keypoints_equal_gpu": int(nq) == int(ref_stats["n_keypoints"])}
 
 
 if __name__ == "__main__":

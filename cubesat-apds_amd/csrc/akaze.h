@@ -24,9 +24,20 @@ struct LevelDesc {
     long long pix_offset;   // offset of this level in the level-major concatenated pixel index space
 };
 
-// level table handed to keypoint kernels by value
+// Batched launches (gridDim.z = images): every image of a batch owns an identical workspace slab `bstride` bytes after the previous
+// one, so a plane of image blockIdx.z is the plane of image 0 shifted by blockIdx.z * bstride (akaze_keypoints.hip lays the slab
+// out). A single image is a batch of one (blockIdx.z = 0).
+#ifdef __HIPCC__
+template <class T>
+__device__ __forceinline__ T* bofs(T* p, size_t bstride) {
+    return p ? reinterpret_cast<T*>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.z * bstride) : p;
+}
+#endif
+
+// level table handed to keypoint kernels by value (pointers: image 0 of the batch)
 struct LevelTable {
     int n;
+    size_t bstride;
     int w[AKAZE_MAX_LEVELS], h[AKAZE_MAX_LEVELS], octave[AKAZE_MAX_LEVELS], sigma_size[AKAZE_MAX_LEVELS], border[AKAZE_MAX_LEVELS];
     float esigma[AKAZE_MAX_LEVELS], ratio[AKAZE_MAX_LEVELS];
     long long pix_offset[AKAZE_MAX_LEVELS + 1];
@@ -34,24 +45,30 @@ struct LevelTable {
     const float2* Lxy[AKAZE_MAX_LEVELS];   // (Lx, Ly) interleaved
     const float* Ldet[AKAZE_MAX_LEVELS];
     uint8_t* mask[AKAZE_MAX_LEVELS];
+    const uint32_t* list[AKAZE_MAX_LEVELS];   // the level's candidate list (unordered), counts in list_count[level]
+};
+
+// A batched launch: `n` images of one size through one grid (gridDim.z = n). Every image owns an identical workspace slab, `stride`
+// bytes apart (so a plane of image i is the plane of image 0 + i * stride); the input images are `img_stride` bytes apart.
+struct Batch {
+    int n = 1;
+    size_t stride = 0, img_stride = 0;
 };
 
 // akaze_filters.hip
-void launch_gray(const void* img, int rows, int cols, int channels, size_t stride, float* out, hipStream_t s);
-void launch_gauss(const float* src, float* dst, int w, int h, const GaussTaps& taps, int radius, hipStream_t s);
-void launch_deriv_pair(const float* src, float* outA, float* outB, int w, int h, int sc, float kside, float kmid, hipStream_t s);
-void launch_flow(const float* src, float* flow, int w, int h, const float* kptr, hipStream_t s);
-void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int h, const GaussTaps& taps, const float* kptr, hipStream_t s);
+void launch_gray(const void* img, int rows, int cols, int channels, size_t stride, float* out, hipStream_t s, const Batch& b);
+void launch_gauss(const float* src, float* dst, int w, int h, const GaussTaps& taps, int radius, hipStream_t s, const Batch& b);
+void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int h, const GaussTaps& taps, const float* kptr, hipStream_t s, const Batch& b);
 void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s,
-                      bool gradient_done = false);
+                      const Batch& b, bool gradient_done = false);
 bool launch_base_strips(const void* img, int rows, int cols, int channels, size_t stride, const GaussTaps& g16, const GaussTaps& g10, float* Lt0, float* modg,
-                        unsigned int* hmax_bits, bool want_modg, hipStream_t s);
-void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s);
-void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s);
+                        unsigned int* hmax_bits, bool want_modg, hipStream_t s, const Batch& b);
+void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b);
+void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s, const Batch& b);
 void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, const int* xofs, const float* xw, const int* xcnt, const int* yofs,
-                        const float* yw, const int* ycnt, hipStream_t s);
+                        const float* yw, const int* ycnt, hipStream_t s, const Batch& b);
 void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
-                      uint32_t* list, int* list_count, hipStream_t s);
+                      uint32_t* list, int* list_count, hipStream_t s, const Batch& b);
 
 // Test hook: when armed (per thread) the next akaze_extract_device copies one intermediate plane to the host.
 // which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet (f32), 7 keypoint mask after cross-level suppression (u8), 8 kcontrast (1 float)

@@ -16,6 +16,9 @@
 namespace apds {
 
 __device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
+
+// APDS_BOFS(p): the plane of image blockIdx.z of a batched launch (akaze.h: bofs)
+#define APDS_BOFS(p) p = bofs(p, bstride)
 __device__ __forceinline__ int reflect101(int i, int n) {
     if (n == 1) return 0;
     while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
@@ -23,8 +26,11 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 
 // ---- a1.1: BGR(A)/gray u8 -> f32 in [0,1] ----------------------------------------------------------
-__global__ void gray_kernel(const uint8_t* __restrict__ img, int rows, int cols, int channels, size_t stride, float* __restrict__ out) {
+__global__ void gray_kernel(const uint8_t* __restrict__ img, int rows, int cols, int channels, size_t stride, float* __restrict__ out, size_t img_bstride,
+                            size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    img += (size_t)blockIdx.z * img_bstride;
+    APDS_BOFS(out);
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= cols) return;
@@ -46,8 +52,10 @@ __global__ void gray_kernel(const uint8_t* __restrict__ img, int rows, int cols,
 static constexpr int TW = 64, TH = 16;   // output tile, 256 threads
 
 template <int R>
-__global__ __launch_bounds__(256) void gauss_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, GaussTaps taps) {
+__global__ __launch_bounds__(256) void gauss_kernel(const float* __restrict__ src, float* __restrict__ dst, int w, int h, GaussTaps taps, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(src);
+    APDS_BOFS(dst);
     __shared__ float s_src[(TH + 2 * R) * (TW + 2 * R)];
     __shared__ float s_tmp[(TH + 2 * R) * TW];
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
@@ -87,8 +95,13 @@ __global__ __launch_bounds__(256) void gauss_kernel(const float* __restrict__ sr
 template <int MODE>
 __global__ __launch_bounds__(256) void deriv_pair_kernel(const float* __restrict__ src, float* __restrict__ outA, float* __restrict__ outB,
                                                          int w, int h, int s, float kside, float kmid, const float* __restrict__ kptr,
-                                                         unsigned int* __restrict__ hmax_bits) {
+                                                         unsigned int* __restrict__ hmax_bits, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(src);
+    APDS_BOFS(outA);
+    APDS_BOFS(outB);
+    APDS_BOFS(kptr);
+    APDS_BOFS(hmax_bits);
     extern __shared__ float smem[];
     const int SW = TW + 2 * s, SH = TH + 2 * s;
     float* s_src = smem;                 // SH x SW
@@ -168,8 +181,12 @@ static constexpr int FW = 64, FH = 32, FNT = APDS_SF_THREADS;
 // registers) before it computes the current one, so the HBM latency of a tile hides behind the three LDS passes of the previous
 // tile instead of being paid once per tile per block.
 __global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow, int w, int h,
-                                                          GaussTaps taps, const float* __restrict__ kptr, int tiles_x, int ntiles, int txi, int tyi) {
+                                                          GaussTaps taps, const float* __restrict__ kptr, int tiles_x, int ntiles, int txi, int tyi, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(src);
+    APDS_BOFS(smooth);
+    APDS_BOFS(flow);
+    APDS_BOFS(kptr);
     constexpr int SW = FW + 6, SH = FH + 6;      // start image, halo 3 (= ring 1 + Gaussian radius 2), replicate on load
     constexpr int TWD = FW + 2;                  // row-pass / Lsmooth width: tile + ring 1
     constexpr int MH = FH + 2;
@@ -295,8 +312,12 @@ static constexpr int SF_RB = 16, SF_VW = 58;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
 void smooth_flow_strip_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow, int w, int h, GaussTaps taps,
-                              const float* __restrict__ kptr, int rx0, int ry0, int rx1, int ry1, int strips, int nwaves) {
+                              const float* __restrict__ kptr, int rx0, int ry0, int rx1, int ry1, int strips, int nwaves, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(src);
+    APDS_BOFS(smooth);
+    APDS_BOFS(flow);
+    APDS_BOFS(kptr);
     constexpr int RB = SF_RB, R = RB + 6;
     const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (id >= nwaves) return;                   // wave-uniform; no barriers in this kernel
@@ -484,8 +505,12 @@ __device__ __forceinline__ void base_strip(const uint8_t* __restrict__ img, int 
 template <int CH>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_BS_WAVES, 8)))
 void base_strip_kernel(const uint8_t* __restrict__ img, int w, int h, int stride, GaussTaps g16, GaussTaps g10, float* __restrict__ Lt0,
-                       float* __restrict__ modg, unsigned int* __restrict__ hmax_bits, int want_modg, int strips, int nwaves) {
+                       float* __restrict__ modg, unsigned int* __restrict__ hmax_bits, int want_modg, int strips, int nwaves, size_t img_bstride, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    img += (size_t)blockIdx.z * img_bstride;
+    APDS_BOFS(Lt0);
+    APDS_BOFS(modg);
+    APDS_BOFS(hmax_bits);
     const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (id >= nwaves) return;                   // wave-uniform; no barriers in this kernel
     const int band = __builtin_amdgcn_readfirstlane(id / strips);
@@ -498,8 +523,11 @@ void base_strip_kernel(const uint8_t* __restrict__ img, int w, int h, int stride
 
 // ---- contrast factor: 300-bin histogram of |grad|/hmax over interior pixels, 70th percentile -----------
 __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __restrict__ modg, int w, int h, const unsigned int* __restrict__ hmax_bits,
-                                                              int* __restrict__ hist) {
+                                                              int* __restrict__ hist, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(modg);
+    APDS_BOFS(hmax_bits);
+    APDS_BOFS(hist);
     __shared__ int s_hist[300];
     for (int i = threadIdx.x; i < 300; i += 256) s_hist[i] = 0;
     __syncthreads();
@@ -521,9 +549,12 @@ __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __rest
 
 // single thread: kcontrast and its per-octave values k, k*0.75, (k*0.75)*0.75, ...
 __global__ void kcontrast_finish_kernel(const int* __restrict__ hist, const unsigned int* __restrict__ hmax_bits, int w, int h,
-                                        float* __restrict__ k_oct, int n_oct) {
+                                        float* __restrict__ k_oct, int n_oct, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     if (threadIdx.x || blockIdx.x) return;
+    APDS_BOFS(hist);
+    APDS_BOFS(hmax_bits);
+    APDS_BOFS(k_oct);
     const float hmax = __uint_as_float(*hmax_bits);
     float k = 0.03f;
     if (hmax != 0.0f && w > 2 && h > 2) {
@@ -672,8 +703,11 @@ __device__ __forceinline__ void nld_multi_tile(const float* __restrict__ Lt, con
 
 template <int S, int NT>
 __global__ __launch_bounds__(NT) void nld_multi_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
-                                                        NldSteps steps) {
+                                                        NldSteps steps, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(Lt);
+    APDS_BOFS(Lf);
+    APDS_BOFS(Lnew);
     constexpr int SW = T2W + 2 * S, SH = T2H + 2 * S;
     __shared__ float s_f[SH * SW];
     __shared__ float s_a[SH * SW];
@@ -763,8 +797,11 @@ template <int S, int RB>
 #define APDS_STRIP_RB 16
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_WAVES, 8))) void nld_strip_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
-                                                         NldSteps steps, int strips, int nwaves) {
+                                                         NldSteps steps, int strips, int nwaves, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(Lt);
+    APDS_BOFS(Lf);
+    APDS_BOFS(Lnew);
     constexpr int VW = 64 - 2 * S;              // columns a wave finishes
     // wave-uniform by construction; readfirstlane tells the compiler, so that row bases and row conditions live in scalar registers
     const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -778,8 +815,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_
 }
 
 // ---- resize(INTER_AREA) by exactly 2: mean of 2x2 ---------------------------------------------------------
-__global__ void half_sample_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh) {
+__global__ void half_sample_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(src);
+    APDS_BOFS(dst);
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= dw || y >= dh) return;
@@ -791,8 +830,10 @@ __global__ void half_sample_kernel(const float* __restrict__ src, int sw, float*
 // general INTER_AREA (odd source sizes): per destination pixel, up to 4 taps per axis from host-built tables
 __global__ void area_resize_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh, const int* __restrict__ xofs,
                                    const float* __restrict__ xw, const int* __restrict__ xcnt, const int* __restrict__ yofs,
-                                   const float* __restrict__ yw, const int* __restrict__ ycnt) {
+                                   const float* __restrict__ yw, const int* __restrict__ ycnt, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(src);
+    APDS_BOFS(dst);
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= dw || y >= dh) return;
@@ -828,8 +869,14 @@ static constexpr int DCAND = 1024;        // strict 3x3 maxima are never adjacen
 template <int S>
 __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict__ Lsmooth, float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h,
                                                         int s_rt, float kside, float kmid, float sq, int border, float thr, uint8_t* __restrict__ mask,
-                                                        uint32_t* __restrict__ list, int* __restrict__ list_count) {
+                                                        uint32_t* __restrict__ list, int* __restrict__ list_count, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(Lsmooth);
+    APDS_BOFS(Lxy);
+    APDS_BOFS(Ldet);
+    APDS_BOFS(mask);
+    APDS_BOFS(list);
+    APDS_BOFS(list_count);
     extern __shared__ float smem[];
     __shared__ int s_n, s_base;
     const int s = S ? S : s_rt;
@@ -943,69 +990,63 @@ static int persistent_grid(int ntiles) {
     static const int cap = getenv("APDS_PERSISTENT_BLOCKS") ? atoi(getenv("APDS_PERSISTENT_BLOCKS")) : 512;
     return std::min((ntiles + 7) & ~7, std::max(8, cap & ~7));
 }
-void launch_gray(const void* img, int rows, int cols, int channels, size_t stride, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(gray_kernel, dim3(ceil_div(cols, 256), rows), dim3(256), 0, s, static_cast<const uint8_t*>(img), rows, cols, channels, stride, out);
+void launch_gray(const void* img, int rows, int cols, int channels, size_t stride, float* out, hipStream_t s, const Batch& b) {
+    hipLaunchKernelGGL(gray_kernel, dim3(ceil_div(cols, 256), rows, b.n), dim3(256), 0, s, static_cast<const uint8_t*>(img), rows, cols, channels, stride, out,
+                       b.img_stride, b.stride);
 }
 
-void launch_gauss(const float* src, float* dst, int w, int h, const GaussTaps& taps, int radius, hipStream_t s) {
-    dim3 grid(ceil_div(w, TW), ceil_div(h, TH));
-    if (radius == 4) hipLaunchKernelGGL((gauss_kernel<4>), grid, dim3(256), 0, s, src, dst, w, h, taps);
-    else hipLaunchKernelGGL((gauss_kernel<2>), grid, dim3(256), 0, s, src, dst, w, h, taps);
+void launch_gauss(const float* src, float* dst, int w, int h, const GaussTaps& taps, int radius, hipStream_t s, const Batch& b) {
+    dim3 grid(ceil_div(w, TW), ceil_div(h, TH), b.n);
+    if (radius == 4) hipLaunchKernelGGL((gauss_kernel<4>), grid, dim3(256), 0, s, src, dst, w, h, taps, b.stride);
+    else hipLaunchKernelGGL((gauss_kernel<2>), grid, dim3(256), 0, s, src, dst, w, h, taps, b.stride);
 }
 
 static size_t deriv_lds_bytes(int s) { return (size_t)((TH + 2 * s) * (TW + 2 * s) + 2 * (TH + 2 * s) * TW) * sizeof(float); }
 
-void launch_deriv_pair(const float* src, float* outA, float* outB, int w, int h, int sc, float kside, float kmid, hipStream_t s) {
-    hipLaunchKernelGGL((deriv_pair_kernel<0>), dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), deriv_lds_bytes(sc), s, src, outA, outB, w, h, sc, kside,
-                       kmid, (const float*)nullptr, (unsigned int*)nullptr);
-}
-void launch_flow(const float* src, float* flow, int w, int h, const float* kptr, hipStream_t s) {
-    hipLaunchKernelGGL((deriv_pair_kernel<1>), dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), deriv_lds_bytes(1), s, src, flow, (float*)nullptr, w, h, 1,
-                       3.0f, 10.0f, kptr, (unsigned int*)nullptr);
-}
-void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int h, const GaussTaps& taps, const float* kptr, hipStream_t s) {
+void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int h, const GaussTaps& taps, const float* kptr, hipStream_t s, const Batch& b) {
     const int tiles_x = ceil_div(w, FW), tiles_y = ceil_div(h, FH), ntiles = tiles_x * tiles_y;
     // tiles [1, txi) x [1, tyi) lie inside the image with their 3-pixel halo: register strips; the frame around them: LDS tiles
     static const int strip_mode = getenv("APDS_SF_STRIP") ? atoi(getenv("APDS_SF_STRIP")) : 1;
     const int txi = w >= FW + 67 ? (w - 67) / FW + 1 : 1, tyi = h >= FH + 35 ? (h - 35) / FH + 1 : 1;
-    const bool strips_on = strip_mode && txi > 1 && tyi > 1 && (size_t)w * h < ((size_t)1 << 29) && ((size_t)w * h >= ((size_t)1 << 21) || strip_mode == 2);
+    // the strips pay once the launch has enough pixels to be throughput-bound: a batch counts as a whole
+    const bool strips_on = strip_mode && txi > 1 && tyi > 1 && (size_t)w * h < ((size_t)1 << 29) && ((size_t)w * h * b.n >= ((size_t)1 << 21) || strip_mode == 2);
     if (strips_on) {
         const int rx0 = FW, ry0 = FH, rx1 = txi * FW, ry1 = tyi * FH;
         const int strips = ceil_div(rx1 - rx0, SF_VW), nwaves = strips * ceil_div(ry1 - ry0, SF_RB);
-        hipLaunchKernelGGL(smooth_flow_strip_kernel, dim3(ceil_div(nwaves, 4)), dim3(256), 0, s, src, smooth, flow, w, h, taps, kptr, rx0, ry0, rx1, ry1, strips,
-                           nwaves);
+        hipLaunchKernelGGL(smooth_flow_strip_kernel, dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, src, smooth, flow, w, h, taps, kptr, rx0, ry0, rx1, ry1,
+                           strips, nwaves, b.stride);
     }
     if (strips_on) {   // the frame: one tile per block
         const int n_frame = tiles_x + (tyi - 1) * (1 + tiles_x - txi) + (tiles_y - tyi) * tiles_x;
-        hipLaunchKernelGGL(smooth_flow_kernel, dim3(n_frame), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr, tiles_x, ntiles, txi, tyi);
+        hipLaunchKernelGGL(smooth_flow_kernel, dim3(n_frame, 1, b.n), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr, tiles_x, ntiles, txi, tyi, b.stride);
     } else {
-        hipLaunchKernelGGL(smooth_flow_kernel, dim3(persistent_grid(ntiles)), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr, tiles_x, ntiles, 0, 0);
+        hipLaunchKernelGGL(smooth_flow_kernel, dim3(persistent_grid(ntiles), 1, b.n), dim3(FNT), 0, s, src, smooth, flow, w, h, taps, kptr, tiles_x, ntiles, 0, 0,
+                           b.stride);
     }
 }
 void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsigned int* hmax_bits, int* hist, float* k_oct, int n_oct, hipStream_t s,
-                      bool gradient_done) {
-    if (!gradient_done) {   // otherwise launch_base_strips has written |grad| to modg_tmp and its maximum to hmax_bits
-        HIP_CHECK(hipMemsetAsync(hmax_bits, 0, sizeof(unsigned int), s));
-        hipLaunchKernelGGL((deriv_pair_kernel<2>), dim3(ceil_div(w, TW), ceil_div(h, TH)), dim3(256), deriv_lds_bytes(1), s, smooth, modg_tmp, (float*)nullptr,
-                           w, h, 1, 3.0f, 10.0f, (const float*)nullptr, hmax_bits);
-    }
-    HIP_CHECK(hipMemsetAsync(hist, 0, 300 * sizeof(int), s));
-    hipLaunchKernelGGL(kcontrast_hist_kernel, dim3(1024), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist);
-    hipLaunchKernelGGL(kcontrast_finish_kernel, dim3(1), dim3(64), 0, s, hist, hmax_bits, w, h, k_oct, n_oct);
+                      const Batch& b, bool gradient_done) {
+    // hmax_bits and hist are zeroed by the caller (one clear of the per-image counter block for the whole batch)
+    if (!gradient_done)    // otherwise launch_base_strips has written |grad| to modg_tmp and its maximum to hmax_bits
+        hipLaunchKernelGGL((deriv_pair_kernel<2>), dim3(ceil_div(w, TW), ceil_div(h, TH), b.n), dim3(256), deriv_lds_bytes(1), s, smooth, modg_tmp,
+                           (float*)nullptr, w, h, 1, 3.0f, 10.0f, (const float*)nullptr, hmax_bits, b.stride);
+    // the histogram's grid shrinks with the image: 1024 blocks for one large frame, a share of that for each image of a batch
+    const int hist_blocks = std::max(8, std::min(1024, ceil_div((long long)w * h, 4096)));
+    hipLaunchKernelGGL(kcontrast_hist_kernel, dim3(hist_blocks, 1, b.n), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist, b.stride);
+    hipLaunchKernelGGL(kcontrast_finish_kernel, dim3(1, 1, b.n), dim3(64), 0, s, hist, hmax_bits, w, h, k_oct, n_oct, b.stride);
 }
 // image -> Lt[0] (and, if want_modg, |grad| of the sigma = 1 image + its interior maximum) in one pass on register strips. Returns
 // false when the image is too small to pay (the launch-bound small tiles keep the separate kernels) or does not fit 32-bit offsets.
 bool launch_base_strips(const void* img, int rows, int cols, int channels, size_t stride, const GaussTaps& g16, const GaussTaps& g10, float* Lt0, float* modg,
-                        unsigned int* hmax_bits, bool want_modg, hipStream_t s) {
+                        unsigned int* hmax_bits, bool want_modg, hipStream_t s, const Batch& b) {
     static const int strip_mode = getenv("APDS_BASE_STRIP") ? atoi(getenv("APDS_BASE_STRIP")) : 1;
     const size_t px = (size_t)rows * cols;
-    if (!strip_mode || (px < ((size_t)1 << 21) && strip_mode != 2) || px >= ((size_t)1 << 29) || (size_t)rows * stride >= ((size_t)1 << 31)) return false;
-    if (channels == 4 && ((reinterpret_cast<uintptr_t>(img) | stride) & 3)) return false;   // dword loads of the BGRA pixels
-    if (want_modg) HIP_CHECK(hipMemsetAsync(hmax_bits, 0, sizeof(unsigned int), s));
+    if (!strip_mode || (px * b.n < ((size_t)1 << 21) && strip_mode != 2) || px >= ((size_t)1 << 29) || (size_t)rows * stride >= ((size_t)1 << 31)) return false;
+    if (channels == 4 && ((reinterpret_cast<uintptr_t>(img) | stride | b.img_stride) & 3)) return false;   // dword loads of the BGRA pixels
     const int strips = ceil_div(cols, BS_VW), nwaves = strips * ceil_div(rows, BS_RB);
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(ceil_div(nwaves, 4)), dim3(256), 0, s, static_cast<const uint8_t*>(img), cols, rows, (int)stride, g16, g10, Lt0, modg,
-                           hmax_bits, want_modg ? 1 : 0, strips, nwaves);
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, static_cast<const uint8_t*>(img), cols, rows, (int)stride, g16, g10, Lt0,
+                           modg, hmax_bits, want_modg ? 1 : 0, strips, nwaves, b.img_stride, b.stride);
     };
     if (channels == 4) go(&base_strip_kernel<4>);
     else if (channels == 3) go(&base_strip_kernel<3>);
@@ -1013,55 +1054,56 @@ bool launch_base_strips(const void* img, int rows, int cols, int channels, size_
     return true;
 }
 template <int S>
-static void nld_multi_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s) {
+static void nld_multi_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s, const Batch& b) {
     // 1024 threads per 64x32 tile: each step is ~3 short dependent LDS passes, so what matters is waves in flight per CU
     static const int nt = getenv("APDS_NLD_THREADS") ? atoi(getenv("APDS_NLD_THREADS")) : 1024;
-    const dim3 grid(ceil_div(w, T2W), ceil_div(h, T2H));
-    if (nt == 256) hipLaunchKernelGGL((nld_multi_kernel<S, 256>), grid, dim3(256), 0, s, Lt, Lf, Lnew, w, h, st);
-    else if (nt == 512) hipLaunchKernelGGL((nld_multi_kernel<S, 512>), grid, dim3(512), 0, s, Lt, Lf, Lnew, w, h, st);
-    else hipLaunchKernelGGL((nld_multi_kernel<S, 1024>), grid, dim3(1024), 0, s, Lt, Lf, Lnew, w, h, st);
+    const dim3 grid(ceil_div(w, T2W), ceil_div(h, T2H), b.n);
+    if (nt == 256) hipLaunchKernelGGL((nld_multi_kernel<S, 256>), grid, dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, b.stride);
+    else if (nt == 512) hipLaunchKernelGGL((nld_multi_kernel<S, 512>), grid, dim3(512), 0, s, Lt, Lf, Lnew, w, h, st, b.stride);
+    else hipLaunchKernelGGL((nld_multi_kernel<S, 1024>), grid, dim3(1024), 0, s, Lt, Lf, Lnew, w, h, st, b.stride);
 }
 template <int S>
-static void nld_strip_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s) {
+static void nld_strip_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s, const Batch& b) {
     constexpr int RB = APDS_STRIP_RB;
     const int strips = ceil_div(w, 64 - 2 * S), nwaves = strips * ceil_div(h, RB);
-    hipLaunchKernelGGL((nld_strip_kernel<S, RB>), dim3(ceil_div(nwaves, 4)), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves);
+    hipLaunchKernelGGL((nld_strip_kernel<S, RB>), dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves, b.stride);
 }
-void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s) {
+void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b) {
     NldSteps st{};
     for (int i = 0; i < nsteps; i++) st.v[i] = step_sizes[i];
-    // register strips for the throughput-bound launches (up to 4 steps on levels of at least 1 Mpx); the LDS tiles keep the
-    // deeply fused launches of the small, latency-bound octaves (their unrolled strip code would not fit the instruction cache)
+    // register strips for the throughput-bound launches (up to 4 steps on launches of at least 1 Mpx, a batch counted as a whole);
+    // the LDS tiles keep the deeply fused launches of the small, latency-bound octaves (their unrolled strip code would not fit the
+    // instruction cache)
     static const int strip_mode = getenv("APDS_NLD_STRIP") ? atoi(getenv("APDS_NLD_STRIP")) : 1;
-    if (strip_mode && nsteps <= 4 && ((size_t)w * h >= ((size_t)1 << 20) || strip_mode == 2) && (size_t)w * h < ((size_t)1 << 29)) {   // 32-bit byte offsets
+    if (strip_mode && nsteps <= 4 && ((size_t)w * h * b.n >= ((size_t)1 << 20) || strip_mode == 2) && (size_t)w * h < ((size_t)1 << 29)) {   // 32-bit byte offsets
         switch (nsteps) {
-            case 1: nld_strip_launch<1>(Lt, Lf, Lnew, w, h, st, s); return;
-            case 2: nld_strip_launch<2>(Lt, Lf, Lnew, w, h, st, s); return;
-            case 3: nld_strip_launch<3>(Lt, Lf, Lnew, w, h, st, s); return;
-            default: nld_strip_launch<4>(Lt, Lf, Lnew, w, h, st, s); return;
+            case 1: nld_strip_launch<1>(Lt, Lf, Lnew, w, h, st, s, b); return;
+            case 2: nld_strip_launch<2>(Lt, Lf, Lnew, w, h, st, s, b); return;
+            case 3: nld_strip_launch<3>(Lt, Lf, Lnew, w, h, st, s, b); return;
+            default: nld_strip_launch<4>(Lt, Lf, Lnew, w, h, st, s, b); return;
         }
     }
     switch (nsteps) {
-        case 1: nld_multi_launch<1>(Lt, Lf, Lnew, w, h, st, s); break;
-        case 2: nld_multi_launch<2>(Lt, Lf, Lnew, w, h, st, s); break;
-        case 3: nld_multi_launch<3>(Lt, Lf, Lnew, w, h, st, s); break;
-        case 4: nld_multi_launch<4>(Lt, Lf, Lnew, w, h, st, s); break;
-        case 5: nld_multi_launch<5>(Lt, Lf, Lnew, w, h, st, s); break;
-        case 6: nld_multi_launch<6>(Lt, Lf, Lnew, w, h, st, s); break;
-        case 7: nld_multi_launch<7>(Lt, Lf, Lnew, w, h, st, s); break;
-        case 8: nld_multi_launch<8>(Lt, Lf, Lnew, w, h, st, s); break;
+        case 1: nld_multi_launch<1>(Lt, Lf, Lnew, w, h, st, s, b); break;
+        case 2: nld_multi_launch<2>(Lt, Lf, Lnew, w, h, st, s, b); break;
+        case 3: nld_multi_launch<3>(Lt, Lf, Lnew, w, h, st, s, b); break;
+        case 4: nld_multi_launch<4>(Lt, Lf, Lnew, w, h, st, s, b); break;
+        case 5: nld_multi_launch<5>(Lt, Lf, Lnew, w, h, st, s, b); break;
+        case 6: nld_multi_launch<6>(Lt, Lf, Lnew, w, h, st, s, b); break;
+        case 7: nld_multi_launch<7>(Lt, Lf, Lnew, w, h, st, s, b); break;
+        case 8: nld_multi_launch<8>(Lt, Lf, Lnew, w, h, st, s, b); break;
         default: fail(APDS_ERR_INTERNAL, "nld_multi: 1..8 steps per launch");
     }
 }
-void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s) {
-    hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, src, sw, dst, dw, dh);
+void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s, const Batch& b) {
+    hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 256), dh, b.n), dim3(256), 0, s, src, sw, dst, dw, dh, b.stride);
 }
 void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, const int* xofs, const float* xw, const int* xcnt, const int* yofs,
-                        const float* yw, const int* ycnt, hipStream_t s) {
-    hipLaunchKernelGGL(area_resize_kernel, dim3(ceil_div(dw, 256), dh), dim3(256), 0, s, src, sw, dst, dw, dh, xofs, xw, xcnt, yofs, yw, ycnt);
+                        const float* yw, const int* ycnt, hipStream_t s, const Batch& b) {
+    hipLaunchKernelGGL(area_resize_kernel, dim3(ceil_div(dw, 256), dh, b.n), dim3(256), 0, s, src, sw, dst, dw, dh, xofs, xw, xcnt, yofs, yw, ycnt, b.stride);
 }
 void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
-                      uint32_t* list, int* list_count, hipStream_t s) {
+                      uint32_t* list, int* list_count, hipStream_t s, const Batch& b) {
     const size_t lds = (size_t)((DW + 4 * sc + 2) * (DH + 4 * sc + 2) + 2 * (DW + 2 * sc + 2) * (DH + 2 * sc + 2)) * sizeof(float);
     APDS_REQUIRE((size_t)(DW + 2) * (DH + 2) + DCAND <= (size_t)(DW + 4 * sc + 2) * (DH + 4 * sc + 2), APDS_ERR_INTERNAL, "doh_fused: LDS aliasing needs sigma_size >= 2");
     // the extrema test of a level that is too small for its border is skipped (border < 0 in the kernel)
@@ -1069,8 +1111,8 @@ void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int
     auto go = [&](auto kernel) {
         if (lds > 64 * 1024)   // above the default dynamic-LDS limit: opt in (idempotent)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        hipLaunchKernelGGL(kernel, dim3(ceil_div(w, DW), ceil_div(h, DH)), dim3(DNT), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
-                           (float)(sc * sc * sc * sc), none ? -1 : border, thr, mask, list, list_count);
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(w, DW), ceil_div(h, DH), b.n), dim3(DNT), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
+                           (float)(sc * sc * sc * sc), none ? -1 : border, thr, mask, list, list_count, b.stride);
     };
     switch (sc) {
         case 2: go(&doh_fused_kernel<2>); break;

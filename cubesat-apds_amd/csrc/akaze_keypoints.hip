@@ -22,6 +22,7 @@ __device__ __forceinline__ int clampi2(int i, int n) { return i < 0 ? 0 : (i >= 
 static constexpr uint8_t ST_PENDING = 255, ST_DONE_OLD = 254;
 
 struct SuppressArgs {
+    size_t bstride;   // batch: slab stride in bytes (all pointers below are image 0's)
     int n_levels;
     int phase;   // 0: compare with the previous level (ascending passes), 1: with the next level
     int w[AKAZE_MAX_LEVELS], h[AKAZE_MAX_LEVELS], sigma_size[AKAZE_MAX_LEVELS], iratio[AKAZE_MAX_LEVELS];
@@ -40,23 +41,30 @@ static constexpr int PEND_PITCH = 32;   // same-line atomics serialise in L2 (~1
 __global__ void suppress_init_status_kernel(SuppressArgs A) {
     APDS_RAISE_WAVE_PRIORITY();
     const int lvl = blockIdx.y;
-    const int cnt = A.list_count[lvl];
+    const int cnt = bofs(A.list_count, A.bstride)[lvl];
+    const uint32_t* __restrict__ list = bofs(A.list[lvl], A.bstride);
+    uint8_t* __restrict__ status = bofs(A.status[lvl], A.bstride);
+    const uint8_t* __restrict__ mask = bofs(A.mask[lvl], A.bstride);
+    if (blockIdx.x == 0 && threadIdx.x < 3)   // the three rotating pending counters of this level start the phase at zero
+        bofs(A.pend_count, A.bstride)[(threadIdx.x * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH] = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
-        const uint32_t e = A.list[lvl][i];
+        const uint32_t e = list[i];
         const size_t p = (size_t)(e >> 16) * A.w[lvl] + (e & 0xFFFF);
-        A.status[lvl][p] = A.mask[lvl][p] ? ST_PENDING : 0;
+        status[p] = mask[p] ? ST_PENDING : 0;
     }
 }
 
 __global__ void suppress_canon_kernel(SuppressArgs A) {
     APDS_RAISE_WAVE_PRIORITY();
     const int lvl = blockIdx.y;
-    const int cnt = A.list_count[lvl];
+    const int cnt = bofs(A.list_count, A.bstride)[lvl];
+    const uint32_t* __restrict__ list = bofs(A.list[lvl], A.bstride);
+    uint8_t* __restrict__ status = bofs(A.status[lvl], A.bstride);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
-        const uint32_t e = A.list[lvl][i];
+        const uint32_t e = list[i];
         const size_t p = (size_t)(e >> 16) * A.w[lvl] + (e & 0xFFFF);
-        const uint8_t s = A.status[lvl][p];
-        if (s >= 1 && s <= 253) A.status[lvl][p] = ST_DONE_OLD;
+        const uint8_t s = status[p];
+        if (s >= 1 && s <= 253) status[p] = ST_DONE_OLD;
     }
 }
 
@@ -71,11 +79,18 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
     const int lvl = blockIdx.y;
     const int other = A.phase == 0 ? lvl - 1 : lvl + 1;
     if (other < 0 || other >= A.n_levels) return;
-    const uint32_t* __restrict__ in = in_sel < 0 ? A.list[lvl] : A.pend[lvl] + (size_t)in_sel * A.pend_cap[lvl];
-    const int cnt = in_sel < 0 ? A.list_count[lvl] : A.pend_count[(in_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH];
-    uint32_t* __restrict__ out = A.pend[lvl] + (size_t)out_sel * A.pend_cap[lvl];
-    int* out_count = &A.pend_count[(out_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH];
-    if (blockIdx.x == 0 && threadIdx.x == 0) A.pend_count[(zero_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH] = 0;
+    const size_t bstride = A.bstride;
+    int* __restrict__ pend_count = bofs(A.pend_count, bstride);
+    uint32_t* __restrict__ pend = bofs(A.pend[lvl], bstride);
+    const uint32_t* __restrict__ in = in_sel < 0 ? bofs(A.list[lvl], bstride) : pend + (size_t)in_sel * A.pend_cap[lvl];
+    const int cnt = in_sel < 0 ? bofs(A.list_count, bstride)[lvl] : pend_count[(in_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH];
+    if (cnt == 0 && in_sel >= 0) {   // nothing pending for this level (every round after convergence): the block has no work
+        if (blockIdx.x == 0 && threadIdx.x == 0) pend_count[(zero_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH] = 0;
+        return;
+    }
+    uint32_t* __restrict__ out = pend + (size_t)out_sel * A.pend_cap[lvl];
+    int* out_count = &pend_count[(out_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH];
+    if (blockIdx.x == 0 && threadIdx.x == 0) pend_count[(zero_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH] = 0;
     // still-blocked candidates are staged per block and appended with one global atomic
     constexpr int STAGE = 192;
     __shared__ uint32_t s_stage[STAGE];
@@ -84,7 +99,10 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
     __syncthreads();
     const int w = A.w[lvl], h = A.h[lvl];
     const int lane = threadIdx.x & 63;
-    uint8_t* status = A.status[lvl];
+    uint8_t* status = bofs(A.status[lvl], bstride);
+    const float* __restrict__ ldet_own = bofs(A.Ldet[lvl], bstride);
+    const float* __restrict__ ldet_other = bofs(A.Ldet[other], bstride);
+    uint8_t* __restrict__ omask_w = bofs(A.mask[other], bstride);
     // interaction distance in this level's pixels (conservative superset of "search windows overlap")
     int D, diff, radius;
     if (A.phase == 0) {
@@ -99,7 +117,7 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
     const int W = 2 * D + 1, total = W * (D + 1);
     const int side = 2 * radius, total2 = side * side;
     const int ow = A.w[other], oh = A.h[other];
-    const uint8_t* __restrict__ omask = A.mask[other];
+    const uint8_t* omask = omask_w;
     for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < cnt; i += gridDim.x * 4) {
         const uint32_t e = in[i];
         const int x = e & 0xFFFF, y = e >> 16;
@@ -128,7 +146,7 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
                 if (ii >= 0 && ii < oh && jj >= 0 && jj < ow) mv[u] = omask[(size_t)ii * ow + jj];
             }
         }
-        const float own_response = A.Ldet[lvl][p];
+        const float own_response = ldet_own[p];
         // ready iff no EARLIER (row-major) keypoint of this level within D is pending or finished only in this round
         bool hit0 = false;
 #pragma unroll
@@ -202,7 +220,7 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
             continue;
         }
         if (lane == 0) {
-            if (found >= 0 && own_response > A.Ldet[other][found]) A.mask[other][found] = 0;
+            if (found >= 0 && own_response > ldet_other[found]) omask_w[found] = 0;
             status[p] = stamp;
         }
     }
@@ -244,18 +262,20 @@ __device__ __forceinline__ Refined refine(const float* __restrict__ ldet, int co
 }
 
 // drop candidates whose refinement is unstable, so the concatenated masks become the final keypoint flags
-__global__ void subpixel_filter_kernel(LevelTable T, const uint32_t* const* __restrict__ lists, const int* __restrict__ list_count) {
+__global__ void subpixel_filter_kernel(LevelTable T, const int* __restrict__ list_count) {
     APDS_RAISE_WAVE_PRIORITY();
     const int lvl = blockIdx.y;
-    const int cnt = list_count[lvl];
-    const uint32_t* list = lists[lvl];
+    const int cnt = bofs(list_count, T.bstride)[lvl];
+    const uint32_t* __restrict__ list = bofs(T.list[lvl], T.bstride);
+    uint8_t* __restrict__ mask = bofs(T.mask[lvl], T.bstride);
+    const float* __restrict__ ldet = bofs(T.Ldet[lvl], T.bstride);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
         const uint32_t e = list[i];
         const int x = e & 0xFFFF, y = e >> 16;
         const size_t p = (size_t)y * T.w[lvl] + x;
-        if (!T.mask[lvl][p]) continue;
-        const Refined r = refine(T.Ldet[lvl], T.w[lvl], x, y, T.ratio[lvl]);
-        if (!r.ok) T.mask[lvl][p] = 0;
+        if (!mask[p]) continue;
+        const Refined r = refine(ldet, T.w[lvl], x, y, T.ratio[lvl]);
+        if (!r.ok) mask[p] = 0;
     }
 }
 
@@ -263,8 +283,11 @@ static constexpr int SCAN_BLOCK = 1024;
 
 __global__ __launch_bounds__(SCAN_BLOCK) void emit_keypoints_kernel(LevelTable T, const uint8_t* __restrict__ flags, long long total,
                                                                     const int* __restrict__ block_offsets, apds_keypoint* __restrict__ kps,
-                                                                    int capacity) {
+                                                                    int capacity, size_t kp_bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    flags = bofs(flags, T.bstride);
+    block_offsets = bofs(block_offsets, T.bstride);
+    kps = bofs(kps, kp_bstride);
     __shared__ int wsum[SCAN_BLOCK / 64];
     const long long base = ((long long)blockIdx.x * SCAN_BLOCK + threadIdx.x) * 16;
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -301,7 +324,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void emit_keypoints_kernel(LevelTable T
         while (lvl + 1 < T.n && e >= T.pix_offset[lvl + 1]) lvl++;
         const long long pix = e - T.pix_offset[lvl];
         const int y = (int)(pix / T.w[lvl]), x = (int)(pix - (long long)y * T.w[lvl]);
-        const Refined r = refine(T.Ldet[lvl], T.w[lvl], x, y, T.ratio[lvl]);
+        const Refined r = refine(bofs(T.Ldet[lvl], T.bstride), T.w[lvl], x, y, T.ratio[lvl]);
         apds_keypoint kp;
         kp.x = r.x;
         kp.y = r.y;
@@ -383,8 +406,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-__global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_keypoint* __restrict__ kps, int n, float ang_step, int nkeys) {
+// n = min(*n_dev of this image, n_cap): the image's keypoint count stays on the device (n_dev == nullptr: n_cap is the count)
+__global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_keypoint* __restrict__ kps, const int* __restrict__ n_dev, int n_cap, size_t kp_bstride,
+                                                          float ang_step, int nkeys) {
     APDS_RAISE_WAVE_PRIORITY();
+    const int n = n_dev ? min(*bofs(n_dev, T.bstride), n_cap) : n_cap;
+    if ((int)blockIdx.x * 4 >= n) return;   // block-uniform: grids are sized for the largest image of the batch
+    kps = bofs(kps, kp_bstride);
     __shared__ float s_x[4][112], s_y[4][112];
     __shared__ uint8_t s_bin[4][112], s_sorted[4][112];
     __shared__ int s_start[4][44];
@@ -397,7 +425,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
     const float ratio = T.ratio[lvl];
     const int scale = __float2int_rn(0.5f * kp.size / ratio);
     const int x0 = __float2int_rn(kp.x / ratio), y0 = __float2int_rn(kp.y / ratio);
-    const float2* __restrict__ Lxy = T.Lxy[lvl];
+    const float2* __restrict__ Lxy = bofs(T.Lxy[lvl], T.bstride);
     const float rad = (float)(3.14159265358979323846 / 180);
     {
         // both of a lane's samples: table entries, then the two gathers, are in flight together (one round trip each)
@@ -553,8 +581,13 @@ __constant__ MldbLut c_mldb = make_mldb_lut();
 // by all 64 lanes (they were gathered 1241 times, once per grid), then 29 lanes, one per cell of any grid, add their cell's
 // samples in the reference's order (k-major, l-minor; float sums are order dependent), and the 486 comparisons are done 32
 // per lane.
-__global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, int n, uint32_t* __restrict__ desc64) {
+__global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, const int* __restrict__ n_dev, int n_cap, size_t kp_bstride,
+                                                   uint32_t* __restrict__ desc64, size_t desc_bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    const int n = n_dev ? min(*bofs(n_dev, T.bstride), n_cap) : n_cap;
+    if ((int)blockIdx.x * 4 >= n) return;   // block-uniform
+    kps = bofs(kps, kp_bstride);
+    desc64 = bofs(desc64, desc_bstride);
     constexpr int LW = 21;                     // lattice width: offsets -10 .. 10
     __shared__ float4 s_samp[4][LW * LW + 7];   // (ri, rrx, rry, valid) per lattice point
     __shared__ int s_val[4][88];
@@ -565,8 +598,8 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
     const apds_keypoint kp = kps[live ? ki : 0];
     const int lvl = kp.class_id;
     const int w = T.w[lvl], h = T.h[lvl];
-    const float* __restrict__ Lt = T.Lt[lvl];
-    const float2* __restrict__ Lxy = T.Lxy[lvl];
+    const float* __restrict__ Lt = bofs(T.Lt[lvl], T.bstride);
+    const float2* __restrict__ Lxy = bofs(T.Lxy[lvl], T.bstride);
     const float ratio = (float)(1 << kp.octave);
     const float scale = (float)__float2int_rn(0.5f * kp.size / ratio);
     const float xf = kp.x / ratio, yf = kp.y / ratio;
@@ -754,8 +787,10 @@ __device__ __forceinline__ int nonzero_bytes(uint32_t w) {
     return __popc(w & 0x01010101u);
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8_t* __restrict__ flags, long long n, int* __restrict__ block_counts) {
+__global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8_t* __restrict__ flags, long long n, int* __restrict__ block_counts, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    flags = bofs(flags, bstride);
+    block_counts = bofs(block_counts, bstride);
     __shared__ int wsum[SCAN_BLOCK / 64];
     const long long base = ((long long)blockIdx.x * SCAN_BLOCK + threadIdx.x) * 16;
     int c = 0;
@@ -773,8 +808,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8
     }
 }
 
-__global__ __launch_bounds__(1024) void kp_scan_offsets_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ total) {
+__global__ __launch_bounds__(1024) void kp_scan_offsets_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ total, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
+    block_counts = bofs(block_counts, bstride);
+    total = bofs(total, bstride);
     __shared__ int buf[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -817,18 +854,37 @@ AkazeDebugRequest& akaze_debug_request() {
     return r;
 }
 
-// feature_extraction/src/lib.rs:61-92 on a device image. Returns the keypoint count; kps/desc64 must hold `capacity` rows.
-int akaze_extract_device(const void* img, int rows, int cols, int channels, size_t stride, int max_points, apds_keypoint* kps_out,
-                         uint8_t* desc64_out, int capacity, hipStream_t s) {
+// Bump layout of one image's workspace slab: run once with base == nullptr to size it, once more with the real base. Every plane
+// starts on a 256-byte boundary.
+namespace {
+struct Arena {
+    char* base = nullptr;
+    size_t off = 0;
+    template <class T>
+    T* take(size_t n) {
+        T* p = reinterpret_cast<T*>(base + off);
+        off += (n * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+};
+}  // namespace
+
+// feature_extraction/src/lib.rs:61-92 on `n_img` device images of one size (a batch goes through every kernel's grid together:
+// gridDim.z = n_img; a single image is a batch of one). Image i starts `img_bstride` bytes after image i-1; its keypoints go to
+// kps_out + i * capacity, its descriptors to desc64_out + i * capacity * 64, its count to counts[i] (host). Returns the largest count.
+int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, int rows, int cols, int channels, size_t stride, int max_points,
+                               apds_keypoint* kps_out, uint8_t* desc64_out, int capacity, int* counts, hipStream_t s) {
     APDS_REQUIRE(img != nullptr, APDS_ERR_BAD_ARG, "null image");
+    APDS_REQUIRE(n_img >= 1 && n_img <= 4096, APDS_ERR_BAD_ARG, "batch must hold 1 .. 4096 images");
     APDS_REQUIRE(channels == 1 || channels == 3 || channels == 4, APDS_ERR_ASSERT, "image must have 1, 3 or 4 channels");
     APDS_REQUIRE(rows > 2 && cols > 2, APDS_ERR_ASSERT, "image must be larger than 2x2");   // AKAZE CV_Assert(img_height > 2 && img_width > 2)
     APDS_REQUIRE(rows < 65536 && cols < 65536, APDS_ERR_ASSERT, "image side must be < 65536");
     APDS_REQUIRE(stride >= (size_t)cols * channels, APDS_ERR_ASSERT, "row stride smaller than a row");
+    APDS_REQUIRE(n_img == 1 || img_bstride >= (size_t)rows * stride, APDS_ERR_ASSERT, "image stride smaller than an image");
     if (max_points <= 0) max_points = APDS_MAX_POINTS;
     ThreadCtx& c = ctx();
-    KernelTimer whole("akaze_extract", s);   // whole extraction (all kernels + the two count read-backs), for bench.py
-    const int W = cols, H = rows;
+    KernelTimer whole("akaze_extract", s);   // whole extraction (all kernels + the count read-backs), for bench.py
+    const int W = cols, H = rows, B = n_img;
     const float soffset = 1.6f, derivative_factor = 1.5f, dthreshold = 0.001f;
 
     // ---- evolution (Allocate_Memory_Evolution)
@@ -861,46 +917,74 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     }
     const int L = (int)ev.size();
     const int n_oct = ev.back().octave + 1;
+    static const bool fork_doh = !(getenv("APDS_AKAZE_FORK") && atoi(getenv("APDS_AKAZE_FORK")) == 0);
 
-    // ---- device planes
+    // ---- one image's workspace slab (all images of the batch: the same layout, `slab` bytes apart)
     const size_t n0 = (size_t)W * H;
-    float* gray = c.alloc_n<float>(n0);
-    float* tmpS = c.alloc_n<float>(n0);
-    float* tmpF = c.alloc_n<float>(n0);
-    float* tmpP = c.alloc_n<float>(n0);
     long long total_pix = 0;
     for (auto& e : ev) {
-        const size_t n = (size_t)e.w * e.h;
-        e.Lt = c.alloc_n<float>(n);
-        e.Lxy = c.alloc_n<float2>(n);
-        e.Ldet = c.alloc_n<float>(n);
         e.pix_offset = total_pix;
-        total_pix += (long long)n;
+        total_pix += (long long)e.w * e.h;
     }
-    uint8_t* mask_all = c.alloc_n<uint8_t>((size_t)total_pix);
-    uint8_t* status_all = c.alloc_n<uint8_t>((size_t)total_pix);
-    unsigned int* hmax_bits = c.alloc_n<unsigned int>(1);
-    int* hist = c.alloc_n<int>(300);
-    float* k_oct = c.alloc_n<float>(8);
-    int* list_count = c.alloc_n<int>(AKAZE_MAX_LEVELS);
-
-    // candidate lists and keypoint masks are filled by the determinant kernel of each level: allocate / clear them first
-    std::vector<uint32_t*> lists(L);
-    for (int i = 0; i < L; i++) lists[i] = c.alloc_n<uint32_t>((size_t)((ev[i].w + 1) / 2) * ((ev[i].h + 1) / 2));   // strict 3x3 maxima are never adjacent
-    HIP_CHECK(hipMemsetAsync(mask_all, 0, (size_t)total_pix, s));
-    HIP_CHECK(hipMemsetAsync(status_all, 0, (size_t)total_pix, s));
-    HIP_CHECK(hipMemsetAsync(list_count, 0, AKAZE_MAX_LEVELS * sizeof(int), s));
+    const int nblocks = ceil_div(total_pix, KP_BYTES_PER_BLOCK);
+    // zero-initialised head of the slab (one 2-D memset clears it for the whole batch): counters, then keypoint masks and statuses
+    int *list_count, *hist, *pend_count, *block_counts, *total_dev;
+    unsigned int* hmax_bits;
+    float *k_oct, *gray, *tmpS, *tmpF, *tmpP;
+    uint8_t *mask_all, *status_all;
+    std::vector<uint32_t*> lists(L), pend(L);
+    std::vector<float*> lsm(L);
+    size_t zero_bytes = 0;
+    auto layout = [&](Arena& A) {
+        list_count = A.take<int>(AKAZE_MAX_LEVELS);
+        hmax_bits = A.take<unsigned int>(1);
+        hist = A.take<int>(300);
+        pend_count = A.take<int>(3 * AKAZE_MAX_LEVELS * PEND_PITCH);
+        mask_all = A.take<uint8_t>((size_t)total_pix);
+        status_all = A.take<uint8_t>((size_t)total_pix);
+        zero_bytes = A.off;
+        k_oct = A.take<float>(8);
+        block_counts = A.take<int>(nblocks + 1);
+        total_dev = block_counts + nblocks;
+        gray = A.take<float>(n0);
+        tmpS = A.take<float>(n0);
+        tmpF = A.take<float>(n0);
+        tmpP = A.take<float>(n0);
+        for (int i = 0; i < L; i++) {
+            LevelDesc& e = ev[i];
+            const size_t n = (size_t)e.w * e.h;
+            e.Lt = A.take<float>(n);
+            e.Lxy = A.take<float2>(n);
+            e.Ldet = A.take<float>(n);
+            const size_t ncand = (size_t)((e.w + 1) / 2) * ((e.h + 1) / 2);   // strict 3x3 maxima are never adjacent
+            lists[i] = A.take<uint32_t>(ncand);
+            pend[i] = A.take<uint32_t>(3 * ncand);
+            // Lsmooth: a plane per level when the Hessian kernels run on the side stream (see below), else one shared plane
+            lsm[i] = (fork_doh && i > 0) ? A.take<float>(n) : tmpS;
+        }
+    };
+    Arena sizing;
+    layout(sizing);
+    const size_t slab = (sizing.off + 4095) & ~(size_t)4095;
+    Arena real;
+    real.base = static_cast<char*>(c.alloc(slab * (size_t)B));
+    layout(real);
+    Batch bt;
+    bt.n = B;
+    bt.stride = slab;
+    bt.img_stride = img_bstride;
+    HIP_CHECK(hipMemset2DAsync(real.base, slab, 0, zero_bytes, (size_t)B, s));
 
     // ---- a1.1 / a1.2 / a1.3
     const GaussTaps g16 = gauss_taps(9, (double)soffset), g10 = gauss_taps(5, 1.0);
-    if (launch_base_strips(img, H, W, channels, stride, g16, g10, ev[0].Lt, tmpF, hmax_bits, L > 1, s)) {   // large images: one fused pass
-        if (L > 1) launch_kcontrast(nullptr, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s, /*gradient_done=*/true);
+    if (launch_base_strips(img, H, W, channels, stride, g16, g10, ev[0].Lt, tmpF, hmax_bits, L > 1, s, bt)) {   // large images: one fused pass
+        if (L > 1) launch_kcontrast(nullptr, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s, bt, /*gradient_done=*/true);
     } else {
-        launch_gray(img, H, W, channels, stride, gray, s);
-        launch_gauss(gray, ev[0].Lt, W, H, g16, 4, s);   // Lt[0] == Lsmooth[0]
+        launch_gray(img, H, W, channels, stride, gray, s, bt);
+        launch_gauss(gray, ev[0].Lt, W, H, g16, 4, s, bt);   // Lt[0] == Lsmooth[0]
         if (L > 1) {
-            launch_gauss(gray, tmpS, W, H, g10, 2, s);
-            launch_kcontrast(tmpS, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s);
+            launch_gauss(gray, tmpS, W, H, g10, 2, s, bt);
+            launch_kcontrast(tmpS, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s, bt);
         }
     }
     auto deriv_weights = [](int sc, float& kside, float& kmid) {
@@ -917,10 +1001,6 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     // The Hessian / extrema kernel of a level hangs off the main chain (it only needs the level's Lsmooth and nothing waits for it
     // before the suppression): it goes to a second stream, so the latency-bound launches of the small octaves overlap the
     // smoothing and diffusion launches of the levels that follow. Lsmooth then needs a plane per level instead of a shared one.
-    static const bool fork_doh = !(getenv("APDS_AKAZE_FORK") && atoi(getenv("APDS_AKAZE_FORK")) == 0);
-    std::vector<float*> lsm(L, tmpS);
-    if (fork_doh)
-        for (int i = 1; i < L; i++) lsm[i] = c.alloc_n<float>((size_t)ev[i].w * ev[i].h);
     hipStream_t s_doh = fork_doh ? c.side_stream() : s;
     if (fork_doh && c.fork_open) {   // an earlier call failed between fork and join: its side-stream kernels may still use the workspace
         HIP_CHECK(hipStreamSynchronize(s_doh));
@@ -939,26 +1019,26 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
             // between e.Lt and tmpP and must end in e.Lt. Deeper fusion for the small octaves, whose launches are latency-bound.
             static const int fuse_big = getenv("APDS_NLD_FUSE_BIG") ? atoi(getenv("APDS_NLD_FUSE_BIG")) : 4;
             static const int fuse_small = getenv("APDS_NLD_FUSE_SMALL") ? atoi(getenv("APDS_NLD_FUSE_SMALL")) : 8;
-            const int fuse = std::min(8, std::max(1, (size_t)e.w * e.h <= (size_t)1 << 20 ? fuse_small : fuse_big));
+            const int fuse = std::min(8, std::max(1, (size_t)e.w * e.h * B <= (size_t)1 << 20 ? fuse_small : fuse_big));
             const int launches = (e.nsteps + fuse - 1) / fuse;
             if (e.octave > p.octave) {
                 float* dstP = (launches % 2 == 0) ? e.Lt : tmpP;   // so that the last pass lands in e.Lt
                 if (p.w == 2 * e.w && p.h == 2 * e.h) {
-                    launch_half_sample(p.Lt, p.w, dstP, e.w, e.h, s);
+                    launch_half_sample(p.Lt, p.w, dstP, e.w, e.h, s, bt);
                 } else {
                     std::vector<int> xo, yo, xc, yc;
                     std::vector<float> xw, yw;
                     area_tables(p.w, e.w, xo, xw, xc);
                     area_tables(p.h, e.h, yo, yw, yc);
                     HIP_CHECK(hipStreamSynchronize(s));   // host tables must outlive the async copies
-                    launch_area_resize(p.Lt, p.w, dstP, e.w, e.h, upload(xo, s), upload(xw, s), upload(xc, s), upload(yo, s), upload(yw, s), upload(yc, s), s);
+                    launch_area_resize(p.Lt, p.w, dstP, e.w, e.h, upload(xo, s), upload(xw, s), upload(xc, s), upload(yo, s), upload(yw, s), upload(yc, s), s, bt);
                     HIP_CHECK(hipStreamSynchronize(s));
                 }
                 P = dstP;
             } else {
                 P = p.Lt;
             }
-            launch_smooth_flow(P, lsm[i], tmpF, e.w, e.h, g10, k_oct + e.octave, s);   // Lsmooth and the conductivity in one pass
+            launch_smooth_flow(P, lsm[i], tmpF, e.w, e.h, g10, k_oct + e.octave, s, bt);   // Lsmooth and the conductivity in one pass
             smooth = lsm[i];
             if (fork_doh) {   // Lsmooth of this level exists from here on
                 HIP_CHECK(hipEventRecord(c.fork_event(i), s));
@@ -972,11 +1052,12 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
                 const int g = (e.nsteps - k + (launches - pass) - 1) / (launches - pass);
                 float st[8];
                 for (int j = 0; j < g; j++) st[j] = e.tau[k + j] * 0.5f;
-                launch_nld_multi(in, tmpF, out, e.w, e.h, st, g, s);
+                launch_nld_multi(in, tmpF, out, e.w, e.h, st, g, s, bt);
                 k += g;
                 in = out;
             }
-            if (e.nsteps == 0 && P != e.Lt) HIP_CHECK(hipMemcpyAsync(e.Lt, P, (size_t)e.w * e.h * 4, hipMemcpyDeviceToDevice, s));
+            if (e.nsteps == 0 && P != e.Lt)
+                HIP_CHECK(hipMemcpy2DAsync(e.Lt, slab, P, slab, (size_t)e.w * e.h * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
         }
         float kside, kmid;
         deriv_weights(e.sigma_size, kside, kmid);
@@ -987,7 +1068,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
             HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
         }
         launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i,
-                         s_doh);
+                         s_doh, bt);
     }
     if (fork_doh) {   // join: everything after this point reads what the Hessian kernels wrote
         if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, hipEventDisableTiming));
@@ -997,10 +1078,11 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     }
     HIP_CHECK(hipGetLastError());
 
-    // ---- level tables for the keypoint kernels
+    // ---- level tables for the keypoint kernels (pointers of image 0; kernels add blockIdx.z * slab)
     LevelTable T{};
     SuppressArgs A{};
     T.n = A.n_levels = L;
+    T.bstride = A.bstride = slab;
     for (int i = 0; i < L; i++) {
         const LevelDesc& e = ev[i];
         T.w[i] = A.w[i] = e.w;
@@ -1017,32 +1099,23 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         T.Ldet[i] = A.Ldet[i] = e.Ldet;
         T.mask[i] = A.mask[i] = mask_all + e.pix_offset;
         A.status[i] = status_all + e.pix_offset;
-        A.list[i] = lists[i];
+        T.list[i] = A.list[i] = lists[i];
         A.pend_cap[i] = ((e.w + 1) / 2) * ((e.h + 1) / 2);
-        A.pend[i] = c.alloc_n<uint32_t>((size_t)3 * A.pend_cap[i]);
+        A.pend[i] = pend[i];
     }
-    int* pend_count = c.alloc_n<int>(3 * AKAZE_MAX_LEVELS * PEND_PITCH);
     A.pend_count = pend_count;
     T.pix_offset[L] = total_pix;
     A.list_count = list_count;
 
     // ---- cross-level suppression: phase 0 (vs previous level), then phase 1 (vs next level)
     if (L > 1) {
-        const dim3 lgrid(256, L), lblock(256);   // 1024 waves per level, one candidate keypoint per wave at a time
+        const dim3 lgrid(B > 1 ? 64 : 256, L, B), lblock(256);   // one candidate keypoint per wave at a time
+        std::vector<int> pc((size_t)B * AKAZE_MAX_LEVELS * PEND_PITCH);
         for (int phase = 0; phase < 2; phase++) {
             A.phase = phase;
-            hipLaunchKernelGGL(suppress_init_status_kernel, lgrid, lblock, 0, s, A);
+            hipLaunchKernelGGL(suppress_init_status_kernel, lgrid, lblock, 0, s, A);   // also zeroes the level's three pending counters
             int round = 0;
             static const bool dbg_rounds = getenv("APDS_AKAZE_DEBUG") != nullptr;
-            if (dbg_rounds) {
-                int counts[AKAZE_MAX_LEVELS];
-                HIP_CHECK(hipMemcpyAsync(counts, list_count, sizeof(counts), hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipStreamSynchronize(s));
-                fprintf(stderr, "[apds] phase %d candidates per level:", phase);
-                for (int i = 0; i < L; i++) fprintf(stderr, " %d", counts[i]);
-                fprintf(stderr, "\n");
-            }
-            HIP_CHECK(hipMemsetAsync(pend_count, 0, 3 * AKAZE_MAX_LEVELS * PEND_PITCH * sizeof(int), s));
             // rounds are cheap once only the still-pending candidates are visited, a host check costs a stream sync: the first
             // batch is as long as this thread's previous image needed in this phase (8 at first; a typical frame needs ~6
             // rounds in phase 0 and ~15 in phase 1), then 4 at a time. Rounds after convergence change nothing.
@@ -1053,25 +1126,22 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
                 for (int b = 0; b < batch; b++) {
                     const uint8_t stamp = (uint8_t)(round % 253 + 1);
                     // after a few rounds only a handful of candidates are left: a small grid keeps the launch itself short
-                    hipLaunchKernelGGL(suppress_round_kernel, round < 8 ? lgrid : dim3(16, L), lblock, 0, s, A, stamp, round == 0 ? -1 : (round - 1) % 3, round % 3,
-                                       (round + 1) % 3);
+                    hipLaunchKernelGGL(suppress_round_kernel, round < 8 ? lgrid : dim3(16, L, B), lblock, 0, s, A, stamp, round == 0 ? -1 : (round - 1) % 3,
+                                       round % 3, (round + 1) % 3);
                     round++;
                     if (round % 253 == 0) hipLaunchKernelGGL(suppress_canon_kernel, lgrid, lblock, 0, s, A);
-                    if (dbg_rounds) {
-                        int pc[AKAZE_MAX_LEVELS * PEND_PITCH], pend = 0;
-                        HIP_CHECK(hipMemcpyAsync(pc, pend_count + ((round - 1) % 3) * AKAZE_MAX_LEVELS * PEND_PITCH, sizeof(pc), hipMemcpyDeviceToHost, s));
-                        HIP_CHECK(hipStreamSynchronize(s));
-                        for (int i = 0; i < L; i++) pend += pc[i * PEND_PITCH];
-                        fprintf(stderr, "[apds]   phase %d round %d pending %d\n", phase, round, pend);
-                    }
                 }
-                int pc[AKAZE_MAX_LEVELS * PEND_PITCH], pending = 0;
-                HIP_CHECK(hipMemcpyAsync(pc, pend_count + ((round - 1) % 3) * AKAZE_MAX_LEVELS * PEND_PITCH, sizeof(pc), hipMemcpyDeviceToHost, s));
+                long long pending = 0;
+                HIP_CHECK(hipMemcpy2DAsync(pc.data(), AKAZE_MAX_LEVELS * PEND_PITCH * sizeof(int),
+                                           pend_count + ((round - 1) % 3) * AKAZE_MAX_LEVELS * PEND_PITCH, slab,
+                                           AKAZE_MAX_LEVELS * PEND_PITCH * sizeof(int), (size_t)B, hipMemcpyDeviceToHost, s));
                 HIP_CHECK(hipStreamSynchronize(s));
-                for (int i = 0; i < L; i++) pending += pc[i * PEND_PITCH];
+                for (int bi = 0; bi < B; bi++)
+                    for (int i = 0; i < L; i++) pending += pc[((size_t)bi * AKAZE_MAX_LEVELS + i) * PEND_PITCH];
+                if (dbg_rounds) fprintf(stderr, "[apds]   phase %d after round %d: pending %lld\n", phase, round, pending);
                 if (pending == 0) {
-                    // converged within the first batch: after eight such images in a row try one round less; otherwise start from
-                    // what this image took
+                    // converged within the first batch: after eight such calls in a row try one round less; otherwise start from
+                    // what this call took
                     if (!first) {
                         first_batch = round;
                         c.akaze_batch_streak[phase] = 0;
@@ -1088,7 +1158,7 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
     }
 
     AkazeDebugRequest& dbg = akaze_debug_request();
-    if (dbg.armed && dbg.level >= 0 && dbg.level < L) {
+    if (dbg.armed && dbg.level >= 0 && dbg.level < L) {   // image 0 of the batch
         const LevelDesc& e = ev[dbg.level];
         const size_t n = (size_t)e.w * e.h;
         const void* src = nullptr;
@@ -1106,32 +1176,67 @@ int akaze_extract_device(const void* img, int rows, int cols, int channels, size
         dbg.armed = false;
     }
 
-    // ---- a1.7 sub-pixel filter, ordered compaction (level-major, row-major)
-    uint32_t** lists_dev = c.alloc_n<uint32_t*>(L);
-    HIP_CHECK(hipMemcpyAsync(lists_dev, lists.data(), L * sizeof(uint32_t*), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(subpixel_filter_kernel, dim3(64, L), dim3(256), 0, s, T, (const uint32_t* const*)lists_dev, (const int*)list_count);
-    const int nblocks = ceil_div(total_pix, KP_BYTES_PER_BLOCK);
-    int* block_counts = c.alloc_n<int>(nblocks + 1);
-    int* total_dev = block_counts + nblocks;
-    hipLaunchKernelGGL(kp_block_counts_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, mask_all, total_pix, block_counts);
-    hipLaunchKernelGGL(kp_scan_offsets_kernel, dim3(1), dim3(1024), 0, s, block_counts, nblocks, total_dev);
-    int K = 0;
-    HIP_CHECK(hipMemcpyAsync(&K, total_dev, sizeof(int), hipMemcpyDeviceToHost, s));
-    HIP_CHECK(hipStreamSynchronize(s));   // lists (host vector) were also consumed by now
-    if (K == 0) return 0;
-    const int keep = std::min(K, max_points);
-    APDS_REQUIRE(keep <= capacity, APDS_ERR_ASSERT, "output capacity smaller than the keypoint count");
-    apds_keypoint* kps_all = (K == keep) ? kps_out : c.alloc_n<apds_keypoint>(K);
-    hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, T, (const uint8_t*)mask_all, total_pix, (const int*)block_counts, kps_all, K);
-    if (K > keep) hipLaunchKernelGGL(rank_select_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, s, (const apds_keypoint*)kps_all, K, keep, kps_out);
-
-    // ---- a1.8 / a1.9
+    // ---- a1.7 sub-pixel filter, ordered compaction (level-major, row-major), per image
+    hipLaunchKernelGGL(subpixel_filter_kernel, dim3(B > 1 ? 16 : 64, L, B), dim3(256), 0, s, T, (const int*)list_count);
+    hipLaunchKernelGGL(kp_block_counts_kernel, dim3(nblocks, 1, B), dim3(SCAN_BLOCK), 0, s, (const uint8_t*)mask_all, total_pix, block_counts, slab);
+    hipLaunchKernelGGL(kp_scan_offsets_kernel, dim3(1, 1, B), dim3(1024), 0, s, block_counts, nblocks, total_dev, slab);
+    std::vector<int> K(B, 0);
+    HIP_CHECK(hipMemcpy2DAsync(K.data(), sizeof(int), total_dev, slab, sizeof(int), (size_t)B, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    int kmax = 0;
+    bool over = false;
+    for (int bi = 0; bi < B; bi++) {
+        counts[bi] = std::min(K[bi], max_points);
+        kmax = std::max(kmax, counts[bi]);
+        over |= K[bi] > max_points;
+        APDS_REQUIRE(counts[bi] <= capacity, APDS_ERR_ASSERT, "output capacity smaller than the keypoint count");
+    }
+    if (kmax == 0) return 0;
+    const size_t kp_bstride = (size_t)capacity * sizeof(apds_keypoint), desc_bstride = (size_t)capacity * 64;
     const float ang_step = (float)(2.0 * M_PI / 42);
     const int nkeys = (int)((float)(2.0 * M_PI) / ang_step);
-    hipLaunchKernelGGL(orientation_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, T, kps_out, keep, ang_step, nkeys);
-    hipLaunchKernelGGL(mldb_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, T, (const apds_keypoint*)kps_out, keep, reinterpret_cast<uint32_t*>(desc64_out));
+    if (!over) {
+        hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nblocks, 1, B), dim3(SCAN_BLOCK), 0, s, T, (const uint8_t*)mask_all, total_pix, (const int*)block_counts,
+                           kps_out, capacity, kp_bstride);
+        // ---- a1.8 / a1.9: grids sized for the largest image, every image reads its own count on the device
+        hipLaunchKernelGGL(orientation_kernel, dim3(ceil_div(kmax, 4), 1, B), dim3(256), 0, s, T, kps_out, (const int*)total_dev, max_points, kp_bstride, ang_step,
+                           nkeys);
+        hipLaunchKernelGGL(mldb_kernel, dim3(ceil_div(kmax, 4), 1, B), dim3(256), 0, s, T, (const apds_keypoint*)kps_out, (const int*)total_dev, max_points,
+                           kp_bstride, reinterpret_cast<uint32_t*>(desc64_out), desc_bstride);
+    } else {
+        // some image has more keypoints than max_points (rare): image by image, through the rank selection (response descending, ties
+        // by detection order); the tables of image bi are image 0's shifted by bi slabs
+        for (int bi = 0; bi < B; bi++) {
+            if (K[bi] == 0) continue;
+            LevelTable Tb = T;
+            Tb.bstride = 0;
+            for (int i = 0; i < L; i++) {
+                Tb.Lt[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(T.Lt[i]) + (size_t)bi * slab);
+                Tb.Lxy[i] = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(T.Lxy[i]) + (size_t)bi * slab);
+                Tb.Ldet[i] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(T.Ldet[i]) + (size_t)bi * slab);
+                Tb.mask[i] = T.mask[i] + (size_t)bi * slab;
+            }
+            const int keep = counts[bi];
+            apds_keypoint* kp_b = kps_out + (size_t)bi * capacity;
+            apds_keypoint* kps_all = (K[bi] == keep) ? kp_b : c.alloc_n<apds_keypoint>(K[bi]);
+            hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, Tb, (const uint8_t*)(mask_all + (size_t)bi * slab), total_pix,
+                               (const int*)(reinterpret_cast<const char*>(block_counts) + (size_t)bi * slab), kps_all, K[bi], (size_t)0);
+            if (K[bi] > keep)
+                hipLaunchKernelGGL(rank_select_kernel, dim3(ceil_div(K[bi], 256)), dim3(256), 0, s, (const apds_keypoint*)kps_all, K[bi], keep, kp_b);
+            hipLaunchKernelGGL(orientation_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, Tb, kp_b, (const int*)nullptr, keep, (size_t)0, ang_step, nkeys);
+            hipLaunchKernelGGL(mldb_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, Tb, (const apds_keypoint*)kp_b, (const int*)nullptr, keep, (size_t)0,
+                               reinterpret_cast<uint32_t*>(desc64_out + (size_t)bi * desc_bstride), (size_t)0);
+        }
+    }
     HIP_CHECK(hipGetLastError());
-    return keep;
+    return kmax;
+}
+
+int akaze_extract_device(const void* img, int rows, int cols, int channels, size_t stride, int max_points, apds_keypoint* kps_out,
+                         uint8_t* desc64_out, int capacity, hipStream_t s) {
+    int count = 0;
+    akaze_extract_batch_device(img, 1, 0, rows, cols, channels, stride, max_points, kps_out, desc64_out, capacity, &count, s);
+    return count;
 }
 
 }  // namespace apds

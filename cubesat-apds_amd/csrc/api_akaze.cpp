@@ -110,6 +110,80 @@ int apds_akaze_debug_plane(const uint8_t* img, int rows, int cols, int channels,
     return rc;
 }
 
+// n_images equal-sized host images in one call: one upload, one batched extraction (every kernel's grid covers all images), one download.
+// Outputs: concatenated keypoints / 61-byte descriptors (image 0's rows first), counts[i] rows per image.
+int apds_akaze_extract_batch(const uint8_t* imgs, int n_images, size_t image_stride, int rows, int cols, int channels, size_t stride, int max_points,
+                             apds_keypoint** kps, uint8_t** desc, int* counts, int* desc_bytes) {
+    return guarded([&] {
+        APDS_REQUIRE(kps && desc && counts && desc_bytes, APDS_ERR_BAD_ARG, "null output");
+        *kps = nullptr;
+        *desc = nullptr;
+        *desc_bytes = APDS_DESC_BYTES;
+        APDS_REQUIRE(imgs != nullptr && rows > 0 && cols > 0, APDS_ERR_ASSERT, "empty image");
+        APDS_REQUIRE(n_images >= 1 && n_images <= 4096, APDS_ERR_BAD_ARG, "batch must hold 1 .. 4096 images");
+        APDS_REQUIRE(channels == 1 || channels == 3 || channels == 4, APDS_ERR_ASSERT, "image must have 1, 3 or 4 channels");
+        APDS_REQUIRE(stride >= (size_t)cols * channels && image_stride >= stride * rows, APDS_ERR_ASSERT, "strides smaller than a row / an image");
+        if (max_points <= 0) max_points = APDS_MAX_POINTS;
+        for (int i = 0; i < n_images; i++) counts[i] = 0;
+        ThreadCtx& c = ctx();
+        c.ws_reset();
+        hipStream_t s = c.stream;
+        const size_t row_bytes = (size_t)cols * channels;
+        const size_t dstride = (row_bytes + 3) & ~size_t(3), dimg_bytes = dstride * rows;
+        uint8_t* dimg = c.alloc_n<uint8_t>(dimg_bytes * n_images);
+        if (stride == dstride && image_stride == dimg_bytes) {
+            HIP_CHECK(hipMemcpyAsync(dimg, imgs, dimg_bytes * n_images, hipMemcpyHostToDevice, s));
+        } else {
+            for (int i = 0; i < n_images; i++)
+                HIP_CHECK(hipMemcpy2DAsync(dimg + i * dimg_bytes, dstride, imgs + i * image_stride, stride, row_bytes, rows, hipMemcpyHostToDevice, s));
+        }
+        // capacity per image: strict 3x3 maxima are never adjacent -> at most a quarter of the pixel-levels; and never more than max_points
+        const long long bound = (long long)((cols + 1) / 2) * ((rows + 1) / 2) * 2;
+        const int capacity = (int)std::min<long long>(max_points, std::max<long long>(bound, 64));
+        apds_keypoint* dk = c.alloc_n<apds_keypoint>((size_t)capacity * n_images);
+        uint8_t* dd = c.alloc_n<uint8_t>((size_t)capacity * 64 * n_images);
+        akaze_extract_batch_device(dimg, n_images, dimg_bytes, rows, cols, channels, dstride, max_points, dk, dd, capacity, counts, s);
+        size_t total = 0;
+        for (int i = 0; i < n_images; i++) total += (size_t)counts[i];
+        apds_keypoint* hk = static_cast<apds_keypoint*>(std::malloc(std::max<size_t>(1, total * sizeof(apds_keypoint))));
+        uint8_t* hd = static_cast<uint8_t*>(std::malloc(std::max<size_t>(1, total * APDS_DESC_BYTES)));
+        if (!hk || !hd) {
+            std::free(hk);
+            std::free(hd);
+            throw std::bad_alloc();
+        }
+        try {
+            uint8_t* d61 = c.alloc_n<uint8_t>(std::max<size_t>(1, total * APDS_DESC_BYTES));
+            size_t off = 0;
+            for (int i = 0; i < n_images; i++) {
+                const int K = counts[i];
+                if (!K) continue;
+                pack_desc61_device(dd + (size_t)i * capacity * 64, K, d61 + off * APDS_DESC_BYTES, s);
+                HIP_CHECK(hipMemcpyAsync(hk + off, dk + (size_t)i * capacity, (size_t)K * sizeof(apds_keypoint), hipMemcpyDeviceToHost, s));
+                off += (size_t)K;
+            }
+            if (total) HIP_CHECK(hipMemcpyAsync(hd, d61, total * APDS_DESC_BYTES, hipMemcpyDeviceToHost, s));
+            HIP_CHECK(hipStreamSynchronize(s));
+        } catch (...) {
+            std::free(hk);
+            std::free(hd);
+            throw;
+        }
+        *kps = hk;
+        *desc = hd;
+    });
+}
+
+int apds_dev_akaze_extract_batch(const void* imgs, int n_images, size_t image_stride, int rows, int cols, int channels, size_t stride, int max_points,
+                                 void* kps, void* desc64, int capacity, int* counts, void* stream) {
+    return guarded([&] {
+        APDS_REQUIRE(counts && kps && desc64, APDS_ERR_BAD_ARG, "null output");
+        ctx().ws_reset();
+        akaze_extract_batch_device(imgs, n_images, image_stride, rows, cols, channels, stride, max_points, static_cast<apds_keypoint*>(kps),
+                                   static_cast<uint8_t*>(desc64), capacity, counts, pick_stream(stream));
+    });
+}
+
 int apds_dev_akaze_extract(const void* img, int rows, int cols, int channels, size_t stride, int max_points, void* kps, void* desc64, int capacity,
                            int* n, void* stream) {
     return guarded([&] {

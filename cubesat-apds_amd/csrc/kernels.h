@@ -20,6 +20,8 @@ void valu_peak_device(int mode, int waves_per_simd, double* lane_ops_per_s, doub
 // akaze.hip
 int akaze_extract_device(const void* img, int rows, int cols, int channels, size_t stride, int max_points, apds_keypoint* kps,
                          uint8_t* desc64, int capacity, hipStream_t s);
+int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, int rows, int cols, int channels, size_t stride, int max_points,
+                               apds_keypoint* kps, uint8_t* desc64, int capacity, int* counts, hipStream_t s);
 void points_from_matches_device(const apds_keypoint* kp1, int n1, const apds_keypoint* kp2, int n2, const apds_dmatch* m, int nm,
                                 int bug_compatible, float* pts1, float* pts2, int* err_flag, hipStream_t s);
 void rgba_to_bgra_device(const uint8_t* rgba, size_t n_pixels, uint8_t* bgra, hipStream_t s);

@@ -71,6 +71,30 @@ def akaze_keypoint_descriptor_extraction_def(img, max_points=None):
     return ExtractedKeyPoint(k, d)
 
 
+def akaze_keypoint_descriptor_extraction_batch(imgs, max_points=None):
+    """lib.rs:61-92 for a batch of equal-sized images (array [B, H, W] or [B, H, W, C] uint8, or a list of such images) in ONE library
+    call: the batch goes through every kernel's grid together. Returns a list of ExtractedKeyPoint, each exactly what
+    akaze_keypoint_descriptor_extraction_def returns for that image. This is how a caller that extracts one tile per task
+    (preprocessor/src/main.rs:227-245,277) should hand its tiles over: a single small tile is launch-latency-bound."""
+    a = np.ascontiguousarray(np.stack([np.asarray(i) for i in imgs]) if isinstance(imgs, (list, tuple)) else np.asarray(imgs))
+    if a.dtype != np.uint8 or a.ndim not in (3, 4) or a.size == 0:
+        raise ApdsError(_lib.ERR_ASSERT, "images must be a non-empty uint8 [B, H, W[, C]] array")
+    b, h, w = a.shape[0], a.shape[1], a.shape[2]
+    ch = 1 if a.ndim == 3 else a.shape[3]
+    kps, desc = C.c_void_p(), C.c_void_p()
+    counts, nb = (C.c_int * b)(), C.c_int(0)
+    check(lib().apds_akaze_extract_batch(ptr(a), b, a.strides[0], h, w, ch, a.strides[1], MAX_POINTS if max_points is None else int(max_points),
+                                         C.byref(kps), C.byref(desc), counts, C.byref(nb)))
+    total = sum(counts)
+    k = take(kps, total, KEYPOINT_DTYPE)
+    d = take(desc, total * nb.value, np.uint8).reshape(total, nb.value)
+    out, off = [], 0
+    for c in counts:
+        out.append(ExtractedKeyPoint(k[off:off + c].copy(), d[off:off + c].copy()))
+        off += c
+    return out
+
+
 def tile_keypoint_descriptor_extraction(red, green, blue, min_max, max_points=None):
     """One preprocessor tile (preprocessor/src/main.rs:258-277): to_rgb's band_merger, raster_to_mat and the extraction above in one
     library call — red/green/blue are equal-shape 2-D float32 views (row-strided views into the mosaic are taken as they are), the

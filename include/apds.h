@@ -78,6 +78,12 @@ const char* apds_build_info(void);            /* "gfx950 ..." */
  * both owned by the caller afterwards (apds_free). */
 int apds_akaze_extract(const uint8_t* img, int rows, int cols, int channels, size_t stride_bytes, int max_points,
                        apds_keypoint** kps, uint8_t** desc, int* n, int* desc_bytes);
+/* The same for n_images images of ONE size in one call (image i starts image_stride_bytes after image i-1): the batch goes through every
+ * kernel's grid together, which is what makes small tiles cheap (a single small tile is launch-latency-bound). This is how a caller
+ * that extracts one tile per task (preprocessor/src/main.rs:227-245,277) should hand its tiles over. Per-image results are exactly those
+ * of apds_akaze_extract. Outputs: *kps / *desc hold the images' rows back to back (image 0 first), counts[i] = rows of image i. */
+int apds_akaze_extract_batch(const uint8_t* imgs, int n_images, size_t image_stride_bytes, int rows, int cols, int channels, size_t stride_bytes,
+                             int max_points, apds_keypoint** kps, uint8_t** desc, int* counts, int* desc_bytes);
 
 /* lib.rs:94-114  get_knn_matches(origin_desc, target_desc, k, filter_strength) -> Vector<DMatch>
  * Hamming k-NN of each origin (query) row over the target (train) rows, then keep m[0] iff
@@ -214,6 +220,10 @@ int apds_dev_cross_check(const void* train_best_keys, int64_t n_train, int n_que
  * Returns the keypoint count in *n (host). capacity >= min(max_points, APDS_MAX_POINTS). */
 int apds_dev_akaze_extract(const void* img, int rows, int cols, int channels, size_t stride_bytes, int max_points,
                            void* kps, void* desc64, int capacity, int* n, void* stream);
+/* Batched form on device images: image i's keypoints land at kps + i * capacity rows, its descriptors at desc64 + i * capacity * 64 bytes,
+ * its count in counts[i] (host). capacity (rows per image) >= the largest count. */
+int apds_dev_akaze_extract_batch(const void* imgs, int n_images, size_t image_stride_bytes, int rows, int cols, int channels, size_t stride_bytes,
+                                 int max_points, void* kps, void* desc64, int capacity, int* counts, void* stream);
 
 /* gather matched coordinates on the device: pts1/pts2 n_matches x 2 float */
 int apds_dev_points_from_matches(const void* kp1, int n1, const void* kp2, int n2, const void* matches, int n_matches,

@@ -131,6 +131,28 @@ def set_threads(n):
     lib().oracle_set_threads(int(n))
 
 
+def host_threads():
+    """(threads to use, nproc): nproc = the CPUs this process may run on (what `nproc` prints); the thread count is the one of
+    8, 16, 32, 64, ..., nproc that runs a small detect+describe fastest, because a container's CPU share can be far below its
+    affinity mask (256 visible CPUs with a 16-CPU quota made 256 OpenMP threads 25x slower than 32)."""
+    import time
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cands = sorted({min(nproc, c) for c in (8, 16, 32, 64, 128, nproc)})
+    rng = np.random.default_rng(7)
+    img = (rng.random((512, 512)) * 255).astype(np.uint8)
+    best, best_t = cands[0], None
+    for c in cands:
+        set_threads(c)
+        akaze(img)
+        t0 = time.perf_counter()
+        akaze(img)
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t * 0.9:      # more threads only if they pay clearly
+            best, best_t = c, dt
+    set_threads(best)
+    return best, nproc
+
+
 def _ptr(a):
     return a.ctypes.data_as(C.c_void_p)
 

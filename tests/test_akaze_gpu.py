@@ -141,3 +141,54 @@ def test_full_size_4096_frame_equals_oracle(gpu_pkg, oracle_mod):
     # extraction is a pure function of the image: a second run gives the same bytes
     again = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(tile, None)
     assert np.array_equal(again.descriptors, got.descriptors) and np.array_equal(again.keypoints, got.keypoints)
+
+
+def test_2048_frame_equals_oracle(gpu_pkg, oracle_mod):
+    # a size of the reference's bench sweep (benchmarks/benches/feature_extraction.rs:14-15) that no other test touches; 3 channels as there
+    tile = gpu_pkg.synth.make_tile(2048, 2048, frame_index=11, channels=3)
+    oracle_mod.set_threads(16)
+    _assert_same_extraction(gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(tile, None), oracle_mod.akaze(tile))
+
+
+def test_8192_frame_equals_oracle(gpu_pkg, oracle_mod):
+    # the largest size of the reference's bench sweep: 8192 x 8192. The image is a 2 x 2 mosaic of one synthetic 4096^2 tile and its three
+    # flips (the tile generator needs 15 s per 4096^2 tile). More than 100 k keypoints: also the largest keypoint set of the suite
+    t = gpu_pkg.synth.make_tile(4096, 4096, frame_index=5, channels=1)
+    img = np.ascontiguousarray(np.block([[t, t[:, ::-1]], [t[::-1], t[::-1, ::-1]]]))
+    assert img.shape == (8192, 8192)
+    got = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(img, None)
+    oracle_mod.set_threads(16)
+    ref = oracle_mod.akaze(img)
+    assert len(ref.keypoints) > 100000
+    _assert_same_extraction(got, ref)
+
+
+@pytest.mark.parametrize("size,ch,batch", [(256, 4, 5), (512, 3, 3), (1024, 4, 4), (200, 1, 7)])
+def test_batched_extraction_equals_oracle_per_image(gpu_pkg, oracle_mod, size, ch, batch):
+    # every image of a batch (one launch per kernel for all of them) against the ORACLE, not only against the unbatched call
+    imgs = np.stack([gpu_pkg.synth.make_tile(size, size + (40 if ch == 1 else 0), frame_index=20 + i, channels=ch) for i in range(batch)])
+    if batch > 2:
+        imgs[1] = 128                      # a flat image in the middle of the batch: no keypoints, its neighbours unaffected
+    got = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_batch(imgs, None)
+    assert len(got) == batch
+    oracle_mod.set_threads(8)
+    for i in range(batch):
+        ref = oracle_mod.akaze(imgs[i])
+        _assert_same_extraction(got[i], ref)
+        one = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(imgs[i], None)
+        assert np.array_equal(one.keypoints, got[i].keypoints) and np.array_equal(one.descriptors, got[i].descriptors)
+    assert len(got[1].keypoints) == 0 if batch > 2 else True
+    assert sum(len(g.keypoints) for g in got) > 0
+
+
+def test_batched_extraction_max_points_path(gpu_pkg, oracle_mod):
+    # an image of the batch has more keypoints than max_points: the rank-selection path runs image by image
+    imgs = np.stack([gpu_pkg.synth.make_tile(384, 384, frame_index=40 + i, channels=4) for i in range(3)])
+    oracle_mod.set_threads(8)
+    full = [len(oracle_mod.akaze(im).keypoints) for im in imgs]
+    cap = max(8, min(full) // 2)
+    got = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_batch(imgs, cap)
+    for i in range(3):
+        ref = oracle_mod.akaze(imgs[i], max_points=cap)
+        assert len(ref.keypoints) == min(cap, full[i])
+        _assert_same_extraction(got[i], ref)
