@@ -38,15 +38,18 @@ struct SuppressArgs {
 };
 static constexpr int PEND_PITCH = 32;   // same-line atomics serialise in L2 (~12 ns each, measured): one line per counter
 
-__global__ void suppress_init_status_kernel(SuppressArgs A) {
+// Snapshot of levels [snap_lo, snap_lo + snap_n) (status = pending where the mask is set) and zeroing of the three rotating
+// pending counters of levels [zero_lo, zero_lo + zero_n) (the levels whose passes are about to run). grid.y = max(snap_n, zero_n).
+__global__ void suppress_init_status_kernel(SuppressArgs A, int snap_lo, int snap_n, int zero_lo, int zero_n) {
     APDS_RAISE_WAVE_PRIORITY();
-    const int lvl = blockIdx.y;
+    if ((int)blockIdx.y < zero_n && blockIdx.x == 0 && threadIdx.x < 3)
+        bofs(A.pend_count, A.bstride)[(threadIdx.x * AKAZE_MAX_LEVELS + zero_lo + blockIdx.y) * PEND_PITCH] = 0;
+    if ((int)blockIdx.y >= snap_n) return;
+    const int lvl = snap_lo + blockIdx.y;
     const int cnt = bofs(A.list_count, A.bstride)[lvl];
     const uint32_t* __restrict__ list = bofs(A.list[lvl], A.bstride);
     uint8_t* __restrict__ status = bofs(A.status[lvl], A.bstride);
     const uint8_t* __restrict__ mask = bofs(A.mask[lvl], A.bstride);
-    if (blockIdx.x == 0 && threadIdx.x < 3)   // the three rotating pending counters of this level start the phase at zero
-        bofs(A.pend_count, A.bstride)[(threadIdx.x * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH] = 0;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
         const uint32_t e = list[i];
         const size_t p = (size_t)(e >> 16) * A.w[lvl] + (e & 0xFFFF);
@@ -54,13 +57,12 @@ __global__ void suppress_init_status_kernel(SuppressArgs A) {
     }
 }
 
-__global__ void suppress_canon_kernel(SuppressArgs A) {
-    APDS_RAISE_WAVE_PRIORITY();
-    const int lvl = blockIdx.y;
+// stamps 1..253 of finished candidates -> ST_DONE_OLD, so that the stamp values can be reused (every 253 rounds)
+__device__ __forceinline__ void suppress_canon_level(const SuppressArgs& A, int lvl, int first, int stride) {
     const int cnt = bofs(A.list_count, A.bstride)[lvl];
     const uint32_t* __restrict__ list = bofs(A.list[lvl], A.bstride);
     uint8_t* __restrict__ status = bofs(A.status[lvl], A.bstride);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+    for (int i = first; i < cnt; i += stride) {
         const uint32_t e = list[i];
         const size_t p = (size_t)(e >> 16) * A.w[lvl] + (e & 0xFFFF);
         const uint8_t s = status[p];
@@ -68,41 +70,26 @@ __global__ void suppress_canon_kernel(SuppressArgs A) {
     }
 }
 
+static constexpr int SUPPRESS_STAGE = 192;   // still-blocked candidates staged per block before one global append
+
+// One round of one level's pass, executed by the `nwaves` waves of the calling block set that share (s_stage, s_n, s_base):
+// wave `wave0` takes candidates wave0, wave0 + nwaves, ... of `in[0, cnt)`.
 // One WAVE per candidate keypoint: the readiness window (up to 37 x 19 status bytes) and the neighbour search window
 // (up to 16 x 16 mask bytes) are scanned 64 elements at a time; "first hit in row-major order" is the lowest set bit
 // of the ballot of the first 64-element slab that has one. (A single thread walking these windows byte by byte took
-// ~48 us per round; a frame needs ~20 rounds.)
-// Round r reads the candidates that were still pending after round r-1 (in_sel: -1 = the level's full candidate list) and
-// appends the ones that are still blocked to buffer out_sel; the counter of buffer zero_sel is cleared for the round after.
-__global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uint8_t stamp, int in_sel, int out_sel, int zero_sel) {
-    APDS_RAISE_WAVE_PRIORITY();
-    const int lvl = blockIdx.y;
-    const int other = A.phase == 0 ? lvl - 1 : lvl + 1;
-    if (other < 0 || other >= A.n_levels) return;
+// ~48 us per round; a frame needs ~20 rounds.) Candidates that are still blocked are appended to `out`.
+__device__ __forceinline__ void suppress_round_body(const SuppressArgs& A, int lvl, int other, uint8_t stamp, const uint32_t* in, int cnt, uint32_t* out,
+                                                    int* out_count, int wave0, int nwaves, uint32_t* s_stage, int* s_n, int* s_base) {
+    constexpr int STAGE = SUPPRESS_STAGE;
     const size_t bstride = A.bstride;
-    int* __restrict__ pend_count = bofs(A.pend_count, bstride);
-    uint32_t* __restrict__ pend = bofs(A.pend[lvl], bstride);
-    const uint32_t* __restrict__ in = in_sel < 0 ? bofs(A.list[lvl], bstride) : pend + (size_t)in_sel * A.pend_cap[lvl];
-    const int cnt = in_sel < 0 ? bofs(A.list_count, bstride)[lvl] : pend_count[(in_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH];
-    if (cnt == 0 && in_sel >= 0) {   // nothing pending for this level (every round after convergence): the block has no work
-        if (blockIdx.x == 0 && threadIdx.x == 0) pend_count[(zero_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH] = 0;
-        return;
-    }
-    uint32_t* __restrict__ out = pend + (size_t)out_sel * A.pend_cap[lvl];
-    int* out_count = &pend_count[(out_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH];
-    if (blockIdx.x == 0 && threadIdx.x == 0) pend_count[(zero_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH] = 0;
-    // still-blocked candidates are staged per block and appended with one global atomic
-    constexpr int STAGE = 192;
-    __shared__ uint32_t s_stage[STAGE];
-    __shared__ int s_n, s_base;
-    if (threadIdx.x == 0) s_n = 0;
+    if (threadIdx.x == 0) *s_n = 0;
     __syncthreads();
-    const int w = A.w[lvl], h = A.h[lvl];
+    const int w = A.w[lvl];
     const int lane = threadIdx.x & 63;
     uint8_t* status = bofs(A.status[lvl], bstride);
-    const float* __restrict__ ldet_own = bofs(A.Ldet[lvl], bstride);
-    const float* __restrict__ ldet_other = bofs(A.Ldet[other], bstride);
-    uint8_t* __restrict__ omask_w = bofs(A.mask[other], bstride);
+    const float* ldet_own = bofs(A.Ldet[lvl], bstride);
+    const float* ldet_other = bofs(A.Ldet[other], bstride);
+    uint8_t* omask_w = bofs(A.mask[other], bstride);
     // interaction distance in this level's pixels (conservative superset of "search windows overlap")
     int D, diff, radius;
     if (A.phase == 0) {
@@ -118,7 +105,7 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
     const int side = 2 * radius, total2 = side * side;
     const int ow = A.w[other], oh = A.h[other];
     const uint8_t* omask = omask_w;
-    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < cnt; i += gridDim.x * 4) {
+    for (int i = wave0; i < cnt; i += nwaves) {
         const uint32_t e = in[i];
         const int x = e & 0xFFFF, y = e >> 16;
         const size_t p = (size_t)y * w + x;
@@ -161,15 +148,16 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
                     const int ry = idx / W, rx = idx - ry * W;
                     const int yy = y - D + ry, xx = x - D + rx;
                     if (yy >= 0 && xx >= 0 && xx < w && (yy < y || xx < x)) {
-                        const uint8_t s = status[(size_t)yy * w + xx];
-                        hit |= s == ST_PENDING || s == stamp;
+                        const uint8_t st = status[(size_t)yy * w + xx];
+                        hit |= st == ST_PENDING || st == stamp;
                     }
                 }
             }
             blocked = __any(hit);
         }
+        // the candidate's victim: the first live keypoint of the other level inside its search window, row-major
         int found = -1;
-        if (!blocked) {
+        {
 #pragma unroll
             for (int u = 0; u < 4; u++) {   // first hit in row-major order: lowest slab, lowest lane
                 const int idx = u * 64 + lane;
@@ -211,9 +199,55 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
                     }
             }
         }
+        if (found < 0) {
+            // No live keypoint of the other level in the window, and keypoints are only ever deleted: whatever the earlier candidates
+            // do, this one deletes nothing. It is finished now and, having no effect, never makes a later candidate wait.
+            if (lane == 0) status[p] = ST_DONE_OLD;
+            continue;
+        }
+        if (blocked) {
+            // An earlier candidate in reach is still pending. It matters only if it can take this candidate's victim v away: victims
+            // ahead of v in the window are dead for good, and a deletion behind v does not change "the first live one". So: blocked
+            // iff an earlier pending (or finished-this-round) candidate e' of this level has v inside ITS search window. The scan
+            // covers every position of this level whose window can contain v, and tests membership exactly as find_neighbor_point
+            // does (half-open square [-r, r) and the disc).
+            const int vy = found / ow, vx = found - vy * ow;
+            int cx0, cx1, cy0, cy1;
+            if (A.phase == 0) {   // e' = (x', y') searches around (x' * diff, y' * diff)
+                cx0 = (vx - radius) / diff - 1, cx1 = (vx + radius) / diff + 1;
+                cy0 = (vy - radius) / diff - 1, cy1 = (vy + radius) / diff + 1;
+            } else {              // around (x' / diff, y' / diff)
+                cx0 = (vx - radius) * diff, cx1 = (vx + radius + 1) * diff;
+                cy0 = (vy - radius) * diff, cy1 = (vy + radius + 1) * diff;
+            }
+            cx0 = max(cx0, 0), cy0 = max(cy0, 0), cx1 = min(cx1, w - 1), cy1 = min(cy1, y);   // rows after y are later candidates
+            const int cw = cx1 - cx0 + 1, cn = cw * (cy1 - cy0 + 1);
+            bool still = false;
+            for (int base = 0; base < cn && !still; base += 256) {
+                bool hit = false;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int idx = base + u * 64 + lane;
+                    if (idx < cn) {
+                        const int ry = idx / cw, rx = idx - ry * cw;
+                        const int yy = cy0 + ry, xx = cx0 + rx;
+                        if (yy < y || xx < x) {
+                            const uint8_t st = status[(size_t)yy * w + xx];
+                            if (st == ST_PENDING || st == stamp) {
+                                const int qx = A.phase == 0 ? xx * diff : xx / diff, qy = A.phase == 0 ? yy * diff : yy / diff;
+                                const int dx = vx - qx, dy = vy - qy;
+                                hit |= dx >= -radius && dx < radius && dy >= -radius && dy < radius && dx * dx + dy * dy <= radius * radius;
+                            }
+                        }
+                    }
+                }
+                still = __any(hit);
+            }
+            blocked = still;
+        }
         if (blocked) {
             if (lane == 0) {
-                const int slot = atomicAdd(&s_n, 1);
+                const int slot = atomicAdd(s_n, 1);
                 if (slot < STAGE) s_stage[slot] = e;
                 else out[atomicAdd(out_count, 1)] = e;   // staging full (dense clusters): append directly
             }
@@ -224,12 +258,70 @@ __global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, uin
             status[p] = stamp;
         }
     }
-    (void)h;
     __syncthreads();
-    const int staged = min(s_n, STAGE);
-    if (threadIdx.x == 0 && staged) s_base = atomicAdd(out_count, staged);
+    const int staged = min(*s_n, STAGE);
+    if (threadIdx.x == 0 && staged) *s_base = atomicAdd(out_count, staged);
     __syncthreads();
-    for (int i = threadIdx.x; i < staged; i += 256) out[s_base + i] = s_stage[i];
+    for (int i = threadIdx.x; i < staged; i += blockDim.x) out[*s_base + i] = s_stage[i];
+}
+
+// Wide form of a round: the passes of levels [lvl0, lvl0 + gridDim.y) with gridDim.x blocks of four waves each. Round r reads the
+// candidates that were still pending after round r-1 (in_sel: -1 = the level's full candidate list) and appends the ones that are
+// still blocked to buffer out_sel; the counter of buffer zero_sel is cleared for the round after.
+__global__ __launch_bounds__(256) void suppress_round_kernel(SuppressArgs A, int lvl0, uint8_t stamp, int in_sel, int out_sel, int zero_sel) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int lvl = lvl0 + blockIdx.y;
+    const int other = A.phase == 0 ? lvl - 1 : lvl + 1;
+    if (other < 0 || other >= A.n_levels) return;
+    const size_t bstride = A.bstride;
+    int* __restrict__ pend_count = bofs(A.pend_count, bstride);
+    uint32_t* __restrict__ pend = bofs(A.pend[lvl], bstride);
+    const uint32_t* __restrict__ in = in_sel < 0 ? bofs(A.list[lvl], bstride) : pend + (size_t)in_sel * A.pend_cap[lvl];
+    const int cnt = in_sel < 0 ? bofs(A.list_count, bstride)[lvl] : pend_count[(in_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH];
+    if (blockIdx.x == 0 && threadIdx.x == 0) pend_count[(zero_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH] = 0;
+    if (cnt == 0) return;   // nothing pending for this level: the block has no work
+    __shared__ uint32_t s_stage[SUPPRESS_STAGE];
+    __shared__ int s_n, s_base;
+    suppress_round_body(A, lvl, other, stamp, in, cnt, pend + (size_t)out_sel * A.pend_cap[lvl], &pend_count[(out_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH],
+                        blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, s_stage, &s_n, &s_base);
+}
+
+// Tail of the passes of levels [lvl0, lvl0 + gridDim.y): ONE block per level runs the remaining rounds (from round `round0`) back to
+// back until the level has no pending candidate left. After the first wide rounds only the ends of the dependency chains are left
+// (tens of candidates, up to ~15 more rounds): as separate launches each of those rounds cost a launch latency plus a host check for
+// convergence every few rounds; inside one block a round costs one candidate's chain of dependent loads and a barrier, and the loop
+// ends exactly when the work does: no host synchronisation at all. The passes of different levels are independent within a phase
+// (see the file header), so the blocks never wait for each other. Every thread leaves the loop on the same block-uniform count.
+__global__ __launch_bounds__(1024) void suppress_tail_kernel(SuppressArgs A, int lvl0, int round0) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int lvl = lvl0 + blockIdx.y;
+    const int other = A.phase == 0 ? lvl - 1 : lvl + 1;
+    if (other < 0 || other >= A.n_levels) return;
+    const size_t bstride = A.bstride;
+    int* pend_count = bofs(A.pend_count, bstride);
+    uint32_t* pend = bofs(A.pend[lvl], bstride);
+    __shared__ uint32_t s_stage[SUPPRESS_STAGE];
+    __shared__ int s_n, s_base, s_cnt;
+    for (int round = round0;; round++) {
+        const int in_sel = (round - 1) % 3, out_sel = round % 3;
+        if (threadIdx.x == 0) {
+            // the counters are updated by L2 atomics: read and reset them there as well, not through this CU's L1
+            s_cnt = round == 0 ? bofs(A.list_count, bstride)[lvl]
+                               : __hip_atomic_load(&pend_count[(in_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicExch(&pend_count[(out_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH], 0);
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        if (cnt == 0) break;   // block-uniform
+        if (round > 0 && round % 253 == 0) {   // the stamp values come round again: retire the old ones first
+            suppress_canon_level(A, lvl, threadIdx.x, blockDim.x);
+            __syncthreads();
+        }
+        const uint32_t* in = round == 0 ? bofs(A.list[lvl], bstride) : pend + (size_t)in_sel * A.pend_cap[lvl];
+        suppress_round_body(A, lvl, other, (uint8_t)(round % 253 + 1), in, cnt, pend + (size_t)out_sel * A.pend_cap[lvl],
+                            &pend_count[(out_sel * AKAZE_MAX_LEVELS + lvl) * PEND_PITCH], threadIdx.x >> 6, blockDim.x >> 6, s_stage, &s_n, &s_base);
+        __syncthreads();       // this round's status / mask / list writes are visible to the whole block before the next round reads them
+    }
 }
 
 // ---- a1.7 sub-pixel refinement ---------------------------------------------------------------------------------
@@ -261,10 +353,11 @@ __device__ __forceinline__ Refined refine(const float* __restrict__ ldet, int co
     return r;
 }
 
-// drop candidates whose refinement is unstable, so the concatenated masks become the final keypoint flags
-__global__ void subpixel_filter_kernel(LevelTable T, const int* __restrict__ list_count) {
+// drop candidates whose refinement is unstable, so bit 0 of the concatenated masks becomes the final keypoint flag (the levels of a
+// stage are final by now: no suppression pass reads their masks as victims any more)
+__global__ void subpixel_filter_kernel(LevelTable T, const int* __restrict__ list_count, int lvl0) {
     APDS_RAISE_WAVE_PRIORITY();
-    const int lvl = blockIdx.y;
+    const int lvl = lvl0 + blockIdx.y;
     const int cnt = bofs(list_count, T.bstride)[lvl];
     const uint32_t* __restrict__ list = bofs(T.list[lvl], T.bstride);
     uint8_t* __restrict__ mask = bofs(T.mask[lvl], T.bstride);
@@ -275,32 +368,36 @@ __global__ void subpixel_filter_kernel(LevelTable T, const int* __restrict__ lis
         const size_t p = (size_t)y * T.w[lvl] + x;
         if (!mask[p]) continue;
         const Refined r = refine(ldet, T.w[lvl], x, y, T.ratio[lvl]);
-        if (!r.ok) mask[p] = 0;
+        if (!r.ok) mask[p] = 2;   // survived the suppression, dropped by the refinement: bit 0 (= "is a keypoint") clear, byte non-zero
     }
 }
 
 static constexpr int SCAN_BLOCK = 1024;
 
-__global__ __launch_bounds__(SCAN_BLOCK) void emit_keypoints_kernel(LevelTable T, const uint8_t* __restrict__ flags, long long total,
-                                                                    const int* __restrict__ block_offsets, apds_keypoint* __restrict__ kps,
-                                                                    int capacity, size_t kp_bstride) {
+// flags[lo, hi) = the masks of a run of consecutive levels (a stage); block b covers the 16 KiB from (lo & ~15) + b * 16 KiB. Bytes
+// outside [lo, hi) belong to other stages and read as zero.
+__device__ __forceinline__ uint4 load_flags16_range(const uint8_t* __restrict__ flags, long long base, long long lo, long long hi) {
+    if (base >= lo && base + 16 <= hi) return *reinterpret_cast<const uint4*>(flags + base);
+    uint32_t w[4] = {0, 0, 0, 0};
+    for (int b = 0; b < 16; b++)
+        if (base + b >= lo && base + b < hi && (flags[base + b] & 1)) w[b >> 2] |= 1u << (8 * (b & 3));
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+// kp_base[0] = index of the stage's first keypoint in the image's output (the keypoints of the earlier stages come first: output
+// order is level-major), written by the stage's scan; kp_base == nullptr: 0.
+__global__ __launch_bounds__(SCAN_BLOCK) void emit_keypoints_kernel(LevelTable T, const uint8_t* __restrict__ flags, long long lo, long long hi,
+                                                                    const int* __restrict__ block_offsets, const int* __restrict__ kp_base,
+                                                                    apds_keypoint* __restrict__ kps, int capacity, size_t kp_bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     flags = bofs(flags, T.bstride);
     block_offsets = bofs(block_offsets, T.bstride);
     kps = bofs(kps, kp_bstride);
+    const int first = kp_base ? bofs(kp_base, T.bstride)[0] : 0;
     __shared__ int wsum[SCAN_BLOCK / 64];
-    const long long base = ((long long)blockIdx.x * SCAN_BLOCK + threadIdx.x) * 16;
+    const long long base = (lo & ~15ll) + ((long long)blockIdx.x * SCAN_BLOCK + threadIdx.x) * 16;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (base < total) {
-        const uint8_t* p = flags + base;
-        if (base + 16 <= total) v = *reinterpret_cast<const uint4*>(p);
-        else {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (int b = 0; b < 16; b++)
-                if (base + b < total && p[b]) w[b >> 2] |= 1u << (8 * (b & 3));
-            v = make_uint4(w[0], w[1], w[2], w[3]);
-        }
-    }
+    if (base < hi) v = load_flags16_range(flags, base, lo, hi);
     const int mine = __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
     // exclusive position of this thread's first keypoint inside the block: wave prefix (shuffles) + earlier waves
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -314,10 +411,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void emit_keypoints_kernel(LevelTable T
     if (!mine) return;
     int before = 0;
     for (int k = 0; k < wv; k++) before += wsum[k];
-    int pos = block_offsets[blockIdx.x] + before + incl - mine;
+    int pos = first + block_offsets[blockIdx.x] + before + incl - mine;
     const uint32_t words[4] = {v.x, v.y, v.z, v.w};
     for (int b = 0; b < 16; b++) {
-        if (!((words[b >> 2] >> (8 * (b & 3))) & 0xFF)) continue;
+        if (!((words[b >> 2] >> (8 * (b & 3))) & 1)) continue;
         if (pos >= capacity) return;
         const long long e = base + b;
         int lvl = 0;
@@ -406,20 +503,22 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
-// n = min(*n_dev of this image, n_cap): the image's keypoint count stays on the device (n_dev == nullptr: n_cap is the count)
-__global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_keypoint* __restrict__ kps, const int* __restrict__ n_dev, int n_cap, size_t kp_bstride,
+// Keypoints [range[0], min(range[1], n_cap)) of this image (range: two consecutive ints of the image's slab, written by the stage's
+// scan; nullptr: [0, n_cap)): the counts stay on the device, and the blocks stride over the range, so the grid need not match it.
+__global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_keypoint* __restrict__ kps, const int* __restrict__ range, int n_cap, size_t kp_bstride,
                                                           float ang_step, int nkeys) {
     APDS_RAISE_WAVE_PRIORITY();
-    const int n = n_dev ? min(*bofs(n_dev, T.bstride), n_cap) : n_cap;
-    if ((int)blockIdx.x * 4 >= n) return;   // block-uniform: grids are sized for the largest image of the batch
+    const int begin = range ? bofs(range, T.bstride)[0] : 0;
+    const int n = range ? min(bofs(range, T.bstride)[1], n_cap) : n_cap;
     kps = bofs(kps, kp_bstride);
     __shared__ float s_x[4][112], s_y[4][112];
     __shared__ uint8_t s_bin[4][112], s_sorted[4][112];
     __shared__ int s_start[4][44];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ki = blockIdx.x * 4 + wv;
+    for (int kb = begin + (int)blockIdx.x * 4; kb < n; kb += (int)gridDim.x * 4) {   // block-uniform trip count
+    const int ki = kb + wv;
     const bool live = ki < n;
-    const apds_keypoint kp = kps[live ? ki : 0];
+    const apds_keypoint kp = kps[live ? ki : kb];
     const int lvl = kp.class_id;
     const int w = T.w[lvl], h = T.h[lvl];
     const float ratio = T.ratio[lvl];
@@ -519,6 +618,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
         }
     }
     if (live && lane == 0) kps[ki].angle = fast_atan2_deg(sumY, sumX);
+    __syncthreads();   // the next keypoint reuses the wave's LDS slices
+    }
 }
 
 // ---- a1.9 M-LDB 486-bit descriptor: one wave per keypoint ----------------------------------------------------------
@@ -581,11 +682,11 @@ __constant__ MldbLut c_mldb = make_mldb_lut();
 // by all 64 lanes (they were gathered 1241 times, once per grid), then 29 lanes, one per cell of any grid, add their cell's
 // samples in the reference's order (k-major, l-minor; float sums are order dependent), and the 486 comparisons are done 32
 // per lane.
-__global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, const int* __restrict__ n_dev, int n_cap, size_t kp_bstride,
+__global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, const int* __restrict__ range, int n_cap, size_t kp_bstride,
                                                    uint32_t* __restrict__ desc64, size_t desc_bstride) {
     APDS_RAISE_WAVE_PRIORITY();
-    const int n = n_dev ? min(*bofs(n_dev, T.bstride), n_cap) : n_cap;
-    if ((int)blockIdx.x * 4 >= n) return;   // block-uniform
+    const int begin = range ? bofs(range, T.bstride)[0] : 0;
+    const int n = range ? min(bofs(range, T.bstride)[1], n_cap) : n_cap;
     kps = bofs(kps, kp_bstride);
     desc64 = bofs(desc64, desc_bstride);
     constexpr int LW = 21;                     // lattice width: offsets -10 .. 10
@@ -593,9 +694,12 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
     __shared__ int s_val[4][88];
     __shared__ uint8_t s_lut[976];              // c_mldb: a[488] then b[488]
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ki = blockIdx.x * 4 + wv;
+    // the comparison table goes to LDS once per block (lane-indexed reads of __constant__ data are global loads)
+    for (int i = threadIdx.x; i < 244; i += 256) reinterpret_cast<uint32_t*>(s_lut)[i] = reinterpret_cast<const uint32_t*>(&c_mldb)[i];
+    for (int kb = begin + (int)blockIdx.x * 4; kb < n; kb += (int)gridDim.x * 4) {   // block-uniform trip count
+    const int ki = kb + wv;
     const bool live = ki < n;
-    const apds_keypoint kp = kps[live ? ki : 0];
+    const apds_keypoint kp = kps[live ? ki : kb];
     const int lvl = kp.class_id;
     const int w = T.w[lvl], h = T.h[lvl];
     const float* __restrict__ Lt = bofs(T.Lt[lvl], T.bstride);
@@ -607,8 +711,6 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
     double sd, cd;
     det_sincos((double)angle, sd, cd);
     const float co = (float)cd, si = (float)sd;
-    // the comparison table goes to LDS once per block (lane-indexed reads of __constant__ data are global loads)
-    for (int i = threadIdx.x; i < 244; i += 256) reinterpret_cast<uint32_t*>(s_lut)[i] = reinterpret_cast<const uint32_t*>(&c_mldb)[i];
     {
         // all of a lane's lattice gathers are issued before the first LDS store: one memory round trip per keypoint, not seven
         constexpr int NS = (LW * LW + 63) / 64;
@@ -684,6 +786,8 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
             if (pos < 486 && s_val[wv][s_lut[pos]] > s_val[wv][s_lut[488 + pos]]) word |= 1u << b;
         }
         desc64[(size_t)ki * 16 + lane] = word;   // 61 payload bytes + 3 zero bytes per 64-byte row
+    }
+    __syncthreads();   // the next keypoint reuses the wave's LDS slices
     }
 }
 
@@ -783,19 +887,20 @@ __device__ __forceinline__ uint4 load_flags16(const uint8_t* __restrict__ flags,
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 __device__ __forceinline__ int nonzero_bytes(uint32_t w) {
-    // mask bytes are 0 or 1
+    // bit 0 of a mask byte = keypoint (2 = dropped by the sub-pixel refinement)
     return __popc(w & 0x01010101u);
 }
 
-__global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8_t* __restrict__ flags, long long n, int* __restrict__ block_counts, size_t bstride) {
+__global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8_t* __restrict__ flags, long long lo, long long hi, int* __restrict__ block_counts,
+                                                                     size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     flags = bofs(flags, bstride);
     block_counts = bofs(block_counts, bstride);
     __shared__ int wsum[SCAN_BLOCK / 64];
-    const long long base = ((long long)blockIdx.x * SCAN_BLOCK + threadIdx.x) * 16;
+    const long long base = (lo & ~15ll) + ((long long)blockIdx.x * SCAN_BLOCK + threadIdx.x) * 16;
     int c = 0;
-    if (base < n) {
-        const uint4 v = load_flags16(flags, base, n);
+    if (base < hi) {
+        const uint4 v = load_flags16_range(flags, base, lo, hi);
         c = nonzero_bytes(v.x) + nonzero_bytes(v.y) + nonzero_bytes(v.z) + nonzero_bytes(v.w);
     }
     for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
@@ -808,10 +913,12 @@ __global__ __launch_bounds__(SCAN_BLOCK) void kp_block_counts_kernel(const uint8
     }
 }
 
-__global__ __launch_bounds__(1024) void kp_scan_offsets_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ total, size_t bstride) {
+// block counts -> exclusive offsets inside the stage; kp_base[1] = kp_base[0] + the stage's keypoint count (kp_base[0]: the count of
+// the stages before it, 0 for the first: the array starts zeroed)
+__global__ __launch_bounds__(1024) void kp_scan_offsets_kernel(int* __restrict__ block_counts, int nblocks, int* __restrict__ kp_base, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     block_counts = bofs(block_counts, bstride);
-    total = bofs(total, bstride);
+    kp_base = bofs(kp_base, bstride);
     __shared__ int buf[1024];
     __shared__ int carry;
     if (threadIdx.x == 0) carry = 0;
@@ -833,7 +940,7 @@ __global__ __launch_bounds__(1024) void kp_scan_offsets_kernel(int* __restrict__
         if (threadIdx.x == 1023) carry += incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = carry;
+    if (threadIdx.x == 0) kp_base[1] = kp_base[0] + carry;
 }
 
 __global__ void pack_desc61_kernel(const uint8_t* __restrict__ d64, int n, uint8_t* __restrict__ d61) {
@@ -928,7 +1035,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     }
     const int nblocks = ceil_div(total_pix, KP_BYTES_PER_BLOCK);
     // zero-initialised head of the slab (one 2-D memset clears it for the whole batch): counters, then keypoint masks and statuses
-    int *list_count, *hist, *pend_count, *block_counts, *total_dev;
+    int *list_count, *hist, *pend_count, *block_counts, *kp_base;
     unsigned int* hmax_bits;
     float *k_oct, *gray, *tmpS, *tmpF, *tmpP;
     uint8_t *mask_all, *status_all;
@@ -940,12 +1047,12 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         hmax_bits = A.take<unsigned int>(1);
         hist = A.take<int>(300);
         pend_count = A.take<int>(3 * AKAZE_MAX_LEVELS * PEND_PITCH);
+        kp_base = A.take<int>(8);                 // kp_base[k] = keypoints of the stages before stage k (kp_base[0] stays 0)
         mask_all = A.take<uint8_t>((size_t)total_pix);
         status_all = A.take<uint8_t>((size_t)total_pix);
         zero_bytes = A.off;
         k_oct = A.take<float>(8);
-        block_counts = A.take<int>(nblocks + 1);
-        total_dev = block_counts + nblocks;
+        block_counts = A.take<int>(nblocks + 4);
         gray = A.take<float>(n0);
         tmpS = A.take<float>(n0);
         tmpF = A.take<float>(n0);
@@ -1002,10 +1109,108 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // before the suppression): it goes to a second stream, so the latency-bound launches of the small octaves overlap the
     // smoothing and diffusion launches of the levels that follow. Lsmooth then needs a plane per level instead of a shared one.
     hipStream_t s_doh = fork_doh ? c.side_stream() : s;
+    // Keypoint stages. Levels 0 .. m are FINAL (cross-level suppression done) once the Hessian of level m + 1 exists (see run_stage).
+    // The last two octaves are a chain of short, latency-bound launches that leaves the GPU almost idle, and the large octaves before
+    // them hold nearly all keypoints: the EARLY stage = suppression passes + sub-pixel filter + ordered compaction + orientation +
+    // descriptors of all octaves but the last two, on a third (lowest-priority) stream, issued as soon as the first level of the
+    // second-to-last octave has its Hessian, runs under that chain instead of after it. (Starting earlier, per octave, only moves
+    // the work under the throughput-bound large levels, where it takes the time away from the chain: measured slower.) Output order
+    // is level-major, so the stages append in order. One stage (all levels, after the join) when the Hessian kernels are not forked,
+    // with fewer than three octaves, or unless APDS_AKAZE_STAGES asks for it.
+    // OFF by default: inside the streamed pipeline (bench.py) the extra stream and launches cost more than the overlap returns
+    // (42.5 frames/s without, 41.2 with; stand-alone 4096^2: 2.18 ms without, 2.14 with). APDS_AKAZE_STAGES=1 turns it on for the
+    // largest frames, =2 for every size (the parity tests run both ways).
+    static const int stages_mode = getenv("APDS_AKAZE_STAGES") ? atoi(getenv("APDS_AKAZE_STAGES")) : 0;
+    // (measured, tools/extract_probe.py: 4096^2 2.18 -> 2.14 ms staged, but 2048^2 1.03 -> 1.10 and 1024^2 0.74 -> 0.77: the
+    // descriptor kernel of the early stage fills the CUs and the chain's 1024-thread blocks wait for room whatever the stream
+    // priorities say (profiles/r02/extract_timeline_staged.txt) - so only the largest frames are staged)
+    const bool staged = fork_doh && stages_mode && n_oct >= 3 && ((size_t)W * H * B >= ((size_t)1 << 23) || stages_mode == 2);
+    const int early_trigger = staged ? 4 * (n_oct - 2) : -1;   // the level whose Hessian launch releases the early stage
+    hipStream_t s_kp = staged ? c.side_stream2() : s;
     if (fork_doh && c.fork_open) {   // an earlier call failed between fork and join: its side-stream kernels may still use the workspace
         HIP_CHECK(hipStreamSynchronize(s_doh));
+        if (c.side2) HIP_CHECK(hipStreamSynchronize(c.side2));
         c.fork_open = false;
     }
+    // ---- level tables for the keypoint kernels (pointers of image 0; kernels add blockIdx.z * slab)
+    LevelTable T{};
+    SuppressArgs A{};
+    T.n = A.n_levels = L;
+    T.bstride = A.bstride = slab;
+    for (int i = 0; i < L; i++) {
+        const LevelDesc& e = ev[i];
+        T.w[i] = A.w[i] = e.w;
+        T.h[i] = A.h[i] = e.h;
+        T.octave[i] = e.octave;
+        T.sigma_size[i] = A.sigma_size[i] = e.sigma_size;
+        T.border[i] = e.border;
+        T.esigma[i] = e.esigma;
+        T.ratio[i] = e.ratio;
+        A.iratio[i] = (int)e.ratio;
+        T.pix_offset[i] = e.pix_offset;
+        T.Lt[i] = e.Lt;
+        T.Lxy[i] = e.Lxy;
+        T.Ldet[i] = A.Ldet[i] = e.Ldet;
+        T.mask[i] = A.mask[i] = mask_all + e.pix_offset;
+        A.status[i] = status_all + e.pix_offset;
+        T.list[i] = A.list[i] = lists[i];
+        A.pend_cap[i] = ((e.w + 1) / 2) * ((e.h + 1) / 2);
+        A.pend[i] = pend[i];
+    }
+    A.pend_count = pend_count;
+    T.pix_offset[L] = total_pix;
+    A.list_count = list_count;
+    const size_t kp_bstride = (size_t)capacity * sizeof(apds_keypoint), desc_bstride = (size_t)capacity * 64;
+    const float ang_step = (float)(2.0 * M_PI / 42);
+    const int nkeys = (int)((float)(2.0 * M_PI) / ang_step);
+    // per-keypoint kernels stride over the stage's keypoints: the grid only has to be of the right order (this thread's last image)
+    const int kp_blocks = std::min(16384, std::max(256, ceil_div((long long)(c.akaze_kp_estimate > 0 ? c.akaze_kp_estimate : 32768) * 5 / 4, 4)));
+
+    // Stage: make levels (prev_m, m] final and emit them. Needs the Hessian kernels of levels <= D = min(m + 1, L - 1).
+    //   phase 0 (a level's candidates delete weaker neighbours in the level below): passes i in (prev_D, D]
+    //   phase 1 (... in the level above): snapshot of levels (prev_m, m] taken after their phase-0 state is final and BEFORE pass i-1
+    //   deletes in them, then passes i in [max(prev_m, 0), min(m, L-1) - 1]; pass prev_m uses the snapshot the previous stage took.
+    // Level j is final after phase-0 pass j+1 and phase-1 pass j-1; both are in this stage or an earlier one for j <= m. Each pass:
+    // a snapshot / counter-reset launch, WIDE_ROUNDS wide rounds (most candidates are ready at once), then suppress_tail_kernel
+    // finishes the chains without any host check.
+    constexpr int WIDE_ROUNDS = 3;
+    int n_stage = 0;
+    auto run_stage = [&](int prev_m, int m) {
+        const int D = std::min(m + 1, L - 1), prev_D = prev_m < 0 ? 0 : std::min(prev_m + 1, L - 1);
+        const dim3 lblock(256);
+        auto run_passes = [&](int phase, int lo, int hi, int snap_lo, int snap_hi) {
+            const int np = hi - lo + 1, ns = snap_hi - snap_lo + 1;
+            if (np <= 0 && ns <= 0) return;
+            A.phase = phase;
+            hipLaunchKernelGGL(suppress_init_status_kernel, dim3(B > 1 ? 64 : 256, std::max(np, ns), B), lblock, 0, s_kp, A, snap_lo, std::max(ns, 0), lo,
+                               std::max(np, 0));
+            if (np <= 0) return;
+            for (int round = 0; round < WIDE_ROUNDS; round++)
+                hipLaunchKernelGGL(suppress_round_kernel, dim3(B > 1 ? 64 : 256, np, B), lblock, 0, s_kp, A, lo, (uint8_t)(round % 253 + 1),
+                                   round == 0 ? -1 : (round - 1) % 3, round % 3, (round + 1) % 3);
+            hipLaunchKernelGGL(suppress_tail_kernel, dim3(1, np, B), dim3(1024), 0, s_kp, A, lo, WIDE_ROUNDS);
+        };
+        if (L > 1) {
+            run_passes(0, prev_D + 1, D, prev_D + 1, D);                                   // phase 0: each pass snapshots its own level
+            run_passes(1, std::max(prev_m, 0), std::min(m, L - 1) - 1, prev_m + 1, m);      // phase 1
+        }
+        const int a = prev_m + 1;
+        hipLaunchKernelGGL(subpixel_filter_kernel, dim3(B > 1 ? 16 : 64, m - a + 1, B), dim3(256), 0, s_kp, T, (const int*)list_count, a);
+        const long long lo = T.pix_offset[a], hi = T.pix_offset[m + 1];
+        const int nb = ceil_div(hi - (lo & ~15ll), KP_BYTES_PER_BLOCK);
+        int* base_k = kp_base + n_stage;
+        hipLaunchKernelGGL(kp_block_counts_kernel, dim3(nb, 1, B), dim3(SCAN_BLOCK), 0, s_kp, (const uint8_t*)mask_all, lo, hi, block_counts, slab);
+        hipLaunchKernelGGL(kp_scan_offsets_kernel, dim3(1, 1, B), dim3(1024), 0, s_kp, block_counts, nb, base_k, slab);
+        hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nb, 1, B), dim3(SCAN_BLOCK), 0, s_kp, T, (const uint8_t*)mask_all, lo, hi, (const int*)block_counts,
+                           (const int*)base_k, kps_out, capacity, kp_bstride);
+        // ---- a1.8 / a1.9 over the stage's keypoints [kp_base[k], kp_base[k + 1]), capped at the output capacity
+        hipLaunchKernelGGL(orientation_kernel, dim3(kp_blocks, 1, B), dim3(256), 0, s_kp, T, kps_out, (const int*)base_k, std::min(capacity, max_points),
+                           kp_bstride, ang_step, nkeys);
+        hipLaunchKernelGGL(mldb_kernel, dim3(kp_blocks, 1, B), dim3(256), 0, s_kp, T, (const apds_keypoint*)kps_out, (const int*)base_k,
+                           std::min(capacity, max_points), kp_bstride, reinterpret_cast<uint32_t*>(desc64_out), desc_bstride);
+        n_stage++;
+    };
+    int stage_prev_m = -1;
     // ---- a1.4 / a1.5 per level: Lsmooth -> (Lx, Ly, Ldet) and flow; FED steps ping-pong into Lt[i]
     for (int i = 0; i < L; i++) {
         LevelDesc& e = ev[i];
@@ -1069,6 +1274,14 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         }
         launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i,
                          s_doh, bt);
+        if (i == early_trigger) {
+            // the Hessian of this level exists once the launch above is done: all levels below can be finished. (The stage also
+            // reads Lt / Lxy of its own levels: complete before this level's smoothing pass, which the launch above follows.)
+            HIP_CHECK(hipEventRecord(c.fork_event(AKAZE_MAX_LEVELS + n_stage), s_doh));
+            HIP_CHECK(hipStreamWaitEvent(s_kp, c.fork_event(AKAZE_MAX_LEVELS + n_stage), 0));
+            run_stage(stage_prev_m, i - 1);
+            stage_prev_m = i - 1;
+        }
     }
     if (fork_doh) {   // join: everything after this point reads what the Hessian kernels wrote
         if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, hipEventDisableTiming));
@@ -1077,85 +1290,17 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         c.fork_open = false;
     }
     HIP_CHECK(hipGetLastError());
-
-    // ---- level tables for the keypoint kernels (pointers of image 0; kernels add blockIdx.z * slab)
-    LevelTable T{};
-    SuppressArgs A{};
-    T.n = A.n_levels = L;
-    T.bstride = A.bstride = slab;
-    for (int i = 0; i < L; i++) {
-        const LevelDesc& e = ev[i];
-        T.w[i] = A.w[i] = e.w;
-        T.h[i] = A.h[i] = e.h;
-        T.octave[i] = e.octave;
-        T.sigma_size[i] = A.sigma_size[i] = e.sigma_size;
-        T.border[i] = e.border;
-        T.esigma[i] = e.esigma;
-        T.ratio[i] = e.ratio;
-        A.iratio[i] = (int)e.ratio;
-        T.pix_offset[i] = e.pix_offset;
-        T.Lt[i] = e.Lt;
-        T.Lxy[i] = e.Lxy;
-        T.Ldet[i] = A.Ldet[i] = e.Ldet;
-        T.mask[i] = A.mask[i] = mask_all + e.pix_offset;
-        A.status[i] = status_all + e.pix_offset;
-        T.list[i] = A.list[i] = lists[i];
-        A.pend_cap[i] = ((e.w + 1) / 2) * ((e.h + 1) / 2);
-        A.pend[i] = pend[i];
+    // ---- last stage: the remaining levels (all of them when not staged), after the join
+    if (staged) {
+        HIP_CHECK(hipEventRecord(c.fork_event(AKAZE_MAX_LEVELS + n_stage), s));
+        HIP_CHECK(hipStreamWaitEvent(s_kp, c.fork_event(AKAZE_MAX_LEVELS + n_stage), 0));
     }
-    A.pend_count = pend_count;
-    T.pix_offset[L] = total_pix;
-    A.list_count = list_count;
-
-    // ---- cross-level suppression: phase 0 (vs previous level), then phase 1 (vs next level)
-    if (L > 1) {
-        const dim3 lgrid(B > 1 ? 64 : 256, L, B), lblock(256);   // one candidate keypoint per wave at a time
-        std::vector<int> pc((size_t)B * AKAZE_MAX_LEVELS * PEND_PITCH);
-        for (int phase = 0; phase < 2; phase++) {
-            A.phase = phase;
-            hipLaunchKernelGGL(suppress_init_status_kernel, lgrid, lblock, 0, s, A);   // also zeroes the level's three pending counters
-            int round = 0;
-            static const bool dbg_rounds = getenv("APDS_AKAZE_DEBUG") != nullptr;
-            // rounds are cheap once only the still-pending candidates are visited, a host check costs a stream sync: the first
-            // batch is as long as this thread's previous image needed in this phase (8 at first; a typical frame needs ~6
-            // rounds in phase 0 and ~15 in phase 1), then 4 at a time. Rounds after convergence change nothing.
-            int& first_batch = c.akaze_first_batch[phase];
-            const int fb = std::min(32, std::max(4, first_batch));
-            bool first = true;
-            for (int batch = fb;; batch = 4) {
-                for (int b = 0; b < batch; b++) {
-                    const uint8_t stamp = (uint8_t)(round % 253 + 1);
-                    // after a few rounds only a handful of candidates are left: a small grid keeps the launch itself short
-                    hipLaunchKernelGGL(suppress_round_kernel, round < 8 ? lgrid : dim3(16, L, B), lblock, 0, s, A, stamp, round == 0 ? -1 : (round - 1) % 3,
-                                       round % 3, (round + 1) % 3);
-                    round++;
-                    if (round % 253 == 0) hipLaunchKernelGGL(suppress_canon_kernel, lgrid, lblock, 0, s, A);
-                }
-                long long pending = 0;
-                HIP_CHECK(hipMemcpy2DAsync(pc.data(), AKAZE_MAX_LEVELS * PEND_PITCH * sizeof(int),
-                                           pend_count + ((round - 1) % 3) * AKAZE_MAX_LEVELS * PEND_PITCH, slab,
-                                           AKAZE_MAX_LEVELS * PEND_PITCH * sizeof(int), (size_t)B, hipMemcpyDeviceToHost, s));
-                HIP_CHECK(hipStreamSynchronize(s));
-                for (int bi = 0; bi < B; bi++)
-                    for (int i = 0; i < L; i++) pending += pc[((size_t)bi * AKAZE_MAX_LEVELS + i) * PEND_PITCH];
-                if (dbg_rounds) fprintf(stderr, "[apds]   phase %d after round %d: pending %lld\n", phase, round, pending);
-                if (pending == 0) {
-                    // converged within the first batch: after eight such calls in a row try one round less; otherwise start from
-                    // what this call took
-                    if (!first) {
-                        first_batch = round;
-                        c.akaze_batch_streak[phase] = 0;
-                    } else if (++c.akaze_batch_streak[phase] >= 8) {
-                        first_batch = std::max(4, fb - 1);
-                        c.akaze_batch_streak[phase] = 0;
-                    }
-                    break;
-                }
-                first = false;
-                APDS_REQUIRE(round < 1000000, APDS_ERR_INTERNAL, "cross-level suppression did not converge");
-            }
-        }
+    run_stage(stage_prev_m, L - 1);
+    if (staged) {   // back to the caller's stream
+        HIP_CHECK(hipEventRecord(c.fork_event(AKAZE_MAX_LEVELS + 8), s_kp));
+        HIP_CHECK(hipStreamWaitEvent(s, c.fork_event(AKAZE_MAX_LEVELS + 8), 0));
     }
+    HIP_CHECK(hipGetLastError());
 
     AkazeDebugRequest& dbg = akaze_debug_request();
     if (dbg.armed && dbg.level >= 0 && dbg.level < L) {   // image 0 of the batch
@@ -1168,7 +1313,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         switch (dbg.which) {
             case 0: src = e.Lt; break;
             case 4: src = e.Ldet; break;
-            case 7: src = T.mask[dbg.level]; bytes = n; break;
+            case 7: src = T.mask[dbg.level]; bytes = n; break;   // NB: after the sub-pixel filter as well (stages run it with the suppression)
             case 8: src = k_oct; bytes = 4; break;
         }
         if (src) HIP_CHECK(hipMemcpyAsync(dbg.host_out, src, bytes, hipMemcpyDeviceToHost, s));
@@ -1176,12 +1321,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         dbg.armed = false;
     }
 
-    // ---- a1.7 sub-pixel filter, ordered compaction (level-major, row-major), per image
-    hipLaunchKernelGGL(subpixel_filter_kernel, dim3(B > 1 ? 16 : 64, L, B), dim3(256), 0, s, T, (const int*)list_count);
-    hipLaunchKernelGGL(kp_block_counts_kernel, dim3(nblocks, 1, B), dim3(SCAN_BLOCK), 0, s, (const uint8_t*)mask_all, total_pix, block_counts, slab);
-    hipLaunchKernelGGL(kp_scan_offsets_kernel, dim3(1, 1, B), dim3(1024), 0, s, block_counts, nblocks, total_dev, slab);
+    // ---- the only read-back of the call: every image's keypoint count
     std::vector<int> K(B, 0);
-    HIP_CHECK(hipMemcpy2DAsync(K.data(), sizeof(int), total_dev, slab, sizeof(int), (size_t)B, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipMemcpy2DAsync(K.data(), sizeof(int), kp_base + n_stage, slab, sizeof(int), (size_t)B, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
     int kmax = 0;
     bool over = false;
@@ -1191,23 +1333,13 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         over |= K[bi] > max_points;
         APDS_REQUIRE(counts[bi] <= capacity, APDS_ERR_ASSERT, "output capacity smaller than the keypoint count");
     }
-    if (kmax == 0) return 0;
-    const size_t kp_bstride = (size_t)capacity * sizeof(apds_keypoint), desc_bstride = (size_t)capacity * 64;
-    const float ang_step = (float)(2.0 * M_PI / 42);
-    const int nkeys = (int)((float)(2.0 * M_PI) / ang_step);
-    if (!over) {
-        hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nblocks, 1, B), dim3(SCAN_BLOCK), 0, s, T, (const uint8_t*)mask_all, total_pix, (const int*)block_counts,
-                           kps_out, capacity, kp_bstride);
-        // ---- a1.8 / a1.9: grids sized for the largest image, every image reads its own count on the device
-        hipLaunchKernelGGL(orientation_kernel, dim3(ceil_div(kmax, 4), 1, B), dim3(256), 0, s, T, kps_out, (const int*)total_dev, max_points, kp_bstride, ang_step,
-                           nkeys);
-        hipLaunchKernelGGL(mldb_kernel, dim3(ceil_div(kmax, 4), 1, B), dim3(256), 0, s, T, (const apds_keypoint*)kps_out, (const int*)total_dev, max_points,
-                           kp_bstride, reinterpret_cast<uint32_t*>(desc64_out), desc_bstride);
-    } else {
-        // some image has more keypoints than max_points (rare): image by image, through the rank selection (response descending, ties
-        // by detection order); the tables of image bi are image 0's shifted by bi slabs
+    c.akaze_kp_estimate = kmax;
+    if (over) {
+        // some image has more keypoints than max_points (rare): those images again, through the rank selection (response descending,
+        // ties by detection order) over ALL their keypoints; the tables of image bi are image 0's shifted by bi slabs
+        const int nb_all = ceil_div(total_pix, KP_BYTES_PER_BLOCK);
         for (int bi = 0; bi < B; bi++) {
-            if (K[bi] == 0) continue;
+            if (K[bi] <= max_points) continue;
             LevelTable Tb = T;
             Tb.bstride = 0;
             for (int i = 0; i < L; i++) {
@@ -1218,17 +1350,22 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             }
             const int keep = counts[bi];
             apds_keypoint* kp_b = kps_out + (size_t)bi * capacity;
-            apds_keypoint* kps_all = (K[bi] == keep) ? kp_b : c.alloc_n<apds_keypoint>(K[bi]);
-            hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, Tb, (const uint8_t*)(mask_all + (size_t)bi * slab), total_pix,
-                               (const int*)(reinterpret_cast<const char*>(block_counts) + (size_t)bi * slab), kps_all, K[bi], (size_t)0);
-            if (K[bi] > keep)
-                hipLaunchKernelGGL(rank_select_kernel, dim3(ceil_div(K[bi], 256)), dim3(256), 0, s, (const apds_keypoint*)kps_all, K[bi], keep, kp_b);
+            apds_keypoint* kps_all = c.alloc_n<apds_keypoint>(K[bi]);
+            int* bc = reinterpret_cast<int*>(reinterpret_cast<char*>(block_counts) + (size_t)bi * slab);
+            int* base2 = bc + nb_all;   // two ints behind the block counts: {0, total}
+            HIP_CHECK(hipMemsetAsync(base2, 0, 2 * sizeof(int), s));
+            hipLaunchKernelGGL(kp_block_counts_kernel, dim3(nb_all), dim3(SCAN_BLOCK), 0, s, (const uint8_t*)(mask_all + (size_t)bi * slab), 0ll, total_pix, bc,
+                               (size_t)0);
+            hipLaunchKernelGGL(kp_scan_offsets_kernel, dim3(1), dim3(1024), 0, s, bc, nb_all, base2, (size_t)0);
+            hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nb_all), dim3(SCAN_BLOCK), 0, s, Tb, (const uint8_t*)(mask_all + (size_t)bi * slab), 0ll, total_pix,
+                               (const int*)bc, (const int*)nullptr, kps_all, K[bi], (size_t)0);
+            hipLaunchKernelGGL(rank_select_kernel, dim3(ceil_div(K[bi], 256)), dim3(256), 0, s, (const apds_keypoint*)kps_all, K[bi], keep, kp_b);
             hipLaunchKernelGGL(orientation_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, Tb, kp_b, (const int*)nullptr, keep, (size_t)0, ang_step, nkeys);
             hipLaunchKernelGGL(mldb_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, Tb, (const apds_keypoint*)kp_b, (const int*)nullptr, keep, (size_t)0,
                                reinterpret_cast<uint32_t*>(desc64_out + (size_t)bi * desc_bstride), (size_t)0);
         }
+        HIP_CHECK(hipGetLastError());
     }
-    HIP_CHECK(hipGetLastError());
     return kmax;
 }
 

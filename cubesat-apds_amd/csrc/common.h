@@ -66,7 +66,11 @@ struct ThreadCtx {
     int akaze_first_batch[2] = {8, 8};          // suppression rounds to launch before the first host check, per phase (adaptive)
     int akaze_batch_streak[2] = {0, 0};
     bool fork_open = false;                     // side-stream work was issued and not yet joined (only after an error in between)
+    hipStream_t side2 = nullptr;                // akaze: keypoint stages of the finished octaves
+    int akaze_kp_estimate = 0;                  // keypoints of this thread's previous image (grid size of the per-keypoint kernels)
     hipStream_t side_stream();                  // created on first use
+    hipStream_t side_stream2();
+    void drop_side();
     hipEvent_t fork_event(size_t i);            // i-th reusable event (no timing)
 
     void ensure();

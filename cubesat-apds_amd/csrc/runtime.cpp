@@ -36,6 +36,33 @@ hipStream_t ThreadCtx::side_stream() {
     return side;
 }
 
+// LOWEST priority: the keypoint stages of finished octaves fill the gaps of the level chain (the critical path, on the caller's stream
+// and the high-priority side stream); at equal priority the descriptor kernel of octave 0 held the CUs and the chain's kernels ran
+// 3 - 7x longer (profiles/r02/extract_timeline_*.txt)
+hipStream_t ThreadCtx::side_stream2() {
+    if (!side2) {
+        int least = 0, greatest = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIP_CHECK(hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, least));
+    }
+    return side2;
+}
+
+// side streams, their events and the join event: dropped with the thread's stream (release, device change)
+void ThreadCtx::drop_side() {
+    for (hipStream_t* st : {&side, &side2})
+        if (*st) {
+            (void)hipStreamSynchronize(*st);
+            (void)hipStreamDestroy(*st);
+            *st = nullptr;
+        }
+    for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
+    fork_events.clear();
+    if (join_event) (void)hipEventDestroy(join_event);
+    join_event = nullptr;
+    fork_open = false;
+}
+
 hipEvent_t ThreadCtx::fork_event(size_t i) {
     while (fork_events.size() <= i) {
         hipEvent_t e = nullptr;
@@ -138,7 +165,8 @@ int apds_set_device(int ordinal) {
         if (g_ctx.ready && g_ctx.device != ordinal) {
             // drop this thread's stream/workspace on the old device
             HIP_CHECK(hipSetDevice(g_ctx.device));
-            (void)hipStreamSynchronize(g_ctx.stream);
+            (void)hipDeviceSynchronize();   // apds_dev_* callers may have used the workspace on streams of their own
+            g_ctx.drop_side();
             for (auto& s : g_ctx.slabs) (void)hipFree(s.first);
             g_ctx.slabs.clear();
             g_ctx.slab_used = 0;
@@ -196,22 +224,16 @@ int apds_thread_release(void) {
         ThreadCtx& c = g_ctx;
         if (!c.ready) return;
         HIP_CHECK(hipSetDevice(c.device));
-        (void)hipStreamSynchronize(c.stream);
+        // apds_dev_* entry points launch kernels that use this thread's workspace on CALLER-supplied streams: wait for the whole
+        // device, not only for the thread's own streams, before the slabs go to the cache where another thread may take them
+        (void)hipDeviceSynchronize();
         for (auto& kv : c.events)
             for (auto& ev : kv.second) {
                 (void)hipEventDestroy(ev.a);
                 (void)hipEventDestroy(ev.b);
             }
         c.events.clear();
-        if (c.side) {
-            (void)hipStreamSynchronize(c.side);
-            (void)hipStreamDestroy(c.side);
-            c.side = nullptr;
-        }
-        for (hipEvent_t e : c.fork_events) (void)hipEventDestroy(e);
-        c.fork_events.clear();
-        if (c.join_event) (void)hipEventDestroy(c.join_event);
-        c.join_event = nullptr;
+        c.drop_side();
         // the stream(s) were synchronised above: nothing uses the slabs any more. A thread that ends before its second call still
         // holds the chain of doubling slabs of its first one: hand ONE slab of the total size to the cache (the next thread would
         // otherwise start from a fragment, grow and consolidate inside somebody's timed region, with a device-wide sync).
