@@ -1036,8 +1036,9 @@ int find_homography_device(const float* src, const float* dst, int n, int method
     APDS_REQUIRE(n >= 4, APDS_ERR_ASSERT, "at least 4 point pairs are required");
     APDS_REQUIRE(method == 0 || method == APDS_HOMOGRAPHY_LMEDS || method == APDS_HOMOGRAPHY_RANSAC || method == APDS_HOMOGRAPHY_RHO, APDS_ERR_BAD_ARG,
                  "unknown homography method");
-    APDS_REQUIRE(method != APDS_HOMOGRAPHY_RHO, APDS_ERR_INTERNAL, "HomographyMethod::RHO (PROSAC) is not implemented");
     APDS_REQUIRE(confidence > 0 && confidence < 1, APDS_ERR_ASSERT, "confidence must be in (0,1)");
+    if (method == APDS_HOMOGRAPHY_RHO && n > 4)   // its own estimator and refinement (homography_rho.hip); n == 4 is the plain solve, as in OpenCV
+        return find_homography_rho_device(src, dst, n, thr, max_iters, confidence, H_host, mask_dev, s);
     if (thr <= 0) thr = 3;
     ThreadCtx& c = ctx();
     const P2* M = reinterpret_cast<const P2*>(src);

@@ -39,6 +39,10 @@ int world_coordinates_device(const double* xy, int n, const double* dgt_host, co
 int find_homography_device(const float* src, const float* dst, int n, int method, double thr, int max_iters, double confidence,
                            double* H_host, uint8_t* mask_dev, hipStream_t s);
 
+// homography_rho.hip
+int find_homography_rho_device(const float* src, const float* dst, int n, double thr, int max_iters, double confidence, double* H_host, uint8_t* mask_dev,
+                               hipStream_t s);
+
 // pnp.hip
 int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const double* K, int iterations, float reproj_thr, double confidence, int method,
                       double* rvec, double* tvec, int32_t* inliers, int* n_inliers, hipStream_t s);

@@ -562,7 +562,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void emit_ratio_matches_kernel(const ui
 //   ahead (three temporaries)
 // Every wave also leaves its s_memtime span, so the host can state cycles per wave-instruction per SIMD without assuming a clock.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-static constexpr int VALU_MODES = 22;
+static constexpr int VALU_MODES = 28;
 static constexpr int VALU_CHAINS = 8, VALU_UNROLL = 16;
 
 template <int MODE>
@@ -613,6 +613,59 @@ __global__ __launch_bounds__(256) void valu_peak_kernel(uint32_t* __restrict__ s
                         APDS_X(t, j, c); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0);
                         APDS_B(t, c); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0);
                     }
+            } else if (MODE == 22) {      // bcnt only (the xor hoisted: 15 xors, then 60 bcnt with an s_nop after each) - is bcnt 4 cycles whatever the phase?
+                uint32_t t[15];
+#pragma unroll
+                for (int j = 0; j < 15; j++) APDS_X(t[j], j, 0);
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int j = 0; j < 15; j++) { APDS_B(t[j], c); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0); }
+            } else if (MODE == 23) {      // X X nop B B
+#pragma unroll
+                for (int c = 0; c < 4; c += 2)
+#pragma unroll
+                    for (int j = 0; j < 15; j++) {
+                        uint32_t t0, t1;
+                        APDS_X(t0, j, c); APDS_X(t1, j, c + 1); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0);
+                        APDS_B(t0, c); APDS_B(t1, c + 1);
+                    }
+            } else if (MODE == 24) {      // X s_nop 1 B
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int j = 0; j < 15; j++) { uint32_t t; APDS_X(t, j, c); asm volatile("s_nop 1"); __builtin_amdgcn_sched_barrier(0); APDS_B(t, c); }
+            } else if (MODE == 25) {      // B nop X (the nop after the bcnt instead of before it): X0, then [B nop X] ...
+                uint32_t t[60];
+                APDS_X(t[0], 0, 0);
+#pragma unroll
+                for (int i = 0; i < 60; i++) {
+                    APDS_B(t[i], i / 15);
+                    asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0);
+                    if (i + 1 < 60) APDS_X(t[i + 1], (i + 1) % 15, (i + 1) / 15);
+                }
+            } else if (MODE == 26) {      // X nop B where the nop is an s_sleep-free scalar ALU op (s_add on a dummy) instead of s_nop
+                int dummy = it;
+#pragma unroll
+                for (int c = 0; c < 4; c++)
+#pragma unroll
+                    for (int j = 0; j < 15; j++) {
+                        uint32_t t;
+                        APDS_X(t, j, c);
+                        asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy));
+                        __builtin_amdgcn_sched_barrier(0);
+                        APDS_B(t, c);
+                    }
+                if (dummy == 0x7ffffff0) a[0]++;
+            } else if (MODE == 27) {      // X nop B with a second independent pair stream interleaved: X0 X1 nop B0 B1 on two queries at a time, dword-major
+#pragma unroll
+                for (int j = 0; j < 15; j++) {
+                    uint32_t t0, t1, t2, t3;
+                    APDS_X(t0, j, 0); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0); APDS_B(t0, 0);
+                    APDS_X(t1, j, 1); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0); APDS_B(t1, 1);
+                    APDS_X(t2, j, 2); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0); APDS_B(t2, 2);
+                    APDS_X(t3, j, 3); asm volatile("s_nop 0"); __builtin_amdgcn_sched_barrier(0); APDS_B(t3, 3);
+                }
             } else if (MODE == 21) {      // 12 with ONE SGPR for the whole row (row[0]) instead of fifteen
 #pragma unroll
                 for (int c = 0; c < 4; c++)
@@ -1014,7 +1067,8 @@ const char* valu_peak_mode_name(int mode) {
                                             "row x 4 queries: query-sequential", "row x 4 queries: dword-major", "dword-major, xor 1 ahead",
                                             "dword-major, row in VGPRs", "query-sequential, xor 1 ahead", "dword-major, xor 2 ahead",
                                             "query-sequential + s_nop before each bcnt", "dword-major + s_nop before each bcnt",
-                                            "query-sequential + s_nop after every op", "query-sequential, one SGPR"};
+                                            "query-sequential + s_nop after every op", "query-sequential, one SGPR",
+                                            "bcnt + s_nop only (75 ops counted as 120)", "X X nop B B", "X s_nop(1) B", "B nop X", "X s_add B", "dword-major X nop B"};
     return mode >= 0 && mode < VALU_MODES ? names[mode] : "?";
 }
 
@@ -1044,6 +1098,12 @@ void valu_peak_device(int mode, int waves_per_simd, double* lane_ops_per_s, doub
         case 19: r = run_valu_peak<19>(waves_per_simd, st); break;
         case 20: r = run_valu_peak<20>(waves_per_simd, st); break;
         case 21: r = run_valu_peak<21>(waves_per_simd, st); break;
+        case 22: r = run_valu_peak<22>(waves_per_simd, st); break;
+        case 23: r = run_valu_peak<23>(waves_per_simd, st); break;
+        case 24: r = run_valu_peak<24>(waves_per_simd, st); break;
+        case 25: r = run_valu_peak<25>(waves_per_simd, st); break;
+        case 26: r = run_valu_peak<26>(waves_per_simd, st); break;
+        case 27: r = run_valu_peak<27>(waves_per_simd, st); break;
         default: fail(APDS_ERR_BAD_ARG, "valu peak: mode out of range");
     }
     if (lane_ops_per_s) *lane_ops_per_s = r.lane_ops_per_s;

@@ -22,7 +22,8 @@ PLANE_LT, PLANE_LSMOOTH, PLANE_LX, PLANE_LY, PLANE_LDET, PLANE_LFLOW, PLANE_MASK
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("akaze_oracle.cpp", "match_oracle.cpp", "homography_oracle.cpp", "ingest_oracle.cpp", "pnp_oracle.cpp", "oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("akaze_oracle.cpp", "match_oracle.cpp", "homography_oracle.cpp", "rho_oracle.cpp", "ingest_oracle.cpp", "pnp_oracle.cpp",
+                                             "oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so

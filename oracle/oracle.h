@@ -92,6 +92,9 @@ int oracle_get_points_from_matches(const oracle_keypoint* kp1, int n1, const ora
 /* mod.rs:231-259. method: 0 least squares, 4 LMEDS, 8 RANSAC. thr<=0 -> 3. max_iters/confidence: OpenCV
  * defaults are 2000 / 0.995. Returns 1 if a model was found (H filled, H[8]==1), 0 if none, <0 on error
  * (-215 bad args, -2 RHO unsupported). mask (n bytes) may be NULL. */
+/* HomographyMethod::RHO (mod.rs:30): OpenCV rho.cpp restated (PROSAC + SPRT + LM refinement, binary32). 1 = model found. */
+int oracle_rho_homography(const float* src_xy, const float* dst_xy, int n, double thr, int max_iters, double confidence, double* H,
+                          uint8_t* mask);
 int oracle_find_homography(const float* src_xy, const float* dst_xy, int n, int method, double thr,
                            int max_iters, double confidence, double* H, uint8_t* mask);
 /* helpers exposed for GPU per-stage parity */

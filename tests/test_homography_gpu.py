@@ -83,8 +83,37 @@ def test_all_outliers_and_degenerate(gpu_pkg, oracle_mod):
     with pytest.raises(hg.MatError) as e:              # fewer than 4 points is an OpenCV error
         hg.find_homography_mat(line[:3], line[:3], hg.HomographyMethod.RANSAC, 3.0)
     assert e.value.kind == "Opencv"
-    with pytest.raises(hg.MatError):                   # RHO is not implemented: loud failure, not a silent substitute
-        hg.find_homography_mat(src, dst, hg.HomographyMethod.RHO, 3.0)
+    _check(gpu_pkg, oracle_mod, src, dst, 16, 0.5)     # RHO on pure outliers / collinear points: found or not, as the oracle
+    _check(gpu_pkg, oracle_mod, line, line, 16, 3.0)
+
+
+@pytest.mark.parametrize("n,inl,noise,thr,iters", [(5, 1.0, 0.0, 3.0, 2000), (60, 0.8, 0.3, 3.0, 2000), (2000, 0.4, 0.5, 3.0, 2000), (50000, 0.4, 0.5, 3.0, 4096),
+                                                   (10000, 0.15, 1.0, 3.0, 2000), (3000, 0.5, 0.4, 1.0, 300), (8000, 0.6, 0.3, 1.5, 500)])
+def test_rho_equals_oracle(gpu_pkg, oracle_mod, n, inl, noise, thr, iters):
+    # HomographyMethod::RHO (mod.rs:30). The GPU path scores speculated batches and replays rho.cpp's sequential loop over the bit
+    # rows; the oracle runs that loop one hypothesis at a time. Every operation is binary32 in the same order on both sides, so the
+    # inlier set AND the refined H are bit-identical (the generic _check tolerance is the fallback bar).
+    src, dst, H_true, flag = gpu_pkg.synth.make_ransac_set(n, seed=0x52484F00 + n, inlier_frac=inl, noise=noise)
+    found, H, mask = _check(gpu_pkg, oracle_mod, src, dst, 16, thr, max_iters=iters)
+    if inl < 0.3 or thr < 1.5:   # few inliers, or a threshold near the noise with a small budget: the algorithm may find nothing (the
+        return                   # oracle does not either); only GPU == oracle is required, and _check has asserted that
+    assert found
+    _, Ho, _ = oracle_mod.find_homography(src, dst, 16, thr, iters, 0.995)
+    assert np.array_equal(H, Ho.reshape(3, 3))
+    if n >= 2000 and thr >= 3.0:
+        assert (mask.astype(bool) & flag).sum() >= (0.9 if noise <= 0.5 else 0.7) * flag.sum()
+        assert np.allclose(H, H_true, rtol=2e-2, atol=1.0)
+
+
+def test_rho_through_the_crate_api(gpu_pkg):
+    # the reference's own KAT (mod.rs:437-472) with RHO: identity; no mask for RHO (mod.rs:253-257)
+    hg = gpu_pkg.homographier
+    pts = np.array([(i, j) for i in range(1, 11) for j in range(1, 11)], np.float32)
+    H, mask = hg.find_homography_mat(pts, pts, hg.HomographyMethod.RHO, 1.0)
+    assert mask is None
+    for r in range(3):
+        for c in range(3):
+            assert round(float(H.at_2d(r, c))) == (1 if r == c else 0)
 
 
 def test_pipeline_extract_match_homography(gpu_pkg, oracle_mod):

@@ -284,3 +284,16 @@ def test_world_coordinates_closed_form(oracle_mod):
     rc, xyz = oracle_mod.world_coordinates([[1e7, 1e7]], [9.0, 1e-4, 0, 57.0, 0, -1e-4], [8.99, 3e-4, 0, 57.01, 0, -3e-4], el)
     assert rc == -211 and np.isnan(xyz).all()
     assert oracle_mod.world_coordinates([[0, 0]], [9.0, 1e-4, 0, 57.0, 0, -1e-4], [0, 0, 0, 0, 0, 0], el)[0] == -5
+
+
+def test_rho_oracle_on_the_reference_kat_and_on_planted_data(pkg, oracle_mod):
+    # HomographyMethod::RHO in the oracle: the reference's homography_success data (mod.rs:437-472) gives the identity, and a planted
+    # homography with 40 % inliers is recovered; deterministic (fixed xorshift128+ seed, as rho.cpp)
+    pts = np.array([(i, j) for i in range(1, 11) for j in range(1, 11)], np.float32)
+    ok, H, mask = oracle_mod.find_homography(pts, pts, 16, 1.0)
+    assert ok and mask.all() and np.allclose(H.reshape(3, 3), np.eye(3), atol=1e-5)
+    src, dst, H_true, flag = pkg.synth.make_ransac_set(3000, seed=99, inlier_frac=0.4, noise=0.5)
+    ok, H, mask = oracle_mod.find_homography(src, dst, 16, 3.0)
+    ok2, H2, mask2 = oracle_mod.find_homography(src, dst, 16, 3.0)
+    assert ok and ok2 and np.array_equal(H, H2) and np.array_equal(mask, mask2)
+    assert (mask.astype(bool) & flag).sum() >= 0.9 * flag.sum() and np.allclose(H.reshape(3, 3), H_true, rtol=2e-2, atol=1.0)
