@@ -25,7 +25,7 @@ SYMBOLS = [
     "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_match_lds_cap", "apds_dev_match_last_launch_lds", "apds_dev_ratio_filter",
     "apds_dev_cross_check", "apds_dev_akaze_extract", "apds_dev_points_from_matches", "apds_dev_find_homography",
     "apds_dev_valu_popcount_peak", "apds_dev_valu_peak", "apds_dev_valu_peak_modes", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane", "apds_stream_create", "apds_stream_destroy",
-    "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective", "apds_pnp_solver_ransac", "apds_pnp_hypotheses", "apds_get_world_coordinates", "apds_l2_knn_match", "apds_dev_l2_topk",
+    "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective", "apds_pnp_solver_ransac", "apds_pnp_hypotheses", "apds_get_world_coordinates", "apds_l2_knn_match", "apds_dev_l2_topk", "apds_dev_l2_topk_ex",
     "apds_db_create", "apds_db_destroy", "apds_db_rows", "apds_db_insert_image", "apds_db_select", "apds_db_view", "apds_db_view_download", "apds_db_knn_match",
 ]
 
@@ -101,6 +101,7 @@ def lib():
             "apds_get_world_coordinates": (i, [vp, i, vp, vp, vp, i, i, vp]),
             "apds_l2_knn_match": (i, [vp, i, vp, i, i, i, vp, vp]),
             "apds_dev_l2_topk": (i, [vp, i, vp, i64, i, u32, i, vp, vp]),
+            "apds_dev_l2_topk_ex": (i, [vp, i, vp, i64, i, u32, i, i, vp, vp, ip, C.POINTER(d)]),
             "apds_db_create": (i, [pp, i64]),
             "apds_db_destroy": (i, [vp]),
             "apds_db_rows": (i64, [vp]),

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void rho_inlier_bits_kernel(const F2* __restri
             in = rx + ry <= maxDsq;
         }
         const unsigned long long b = __ballot(in);
-        if ((threadIdx.x & 63) == 0) bits[(size_t)blockIdx.y * words + (i >> 6)] = b;
+        if ((threadIdx.x & 63) == 0 && (i >> 6) < words) bits[(size_t)blockIdx.y * words + (i >> 6)] = b;   // (a block may reach past the last word)
     }
 }
 

@@ -39,6 +39,12 @@ int world_coordinates_device(const double* xy, int n, const double* dgt_host, co
 int find_homography_device(const float* src, const float* dst, int n, int method, double thr, int max_iters, double confidence,
                            double* H_host, uint8_t* mask_dev, hipStream_t s);
 
+// l2_match.hip / l2_screen.hip
+void l2_row_norms_device(const float* x, long long n, int dim, float* out, hipStream_t s);
+void l2_topk_device(const float* q, int nq, const float* t, long long nt, int dim, uint32_t index_base, int k, uint64_t* out, hipStream_t s);
+bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt, int dim, uint32_t index_base, int k, uint64_t* out, hipStream_t s,
+                           double* candidates_per_query);
+
 // homography_rho.hip
 int find_homography_rho_device(const float* src, const float* dst, int n, double thr, int max_iters, double confidence, double* H_host, uint8_t* mask_dev,
                                hipStream_t s);

@@ -263,6 +263,10 @@ __global__ __launch_bounds__(512) void l2_topk_kernel(const float* __restrict__ 
     }
 }
 
+void l2_row_norms_device(const float* x, long long n, int dim, float* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(row_norms_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, s, x, n, dim, out);
+}
+
 void l2_topk_device(const float* q, int nq, const float* t, long long nt, int dim, uint32_t index_base, int k, uint64_t* out, hipStream_t s) {
     APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "L2 top-k supports k in {1,2}");
     APDS_REQUIRE(dim >= 1 && dim <= L2_KMAX, APDS_ERR_ASSERT, "float descriptor length must be 1..128");
@@ -319,6 +323,25 @@ void l2_topk_device(const float* q, int nq, const float* t, long long nt, int di
 using namespace apds;
 
 extern "C" {
+
+int apds_dev_l2_topk_ex(const void* q, int nq, const void* t, int64_t nt, int dim, uint32_t index_base, int k, int mode, void* out_keys, void* stream,
+                        int* mode_used, double* candidates_per_query) {
+    return guarded([&] {
+        APDS_REQUIRE(nq >= 0 && nt >= 0, APDS_ERR_ASSERT, "negative row count");
+        APDS_REQUIRE(mode == APDS_L2_EXACT || mode == APDS_L2_SCREEN, APDS_ERR_BAD_ARG, "mode must be APDS_L2_EXACT or APDS_L2_SCREEN");
+        ctx().ws_reset();
+        hipStream_t s = pick_stream(stream);
+        if (mode_used) *mode_used = APDS_L2_EXACT;
+        if (candidates_per_query) *candidates_per_query = 0;
+        if (mode == APDS_L2_SCREEN && l2_topk_screen_device(static_cast<const float*>(q), nq, static_cast<const float*>(t), nt, dim, index_base, k,
+                                                            static_cast<uint64_t*>(out_keys), s, candidates_per_query)) {
+            if (mode_used) *mode_used = APDS_L2_SCREEN;
+            return;
+        }
+        ctx().ws_reset();   // the screen does not apply (shape, alignment, candidate overflow): the exact kernel
+        l2_topk_device(static_cast<const float*>(q), nq, static_cast<const float*>(t), nt, dim, index_base, k, static_cast<uint64_t*>(out_keys), s);
+    });
+}
 
 int apds_dev_l2_topk(const void* q, int nq, const void* t, int64_t nt, int dim, uint32_t index_base, int k, void* out_keys, void* stream) {
     return guarded([&] {

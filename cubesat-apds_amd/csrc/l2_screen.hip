@@ -1,0 +1,355 @@
+// csrc/l2_screen.hip — float-descriptor L2 top-2 as a BF16 MFMA screen + exact f32 re-rank (BASELINE config 3, fast mode).
+//
+// l2_match.hip computes every one of the Q x N distances with f32 MFMA (157 TFLOP/s peak). The bf16 matrix pipe is 16 times
+// faster, and a top-2 search only needs exact arithmetic for the handful of rows that can still be among the two nearest. So:
+//
+//   pass A  S(q,t) = |q|^2 + |t|^2 - 2 q~.t~ with q~, t~ the operands rounded to bf16, products exact and accumulation in f32
+//           inside v_mfma_f32_16x16x32_bf16; fused running top-2 per query -> s2(q), the second smallest screen value;
+//   pass B  the same products again; every row with S(q,t) <= s2(q) + 2 eps(q) is appended to a candidate list;
+//   pass C  the candidates are re-ranked with EXACTLY the arithmetic of l2_match.hip (the same binary32 fmaf chain over k, the same
+//           |t|^2 - 2 q.t and |q|^2 + . and max(., 0)), keys (distance bits << 32 | row) reduced by 64-bit atomic min.
+//
+// Bound (F = the value l2_match.hip computes, S = the screen value): with u = 2^-8 the unit roundoff of bf16,
+//   |q_i t_i - q~_i t~_i| <= (2u + u^2) |q_i| |t_i|, summed and with Cauchy-Schwarz: |q.t - q~.t~| <= (2u + u^2) |q| |t|;
+//   the f32 accumulations on either side and the few f32 operations around them add at most 2^-13 (|q|^2 + |t|^2) (K = 128 terms
+//   at 2^-24 relative each is 2^-17 |q| |t|; the slack is generous on purpose). Hence |F - S| <= eps(q) with
+//   eps(q) = 2 (2u + u^2) |q| Tmax + 2^-13 (|q|^2 + Tmax^2),   Tmax = the largest row norm of the train set.
+// Two rows have S <= s2, hence F <= s2 + eps, so the second smallest F is <= s2 + eps; every row of the exact top-2 (ties included)
+// has F <= that, hence S <= s2 + 2 eps: it is a candidate. The re-rank therefore returns the keys l2_match.hip returns, bit for bit
+// (tests/test_l2_match_gpu.py compares the two modes directly).
+//
+// Screen kernel (CDNA4): block = 8 waves = 256 queries x a stream of 128-row train tiles. A wave keeps its 32 queries (two 16-column
+// blocks) as MFMA B operands in registers for the whole kernel (bf16: 32 VGPRs); train tiles are staged in LDS (bf16, pre-scaled by
+// -2, row pitch 272 B so that the 16 rows of a ds_read_b128 group fall in different banks), double buffered, one barrier per tile;
+// each A read feeds two MFMAs. The accumulator starts from |t|^2 of its four rows, so an accumulator IS the ranking value
+// |t|^2 - 2 q~.t~ and the epilogue is two min and one compare per 16 x 16 block; like in the other matchers a lane owns one query
+// column, so the running top-2 (or the threshold) lives in the lane and insertions / appends are rare.
+#include <cmath>
+
+#include "kernels.h"
+
+namespace apds {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int SC_TM = 128;            // train rows per tile
+static constexpr int SC_Q = 256;             // queries per block
+static constexpr int SC_D = 128;             // descriptor length (the screen is built for it)
+static constexpr int SC_PITCH = 272;         // bytes per staged train row (256 + 16)
+static constexpr uint64_t SC_EMPTY = ~0ull;
+
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t x = __float_as_uint(f);
+    if ((x & 0x7F800000u) == 0x7F800000u) return (uint16_t)(x >> 16) | ((x & 0xFFFFu) ? 0x40 : 0);   // inf / nan
+    x += 0x7FFFu + ((x >> 16) & 1u);
+    return (uint16_t)(x >> 16);
+}
+
+// rows of f32 -> bf16 (scaled by `scale`, a power of two: exact), and |row|^2 in f32 exactly as row_norms_kernel of l2_match.hip
+__global__ void to_bf16_rows_kernel(const float* __restrict__ x, long long n, float scale, uint16_t* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n * SC_D) return;
+    const float4 v = *reinterpret_cast<const float4*>(x + i);
+    uint2 o;
+    o.x = (uint32_t)f32_to_bf16_rne(v.x * scale) | ((uint32_t)f32_to_bf16_rne(v.y * scale) << 16);
+    o.y = (uint32_t)f32_to_bf16_rne(v.z * scale) | ((uint32_t)f32_to_bf16_rne(v.w * scale) << 16);
+    *reinterpret_cast<uint2*>(out + i) = o;
+}
+
+__global__ void max_norm_kernel(const float* __restrict__ norms_sq, long long n, unsigned int* __restrict__ out_bits) {
+    APDS_RAISE_WAVE_PRIORITY();
+    float m = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) m = fmaxf(m, norms_sq[i]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+struct ScTop2 {
+    float d0, d1;
+    uint32_t i0, i1;
+};
+__device__ __forceinline__ void sc_insert(ScTop2& b, float d, uint32_t idx) {
+    if (d < b.d1) {
+        if (d < b.d0) {
+            b.d1 = b.d0;
+            b.i1 = b.i0;
+            b.d0 = d;
+            b.i0 = idx;
+        } else {
+            b.d1 = d;
+            b.i1 = idx;
+        }
+    }
+}
+__device__ __forceinline__ uint64_t sc_key(float d, uint32_t idx) { return idx == 0xFFFFFFFFu ? SC_EMPTY : ((uint64_t)__float_as_uint(d) << 32) | idx; }
+
+// PASS 0: running top-2 of the screen value per query -> out[split][nq][2] keys (d^2 = max(|q|^2 + u, 0) bits << 32 | row).
+// PASS 1: rows with u <= theta[q] are appended to cand (query << 32 | row), counted in *cand_count (entries past cand_cap are dropped;
+//         the host checks the count).
+template <int PASS>
+__global__ __launch_bounds__(512) void l2_screen_kernel(const uint16_t* __restrict__ train_bf, const float* __restrict__ tnorm, int n_train,
+                                                        const uint16_t* __restrict__ query_bf, const float* __restrict__ qnorm, int nq, int tiles_per_split,
+                                                        uint32_t index_base, uint64_t* __restrict__ out, const float* __restrict__ theta,
+                                                        unsigned long long* __restrict__ cand, unsigned long long cand_cap,
+                                                        unsigned long long* __restrict__ cand_count) {
+    APDS_RAISE_WAVE_PRIORITY();
+    extern __shared__ unsigned char sc_lds[];
+    auto tile_lds = [&](int buf) { return sc_lds + buf * (SC_TM * SC_PITCH); };
+    auto norm_lds = [&](int buf) { return reinterpret_cast<float*>(sc_lds + 2 * SC_TM * SC_PITCH) + buf * SC_TM; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.x * SC_Q + wave * 32;                 // this wave's 32 queries
+    const int n_tiles = (n_train + SC_TM - 1) / SC_TM;
+    const int tile_begin = blockIdx.y * tiles_per_split, tile_end = min(n_tiles, tile_begin + tiles_per_split);
+    if (tile_begin >= tile_end) return;
+    const int col = lane & 15, kq = lane >> 4;                     // accumulator column / k chunk (operands) / row group (accumulators)
+
+    // B operands: query (q0 + 16 c + col), k = 32 s + 8 kq .. + 7, for c = 0, 1 and the four k steps s
+    bf16x8 B[2][4];
+    float qq[2], th[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int qi = min(q0 + 16 * c + col, nq - 1);
+#pragma unroll
+        for (int s = 0; s < 4; s++) B[c][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(query_bf + (size_t)qi * SC_D + 32 * s + 8 * kq));
+        qq[c] = qnorm[qi];
+        th[c] = PASS == 1 ? theta[qi] : 0.f;
+    }
+    ScTop2 best[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        best[c].d0 = best[c].d1 = INFINITY;
+        best[c].i0 = best[c].i1 = 0xFFFFFFFFu;
+    }
+
+    // staging: the tile is 128 rows x 256 B = 2048 pieces of 16 B, four per thread; rows past the end re-read the last row and get
+    // a norm of +inf, so they never rank
+    uint4 pre0, pre1, pre2, pre3;   // (separate variables: as an array indexed inside the lambdas they went to scratch)
+    float pre_norm = INFINITY;
+    const int pr = tid >> 4, pg = tid & 15;   // piece p of this thread: row 32 p + pr, 16-byte group pg
+    auto load_tile = [&](int tile) {
+        const int r0 = tile * SC_TM + pr;
+        pre0 = *reinterpret_cast<const uint4*>(train_bf + (size_t)min(r0, n_train - 1) * SC_D + 8 * pg);
+        pre1 = *reinterpret_cast<const uint4*>(train_bf + (size_t)min(r0 + 32, n_train - 1) * SC_D + 8 * pg);
+        pre2 = *reinterpret_cast<const uint4*>(train_bf + (size_t)min(r0 + 64, n_train - 1) * SC_D + 8 * pg);
+        pre3 = *reinterpret_cast<const uint4*>(train_bf + (size_t)min(r0 + 96, n_train - 1) * SC_D + 8 * pg);
+        if (tid < SC_TM) {
+            const int row = tile * SC_TM + tid;
+            pre_norm = row < n_train ? tnorm[row] : INFINITY;
+        }
+    };
+    auto commit = [&](int buf) {
+        unsigned char* d = tile_lds(buf) + pr * SC_PITCH + 16 * pg;
+        *reinterpret_cast<uint4*>(d) = pre0;
+        *reinterpret_cast<uint4*>(d + 32 * SC_PITCH) = pre1;
+        *reinterpret_cast<uint4*>(d + 64 * SC_PITCH) = pre2;
+        *reinterpret_cast<uint4*>(d + 96 * SC_PITCH) = pre3;
+        if (tid < SC_TM) norm_lds(buf)[tid] = pre_norm;
+    };
+    load_tile(tile_begin);
+    commit(0);
+    __syncthreads();
+
+    for (int tile = tile_begin; tile < tile_end; tile++) {
+        const int buf = (tile - tile_begin) & 1;
+        const bool more = tile + 1 < tile_end;
+        if (more) load_tile(tile + 1);
+        const unsigned char* T = tile_lds(buf);
+        const float* Nn = norm_lds(buf);
+#pragma unroll 2
+        for (int rb = 0; rb < 8; rb++) {                           // 16-row blocks of the tile
+            const f32x4 init = *reinterpret_cast<const f32x4*>(Nn + rb * 16 + 4 * kq);   // |t|^2 of this lane's four rows
+            f32x4 acc0 = init, acc1 = init;
+            const unsigned char* arow = T + (rb * 16 + col) * SC_PITCH + 16 * kq;
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow + 64 * s));
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B[0][s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B[1][s], acc1, 0, 0, 0);
+            }
+            // epilogue: acc = |t|^2 - 2 q~.t~ for rows 4 kq + j of the block, query column `col` of each of the two query blocks
+            const float m0 = fminf(fminf(acc0[0], acc0[1]), fminf(acc0[2], acc0[3]));
+            const float m1 = fminf(fminf(acc1[0], acc1[1]), fminf(acc1[2], acc1[3]));
+            const uint32_t row0 = (uint32_t)(tile * SC_TM + rb * 16 + 4 * kq);
+            if (PASS == 0) {
+                if (__any(m0 < best[0].d1 || m1 < best[1].d1)) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        sc_insert(best[0], acc0[j], row0 + j + index_base);
+                        sc_insert(best[1], acc1[j], row0 + j + index_base);
+                    }
+                }
+            } else {
+                if (__any(m0 <= th[0] || m1 <= th[1])) {
+#pragma unroll
+                    for (int c = 0; c < 2; c++) {
+                        const f32x4 a = c ? acc1 : acc0;
+                        const int qi = q0 + 16 * c + col;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (a[j] <= th[c] && qi < nq && (int)(row0 + j) < n_train) {
+                                const unsigned long long pos = atomicAdd(cand_count, 1ull);
+                                if (pos < cand_cap) cand[pos] = ((unsigned long long)(uint32_t)qi << 32) | (row0 + j + index_base);
+                            }
+                    }
+                }
+            }
+        }
+        if (more) commit(buf ^ 1);
+        __syncthreads();   // the next tile is staged; everybody is done with this one
+    }
+    if (PASS == 0) {
+        // a query column lives in four lanes (kq = 0..3, different rows): fold them with shuffles, lanes 0..15 write
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            ScTop2 b = best[c];
+#pragma unroll
+            for (int off = 16; off < 64; off <<= 1) {
+                const float od0 = __shfl_xor(b.d0, off), od1 = __shfl_xor(b.d1, off);
+                const uint32_t oi0 = (uint32_t)__shfl_xor((int)b.i0, off), oi1 = (uint32_t)__shfl_xor((int)b.i1, off);
+                // merge two sorted pairs; equal values: lower row first
+                ScTop2 m = b;
+                auto ins = [&](float d, uint32_t i) {
+                    if (i == 0xFFFFFFFFu) return;
+                    if (d < m.d0 || (d == m.d0 && i < m.i0)) {
+                        m.d1 = m.d0;
+                        m.i1 = m.i0;
+                        m.d0 = d;
+                        m.i0 = i;
+                    } else if ((d < m.d1 || (d == m.d1 && i < m.i1)) && i != m.i0) {
+                        m.d1 = d;
+                        m.i1 = i;
+                    }
+                };
+                ins(od0, oi0);
+                ins(od1, oi1);
+                b = m;
+            }
+            const int qi = q0 + 16 * c + col;
+            if (kq == 0 && qi < nq) {
+                uint64_t* o = out + ((size_t)blockIdx.y * nq + qi) * 2;
+                o[0] = sc_key(fmaxf(qq[c] + b.d0, 0.f), b.i0);
+                o[1] = sc_key(fmaxf(qq[c] + b.d1, 0.f), b.i1);
+            }
+        }
+    }
+}
+
+// theta[q] (in units of u = d^2 - |q|^2): second screen distance + 2 eps(q) - |q|^2
+__global__ void screen_theta_kernel(const uint64_t* __restrict__ top2, const float* __restrict__ qnorm, int nq, const unsigned int* __restrict__ tmax_sq_bits,
+                                    float* __restrict__ theta) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const uint64_t k2 = top2[(size_t)i * 2 + 1];
+    if (k2 == SC_EMPTY) {   // fewer than two rows: everything is a candidate
+        theta[i] = INFINITY;
+        return;
+    }
+    const float s2 = __uint_as_float((uint32_t)(k2 >> 32));
+    const float qn = qnorm[i], tm = __uint_as_float(*tmax_sq_bits);
+    const float u = 0.00390625f;   // 2^-8
+    const float eps = 2.0f * (2.0f * u + u * u) * sqrtf(qn) * sqrtf(tm) + (qn + tm) * 0.0001220703125f;   // + 2^-13 (|q|^2 + Tmax^2)
+    // s2 is max(|q|^2 + u2, 0): if the clamp was active the true value is <= 0, and using 0 only loosens the threshold
+    theta[i] = (s2 + 2.0f * eps) * 1.0000002f - qn;
+}
+
+// exact keys of the candidates: the binary32 arithmetic of l2_topk_kernel (fmaf chain over k ascending from 0, u = fmaf(-2, dot, |t|^2),
+// d^2 = max(|q|^2 + u, 0)); STEP 0: atomic min into best[q]; STEP 1: atomic min into second[q] of the keys != best[q]
+template <int STEP>
+__global__ void screen_rerank_kernel(const unsigned long long* __restrict__ cand, unsigned long long n_cand, const float* __restrict__ q,
+                                     const float* __restrict__ qnorm, const float* __restrict__ t, const float* __restrict__ tnorm, uint32_t index_base,
+                                     unsigned long long* __restrict__ keys, unsigned long long* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cand) return;
+    const unsigned long long c = cand[i];
+    const uint32_t qi = (uint32_t)(c >> 32), row = (uint32_t)c;
+    unsigned long long key;
+    if (STEP == 0) {
+        const float4* a = reinterpret_cast<const float4*>(t + (size_t)(row - index_base) * SC_D);
+        const float4* b = reinterpret_cast<const float4*>(q + (size_t)qi * SC_D);
+        float dot = 0.0f;
+#pragma unroll 8
+        for (int k = 0; k < SC_D / 4; k++) {
+            const float4 x = a[k], y = b[k];
+            dot = __builtin_fmaf(x.x, y.x, dot);
+            dot = __builtin_fmaf(x.y, y.y, dot);
+            dot = __builtin_fmaf(x.z, y.z, dot);
+            dot = __builtin_fmaf(x.w, y.w, dot);
+        }
+        const float u = __builtin_fmaf(-2.0f, dot, tnorm[row - index_base]);
+        const float d2 = fmaxf(qnorm[qi] + u, 0.f);
+        key = ((unsigned long long)__float_as_uint(d2) << 32) | row;
+        keys[i] = key;
+        atomicMin(&out[(size_t)qi * 2], key);
+    } else {
+        key = keys[i];
+        if (key != out[(size_t)qi * 2]) atomicMin(&out[(size_t)qi * 2 + 1], key);
+    }
+}
+
+// returns false if the screen could not be used (shape, alignment, candidate overflow): the caller falls back to the f32 kernel
+bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt, int dim, uint32_t index_base, int k, uint64_t* out, hipStream_t s,
+                           double* candidates_per_query) {
+    if (dim != SC_D || k != 2 || nt < 2 || nq < 1) return false;
+    if (((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(t)) & 15) != 0) return false;
+    ThreadCtx& c = ctx();
+    float* qn = c.alloc_n<float>(nq);
+    float* tn = c.alloc_n<float>(nt);
+    uint16_t* qb = c.alloc_n<uint16_t>((size_t)nq * SC_D);
+    uint16_t* tb = c.alloc_n<uint16_t>((size_t)nt * SC_D);
+    unsigned int* tmax = c.alloc_n<unsigned int>(4);
+    unsigned long long* count = reinterpret_cast<unsigned long long*>(tmax + 2);
+    HIP_CHECK(hipMemsetAsync(tmax, 0, 16, s));
+    l2_row_norms_device(q, nq, dim, qn, s);
+    l2_row_norms_device(t, nt, dim, tn, s);
+    hipLaunchKernelGGL(to_bf16_rows_kernel, dim3(ceil_div((long long)nq * SC_D / 4, 256)), dim3(256), 0, s, q, (long long)nq, 1.0f, qb);
+    hipLaunchKernelGGL(to_bf16_rows_kernel, dim3(ceil_div(nt * SC_D / 4, 256)), dim3(256), 0, s, t, nt, -2.0f, tb);
+    hipLaunchKernelGGL(max_norm_kernel, dim3(256), dim3(256), 0, s, (const float*)tn, nt, tmax);
+    const int q_tiles = ceil_div(nq, SC_Q), t_tiles = ceil_div(nt, SC_TM);
+    int splits = std::max(1, std::min(t_tiles, ceil_div(256 * 2, q_tiles)));
+    const int tiles_per_split = ceil_div(t_tiles, splits);
+    splits = ceil_div(t_tiles, tiles_per_split);
+    uint64_t* parts = c.alloc_n<uint64_t>((size_t)splits * nq * 2);
+    uint64_t* top2 = splits == 1 ? parts : c.alloc_n<uint64_t>((size_t)nq * 2);
+    float* theta = c.alloc_n<float>(nq);
+    const unsigned long long cap = std::max<unsigned long long>(1ull << 20, (unsigned long long)nq * 48);
+    unsigned long long* cand = c.alloc_n<unsigned long long>(cap);
+    unsigned long long* keys = c.alloc_n<unsigned long long>(cap);
+    const size_t lds = (size_t)2 * SC_TM * SC_PITCH + 2 * SC_TM * sizeof(float);
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        KernelTimer timer("l2_screen", s);
+        hipLaunchKernelGGL((l2_screen_kernel<0>), dim3(q_tiles, splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)nt, (const uint16_t*)qb,
+                           (const float*)qn, nq, tiles_per_split, index_base, parts, (const float*)nullptr, (unsigned long long*)nullptr, 0ull,
+                           (unsigned long long*)nullptr);
+    }
+    if (splits > 1) merge_topk_device(parts, splits, nq, 2, top2, s);
+    hipLaunchKernelGGL(screen_theta_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, (const uint64_t*)top2, (const float*)qn, nq, (const unsigned int*)tmax, theta);
+    {
+        KernelTimer timer("l2_screen", s);
+        hipLaunchKernelGGL((l2_screen_kernel<1>), dim3(q_tiles, splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)nt, (const uint16_t*)qb,
+                           (const float*)qn, nq, tiles_per_split, index_base, (uint64_t*)nullptr, (const float*)theta, cand, cap, count);
+    }
+    unsigned long long n_cand = 0;
+    HIP_CHECK(hipMemcpyAsync(&n_cand, count, sizeof(n_cand), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    if (candidates_per_query) *candidates_per_query = (double)n_cand / nq;
+    if (n_cand > cap) return false;   // pathological input (near-duplicate rows everywhere): the exact kernel takes over
+    HIP_CHECK(hipMemsetAsync(out, 0xFF, (size_t)nq * 2 * sizeof(uint64_t), s));
+    if (n_cand) {
+        const unsigned int blocks = (unsigned int)((n_cand + 255) / 256);
+        KernelTimer timer("l2_rerank", s);
+        hipLaunchKernelGGL((screen_rerank_kernel<0>), dim3(blocks), dim3(256), 0, s, (const unsigned long long*)cand, n_cand, q, (const float*)qn, t, (const float*)tn,
+                           index_base, keys, reinterpret_cast<unsigned long long*>(out));
+        hipLaunchKernelGGL((screen_rerank_kernel<1>), dim3(blocks), dim3(256), 0, s, (const unsigned long long*)cand, n_cand, q, (const float*)qn, t, (const float*)tn,
+                           index_base, keys, reinterpret_cast<unsigned long long*>(out));
+    }
+    HIP_CHECK(hipGetLastError());
+    return true;
+}
+
+}  // namespace apds

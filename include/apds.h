@@ -171,6 +171,14 @@ int apds_l2_knn_match(const float* query, int n_query, const float* train, int n
 /* device form: out_keys = n_query*k uint64 (f32 bits of the SQUARED distance << 32 | train_index + index_base), ascending */
 int apds_dev_l2_topk(const void* query, int n_query, const void* train, int64_t n_train, int dim, uint32_t index_base, int k, void* out_keys,
                      void* stream);
+/* The same with a choice of arithmetic. APDS_L2_EXACT: every distance in f32 MFMA (what apds_dev_l2_topk does). APDS_L2_SCREEN: a bf16
+ * MFMA screen (16x the f32 matrix rate) selects, with a proved error bound, every row that can be among the two nearest; those are
+ * re-ranked with exactly the f32 arithmetic of the exact mode, so the returned keys are the exact mode's, bit for bit. The screen is built
+ * for dim == 128, k == 2, 16-byte aligned rows; otherwise (or if the candidate buffer overflows) the exact kernel runs: *mode_used says
+ * which one did; *candidates_per_query = re-ranked rows per query (both may be NULL). */
+enum { APDS_L2_EXACT = 0, APDS_L2_SCREEN = 1 };
+int apds_dev_l2_topk_ex(const void* query, int n_query, const void* train, int64_t n_train, int dim, uint32_t index_base, int k, int mode, void* out_keys,
+                        void* stream, int* mode_used, double* candidates_per_query);
 
 /* GPU-resident keypoint table: the reference's `keypoint` table and its access paths without Postgres.
  * insert: preprocessor/src/main.rs:296-324 (x,y lifted to level-of-detail-0 pixels: v * 2^lod + index * tile * 2^lod).
