@@ -106,7 +106,7 @@ class ShardedMatcher:
     group's internal stream; two communicators driven from two threads could be launched in different orders on different ranks
     and dead-lock). No per-frame allocations."""
 
-    def __init__(self, local_rows64, index_base, group=None, backend=None, pad_rows=32768, meta_group=None, kmax=2):
+    def __init__(self, local_rows64, index_base, group=None, backend=None, pad_rows=32768, meta_group=None, kmax=2, always_exchange=False):
         self.rows = local_rows64
         self.index_base = int(index_base)
         self.group = group
@@ -115,6 +115,7 @@ class ShardedMatcher:
         self.pad_rows = pad_rows          # smallest buffer capacity (rows per rank)
         self.msg_round = 1024             # the query all-gather's row count is the frame's largest count rounded up to this
         self.kmax = kmax
+        self.always_exchange = always_exchange   # run the collectives even with one rank (RCCL self-test on a one-GPU box)
         self._own = None                  # buffers of the plain knn() form
         if group is not None:
             import torch.distributed as dist
@@ -128,7 +129,7 @@ class ShardedMatcher:
         """Every rank's query count for one frame, as host ints, through the host-side group: no device work and no stream
         synchronisation, so the thread that later issues the match keeps queueing kernels ahead of the GPU. Must be called
         once per frame, in frame order, by the same thread on every rank."""
-        if self.world == 1:
+        if self.world == 1 and not self.always_exchange:
             return [int(nq)]
         if self.meta_group is None:
             return None
@@ -189,7 +190,7 @@ class ShardedMatcher:
         query count (exchange_counts); without it the counts are gathered on the device, which costs a host synchronisation.
         Without `out` the result is a view of an internal buffer, valid until the next call."""
         be = self.backend
-        if self.world == 1:
+        if self.world == 1 and not (self.always_exchange and self.dist is not None):
             if out is not None:
                 return be.topk(q_rows64, self.rows, self.index_base, k, out=out[:q_rows64.shape[0]])
             return be.topk(q_rows64, self.rows, self.index_base, k)

@@ -29,21 +29,28 @@ q, src = pkg.synth.make_queries(db, 2000)
 db64 = np.zeros((len(db), 64), np.uint8); db64[:, :61] = db
 q64 = np.zeros((len(q), 64), np.uint8); q64[:, :61] = q
 with torch.cuda.stream(torch.cuda.Stream(dev)):
-    m = pl.ShardedMatcher(torch.from_numpy(db64).to(dev), 0, group=dist.group.WORLD, meta_group=meta)
-    keys_direct = m.knn(torch.from_numpy(q64).to(dev), 2).cpu().numpy().view(np.uint64)
-    # the collective path by hand, world 1
+    rows = torch.from_numpy(db64).to(dev)
     qd = torch.from_numpy(q64).to(dev)
-    g = torch.empty((1, len(q), 64), dtype=torch.uint8, device=dev)
-    pl._gather_into(dist, dist.group.WORLD, g, qd)
-    local = pl.HipBackend().topk(g[0].contiguous(), m.rows, 0, 2)
-    parts = torch.empty((1, len(q), 2), dtype=torch.int64, device=dev)
-    pl._gather_into(dist, dist.group.WORLD, parts, local)
-    merged = pl.HipBackend().merge(parts, 2).cpu().numpy().view(np.uint64)
+    direct = pl.ShardedMatcher(rows, 0).knn(qd, 2).cpu().numpy().view(np.uint64)          # no collectives
+    # the collective path of the multi-GPU matcher on ONE rank: RCCL all_gather_into_tensor of the queries, the scan,
+    # RCCL all_to_all_single of the keys (unequal-split form), the merge; first in one call, then in the split form the pipeline uses
+    m = pl.ShardedMatcher(rows, 0, group=dist.group.WORLD, meta_group=meta, always_exchange=True)
     cnt = m.exchange_counts(len(q))
+    one_call = m.knn(qd, 2, counts=cnt).cpu().numpy().view(np.uint64).copy()
+    bufs = [m.make_buffers(len(q)), m.make_buffers(len(q))]
+    gs = torch.cuda.Stream(dev)
+    with torch.cuda.stream(gs):
+        m.gather_queries(qd, cnt, bufs[0])
+    m.scan_gathered(bufs[0], 2)
+    with torch.cuda.stream(gs):
+        m.gather_queries(torch.flip(qd, dims=(0,)).contiguous(), cnt, bufs[1])      # the next frame's gather goes out before this frame's exchange
+    split_a = m.exchange_merge(bufs[0], 2).cpu().numpy().view(np.uint64).copy()
+    m.scan_gathered(bufs[1], 2)
+    split_b = m.exchange_merge(bufs[1], 2).cpu().numpy().view(np.uint64).copy()
 torch.cuda.synchronize()
-assert np.array_equal(merged, keys_direct) and cnt == [len(q)]
+assert cnt == [len(q)] and np.array_equal(one_call, direct) and np.array_equal(split_a, direct) and np.array_equal(split_b[::-1], direct)
 planted = src >= 0
-assert np.array_equal((merged[planted, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64), src[planted])
+assert np.array_equal((direct[planted, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64), src[planted])
 dist.barrier()
 dist.destroy_process_group()
-print("nccl selftest OK: RCCL world-1 all_gather + kernels on one stream, gloo meta group, barrier")
+print("nccl selftest OK: RCCL world-1 all_gather_into_tensor + all_to_all_single between library kernels (one-call and split forms), gloo meta group, barrier")
