@@ -4,8 +4,10 @@
 // faster, and a top-2 search only needs exact arithmetic for the handful of rows that can still be among the two nearest. So:
 //
 //   pass A  S(q,t) = |q|^2 + |t|^2 - 2 q~.t~ with q~, t~ the operands rounded to bf16, products exact and accumulation in f32
-//           inside v_mfma_f32_16x16x32_bf16; fused running top-2 per query -> s2(q), the second smallest screen value;
-//   pass B  the same products again; every row with S(q,t) <= s2(q) + 2 eps(q) is appended to a candidate list;
+//           inside v_mfma_f32_16x16x32_bf16; fused running top-2 per query -> s2(q), the second smallest screen value. Run over a
+//           SAMPLE of the train rows (the first 1/16, at least 8192): its s2 is an upper bound of the whole set's, which is all the
+//           proof below needs, and it costs 1/16 of a pass;
+//   pass B  the products of ALL rows; every row with S(q,t) <= s2(q) + 2 eps(q) is appended to a candidate list;
 //   pass C  the candidates are re-ranked with EXACTLY the arithmetic of l2_match.hip (the same binary32 fmaf chain over k, the same
 //           |t|^2 - 2 q.t and |q|^2 + . and max(., 0)), keys (distance bits << 32 | row) reduced by 64-bit atomic min.
 //
@@ -14,14 +16,16 @@
 //   the f32 accumulations on either side and the few f32 operations around them add at most 2^-13 (|q|^2 + |t|^2) (K = 128 terms
 //   at 2^-24 relative each is 2^-17 |q| |t|; the slack is generous on purpose). Hence |F - S| <= eps(q) with
 //   eps(q) = 2 (2u + u^2) |q| Tmax + 2^-13 (|q|^2 + Tmax^2),   Tmax = the largest row norm of the train set.
-// Two rows have S <= s2, hence F <= s2 + eps, so the second smallest F is <= s2 + eps; every row of the exact top-2 (ties included)
-// has F <= that, hence S <= s2 + 2 eps: it is a candidate. The re-rank therefore returns the keys l2_match.hip returns, bit for bit
+// Two rows (of the sample, hence of the set) have S <= s2, hence F <= s2 + eps, so the second smallest F over the whole set is
+// <= s2 + eps; every row of the exact top-2 (ties included) has F <= that, hence S <= s2 + 2 eps: it is a candidate. (A looser s2
+// only admits more candidates: a sample of 1/12 of the rows admits ~2 * 12 * 2.5 = 60 per query on BASELINE config 3, ~5 with the
+// exact s2: 25 ms more re-rank against 190 ms less screening.) The re-rank therefore returns the keys l2_match.hip returns, bit for bit
 // (tests/test_l2_match_gpu.py compares the two modes directly).
 //
-// Screen kernel (CDNA4): block = 8 waves = 256 queries x a stream of 128-row train tiles. A wave keeps its 32 queries (two 16-column
-// blocks) as MFMA B operands in registers for the whole kernel (bf16: 32 VGPRs); train tiles are staged in LDS (bf16, pre-scaled by
+// Screen kernel (CDNA4): block = 8 waves = 384 queries x a stream of 128-row train tiles. A wave keeps its 48 queries (three 16-column
+// blocks) as MFMA B operands in registers for the whole kernel (bf16: 48 VGPRs); train tiles are staged in LDS (bf16, pre-scaled by
 // -2, row pitch 272 B so that the 16 rows of a ds_read_b128 group fall in different banks), double buffered, one barrier per tile;
-// each A read feeds two MFMAs. The accumulator starts from |t|^2 of its four rows, so an accumulator IS the ranking value
+// each A read feeds three MFMAs. The accumulator starts from |t|^2 of its four rows, so an accumulator IS the ranking value
 // |t|^2 - 2 q~.t~ and the epilogue is two min and one compare per 16 x 16 block; like in the other matchers a lane owns one query
 // column, so the running top-2 (or the threshold) lives in the lane and insertions / appends are rare.
 #include <cmath>
@@ -34,7 +38,11 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int SC_TM = 128;            // train rows per tile
-static constexpr int SC_Q = 256;             // queries per block
+#ifndef APDS_SC_NC
+#define APDS_SC_NC 3
+#endif
+static constexpr int SC_NC = APDS_SC_NC;     // 16-query column blocks per wave (each A read from LDS feeds SC_NC MFMAs)
+static constexpr int SC_Q = 8 * 16 * SC_NC;  // queries per block (8 waves)
 static constexpr int SC_D = 128;             // descriptor length (the screen is built for it)
 static constexpr int SC_PITCH = 272;         // bytes per staged train row (256 + 16)
 static constexpr uint64_t SC_EMPTY = ~0ull;
@@ -86,8 +94,10 @@ __device__ __forceinline__ void sc_insert(ScTop2& b, float d, uint32_t idx) {
 __device__ __forceinline__ uint64_t sc_key(float d, uint32_t idx) { return idx == 0xFFFFFFFFu ? SC_EMPTY : ((uint64_t)__float_as_uint(d) << 32) | idx; }
 
 // PASS 0: running top-2 of the screen value per query -> out[split][nq][2] keys (d^2 = max(|q|^2 + u, 0) bits << 32 | row).
-// PASS 1: rows with u <= theta[q] are appended to cand (query << 32 | row), counted in *cand_count (entries past cand_cap are dropped;
-//         the host checks the count).
+// PASS 1: rows with u <= theta[q] are appended to the block's own region of cand (query << 32 | row; region = cand_cap entries per
+//         block, position from an LDS counter: one global counter for all blocks serialised at ~12 ns per append, 0.65 s for the
+//         54 M candidates of config 3); the block's count goes to cand_count[block] (entries past the region are dropped and show
+//         in the count: the host checks it).
 template <int PASS>
 __global__ __launch_bounds__(512) void l2_screen_kernel(const uint16_t* __restrict__ train_bf, const float* __restrict__ tnorm, int n_train,
                                                         const uint16_t* __restrict__ query_bf, const float* __restrict__ qnorm, int nq, int tiles_per_split,
@@ -95,30 +105,38 @@ __global__ __launch_bounds__(512) void l2_screen_kernel(const uint16_t* __restri
                                                         unsigned long long* __restrict__ cand, unsigned long long cand_cap,
                                                         unsigned long long* __restrict__ cand_count) {
     APDS_RAISE_WAVE_PRIORITY();
-    extern __shared__ unsigned char sc_lds[];
+    // 16-byte aligned: the static LDS word below would otherwise push this array to offset 4 and turn every ds_read_b128 /
+    // ds_write_b128 of the tiles into misaligned accesses (measured: 209 -> 1185 ms per pass)
+    extern __shared__ __attribute__((aligned(128))) unsigned char sc_lds[];
     auto tile_lds = [&](int buf) { return sc_lds + buf * (SC_TM * SC_PITCH); };
     auto norm_lds = [&](int buf) { return reinterpret_cast<float*>(sc_lds + 2 * SC_TM * SC_PITCH) + buf * SC_TM; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * SC_Q + wave * 32;                 // this wave's 32 queries
+    const int q0 = blockIdx.x * SC_Q + wave * 16 * SC_NC;         // this wave's queries
     const int n_tiles = (n_train + SC_TM - 1) / SC_TM;
     const int tile_begin = blockIdx.y * tiles_per_split, tile_end = min(n_tiles, tile_begin + tiles_per_split);
-    if (tile_begin >= tile_end) return;
+    const int block_id = blockIdx.y * gridDim.x + blockIdx.x;
+    __shared__ unsigned int s_cand_n;
+    if (PASS == 1 && tid == 0) s_cand_n = 0;
+    if (tile_begin >= tile_end) {
+        if (PASS == 1 && tid == 0) cand_count[block_id] = 0;
+        return;
+    }
     const int col = lane & 15, kq = lane >> 4;                     // accumulator column / k chunk (operands) / row group (accumulators)
 
     // B operands: query (q0 + 16 c + col), k = 32 s + 8 kq .. + 7, for c = 0, 1 and the four k steps s
-    bf16x8 B[2][4];
-    float qq[2], th[2];
+    bf16x8 B[SC_NC][4];
+    float qq[SC_NC], th[SC_NC];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
+    for (int c = 0; c < SC_NC; c++) {
         const int qi = min(q0 + 16 * c + col, nq - 1);
 #pragma unroll
         for (int s = 0; s < 4; s++) B[c][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(query_bf + (size_t)qi * SC_D + 32 * s + 8 * kq));
         qq[c] = qnorm[qi];
         th[c] = PASS == 1 ? theta[qi] : 0.f;
     }
-    ScTop2 best[2];
+    ScTop2 best[SC_NC];
 #pragma unroll
-    for (int c = 0; c < 2; c++) {
+    for (int c = 0; c < SC_NC; c++) {
         best[c].d0 = best[c].d1 = INFINITY;
         best[c].i0 = best[c].i1 = 0xFFFFFFFFu;
     }
@@ -160,37 +178,40 @@ __global__ __launch_bounds__(512) void l2_screen_kernel(const uint16_t* __restri
 #pragma unroll 2
         for (int rb = 0; rb < 8; rb++) {                           // 16-row blocks of the tile
             const f32x4 init = *reinterpret_cast<const f32x4*>(Nn + rb * 16 + 4 * kq);   // |t|^2 of this lane's four rows
-            f32x4 acc0 = init, acc1 = init;
+            f32x4 acc[SC_NC];
+#pragma unroll
+            for (int c = 0; c < SC_NC; c++) acc[c] = init;
             const unsigned char* arow = T + (rb * 16 + col) * SC_PITCH + 16 * kq;
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow + 64 * s));
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B[0][s], acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B[1][s], acc1, 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < SC_NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B[c][s], acc[c], 0, 0, 0);
             }
-            // epilogue: acc = |t|^2 - 2 q~.t~ for rows 4 kq + j of the block, query column `col` of each of the two query blocks
-            const float m0 = fminf(fminf(acc0[0], acc0[1]), fminf(acc0[2], acc0[3]));
-            const float m1 = fminf(fminf(acc1[0], acc1[1]), fminf(acc1[2], acc1[3]));
+            // epilogue: acc = |t|^2 - 2 q~.t~ for rows 4 kq + j of the block, query column `col` of each of the wave's query blocks
+            float mn[SC_NC];
+            bool any_hit = false;
+#pragma unroll
+            for (int c = 0; c < SC_NC; c++) {
+                mn[c] = fminf(fminf(acc[c][0], acc[c][1]), fminf(acc[c][2], acc[c][3]));
+                any_hit |= PASS == 0 ? mn[c] < best[c].d1 : mn[c] <= th[c];
+            }
             const uint32_t row0 = (uint32_t)(tile * SC_TM + rb * 16 + 4 * kq);
-            if (PASS == 0) {
-                if (__any(m0 < best[0].d1 || m1 < best[1].d1)) {
+            if (__any(any_hit)) {
+                if (PASS == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        sc_insert(best[0], acc0[j], row0 + j + index_base);
-                        sc_insert(best[1], acc1[j], row0 + j + index_base);
-                    }
-                }
-            } else {
-                if (__any(m0 <= th[0] || m1 <= th[1])) {
+                    for (int c = 0; c < SC_NC; c++)
 #pragma unroll
-                    for (int c = 0; c < 2; c++) {
-                        const f32x4 a = c ? acc1 : acc0;
+                        for (int j = 0; j < 4; j++) sc_insert(best[c], acc[c][j], row0 + j + index_base);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < SC_NC; c++) {
                         const int qi = q0 + 16 * c + col;
 #pragma unroll
                         for (int j = 0; j < 4; j++)
-                            if (a[j] <= th[c] && qi < nq && (int)(row0 + j) < n_train) {
-                                const unsigned long long pos = atomicAdd(cand_count, 1ull);
-                                if (pos < cand_cap) cand[pos] = ((unsigned long long)(uint32_t)qi << 32) | (row0 + j + index_base);
+                            if (acc[c][j] <= th[c] && qi < nq && (int)(row0 + j) < n_train) {
+                                const unsigned int pos = atomicAdd(&s_cand_n, 1u);
+                                if (pos < cand_cap) cand[(size_t)block_id * cand_cap + pos] = ((unsigned long long)(uint32_t)qi << 32) | (row0 + j + index_base);
                             }
                     }
                 }
@@ -199,10 +220,11 @@ __global__ __launch_bounds__(512) void l2_screen_kernel(const uint16_t* __restri
         if (more) commit(buf ^ 1);
         __syncthreads();   // the next tile is staged; everybody is done with this one
     }
+    if (PASS == 1 && tid == 0) cand_count[block_id] = s_cand_n;   // (after the loop's closing barrier: every append has happened)
     if (PASS == 0) {
         // a query column lives in four lanes (kq = 0..3, different rows): fold them with shuffles, lanes 0..15 write
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < SC_NC; c++) {
             ScTop2 b = best[c];
 #pragma unroll
             for (int off = 16; off < 64; off <<= 1) {
@@ -257,13 +279,15 @@ __global__ void screen_theta_kernel(const uint64_t* __restrict__ top2, const flo
 
 // exact keys of the candidates: the binary32 arithmetic of l2_topk_kernel (fmaf chain over k ascending from 0, u = fmaf(-2, dot, |t|^2),
 // d^2 = max(|q|^2 + u, 0)); STEP 0: atomic min into best[q]; STEP 1: atomic min into second[q] of the keys != best[q]
+// grid.y = the screen kernel's blocks (one candidate region each), grid.x strides over the region's entries
 template <int STEP>
-__global__ void screen_rerank_kernel(const unsigned long long* __restrict__ cand, unsigned long long n_cand, const float* __restrict__ q,
-                                     const float* __restrict__ qnorm, const float* __restrict__ t, const float* __restrict__ tnorm, uint32_t index_base,
-                                     unsigned long long* __restrict__ keys, unsigned long long* __restrict__ out) {
+__global__ void screen_rerank_kernel(const unsigned long long* __restrict__ cand, const unsigned long long* __restrict__ counts, unsigned long long region,
+                                     const float* __restrict__ q, const float* __restrict__ qnorm, const float* __restrict__ t, const float* __restrict__ tnorm,
+                                     uint32_t index_base, unsigned long long* __restrict__ keys, unsigned long long* __restrict__ out) {
     APDS_RAISE_WAVE_PRIORITY();
-    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cand) return;
+    const unsigned long long n = min(counts[blockIdx.y], region);
+    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * blockDim.x) {
+    const unsigned long long i = (unsigned long long)blockIdx.y * region + e;
     const unsigned long long c = cand[i];
     const uint32_t qi = (uint32_t)(c >> 32), row = (uint32_t)c;
     unsigned long long key;
@@ -288,6 +312,7 @@ __global__ void screen_rerank_kernel(const unsigned long long* __restrict__ cand
         key = keys[i];
         if (key != out[(size_t)qi * 2]) atomicMin(&out[(size_t)qi * 2 + 1], key);
     }
+    }
 }
 
 // returns false if the screen could not be used (shape, alignment, candidate overflow): the caller falls back to the f32 kernel
@@ -301,7 +326,6 @@ bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt,
     uint16_t* qb = c.alloc_n<uint16_t>((size_t)nq * SC_D);
     uint16_t* tb = c.alloc_n<uint16_t>((size_t)nt * SC_D);
     unsigned int* tmax = c.alloc_n<unsigned int>(4);
-    unsigned long long* count = reinterpret_cast<unsigned long long*>(tmax + 2);
     HIP_CHECK(hipMemsetAsync(tmax, 0, 16, s));
     l2_row_norms_device(q, nq, dim, qn, s);
     l2_row_norms_device(t, nt, dim, tn, s);
@@ -312,41 +336,59 @@ bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt,
     int splits = std::max(1, std::min(t_tiles, ceil_div(256 * 2, q_tiles)));
     const int tiles_per_split = ceil_div(t_tiles, splits);
     splits = ceil_div(t_tiles, tiles_per_split);
-    uint64_t* parts = c.alloc_n<uint64_t>((size_t)splits * nq * 2);
-    uint64_t* top2 = splits == 1 ? parts : c.alloc_n<uint64_t>((size_t)nq * 2);
+    // pass A runs over a sample of the rows: the first n_sample (whole tiles)
+    // (a threshold taken from a fraction f of the rows admits ~2 / f rows of the whole set, times ~2.5 for the 2 eps margin: pass A
+    // costs f of a pass, the re-rank ~0.36 ms per candidate per query at config 3 => the sum is flat around f = 1/8 .. 1/16)
+    static const int sample_div = getenv("APDS_L2_SAMPLE_DIV") ? std::max(1, atoi(getenv("APDS_L2_SAMPLE_DIV"))) : 12;
+    const long long n_sample = std::min<long long>(nt, std::max<long long>(8192, (nt / sample_div + SC_TM - 1) / SC_TM * SC_TM));
+    const int s_tiles = ceil_div(n_sample, SC_TM);
+    int s_splits = std::max(1, std::min(s_tiles, ceil_div(256 * 2, q_tiles)));
+    const int s_tiles_per_split = ceil_div(s_tiles, s_splits);
+    s_splits = ceil_div(s_tiles, s_tiles_per_split);
+    uint64_t* parts = c.alloc_n<uint64_t>((size_t)s_splits * nq * 2);
+    uint64_t* top2 = s_splits == 1 ? parts : c.alloc_n<uint64_t>((size_t)nq * 2);
     float* theta = c.alloc_n<float>(nq);
-    const unsigned long long cap = std::max<unsigned long long>(1ull << 20, (unsigned long long)nq * 48);
-    unsigned long long* cand = c.alloc_n<unsigned long long>(cap);
-    unsigned long long* keys = c.alloc_n<unsigned long long>(cap);
+    // candidate regions: one per block of pass B, `region` entries each (256 queries x 256 candidates: 4x what config 3 needs)
+    const int n_blocks = q_tiles * splits;
+    const unsigned long long region = (unsigned long long)SC_Q * 192;
+    if ((unsigned long long)n_blocks * region > (1ull << 29)) return false;
+    unsigned long long* cand = c.alloc_n<unsigned long long>((size_t)n_blocks * region);
+    unsigned long long* keys = c.alloc_n<unsigned long long>((size_t)n_blocks * region);
+    unsigned long long* counts = c.alloc_n<unsigned long long>(n_blocks);
     const size_t lds = (size_t)2 * SC_TM * SC_PITCH + 2 * SC_TM * sizeof(float);
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         KernelTimer timer("l2_screen", s);
-        hipLaunchKernelGGL((l2_screen_kernel<0>), dim3(q_tiles, splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)nt, (const uint16_t*)qb,
-                           (const float*)qn, nq, tiles_per_split, index_base, parts, (const float*)nullptr, (unsigned long long*)nullptr, 0ull,
+        hipLaunchKernelGGL((l2_screen_kernel<0>), dim3(q_tiles, s_splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)n_sample,
+                           (const uint16_t*)qb, (const float*)qn, nq, s_tiles_per_split, index_base, parts, (const float*)nullptr, (unsigned long long*)nullptr, 0ull,
                            (unsigned long long*)nullptr);
     }
-    if (splits > 1) merge_topk_device(parts, splits, nq, 2, top2, s);
+    if (s_splits > 1) merge_topk_device(parts, s_splits, nq, 2, top2, s);
     hipLaunchKernelGGL(screen_theta_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, (const uint64_t*)top2, (const float*)qn, nq, (const unsigned int*)tmax, theta);
     {
         KernelTimer timer("l2_screen", s);
         hipLaunchKernelGGL((l2_screen_kernel<1>), dim3(q_tiles, splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)nt, (const uint16_t*)qb,
-                           (const float*)qn, nq, tiles_per_split, index_base, (uint64_t*)nullptr, (const float*)theta, cand, cap, count);
+                           (const float*)qn, nq, tiles_per_split, index_base, (uint64_t*)nullptr, (const float*)theta, cand, region, counts);
     }
-    unsigned long long n_cand = 0;
-    HIP_CHECK(hipMemcpyAsync(&n_cand, count, sizeof(n_cand), hipMemcpyDeviceToHost, s));
+    std::vector<unsigned long long> hc(n_blocks);
+    HIP_CHECK(hipMemcpyAsync(hc.data(), counts, (size_t)n_blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    unsigned long long n_cand = 0, largest = 0;
+    for (unsigned long long v : hc) {
+        n_cand += v;
+        largest = std::max(largest, v);
+    }
     if (candidates_per_query) *candidates_per_query = (double)n_cand / nq;
-    if (n_cand > cap) return false;   // pathological input (near-duplicate rows everywhere): the exact kernel takes over
+    if (largest > region) return false;   // pathological input (near-duplicate rows everywhere): the exact kernel takes over
     HIP_CHECK(hipMemsetAsync(out, 0xFF, (size_t)nq * 2 * sizeof(uint64_t), s));
     if (n_cand) {
-        const unsigned int blocks = (unsigned int)((n_cand + 255) / 256);
+        const dim3 grid((unsigned int)std::max<unsigned long long>(1, std::min<unsigned long long>(64, (largest + 255) / 256)), n_blocks);
         KernelTimer timer("l2_rerank", s);
-        hipLaunchKernelGGL((screen_rerank_kernel<0>), dim3(blocks), dim3(256), 0, s, (const unsigned long long*)cand, n_cand, q, (const float*)qn, t, (const float*)tn,
-                           index_base, keys, reinterpret_cast<unsigned long long*>(out));
-        hipLaunchKernelGGL((screen_rerank_kernel<1>), dim3(blocks), dim3(256), 0, s, (const unsigned long long*)cand, n_cand, q, (const float*)qn, t, (const float*)tn,
-                           index_base, keys, reinterpret_cast<unsigned long long*>(out));
+        hipLaunchKernelGGL((screen_rerank_kernel<0>), grid, dim3(256), 0, s, (const unsigned long long*)cand, (const unsigned long long*)counts, region, q,
+                           (const float*)qn, t, (const float*)tn, index_base, keys, reinterpret_cast<unsigned long long*>(out));
+        hipLaunchKernelGGL((screen_rerank_kernel<1>), grid, dim3(256), 0, s, (const unsigned long long*)cand, (const unsigned long long*)counts, region, q,
+                           (const float*)qn, t, (const float*)tn, index_base, keys, reinterpret_cast<unsigned long long*>(out));
     }
     HIP_CHECK(hipGetLastError());
     return true;
