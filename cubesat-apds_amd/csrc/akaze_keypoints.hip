@@ -10,6 +10,7 @@
 // exactly by dependency rounds: a keypoint is processed in the first round in which no EARLIER (row-major)
 // keypoint of its own level with an overlapping search window is still pending. All levels run in the same
 // rounds because the passes of one phase only read snapshots of the level they iterate over.
+#include <atomic>
 #include <cstdlib>
 
 #include "akaze.h"
@@ -961,6 +962,24 @@ AkazeDebugRequest& akaze_debug_request() {
     return r;
 }
 
+// Zero the first `bytes` (a multiple of 16) of every image's slab: one launch for the batch. (hipMemset2DAsync / hipMemcpy2DAsync take a
+// slow, serialising path in the runtime: with them N host threads extracting concurrently stopped scaling, 2200 -> 880 tiles/s.)
+__global__ void zero_slab_heads_kernel(uint4* __restrict__ base, size_t bytes, size_t bstride) {
+    APDS_RAISE_WAVE_PRIORITY();
+    uint4* p = reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + (size_t)blockIdx.z * bstride);
+    const size_t n = bytes / 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
+}
+
+// out[b * n + i] = src_b[i] for the first n ints at `src` of every image's slab
+__global__ void gather_slab_ints_kernel(const int* __restrict__ src, int n, size_t bstride, int batch, int* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * batch) return;
+    const int b = i / n, k = i - b * n;
+    out[i] = reinterpret_cast<const int*>(reinterpret_cast<const char*>(src) + (size_t)b * bstride)[k];
+}
+
 // Bump layout of one image's workspace slab: run once with base == nullptr to size it, once more with the real base. Every plane
 // starts on a 256-byte boundary.
 namespace {
@@ -1024,7 +1043,13 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     }
     const int L = (int)ev.size();
     const int n_oct = ev.back().octave + 1;
-    static const bool fork_doh = !(getenv("APDS_AKAZE_FORK") && atoi(getenv("APDS_AKAZE_FORK")) == 0);
+    // The Hessian kernels on a side stream shorten a LONE caller's extraction (4096^2: 2.19 -> 2.08 ms, 512^2: 0.48 -> 0.45), but
+    // when several host threads extract at once (the reference's rayon pool, main.rs:233-243) extra streams make the threads'
+    // streams share the few hardware queues and the threads serialise each other — even an idle side stream shifts the mapping:
+    // 4 threads reach 2400 tiles/s of 1024^2 when no thread ever forked, 1240 - 1320 when some did. So a thread forks only while it
+    // is the ONLY host thread holding a library context (apds_thread_release drops one); APDS_AKAZE_FORK = 0 never, 2 always.
+    static const int fork_env = getenv("APDS_AKAZE_FORK") ? atoi(getenv("APDS_AKAZE_FORK")) : 1;
+    const bool fork_doh = fork_env == 2 || (fork_env == 1 && live_contexts().load() <= 1);
 
     // ---- one image's workspace slab (all images of the batch: the same layout, `slab` bytes apart)
     const size_t n0 = (size_t)W * H;
@@ -1080,7 +1105,11 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     bt.n = B;
     bt.stride = slab;
     bt.img_stride = img_bstride;
-    HIP_CHECK(hipMemset2DAsync(real.base, slab, 0, zero_bytes, (size_t)B, s));
+    if (B == 1) HIP_CHECK(hipMemsetAsync(real.base, 0, zero_bytes, s));
+    else
+        hipLaunchKernelGGL(zero_slab_heads_kernel, dim3((unsigned)std::min<size_t>(1024, (zero_bytes / 16 + 255) / 256), 1, B), dim3(256), 0, s,
+                           reinterpret_cast<uint4*>(real.base), zero_bytes, slab);
+    int* counts_dev = B > 1 ? c.alloc_n<int>(B) : nullptr;
 
     // ---- a1.1 / a1.2 / a1.3
     const GaussTaps g16 = gauss_taps(9, (double)soffset), g10 = gauss_taps(5, 1.0);
@@ -1261,8 +1290,10 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
                 k += g;
                 in = out;
             }
-            if (e.nsteps == 0 && P != e.Lt)
-                HIP_CHECK(hipMemcpy2DAsync(e.Lt, slab, P, slab, (size_t)e.w * e.h * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
+            if (e.nsteps == 0 && P != e.Lt)   // (never with AKAZE's parameters: every level but the first has FED steps)
+                for (int bi = 0; bi < B; bi++)
+                    HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(e.Lt) + (size_t)bi * slab, reinterpret_cast<const char*>(P) + (size_t)bi * slab,
+                                             (size_t)e.w * e.h * 4, hipMemcpyDeviceToDevice, s));
         }
         float kside, kmid;
         deriv_weights(e.sigma_size, kside, kmid);
@@ -1323,7 +1354,12 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
 
     // ---- the only read-back of the call: every image's keypoint count
     std::vector<int> K(B, 0);
-    HIP_CHECK(hipMemcpy2DAsync(K.data(), sizeof(int), kp_base + n_stage, slab, sizeof(int), (size_t)B, hipMemcpyDeviceToHost, s));
+    if (B == 1) {
+        HIP_CHECK(hipMemcpyAsync(K.data(), kp_base + n_stage, sizeof(int), hipMemcpyDeviceToHost, s));
+    } else {
+        hipLaunchKernelGGL(gather_slab_ints_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, (const int*)(kp_base + n_stage), 1, slab, B, counts_dev);
+        HIP_CHECK(hipMemcpyAsync(K.data(), counts_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+    }
     HIP_CHECK(hipStreamSynchronize(s));
     int kmax = 0;
     bool over = false;

@@ -110,6 +110,77 @@ int apds_akaze_debug_plane(const uint8_t* img, int rows, int cols, int channels,
     return rc;
 }
 
+// device results of a batch (capacity rows per image) -> malloc'ed host arrays holding the images' rows back to back
+static void batch_results_to_host(ThreadCtx& c, hipStream_t s, const apds_keypoint* dk, const uint8_t* dd, int capacity, int n_images, const int* counts,
+                                  apds_keypoint** kps, uint8_t** desc) {
+    size_t total = 0;
+    for (int i = 0; i < n_images; i++) total += (size_t)counts[i];
+    apds_keypoint* hk = static_cast<apds_keypoint*>(std::malloc(std::max<size_t>(1, total * sizeof(apds_keypoint))));
+    uint8_t* hd = static_cast<uint8_t*>(std::malloc(std::max<size_t>(1, total * APDS_DESC_BYTES)));
+    if (!hk || !hd) {
+        std::free(hk);
+        std::free(hd);
+        throw std::bad_alloc();
+    }
+    try {
+        uint8_t* d61 = c.alloc_n<uint8_t>(std::max<size_t>(1, total * APDS_DESC_BYTES));
+        size_t off = 0;
+        for (int i = 0; i < n_images; i++) {
+            const int K = counts[i];
+            if (!K) continue;
+            pack_desc61_device(dd + (size_t)i * capacity * 64, K, d61 + off * APDS_DESC_BYTES, s);
+            HIP_CHECK(hipMemcpyAsync(hk + off, dk + (size_t)i * capacity, (size_t)K * sizeof(apds_keypoint), hipMemcpyDeviceToHost, s));
+            off += (size_t)K;
+        }
+        if (total) HIP_CHECK(hipMemcpyAsync(hd, d61, total * APDS_DESC_BYTES, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    } catch (...) {
+        std::free(hk);
+        std::free(hd);
+        throw;
+    }
+    *kps = hk;
+    *desc = hd;
+}
+
+// B tiles of the preprocessor in one call (preprocessor/src/main.rs:227-245 spawns one task per tile; 258-277 is the per-tile chain): the
+// band windows of all tiles go up (3 B strided copies), ONE band_merger pass writes the B BGRA images and the batched extraction runs
+// every kernel once for all of them. red / green / blue: n_tiles pointers each (windows of one size, row_stride elements between rows).
+int apds_tile_extract_batch(const float* const* red, const float* const* green, const float* const* blue, int n_tiles, int rows, int cols, size_t row_stride,
+                            const double* minmax6, int max_points, apds_keypoint** kps, uint8_t** desc, int* counts, int* desc_bytes) {
+    return guarded([&] {
+        APDS_REQUIRE(kps && desc && counts && desc_bytes, APDS_ERR_BAD_ARG, "null output");
+        *kps = nullptr;
+        *desc = nullptr;
+        *desc_bytes = APDS_DESC_BYTES;
+        APDS_REQUIRE(red && green && blue && minmax6, APDS_ERR_BAD_ARG, "null argument");
+        APDS_REQUIRE(n_tiles >= 1 && n_tiles <= 4096, APDS_ERR_BAD_ARG, "batch must hold 1 .. 4096 tiles");
+        APDS_REQUIRE(rows > 0 && cols > 0, APDS_ERR_ASSERT, "empty tile");
+        APDS_REQUIRE(row_stride >= (size_t)cols, APDS_ERR_ASSERT, "row stride smaller than a row");
+        if (max_points <= 0) max_points = APDS_MAX_POINTS;
+        for (int i = 0; i < n_tiles; i++) counts[i] = 0;
+        ThreadCtx& c = ctx();
+        c.ws_reset();
+        hipStream_t s = c.stream;
+        const size_t px = (size_t)rows * cols, all = px * n_tiles;
+        float* bands = c.alloc_n<float>(3 * all);   // band-major: all tiles' red, then green, then blue
+        const float* const* src[3] = {red, green, blue};
+        for (int b = 0; b < 3; b++)
+            for (int i = 0; i < n_tiles; i++) {
+                APDS_REQUIRE(src[b][i] != nullptr, APDS_ERR_BAD_ARG, "null band window");
+                HIP_CHECK(hipMemcpy2DAsync(bands + b * all + i * px, (size_t)cols * 4, src[b][i], row_stride * 4, (size_t)cols * 4, rows, hipMemcpyHostToDevice, s));
+            }
+        uint8_t* dimg = c.alloc_n<uint8_t>(all * 4);
+        band_merger_device(bands, bands + all, bands + 2 * all, all, minmax6, /*bgra=*/1, dimg, s);
+        const long long bound = (long long)((cols + 1) / 2) * ((rows + 1) / 2) * 2;
+        const int capacity = (int)std::min<long long>(max_points, std::max<long long>(bound, 64));
+        apds_keypoint* dk = c.alloc_n<apds_keypoint>((size_t)capacity * n_tiles);
+        uint8_t* dd = c.alloc_n<uint8_t>((size_t)capacity * 64 * n_tiles);
+        akaze_extract_batch_device(dimg, n_tiles, px * 4, rows, cols, 4, (size_t)cols * 4, max_points, dk, dd, capacity, counts, s);
+        batch_results_to_host(c, s, dk, dd, capacity, n_tiles, counts, kps, desc);
+    });
+}
+
 // n_images equal-sized host images in one call: one upload, one batched extraction (every kernel's grid covers all images), one download.
 // Outputs: concatenated keypoints / 61-byte descriptors (image 0's rows first), counts[i] rows per image.
 int apds_akaze_extract_batch(const uint8_t* imgs, int n_images, size_t image_stride, int rows, int cols, int channels, size_t stride, int max_points,
@@ -143,34 +214,7 @@ int apds_akaze_extract_batch(const uint8_t* imgs, int n_images, size_t image_str
         apds_keypoint* dk = c.alloc_n<apds_keypoint>((size_t)capacity * n_images);
         uint8_t* dd = c.alloc_n<uint8_t>((size_t)capacity * 64 * n_images);
         akaze_extract_batch_device(dimg, n_images, dimg_bytes, rows, cols, channels, dstride, max_points, dk, dd, capacity, counts, s);
-        size_t total = 0;
-        for (int i = 0; i < n_images; i++) total += (size_t)counts[i];
-        apds_keypoint* hk = static_cast<apds_keypoint*>(std::malloc(std::max<size_t>(1, total * sizeof(apds_keypoint))));
-        uint8_t* hd = static_cast<uint8_t*>(std::malloc(std::max<size_t>(1, total * APDS_DESC_BYTES)));
-        if (!hk || !hd) {
-            std::free(hk);
-            std::free(hd);
-            throw std::bad_alloc();
-        }
-        try {
-            uint8_t* d61 = c.alloc_n<uint8_t>(std::max<size_t>(1, total * APDS_DESC_BYTES));
-            size_t off = 0;
-            for (int i = 0; i < n_images; i++) {
-                const int K = counts[i];
-                if (!K) continue;
-                pack_desc61_device(dd + (size_t)i * capacity * 64, K, d61 + off * APDS_DESC_BYTES, s);
-                HIP_CHECK(hipMemcpyAsync(hk + off, dk + (size_t)i * capacity, (size_t)K * sizeof(apds_keypoint), hipMemcpyDeviceToHost, s));
-                off += (size_t)K;
-            }
-            if (total) HIP_CHECK(hipMemcpyAsync(hd, d61, total * APDS_DESC_BYTES, hipMemcpyDeviceToHost, s));
-            HIP_CHECK(hipStreamSynchronize(s));
-        } catch (...) {
-            std::free(hk);
-            std::free(hd);
-            throw;
-        }
-        *kps = hk;
-        *desc = hd;
+        batch_results_to_host(c, s, dk, dd, capacity, n_images, counts, kps, desc);
     });
 }
 

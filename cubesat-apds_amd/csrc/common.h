@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -80,6 +81,7 @@ struct ThreadCtx {
     T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
 };
 ThreadCtx& ctx();
+std::atomic<int>& live_contexts();   // host threads that currently own a stream + workspace
 
 inline hipStream_t pick_stream(void* s) { return s ? static_cast<hipStream_t>(s) : ctx().stream; }
 

@@ -117,6 +117,38 @@ def tile_keypoint_descriptor_extraction(red, green, blue, min_max, max_points=No
     return ExtractedKeyPoint(k, d)
 
 
+def tiles_keypoint_descriptor_extraction(windows, min_max, max_points=None):
+    """A batch of preprocessor tiles in ONE library call: `windows` = list of [3, h, w] float32 band windows of one size (strided views
+    into the mosaic are taken as they are). Returns a list of ExtractedKeyPoint, each exactly what tile_keypoint_descriptor_extraction
+    returns for that tile."""
+    wins = [np.asarray(w) for w in windows]
+    if not wins:
+        return []
+    _, h, w = wins[0].shape
+    stride = wins[0].strides[1]
+    ok = all(x.dtype == np.float32 and x.ndim == 3 and x.shape == (3, h, w) and x.strides[2] == 4 and x.strides[1] == stride and stride % 4 == 0 for x in wins)
+    if not ok:
+        wins = [np.ascontiguousarray(x, np.float32) for x in wins]
+        if any(x.shape != (3, h, w) for x in wins):
+            raise ApdsError(_lib.ERR_ASSERT, "tile windows must all be [3, h, w] float32 of one size")
+        stride = w * 4
+    b = len(wins)
+    ptrs = [(C.c_void_p * b)(*[x[band].ctypes.data for x in wins]) for band in range(3)]
+    mm = min_max.as_array()
+    kps, desc = C.c_void_p(), C.c_void_p()
+    counts, nb = (C.c_int * b)(), C.c_int(0)
+    check(lib().apds_tile_extract_batch(ptrs[0], ptrs[1], ptrs[2], b, h, w, stride // 4, ptr(mm), MAX_POINTS if max_points is None else int(max_points),
+                                        C.byref(kps), C.byref(desc), counts, C.byref(nb)))
+    total = sum(counts)
+    k = take(kps, total, KEYPOINT_DTYPE)
+    d = take(desc, total * nb.value, np.uint8).reshape(total, nb.value)
+    out, off = [], 0
+    for c in counts:
+        out.append(ExtractedKeyPoint(k[off:off + c].copy(), d[off:off + c].copy()))
+        off += c
+    return out
+
+
 def _desc(a):
     a = np.ascontiguousarray(a, np.uint8)
     if a.ndim != 2:

@@ -54,16 +54,27 @@ def feature_extraction_to_database(table, images, dataset, tile_size, column, ro
     return store_tile(table, images, extract_tile(dataset, tile_size, column, row, lod, fused), tile_size, column, row, lod)
 
 
-def downscale_from_lod(table, images, dataset, amount_lod, lod, workers=1, fused=True):
+def downscale_from_lod(table, images, dataset, amount_lod, lod, workers=1, fused=True, batch=1):
     """main.rs:197-246 — every tile of one level. The reference spawns the tiles on a rayon pool (main.rs:233-243) and image ids
-    follow whatever order the inserts reach Postgres in; here `workers` threads extract tiles concurrently (small tiles are
-    launch-latency-bound on the GPU: concurrent streams fill it) and the rows are stored in row-major tile order, so ids and
-    table contents do not depend on `workers`."""
+    follow whatever order the inserts reach Postgres in; here the rows are stored in row-major tile order, so ids and table contents
+    depend neither on `workers` nor on `batch`. Small tiles are launch-latency-bound on the GPU, so either `batch` tiles go through
+    ONE library call (apds_tile_extract_batch: every kernel's grid covers all of them; the preferred form, one host thread) or
+    `workers` threads extract tiles concurrently on their own streams."""
     tile_size, columns, rows = tile_grid(dataset.raster_size(), amount_lod, lod)
     cells = [(j, i) for i in range(rows) for j in range(columns)]
+    if batch > 1:
+        span = (tile_size[0] * 2 ** lod, tile_size[1] * 2 ** lod)
+        out = []
+        for k in range(0, len(cells), batch):
+            group = cells[k:k + batch]
+            wins = [dataset.window((j * span[0], i * span[1]), span, tile_size) for j, i in group]
+            extracted = feature_extraction.tiles_keypoint_descriptor_extraction(wins, dataset.datasets_min_max(), None)
+            for (j, i), kp in zip(group, extracted):
+                out.append(store_tile(table, images, kp, tile_size, j, i, lod))
+        return out
     if workers <= 1:
         return [feature_extraction_to_database(table, images, dataset, tile_size, j, i, lod, fused) for j, i in cells]
-    from concurrent.futures import ThreadPoolExecutor
+    from concurrent.futures import ThreadPoolExecutor, wait
     import threading
     from ._lib import lib
 
@@ -75,27 +86,36 @@ def downscale_from_lod(table, images, dataset, amount_lod, lod, workers=1, fused
     barrier = threading.Barrier(workers)
 
     def release():
-        barrier.wait(timeout=60)
+        barrier.wait()
         lib().apds_thread_release()
 
-    out = []
+    out, pending = [], []
     with ThreadPoolExecutor(max_workers=workers) as pool:
         try:
             # bounded look-ahead: at most 2 x workers extracted tiles wait for their turn to be stored
-            pending, it = [], iter(cells)
-            for cell in it:
+            for cell in cells:
                 pending.append((cell, pool.submit(work, cell)))
                 if len(pending) >= 2 * workers:
                     (j, i), fut = pending.pop(0)
                     out.append(store_tile(table, images, fut.result(), tile_size, j, i, lod))
-            for (j, i), fut in pending:
+            while pending:
+                (j, i), fut = pending.pop(0)
                 out.append(store_tile(table, images, fut.result(), tile_size, j, i, lod))
         finally:
+            # on an error above tiles may still be running: drain them first (cancel what has not started), so that every pool thread
+            # is free to take its release task and the barrier cannot be left waiting; a failing release never replaces the
+            # exception that brought us here
+            for _, fut in pending:
+                fut.cancel()
+            wait([fut for _, fut in pending])
             for f in [pool.submit(release) for _ in range(workers)]:
-                f.result()
+                try:
+                    f.result()
+                except Exception:   # noqa: BLE001
+                    pass
     return out
 
 
-def process_lod_from_mosaic(table, images, dataset, lod, workers=1, fused=True):
+def process_lod_from_mosaic(table, images, dataset, lod, workers=1, fused=True, batch=1):
     """main.rs:175-194 — all levels 0 .. lod-1."""
-    return [downscale_from_lod(table, images, dataset, lod, i, workers, fused) for i in range(lod)]
+    return [downscale_from_lod(table, images, dataset, lod, i, workers, fused, batch) for i in range(lod)]

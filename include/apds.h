@@ -134,6 +134,11 @@ int apds_dev_band_merger(const void* red, const void* green, const void* blue, s
  * `row_stride` elements between rows (they may point into the mosaic); the RGBA / BGRA image exists on the device only. Outputs as apds_akaze_extract. */
 int apds_tile_extract(const float* red, const float* green, const float* blue, int rows, int cols, size_t row_stride, const double* minmax6,
                       int max_points, apds_keypoint** kps, uint8_t** desc, int* n, int* desc_bytes);
+/* The same for n_tiles equal-sized tiles in one call (the reference spawns one task per tile, main.rs:227-245): red / green / blue are arrays
+ * of n_tiles window pointers (one row_stride for all); ONE band_merger pass and ONE batched extraction (apds_akaze_extract_batch) serve all
+ * tiles. Per-tile results are exactly those of apds_tile_extract. Outputs as apds_akaze_extract_batch. */
+int apds_tile_extract_batch(const float* const* red, const float* const* green, const float* const* blue, int n_tiles, int rows, int cols, size_t row_stride,
+                            const double* minmax6, int max_points, apds_keypoint** kps, uint8_t** desc, int* counts, int* desc_bytes);
 
 /* homographier/src/homographier/mod.rs:271-300 warp_image_perspective: warpPerspective(src, M, size, INTER_LINEAR, BORDER_CONSTANT,
  * Scalar(1,1,1,1)). M (9 doubles) maps source to destination coordinates. channels must be 4 (Vec4b). */

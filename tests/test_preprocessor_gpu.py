@@ -60,9 +60,10 @@ def test_concurrent_tile_workers_give_the_same_tables(gpu_pkg):
     ge, pp, fd = gpu_pkg.geotiff_extractor, gpu_pkg.preprocessor, gpu_pkg.feature_database
     ds = ge.MosaicedDataset(_mosaic(gpu_pkg, 2048))
     runs = []
-    for workers, fused in ((1, False), (4, True), (1, True)):      # fused: band_merger -> BGRA -> AKAZE inside one library call
+    # fused: band_merger -> BGRA -> AKAZE inside one library call; batch: that call for several tiles at once (apds_tile_extract_batch)
+    for workers, fused, batch in ((1, False, 1), (4, True, 1), (1, True, 1), (1, True, 5), (1, True, 16)):
         table, images = fd.KeypointTable(400000), pp.ImageTable()
-        out = pp.process_lod_from_mosaic(table, images, ds, 3, workers=workers, fused=fused)     # 16 + 4 + 1 tiles of 512
+        out = pp.process_lod_from_mosaic(table, images, ds, 3, workers=workers, fused=fused, batch=batch)     # 16 + 4 + 1 tiles of 512
         assert [len(level) for level in out] == [16, 4, 1]
         allk = table.read_keypoints_from_lod(0), table.read_keypoints_from_lod(1), table.read_keypoints_from_lod(2)
         runs.append((out, images.rows, [(k.keypoints.copy(), k.descriptors.copy(), k.image_ids.copy()) for k in allk]))
