@@ -17,6 +17,7 @@
 namespace {
 
 struct P2f { float x, y; };
+inline double epsilon_f() { return FLT_EPSILON; }
 
 double hypot_cv(double a, double b) {
     a = std::fabs(a);
@@ -468,6 +469,191 @@ void lm_refine(const P2f* M, const P2f* m, int count, double* H, int maxIters) {
     for (int i = 0; i < 8; i++) H[i] = x[i];
 }
 
+// ---- the refit over MANY points: the summation order of the GPU's reduction ---------------------------------------------------
+// Above 256 selected points the product sums the per-point terms of runKernel and of the LM normal equations with a parallel
+// reduction (csrc/homography.hip reduce_kernel: 64 blocks x 256 threads, thread (b, t) takes the points b*256 + t + 16384 j in
+// order; a wave folds its 64 partial sums with the shuffle-down tree 32, 16, ..., 1; the four waves of a block, then the 64 blocks,
+// are added in order). Floating-point sums depend on their order, so a sequential loop here could only agree to ~1e-6 (round 1).
+// This restates that ORDER ("mirror the device reduction tree on the CPU side"), with the per-point terms written
+// as the reference algorithm defines them, so that H is comparable bit for bit at every size. The control flow around the sums
+// (runKernel, LMSolver::run) is the sequential code above.
+constexpr int MIRROR_MIN = 257, MIRROR_BLOCKS = 64, MIRROR_THREADS = 256;
+
+template <int K, class Term>
+void mirrored_sums(int n, const uint8_t* mask, Term term, double* out) {
+    std::vector<double> block((size_t)MIRROR_BLOCKS * K, 0.0);
+    double lanes[K][64], part[4][K];
+    for (int b = 0; b < MIRROR_BLOCKS; b++) {
+        for (int w = 0; w < MIRROR_THREADS / 64; w++) {
+            for (int l = 0; l < 64; l++) {
+                double acc[K];
+                for (int k = 0; k < K; k++) acc[k] = 0;
+                for (long long i = (long long)b * MIRROR_THREADS + w * 64 + l; i < n; i += (long long)MIRROR_BLOCKS * MIRROR_THREADS)
+                    if (!mask || mask[i]) term((int)i, acc);
+                for (int k = 0; k < K; k++) lanes[k][l] = acc[k];
+            }
+            for (int k = 0; k < K; k++) {
+                double* v = lanes[k];
+                for (int off = 32; off > 0; off >>= 1) {
+                    double nv[64];
+                    for (int l = 0; l < 64; l++) nv[l] = v[l] + (l + off < 64 ? v[l + off] : v[l]);   // shfl_down: out of range = own value
+                    for (int l = 0; l < 64; l++) v[l] = nv[l];
+                }
+                part[w][k] = v[0];
+            }
+        }
+        for (int k = 0; k < K; k++) {
+            double v = 0;
+            for (int w = 0; w < MIRROR_THREADS / 64; w++) v += part[w][k];
+            block[(size_t)b * K + k] = v;
+        }
+    }
+    for (int k = 0; k < K; k++) {
+        double v = 0;
+        for (int b = 0; b < MIRROR_BLOCKS; b++) v += block[(size_t)b * K + k];
+        out[k] = v;
+    }
+}
+
+int run_kernel_mirrored(const P2f* M, const P2f* m, int n, const uint8_t* mask, double* Hout) {
+    double r[5];
+    mirrored_sums<5>(n, mask, [&](int i, double* a) { a[0] += m[i].x; a[1] += m[i].y; a[2] += M[i].x; a[3] += M[i].y; a[4] += 1.0; }, r);
+    const double count = r[4];
+    if (count < 1) return 0;
+    const double cmx = r[0] / count, cmy = r[1] / count, cMx = r[2] / count, cMy = r[3] / count;
+    double sc[4];
+    mirrored_sums<4>(n, mask, [&](int i, double* a) {
+        a[0] += std::fabs(m[i].x - cmx); a[1] += std::fabs(m[i].y - cmy);
+        a[2] += std::fabs(M[i].x - cMx); a[3] += std::fabs(M[i].y - cMy);
+    }, sc);
+    double smx = sc[0], smy = sc[1], sMx = sc[2], sMy = sc[3];
+    if (std::fabs(smx) < DBL_EPSILON || std::fabs(smy) < DBL_EPSILON || std::fabs(sMx) < DBL_EPSILON || std::fabs(sMy) < DBL_EPSILON) return 0;
+    smx = count / smx; smy = count / smy; sMx = count / sMx; sMy = count / sMy;
+    double tri[45];
+    mirrored_sums<45>(n, mask, [&](int i, double* a) {
+        const double x = (m[i].x - cmx) * smx, y = (m[i].y - cmy) * smy;
+        const double X = (M[i].x - cMx) * sMx, Y = (M[i].y - cMy) * sMy;
+        const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+        const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+        int q = 0;
+        for (int j = 0; j < 9; j++)
+            for (int k = j; k < 9; k++) a[q++] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
+    }, tri);
+    double LtL[9][9], W[9], V[9][9];
+    int q = 0;
+    for (int j = 0; j < 9; j++)
+        for (int k = j; k < 9; k++) LtL[j][k] = LtL[k][j] = tri[q++];
+    const double invHnorm[9] = {1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1};
+    const double Hnorm2[9] = {sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1};
+    jacobi_eigen(&LtL[0][0], 9, W, &V[0][0]);
+    const double* H0 = V[8];
+    double Ht[9], H[9];
+    for (int rr = 0; rr < 3; rr++)
+        for (int c = 0; c < 3; c++) {
+            double sacc = 0;
+            for (int k = 0; k < 3; k++) sacc += invHnorm[rr * 3 + k] * H0[k * 3 + c];
+            Ht[rr * 3 + c] = sacc;
+        }
+    for (int rr = 0; rr < 3; rr++)
+        for (int c = 0; c < 3; c++) {
+            double sacc = 0;
+            for (int k = 0; k < 3; k++) sacc += Ht[rr * 3 + k] * Hnorm2[k * 3 + c];
+            H[rr * 3 + c] = sacc;
+        }
+    const double scl = 1. / H[8];
+    for (int i = 0; i < 9; i++) Hout[i] = H[i] * scl;
+    return 1;
+}
+
+// LMSolver::run with the normal equations J^T J, J^T r and |r|^2, |r|_inf summed in the mirrored order
+void lm_refine_mirrored(const P2f* M, const P2f* m, int n, const uint8_t* mask, double* H, int maxIters) {
+    const int lx = 8;
+    double x[8], xd[8], A[64], Ap[64], v[8], d[8], temp_d[8], D[8];
+    for (int i = 0; i < 8; i++) x[i] = H[i];
+    auto normal_eq = [&](const double* h, bool needJ, double* Aout, double* vout, double& S, double& rinf) {
+        double r[45];
+        double rmax = 0;
+        mirrored_sums<45>(n, mask, [&](int i, double* a) {
+            const double Mx = M[i].x, My = M[i].y;
+            double ww = h[6] * Mx + h[7] * My + 1.;
+            ww = std::fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+            const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+            const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+            const double r0 = xi - m[i].x, r1 = yi - m[i].y;
+            a[44] += r0 * r0 + r1 * r1;
+            rmax = std::max(rmax, std::max(std::fabs(r0), std::fabs(r1)));
+            if (needJ) {
+                const double J0[8] = {Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi};
+                const double J1[8] = {0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi};
+                int q = 0;
+                for (int aa = 0; aa < 8; aa++)
+                    for (int bb = aa; bb < 8; bb++) a[q++] += J0[aa] * J0[bb] + J1[aa] * J1[bb];
+                for (int aa = 0; aa < 8; aa++) a[36 + aa] += J0[aa] * r0 + J1[aa] * r1;
+            }
+        }, r);
+        S = r[44];
+        rinf = rmax;
+        if (needJ) {
+            int q = 0;
+            for (int aa = 0; aa < 8; aa++)
+                for (int bb = aa; bb < 8; bb++) Aout[aa * 8 + bb] = Aout[bb * 8 + aa] = r[q++];
+            for (int aa = 0; aa < 8; aa++) vout[aa] = r[36 + aa];
+        }
+    };
+    double S, rinf, rinf_d;
+    normal_eq(x, true, A, v, S, rinf);
+    for (int i = 0; i < lx; i++) D[i] = A[i * 8 + i];
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    int iter = 0;
+    for (;;) {
+        std::memcpy(Ap, A, sizeof(A));
+        for (int i = 0; i < lx; i++) Ap[i * 8 + i] += lambda * D[i];
+        eig_solve(Ap, 8, v, 1, d);
+        for (int i = 0; i < lx; i++) xd[i] = x[i] - d[i];
+        double Sd;
+        normal_eq(xd, false, nullptr, nullptr, Sd, rinf_d);
+        for (int a = 0; a < 8; a++) {
+            double sacc = 0;
+            for (int b = 0; b < 8; b++) sacc += A[a * 8 + b] * d[b];
+            temp_d[a] = -sacc + 2 * v[a];
+        }
+        double dS = 0;
+        for (int a = 0; a < 8; a++) dS += d[a] * temp_d[a];
+        const double R = (S - Sd) / (std::fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (R > Rhi) {
+            lambda *= 0.5;
+            if (lambda < lc) lambda = 0;
+        } else if (R < Rlo) {
+            double t = 0;
+            for (int a = 0; a < 8; a++) t += d[a] * v[a];
+            double nu = (Sd - S) / (std::fabs(t) > DBL_EPSILON ? t : 1) + 2;
+            nu = std::min(std::max(nu, 2.), 10.);
+            if (lambda == 0) {
+                double I8[64] = {0};
+                for (int i = 0; i < 8; i++) I8[i * 8 + i] = 1;
+                eig_solve(A, 8, I8, 8, Ap);
+                double maxval = DBL_EPSILON;
+                for (int i = 0; i < lx; i++) maxval = std::max(maxval, std::fabs(Ap[i * 8 + i]));
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            std::memcpy(x, xd, sizeof(x));
+            normal_eq(x, true, A, v, S, rinf);
+        }
+        iter++;
+        double dinf = 0;
+        for (int i = 0; i < 8; i++) dinf = std::max(dinf, std::fabs(d[i]));
+        const bool proceed = iter < maxIters && dinf >= epsilon_f() && rinf >= epsilon_f();
+        if (!proceed) break;
+    }
+    for (int i = 0; i < 8; i++) H[i] = x[i];
+}
+
 }  // namespace
 
 extern "C" {
@@ -506,13 +692,20 @@ int oracle_find_homography(const float* src_xy, const float* dst_xy, int n, int 
     const P2f* dst = reinterpret_cast<const P2f*>(dst_xy);
     std::vector<uint8_t> mask(n, 1);
     bool result = false;
-    if (method == 0 || n == 4)
+    if ((method == 0 || n == 4) && n >= MIRROR_MIN)
+        result = run_kernel_mirrored(src, dst, n, nullptr, H) > 0;
+    else if (method == 0 || n == 4)
         result = run_kernel(src, dst, n, H) > 0;
     else if (method == 8)
         result = ransac_run(src, dst, n, thr, confidence, max_iters, H, mask.data());
     else
         result = lmeds_run(src, dst, n, confidence, max_iters, H, mask.data());
-    if (result && n > 4) {
+    int selected = 0;
+    for (int i = 0; i < n; i++) selected += mask[i] ? 1 : 0;
+    if (result && n > 4 && selected >= MIRROR_MIN) {   // many points: the sums in the order of the GPU's reduction (see mirrored_sums)
+        if (method == 8 || method == 4) run_kernel_mirrored(src, dst, n, mask.data(), H);
+        lm_refine_mirrored(src, dst, n, mask.data(), H, 10);
+    } else if (result && n > 4) {
         std::vector<P2f> s, d;
         for (int i = 0; i < n; i++)
             if (mask[i]) {

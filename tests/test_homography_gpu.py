@@ -1,6 +1,8 @@
 """GPU: findHomography parity, HIP path (through the C ABI) vs the oracle.
-Bar: inlier masks bit-exact (the 4-point models are bit-identical and scored in f32 with the same operations);
-H within rtol 1e-6 / atol 1e-8 after H[2][2] = 1 (the refit's per-point sums are parallel reductions in f64)."""
+Bar: inlier masks bit-exact (the 4-point models are bit-identical and scored in f32 with the same operations) and H BIT-EXACT at
+every size: up to 256 selected points the refit runs on the host in index order; above that its per-point sums are parallel f64
+reductions on the GPU, and the oracle adds the same terms in the same order (oracle/homography_oracle.cpp mirrored_sums).
+RTOL / ATOL (after H[2][2] = 1) remain as the stated fallback bar of SURVEY 8c."""
 import numpy as np
 import pytest
 
@@ -20,6 +22,7 @@ def _check(pkg, oracle_mod, src, dst, method, thr, max_iters=2000, conf=0.995):
     if found:
         assert np.array_equal(mask, mo), (mask.sum(), mo.sum())
         assert np.allclose(H.reshape(3, 3), Ho, rtol=RTOL, atol=ATOL), np.abs(H.reshape(3, 3) - Ho).max()
+        assert np.array_equal(H.reshape(3, 3), Ho.reshape(3, 3)), np.abs(H.reshape(3, 3) - Ho.reshape(3, 3)).max()
     else:
         assert rc == -1000
     return found, H.reshape(3, 3), mask
