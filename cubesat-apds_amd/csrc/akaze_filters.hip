@@ -522,29 +522,44 @@ void base_strip_kernel(const uint8_t* __restrict__ img, int w, int h, int stride
 }
 
 // ---- contrast factor: 300-bin histogram of |grad|/hmax over interior pixels, 70th percentile -----------
+// Eight sub-histograms per block (lane & 7 picks one): gradient magnitudes crowd the low bins, so with one histogram most of a
+// wave's 64 LDS atomics hit a handful of addresses and serialise; each thread reads four consecutive pixels of a row per step.
 __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __restrict__ modg, int w, int h, const unsigned int* __restrict__ hmax_bits,
                                                               int* __restrict__ hist, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     APDS_BOFS(modg);
     APDS_BOFS(hmax_bits);
     APDS_BOFS(hist);
-    __shared__ int s_hist[300];
-    for (int i = threadIdx.x; i < 300; i += 256) s_hist[i] = 0;
+    constexpr int SUB = 8, PITCH = 301;                 // odd pitch: the eight copies of a bin sit in different banks
+    __shared__ int s_hist[SUB * PITCH];
+    for (int i = threadIdx.x; i < SUB * PITCH; i += 256) s_hist[i] = 0;
     __syncthreads();
     const float hmax = __uint_as_float(*hmax_bits);
     if (hmax != 0.0f) {
         const float scale = 299.0f / hmax;
         const int cw = w - 2, ch = h - 2;
-        const long long total = (long long)cw * ch;
+        int* mine = s_hist + (threadIdx.x & (SUB - 1)) * PITCH;
+        const int groups = (cw + 3) >> 2;               // 4-pixel groups per interior row
+        const long long total = (long long)groups * ch;
         for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-            const int y = (int)(i / cw), x = (int)(i - (long long)y * cw);
-            const float v = modg[(size_t)(y + 1) * w + (x + 1)];
-            atomicAdd(&s_hist[(int)(v * scale)], 1);
+            const int y = (int)(i / groups), x = (int)(i - (long long)y * groups) * 4;
+            const float* p = modg + (size_t)(y + 1) * w + (x + 1);
+            const int n = min(4, cw - x);
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = k < n ? p[k] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < n) atomicAdd(&mine[(int)(v[k] * scale)], 1);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 300; i += 256)
-        if (s_hist[i]) atomicAdd(&hist[i], s_hist[i]);
+    for (int i = threadIdx.x; i < 300; i += 256) {
+        int sum = 0;
+#pragma unroll
+        for (int sidx = 0; sidx < SUB; sidx++) sum += s_hist[sidx * PITCH + i];
+        if (sum) atomicAdd(&hist[i], sum);
+    }
 }
 
 // single thread: kcontrast and its per-octave values k, k*0.75, (k*0.75)*0.75, ...

@@ -1105,10 +1105,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     bt.n = B;
     bt.stride = slab;
     bt.img_stride = img_bstride;
-    if (B == 1) HIP_CHECK(hipMemsetAsync(real.base, 0, zero_bytes, s));
-    else
-        hipLaunchKernelGGL(zero_slab_heads_kernel, dim3((unsigned)std::min<size_t>(1024, (zero_bytes / 16 + 255) / 256), 1, B), dim3(256), 0, s,
-                           reinterpret_cast<uint4*>(real.base), zero_bytes, slab);
+    // (the runtime's fill kernel clears the 44 MB of a 4096^2 frame at 1.7 TB/s; 16-byte stores from a wide grid are quicker)
+    hipLaunchKernelGGL(zero_slab_heads_kernel, dim3((unsigned)std::min<size_t>(B > 1 ? 1024 : 4096, (zero_bytes / 16 + 255) / 256), 1, B), dim3(256), 0, s,
+                       reinterpret_cast<uint4*>(real.base), zero_bytes, slab);
     int* counts_dev = B > 1 ? c.alloc_n<int>(B) : nullptr;
 
     // ---- a1.1 / a1.2 / a1.3

@@ -312,19 +312,20 @@ class StreamedFramePipeline:
             self.slots.append(s)
         # the match kernel alone fills every CU for ~30 ms; the short extraction / homography kernels get the high-priority
         # queues so that their blocks are dispatched as soon as match workgroups retire
-        self.streams = [torch.cuda.Stream(self.dev, priority=-1), torch.cuda.Stream(self.dev, priority=0), torch.cuda.Stream(self.dev, priority=-1)]
+        hp = int(os.environ.get("APDS_PIPE_PRIO", "-1"))      # priority of the short-kernel streams (extraction, homography, query gather)
+        self.streams = [torch.cuda.Stream(self.dev, priority=hp), torch.cuda.Stream(self.dev, priority=0), torch.cuda.Stream(self.dev, priority=hp)]
         # Optional (APDS_MATCH_WORKERS=2, single GPU only): two match workers alternate frames on two streams, so the short,
         # poorly filled phases of one frame's match (threshold pre-pass, merges, grid tail) run under the other frame's
         # main kernel: +1 % frames/s, but per-launch kernel times then overlap and no longer read as kernel efficiency,
         # so the default is one worker. With a sharded DB the collectives must be issued in frame order by one thread.
-        self.extract_streams = [self.streams[0]] + [torch.cuda.Stream(self.dev, priority=-1) for _ in range(self.extract_workers - 1)]
+        self.extract_streams = [self.streams[0]] + [torch.cuda.Stream(self.dev, priority=hp) for _ in range(self.extract_workers - 1)]
         # 1: cap the match kernel's occupancy when the match stream is seen starving (see match_worker); APDS_ADAPTIVE_CAP=0 turns it off
         self.adaptive_cap = os.environ.get("APDS_ADAPTIVE_CAP", "1") != "0"
         self.cap_events = []
         self.gap_log = []                 # idle time of the match stream before each frame's match (ms), for diagnosis
         self.debug_extract_delay = float(os.environ.get("APDS_DEBUG_EXTRACT_DELAY_MS", "0")) * 1e-3
         self.match_workers = 2 if (group is None and os.environ.get("APDS_MATCH_WORKERS", "1") == "2") else 1
-        self.gather_stream = torch.cuda.Stream(self.dev, priority=-1) if self.matcher.world > 1 else None
+        self.gather_stream = torch.cuda.Stream(self.dev, priority=hp) if self.matcher.world > 1 else None
         if reserve_cus > 0:
             # keep `reserve_cus` CUs (spread evenly over the CU index space) out of the MATCH stream only
             words = (n_cus + 31) // 32
