@@ -288,8 +288,13 @@ __global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restric
                 const int ly = i / FW, lx = i - ly * FW;
                 const int gx = x0 + lx, gy = y0 + ly;
                 if (gx >= w || gy >= h) continue;
+                const float* r1 = &s_sm[(ly + 1) * TWD];
+                if (gx >= 1 && gx <= w - 2 && gy >= 1 && gy <= h - 2) {   // only the image's outermost pixels need reflected coordinates
+                    flow[(size_t)gy * w + gx] = flow_point(r1 - TWD, r1, r1 + TWD, lx, lx + 1, lx + 2);
+                    continue;
+                }
                 const int cxm = reflect101(gx - 1, w) - (x0 - 1), cxp = reflect101(gx + 1, w) - (x0 - 1);
-                flow[(size_t)gy * w + gx] = flow_point(&s_sm[(reflect101(gy - 1, h) - (y0 - 1)) * TWD], &s_sm[(ly + 1) * TWD],
+                flow[(size_t)gy * w + gx] = flow_point(&s_sm[(reflect101(gy - 1, h) - (y0 - 1)) * TWD], r1,
                                                        &s_sm[(reflect101(gy + 1, h) - (y0 - 1)) * TWD], cxm, lx + 1, cxp);
             }
         }
@@ -733,6 +738,278 @@ __global__ __launch_bounds__(NT) void nld_multi_kernel(const float* __restrict__
     else nld_multi_tile<S, NT, false>(Lt, Lf, Lnew, w, h, steps, s_f, s_a, s_b, x0, y0);
 }
 
+// ---- a whole level in one launch (the small, latency-bound levels) -----------------------------------------------
+// Lsmooth = Gaussian(Lt_prev), conductivity = g2(Scharr(Lsmooth)), then all of the level's FED steps, in ONE kernel per level: a
+// 512^2 or 1024^2 level used to take four or five dependent launches of ~10 us each, nearly all of it launch and drain latency.
+// A block owns a 32x32 tile of the level and recomputes everything it needs around it (temporal blocking): with S FED steps the
+// start image is loaded with a halo of S + 3 (S for the steps, 1 for the Scharr ring, 2 for the Gaussian), and every stage is
+// evaluated on the region the following stages read. Per value the operations (and their order) are those of smooth_flow_kernel
+// and nld_point, so the planes are bit-identical to the unfused path. Four LDS planes with one pitch and one origin: local (0, 0)
+// is the global pixel (x0 - S - 3, y0 - S - 3).
+//   out-of-image positions: the start image is loaded through clamped coordinates (BORDER_REPLICATE, what the Gaussian wants);
+//   the Scharr ring of a border pixel goes through reflect-101 coordinates (in-image, inside the region); a FED step of a border
+//   pixel is nld_point's border case, which never uses the out-of-image neighbour. Positions outside the image are evaluated
+//   with whatever LDS holds and never read by an in-image position.
+struct LevelSteps {
+    int n;
+    float v[32];
+};
+static constexpr int LFT = 32;              // output tile (square)
+static constexpr int LF_MAX_STEPS = 29;     // 1024 threads: 3 x 3 patches cover (32 + 2 * 29)^2; 3 planes x 96^2 floats = 108 KB of LDS
+static constexpr int LF_MAX_STEPS_512 = 17; // 512 threads: 3 x 3 patches cover (32 + 2 * 17)^2
+
+__device__ __forceinline__ int div_small(int i, float inv) { return (int)(((float)i + 0.5f) * inv); }   // floor(i / d): exact for i < 2^15, d < 2^7
+
+__device__ __forceinline__ float pm_g2_point(const float* r0, const float* r1, const float* r2, int cxm, int cx, int cxp, float k2inv) {
+    const float kside = 3.0f, kmid = 10.0f;
+    const float rd0 = r0[cxp] - r0[cxm], rd1 = r1[cxp] - r1[cxm], rd2 = r2[cxp] - r2[cxm];
+    float ax = kmid * rd1;
+    ax += kside * (rd0 + rd2);
+    float rs0 = kmid * r0[cx];
+    rs0 += kside * (r0[cxm] + r0[cxp]);
+    float rs2 = kmid * r2[cx];
+    rs2 += kside * (r2[cxm] + r2[cxp]);
+    const float ay = rs2 - rs0;
+    return 1.0f / (1.0f + ((ax * ax + ay * ay) * k2inv));
+}
+
+// The FED steps of level_fused_kernel: every thread keeps a PW x PW patch of the (32 + 2S)^2 region in registers for ALL steps and
+// exchanges only its values with the four neighbouring patches through LDS (two planes, alternating: one barrier per step). The
+// conductivity enters only as the pair sums f[x] + f[x+1] of the fluxes
+//   P[x] = (f[x] + f[x+1]) * (t[x+1] - t[x])        Q[r] = (f[r] + f[r+1]) * (t[r+1] - t[r])
+// which are loop constants in registers; a step is  t += (((P[x] - P[x-1]) + Q[r]) - Q[r-1]) * step  — nld_point's four terms exactly
+// (see nld_strip: a - b == -(b - a), (-a) * b == -(a * b), x + (-y) == x - y). A flux that crosses the image border, or lies outside
+// the image, gets the pair sum 0: the reference drops that term, and adding or subtracting a zero product changes nothing (the sum's
+// first operand is never -0 ...); out-of-image positions therefore keep their (finite, replicated) start value. The four image
+// corners keep their value (the reference's step is 0 there). Nothing shrinks: every step evaluates the whole region, and the
+// values within j positions of the region's edge are wrong after step j — the tile in the middle is S positions away.
+template <int PW, int NT>
+__device__ __forceinline__ void fed_patches(const float* __restrict__ s_t, const float* __restrict__ s_f, float* __restrict__ e0, float* __restrict__ e1,
+                                            int P, int S, const LevelSteps& steps, int gx0, int gy0, int w, int h, bool inside,
+                                            float* __restrict__ Lnew) {
+    const int R = P - 6;                       // the region is local [3, P - 3)^2
+    const int TG = (R + PW - 1) / PW;          // patches per row
+    const int tid = threadIdx.x;
+    const int ty = div_small(tid, 1.0f / (float)TG), tx = tid - ty * TG;
+    const bool active = ty < TG;
+    const int x0 = 3 + PW * tx, y0 = 3 + PW * ty;   // (patches of the last row / column may reach up to PW - 1 positions past the region)
+    float t[PW][PW], fx[PW][PW + 1], fy[PW + 1][PW];
+    unsigned corner = 0;
+    if (active) {
+#pragma unroll
+        for (int a = 0; a < PW; a++)
+#pragma unroll
+            for (int b = 0; b < PW; b++) t[a][b] = s_t[(y0 + a) * P + x0 + b];
+#pragma unroll
+        for (int a = 0; a < PW; a++)
+#pragma unroll
+            for (int b = 0; b <= PW; b++) {     // flux between (x0 + b - 1, y0 + a) and (x0 + b, y0 + a)
+                const float* q = &s_f[(y0 + a) * P + x0 + b];
+                float v = q[-1] + q[0];
+                if (!inside) {
+                    const int gx = gx0 + x0 + b, gy = gy0 + y0 + a;
+                    if (gx - 1 < 0 || gx >= w || gy < 0 || gy >= h) v = 0.0f;
+                }
+                fx[a][b] = v;
+            }
+#pragma unroll
+        for (int a = 0; a <= PW; a++)
+#pragma unroll
+            for (int b = 0; b < PW; b++) {      // flux between (x0 + b, y0 + a - 1) and (x0 + b, y0 + a)
+                const float* q = &s_f[(y0 + a) * P + x0 + b];
+                float v = q[-P] + q[0];
+                if (!inside) {
+                    const int gx = gx0 + x0 + b, gy = gy0 + y0 + a;
+                    if (gy - 1 < 0 || gy >= h || gx < 0 || gx >= w) v = 0.0f;
+                }
+                fy[a][b] = v;
+            }
+        if (!inside) {
+#pragma unroll
+            for (int a = 0; a < PW; a++)
+#pragma unroll
+                for (int b = 0; b < PW; b++) {
+                    const int gx = gx0 + x0 + b, gy = gy0 + y0 + a;
+                    if ((gx == 0 || gx == w - 1) && (gy == 0 || gy == h - 1)) corner |= 1u << (a * PW + b);
+                }
+        }
+    }
+    __syncthreads();   // every thread has read its start values: e0 / e1 (the smoothing planes) may be overwritten
+    for (int k = 0; k < S; k++) {
+        float* __restrict__ e = (k & 1) ? e1 : e0;
+        if (active) {
+#pragma unroll
+            for (int a = 0; a < PW; a++)
+#pragma unroll
+                for (int b = 0; b < PW; b++) e[(y0 + a) * P + x0 + b] = t[a][b];
+        }
+        __syncthreads();
+        if (active) {
+            float lf[PW], rt[PW], up[PW], dn[PW];
+#pragma unroll
+            for (int a = 0; a < PW; a++) {
+                lf[a] = e[(y0 + a) * P + x0 - 1];
+                rt[a] = e[(y0 + a) * P + x0 + PW];
+            }
+#pragma unroll
+            for (int b = 0; b < PW; b++) {
+                up[b] = e[(y0 - 1) * P + x0 + b];
+                dn[b] = e[(y0 + PW) * P + x0 + b];
+            }
+            float px[PW][PW + 1], qy[PW + 1][PW];
+#pragma unroll
+            for (int a = 0; a < PW; a++)
+#pragma unroll
+                for (int b = 0; b <= PW; b++) {
+                    const float hi = b == PW ? rt[a] : t[a][b], lo = b == 0 ? lf[a] : t[a][b - 1];
+                    px[a][b] = fx[a][b] * (hi - lo);
+                }
+#pragma unroll
+            for (int a = 0; a <= PW; a++)
+#pragma unroll
+                for (int b = 0; b < PW; b++) {
+                    const float hi = a == PW ? dn[b] : t[a][b], lo = a == 0 ? up[b] : t[a - 1][b];
+                    qy[a][b] = fy[a][b] * (hi - lo);
+                }
+            const float step = steps.v[k];
+#pragma unroll
+            for (int a = 0; a < PW; a++)
+#pragma unroll
+                for (int b = 0; b < PW; b++) {
+                    const float sr = ((px[a][b + 1] - px[a][b]) + qy[a + 1][b]) - qy[a][b];
+                    const float v = t[a][b] + sr * step;
+                    t[a][b] = (corner >> (a * PW + b)) & 1u ? t[a][b] : v;
+                }
+        }
+    }
+    if (active) {
+        const int c_lo = S + 3, c_hi = S + 3 + LFT;
+#pragma unroll
+        for (int a = 0; a < PW; a++)
+#pragma unroll
+            for (int b = 0; b < PW; b++) {
+                const int lx = x0 + b, ly = y0 + a, gx = gx0 + lx, gy = gy0 + ly;
+                if (lx >= c_lo && lx < c_hi && ly >= c_lo && ly < c_hi && gx < w && gy < h) Lnew[(size_t)gy * w + gx] = t[a][b];
+            }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void level_fused_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow_out,
+                                                          const float* __restrict__ flow_in, float* __restrict__ Lnew, int w, int h, GaussTaps taps,
+                                                          const float* __restrict__ kptr, LevelSteps steps, size_t bstride) {
+    APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(src);
+    APDS_BOFS(smooth);
+    APDS_BOFS(Lnew);
+    APDS_BOFS(kptr);
+    if (flow_out) APDS_BOFS(flow_out);
+    if (flow_in) APDS_BOFS(flow_in);
+    extern __shared__ __attribute__((aligned(16))) float lf_lds[];
+    const int S = steps.n;
+    const int P = LFT + 2 * S + 6;
+    // three planes: start image | Gaussian rows, then the conductivity | Lsmooth; the FED steps exchange through the first and the last
+    float* s_a = lf_lds;
+    float* s_b = s_a + P * P;
+    float* s_sm = s_b + P * P;
+    float* s_f = s_b;
+    const int gx0 = blockIdx.x * LFT - S - 3, gy0 = blockIdx.y * LFT - S - 3;
+    // block-uniform: the whole region lies inside the image and holds no border pixel
+    const bool inside = gx0 >= 0 && gy0 >= 0 && gx0 + P <= w && gy0 + P <= h;
+    const int tid = threadIdx.x;
+    {
+        constexpr int PMAX = LFT + 2 * (NT == 1024 ? LF_MAX_STEPS : LF_MAX_STEPS_512) + 6;
+        constexpr int NL = (PMAX * PMAX + NT - 1) / NT;
+        const float invP = 1.0f / (float)P;
+        float v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; k++) {   // all loads in flight before the first LDS store
+            const int i = tid + k * NT;
+            if (i < P * P) {
+                const int ly = div_small(i, invP), lx = i - ly * P;
+                v[k] = inside ? src[(size_t)(gy0 + ly) * w + (gx0 + lx)] : src[(size_t)clampi(gy0 + ly, h) * w + clampi(gx0 + lx, w)];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            const int i = tid + k * NT;
+            if (i < P * P) s_a[i] = v[k];
+        }
+    }
+    if (flow_in) {   // the caller has run the smoothing pass (its Lsmooth was wanted early): the conductivity comes from HBM
+        const int fw = P - 6;
+        const float inv = 1.0f / (float)fw;
+        for (int i = tid; i < fw * fw; i += NT) {
+            const int ry = div_small(i, inv);
+            const int ly = 3 + ry, lx = 3 + (i - ry * fw);
+            s_f[ly * P + lx] = flow_in[(size_t)clampi(gy0 + ly, h) * w + clampi(gx0 + lx, w)];
+        }
+        __syncthreads();
+    } else {
+        const float kc = *kptr;
+        const float k2inv = 1.0f / (kc * kc);
+        __syncthreads();
+        // every stage is evaluated on (its region) x (the image): block-uniform bounds in local coordinates
+        const int ix0 = -gx0, ix1 = w - gx0, iy0 = -gy0, iy1 = h - gy0;   // the image is local [ix0, ix1) x [iy0, iy1)
+        const int c_lo = S + 3, c_hi = S + 3 + LFT;                        // the tile
+        {   // Gaussian rows: rows within 2 of the image (the column pass reads the replicated rows), in-image columns of [2, P - 2)
+            const int xl = max(2, ix0), xh = min(P - 2, ix1), yl = max(0, iy0 - 2), yh = min(P, iy1 + 2);
+            const int rw = xh - xl, n = rw * (yh - yl);
+            const float inv = 1.0f / (float)rw;
+            for (int i = tid; i < n; i += NT) {
+                const int ry = div_small(i, inv);
+                const int ly = yl + ry, lx = xl + (i - ry * rw);
+                const float* p = &s_a[ly * P + lx];
+                float acc = taps.k[0] * p[0];
+                acc += taps.k[1] * (p[-1] + p[1]);
+                acc += taps.k[2] * (p[-2] + p[2]);
+                s_b[ly * P + lx] = acc;
+            }
+        }
+        __syncthreads();
+        {   // Gaussian columns: Lsmooth on the in-image part of [2, P - 2)^2
+            const int xl = max(2, ix0), xh = min(P - 2, ix1), yl = max(2, iy0), yh = min(P - 2, iy1);
+            const int rw = xh - xl, n = rw * (yh - yl);
+            const float inv = 1.0f / (float)rw;
+            for (int i = tid; i < n; i += NT) {
+                const int ry = div_small(i, inv);
+                const int ly = yl + ry, lx = xl + (i - ry * rw);
+                const float* p = &s_b[ly * P + lx];
+                float acc = taps.k[0] * p[0];
+                acc += taps.k[1] * (p[-P] + p[P]);
+                acc += taps.k[2] * (p[-2 * P] + p[2 * P]);
+                s_sm[ly * P + lx] = acc;
+                if (lx >= c_lo && lx < c_hi && ly >= c_lo && ly < c_hi) smooth[(size_t)(gy0 + ly) * w + (gx0 + lx)] = acc;
+            }
+        }
+        __syncthreads();
+        {   // conductivity on the in-image part of [3, P - 3)^2
+            const int xl = max(3, ix0), xh = min(P - 3, ix1), yl = max(3, iy0), yh = min(P - 3, iy1);
+            const int rw = xh - xl, n = rw * (yh - yl);
+            const float inv = 1.0f / (float)rw;
+            for (int i = tid; i < n; i += NT) {
+                const int ry = div_small(i, inv);
+                const int ly = yl + ry, lx = xl + (i - ry * rw);
+                const int gx = gx0 + lx, gy = gy0 + ly;
+                float g;
+                if (inside || (gx >= 1 && gx <= w - 2 && gy >= 1 && gy <= h - 2)) {
+                    const float* r1 = &s_sm[ly * P];
+                    g = pm_g2_point(r1 - P, r1, r1 + P, lx - 1, lx, lx + 1, k2inv);
+                } else {   // image border: reflect-101 ring
+                    g = pm_g2_point(&s_sm[(reflect101(gy - 1, h) - gy0) * P], &s_sm[ly * P], &s_sm[(reflect101(gy + 1, h) - gy0) * P], reflect101(gx - 1, w) - gx0,
+                                    lx, reflect101(gx + 1, w) - gx0, k2inv);
+                }
+                s_f[ly * P + lx] = g;
+                if (flow_out && lx >= c_lo && lx < c_hi && ly >= c_lo && ly < c_hi) flow_out[(size_t)gy * w + gx] = g;
+            }
+        }
+        __syncthreads();
+    }
+    const int hr = (P - 5) >> 1;   // patches per row with 2 x 2 patches
+    if (hr * hr <= NT) fed_patches<2, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew);
+    else fed_patches<3, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew);
+}
+
 // ---- FED steps on register strips (the large levels) -------------------------------------------------------------
 // One wave owns a strip of 64 columns x (RB + 2S) rows of Lt and of the conductivity, one column per lane, all rows in registers
 // (fully unrolled, static register indices): no LDS, no barriers. Horizontal neighbours come through DPP wave shifts. With
@@ -1109,6 +1386,33 @@ void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int 
         case 8: nld_multi_launch<8>(Lt, Lf, Lnew, w, h, st, s, b); break;
         default: fail(APDS_ERR_INTERNAL, "nld_multi: 1..8 steps per launch");
     }
+}
+// one launch for a level: Lsmooth, conductivity (kept in LDS; written to flow_out only if the caller continues with more steps)
+// and `nsteps` <= level_fused_max_steps() FED steps from `src` into `Lnew` (src, smooth, Lnew distinct planes)
+int level_fused_max_steps() { return LF_MAX_STEPS; }
+void launch_level_fused(const float* src, float* smooth, float* flow_out, const float* flow_in, float* Lnew, int w, int h, const GaussTaps& taps,
+                        const float* kptr, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b) {
+    APDS_REQUIRE(nsteps >= 1 && nsteps <= LF_MAX_STEPS, APDS_ERR_INTERNAL, "level_fused: 1..29 steps");
+    LevelSteps st{};
+    st.n = nsteps;
+    for (int i = 0; i < nsteps; i++) st.v[i] = step_sizes[i];
+    const int P = LFT + 2 * nsteps + 6;
+    const size_t lds = (size_t)(3 * P * P) * sizeof(float);
+    static bool opted = false;   // above the default dynamic-LDS limit: opt in once (idempotent, so a race is harmless)
+    if (!opted) {
+        constexpr int PM = LFT + 2 * LF_MAX_STEPS + 6, PM5 = LFT + 2 * LF_MAX_STEPS_512 + 6;
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&level_fused_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PM * PM * 4));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&level_fused_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PM5 * PM5 * 4));
+        opted = true;
+    }
+    const dim3 grid(ceil_div(w, LFT), ceil_div(h, LFT), b.n);
+    // several tiles per CU: 512-thread blocks, so that three or four of them share a CU; otherwise all the threads one tile can use
+    static const int nt_env = getenv("APDS_LEVEL_FUSE_THREADS") ? atoi(getenv("APDS_LEVEL_FUSE_THREADS")) : 0;
+    const bool small_blocks = nsteps <= LF_MAX_STEPS_512 && (nt_env ? nt_env == 512 : (size_t)grid.x * grid.y * grid.z >= 512);
+    if (small_blocks)
+        hipLaunchKernelGGL((level_fused_kernel<512>), grid, dim3(512), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride);
+    else
+        hipLaunchKernelGGL((level_fused_kernel<1024>), grid, dim3(1024), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride);
 }
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s, const Batch& b) {
     hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 256), dh, b.n), dim3(256), 0, s, src, sw, dst, dw, dh, b.stride);

@@ -1253,7 +1253,11 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             static const int fuse_big = getenv("APDS_NLD_FUSE_BIG") ? atoi(getenv("APDS_NLD_FUSE_BIG")) : 4;
             static const int fuse_small = getenv("APDS_NLD_FUSE_SMALL") ? atoi(getenv("APDS_NLD_FUSE_SMALL")) : 8;
             const int fuse = std::min(8, std::max(1, (size_t)e.w * e.h * B <= (size_t)1 << 20 ? fuse_small : fuse_big));
-            const int launches = (e.nsteps + fuse - 1) / fuse;
+            // small levels: Lsmooth, conductivity and the first (usually all) FED steps in ONE launch (level_fused_kernel)
+            static const int level_fuse = getenv("APDS_LEVEL_FUSE") ? atoi(getenv("APDS_LEVEL_FUSE")) : 1;
+            const bool fused_level = e.nsteps > 0 && level_fuse && ((size_t)e.w * e.h * B <= (size_t)1 << 20 || level_fuse == 2);
+            const int head = fused_level ? std::min(e.nsteps, level_fused_max_steps()) : 0;
+            const int launches = (e.nsteps - head + fuse - 1) / fuse + (fused_level ? 1 : 0);
             if (e.octave > p.octave) {
                 float* dstP = (launches % 2 == 0) ? e.Lt : tmpP;   // so that the last pass lands in e.Lt
                 if (p.w == 2 * e.w && p.h == 2 * e.h) {
@@ -1271,19 +1275,34 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             } else {
                 P = p.Lt;
             }
-            launch_smooth_flow(P, lsm[i], tmpF, e.w, e.h, g10, k_oct + e.octave, s, bt);   // Lsmooth and the conductivity in one pass
+            const float* in = P;
+            int pass = 0, k = 0;
+            float st[32];
+            // the last level's Hessian kernel is on the critical path (nothing follows to hide it): its Lsmooth comes from a separate
+            // smoothing pass, so that it runs beside the level's FED steps
+            const bool smooth_first = !fused_level || (fork_doh && i == L - 1);
+            if (smooth_first) launch_smooth_flow(P, lsm[i], tmpF, e.w, e.h, g10, k_oct + e.octave, s, bt);   // Lsmooth and the conductivity in one pass
             smooth = lsm[i];
-            if (fork_doh) {   // Lsmooth of this level exists from here on
+            auto fork_here = [&]() {   // Lsmooth of this level exists from here on
+                if (!fork_doh) return;
                 HIP_CHECK(hipEventRecord(c.fork_event(i), s));
                 HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(i), 0));
+            };
+            if (smooth_first) fork_here();
+            if (fused_level) {
+                float* out = ((launches - 1) % 2 == 0) ? e.Lt : tmpP;
+                for (int j = 0; j < head; j++) st[j] = e.tau[j] * 0.5f;
+                launch_level_fused(P, lsm[i], !smooth_first && head < e.nsteps ? tmpF : nullptr, smooth_first ? tmpF : nullptr, out, e.w, e.h, g10,
+                                   k_oct + e.octave, st, head, s, bt);
+                k = head;
+                in = out;
+                pass = 1;
+                if (!smooth_first) fork_here();
             }
-            const float* in = P;
-            int pass = 0;
-            for (int k = 0; k < e.nsteps; pass++) {
+            for (; k < e.nsteps; pass++) {
                 float* out = ((launches - 1 - pass) % 2 == 0) ? e.Lt : tmpP;
                 // spread the steps evenly over the launches (e.g. 11 steps, fuse 8 -> 6 + 5)
                 const int g = (e.nsteps - k + (launches - pass) - 1) / (launches - pass);
-                float st[8];
                 for (int j = 0; j < g; j++) st[j] = e.tau[k + j] * 0.5f;
                 launch_nld_multi(in, tmpF, out, e.w, e.h, st, g, s, bt);
                 k += g;
@@ -1352,14 +1371,14 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     }
 
     // ---- the only read-back of the call: every image's keypoint count
-    std::vector<int> K(B, 0);
+    int* K = c.pinned_ints(B);
     if (B == 1) {
-        HIP_CHECK(hipMemcpyAsync(K.data(), kp_base + n_stage, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(K, kp_base + n_stage, sizeof(int), hipMemcpyDeviceToHost, s));
     } else {
         hipLaunchKernelGGL(gather_slab_ints_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, (const int*)(kp_base + n_stage), 1, slab, B, counts_dev);
-        HIP_CHECK(hipMemcpyAsync(K.data(), counts_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipMemcpyAsync(K, counts_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
     }
-    HIP_CHECK(hipStreamSynchronize(s));
+    stream_wait(s);
     int kmax = 0;
     bool over = false;
     for (int bi = 0; bi < B; bi++) {

@@ -69,6 +69,9 @@ struct ThreadCtx {
     bool fork_open = false;                     // side-stream work was issued and not yet joined (only after an error in between)
     hipStream_t side2 = nullptr;                // akaze: keypoint stages of the finished octaves
     int akaze_kp_estimate = 0;                  // keypoints of this thread's previous image (grid size of the per-keypoint kernels)
+    int* host_ints = nullptr;                   // pinned host memory for count read-backs (a pageable target makes the copy a staged, blocking one)
+    size_t host_ints_cap = 0;
+    int* pinned_ints(size_t n);                 // valid until the next call with a larger n
     hipStream_t side_stream();                  // created on first use
     hipStream_t side_stream2();
     void drop_side();
@@ -82,6 +85,10 @@ struct ThreadCtx {
 };
 ThreadCtx& ctx();
 std::atomic<int>& live_contexts();   // host threads that currently own a stream + workspace
+
+// wait for a stream: poll for a bounded time (a blocking wait costs tens of microseconds to wake up, which is a tenth of a small
+// tile's extraction), then block
+void stream_wait(hipStream_t s);
 
 inline hipStream_t pick_stream(void* s) { return s ? static_cast<hipStream_t>(s) : ctx().stream; }
 

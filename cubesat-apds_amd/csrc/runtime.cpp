@@ -1,4 +1,5 @@
 // csrc/runtime.cpp — library-level entry points and the per-thread runtime (stream, workspace, timing).
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 
@@ -62,8 +63,37 @@ hipStream_t ThreadCtx::side_stream2() {
     return side2;
 }
 
+int* ThreadCtx::pinned_ints(size_t n) {
+    if (n > host_ints_cap) {
+        if (host_ints) (void)hipHostFree(host_ints);
+        host_ints = nullptr;
+        host_ints_cap = 0;
+        const size_t cap = std::max<size_t>(64, n * 2);
+        HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&host_ints), cap * sizeof(int), hipHostMallocDefault));
+        host_ints_cap = cap;
+    }
+    return host_ints;
+}
+
+void stream_wait(hipStream_t s) {
+    static const int spin_us = getenv("APDS_SPIN_US") ? atoi(getenv("APDS_SPIN_US")) : 0;   // (measured: no gain over the runtime's own wait on this box; kept as a switch)
+    if (spin_us > 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            const hipError_t e = hipStreamQuery(s);
+            if (e == hipSuccess) return;
+            if (e != hipErrorNotReady) HIP_CHECK(e);
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
+        }
+    }
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
 // side streams, their events and the join event: dropped with the thread's stream (release, device change)
 void ThreadCtx::drop_side() {
+    if (host_ints) (void)hipHostFree(host_ints);
+    host_ints = nullptr;
+    host_ints_cap = 0;
     for (hipStream_t* st : {&side, &side2})
         if (*st) {
             (void)hipStreamSynchronize(*st);
