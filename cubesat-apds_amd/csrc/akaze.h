@@ -46,6 +46,7 @@ struct LevelTable {
     const float* Ldet[AKAZE_MAX_LEVELS];
     uint8_t* mask[AKAZE_MAX_LEVELS];
     const uint32_t* list[AKAZE_MAX_LEVELS];   // the level's candidate list (unordered), counts in list_count[level]
+    float* ref[AKAZE_MAX_LEVELS];             // three floats per list entry: the refined (x, y, response) of a surviving candidate
 };
 
 // A batched launch: `n` images of one size through one grid (gridDim.z = n). Every image owns an identical workspace slab, `stride`

@@ -373,6 +373,140 @@ __global__ void subpixel_filter_kernel(LevelTable T, const int* __restrict__ lis
     }
 }
 
+// ---- ordered compaction without passes over the masks ------------------------------------------------------------------------------
+// Output order is level-major, row-major: a keypoint's position is the number of keypoints before it in the concatenated masks.
+// The mask-scan path below (kp_block_counts / kp_scan_offsets / emit_keypoints) reads all the masks twice (85 MB at 4096^2) to place
+// ~35 000 keypoints. Here the candidates place themselves: (1) subpixel_count_kernel, one thread per list entry: a survivor of the
+// suppression is refined; if it stays it keeps its refined values next to its list entry and counts itself in the 128-byte chunk
+// (`fine`) and the 128 KiB block (`coarse`, one counter per 128-byte line: same-line atomics serialise) of the masks it lies in;
+// (2) kp_scan_fine_kernel, one block per coarse block: exclusive prefix of the fine counts (+ the coarse blocks before it);
+// (3) emit_ranked_kernel, one thread per list entry: position = prefix of its chunk + the set flags before it inside the chunk
+// (one cache line of the mask). Same keypoints, same order, same values as the mask-scan path.
+static constexpr int FINE_SHIFT = 7, COARSE_SHIFT = 17, COARSE_PITCH = 32;
+static constexpr uint32_t REF_DEAD = 0xFFFFFFFFu;
+
+__global__ void subpixel_count_kernel(LevelTable T, const int* __restrict__ list_count, int lvl0, int* __restrict__ fine, int* __restrict__ coarse) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int lvl = lvl0 + blockIdx.y;
+    const int cnt = bofs(list_count, T.bstride)[lvl];
+    const uint32_t* __restrict__ list = bofs(T.list[lvl], T.bstride);
+    uint8_t* __restrict__ mask = bofs(T.mask[lvl], T.bstride);
+    const float* __restrict__ ldet = bofs(T.Ldet[lvl], T.bstride);
+    float* __restrict__ ref = bofs(T.ref[lvl], T.bstride);
+    fine = bofs(fine, T.bstride);
+    coarse = bofs(coarse, T.bstride);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const uint32_t e = list[i];
+        const int x = e & 0xFFFF, y = e >> 16;
+        const size_t p = (size_t)y * T.w[lvl] + x;
+        bool keep = mask[p] & 1;
+        Refined r{};
+        if (keep) {
+            r = refine(ldet, T.w[lvl], x, y, T.ratio[lvl]);
+            if (!r.ok) {
+                mask[p] = 2;   // survived the suppression, dropped by the refinement: bit 0 (= "is a keypoint") clear, byte non-zero
+                keep = false;
+            }
+        }
+        if (!keep) {
+            reinterpret_cast<uint32_t*>(ref)[3 * (size_t)i] = REF_DEAD;
+            continue;
+        }
+        ref[3 * (size_t)i] = r.x;
+        ref[3 * (size_t)i + 1] = r.y;
+        ref[3 * (size_t)i + 2] = r.response;
+        const long long eg = T.pix_offset[lvl] + (long long)p;
+        atomicAdd(&fine[eg >> FINE_SHIFT], 1);
+        atomicAdd(&coarse[(eg >> COARSE_SHIFT) * COARSE_PITCH], 1);
+    }
+}
+
+// fine[i] <- kp_base[0] + (number of keypoints in the chunks before chunk i); kp_base[1] <- kp_base[0] + all keypoints
+__global__ __launch_bounds__(1024) void kp_scan_fine_kernel(int* __restrict__ fine, const int* __restrict__ coarse, int n_fine, int* __restrict__ kp_base,
+                                                            size_t bstride) {
+    APDS_RAISE_WAVE_PRIORITY();
+    fine = bofs(fine, bstride);
+    coarse = bofs(coarse, bstride);
+    kp_base = bofs(kp_base, bstride);
+    __shared__ int wsum[16];
+    __shared__ int s_prefix;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int part = 0;
+    for (int cb = tid; cb < b; cb += 1024) part += coarse[(size_t)cb * COARSE_PITCH];
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) wsum[wv] = part;
+    __syncthreads();
+    if (tid == 0) {
+        int t = kp_base[0];
+        for (int k = 0; k < 16; k++) t += wsum[k];
+        s_prefix = t;
+    }
+    __syncthreads();
+    const int prefix = s_prefix;
+    const int idx = b * 1024 + tid;
+    const int v = idx < n_fine ? fine[idx] : 0;
+    int incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off);
+        if (lane >= off) incl += t;
+    }
+    __syncthreads();   // wsum is reused
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < wv; k++) before += wsum[k];
+    if (idx < n_fine) fine[idx] = prefix + before + incl - v;
+    if (b == (int)gridDim.x - 1 && tid == 1023) kp_base[1] = prefix + before + incl;
+}
+
+__global__ void emit_ranked_kernel(LevelTable T, const int* __restrict__ list_count, int lvl0, const uint8_t* __restrict__ flags,
+                                   const int* __restrict__ fine_excl, apds_keypoint* __restrict__ kps, int capacity, size_t kp_bstride) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int lvl = lvl0 + blockIdx.y;
+    const int cnt = bofs(list_count, T.bstride)[lvl];
+    const uint32_t* __restrict__ list = bofs(T.list[lvl], T.bstride);
+    const float* __restrict__ ref = bofs(T.ref[lvl], T.bstride);
+    flags = bofs(flags, T.bstride);
+    fine_excl = bofs(fine_excl, T.bstride);
+    kps = bofs(kps, kp_bstride);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cnt; i += gridDim.x * blockDim.x) {
+        const uint32_t rx = reinterpret_cast<const uint32_t*>(ref)[3 * (size_t)i];
+        if (rx == REF_DEAD) continue;
+        const uint32_t e = list[i];
+        const int x = e & 0xFFFF, y = e >> 16;
+        const long long eg = T.pix_offset[lvl] + (long long)y * T.w[lvl] + x;
+        // set flags (bit 0) in [chunk, eg): the chunk is one 128-byte line of the masks
+        const uint4* __restrict__ line = reinterpret_cast<const uint4*>(flags + (eg & ~127ll));
+        const int nb = (int)(eg & 127);
+        int pos = fine_excl[eg >> FINE_SHIFT];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint4 v = line[j];
+            const int r = nb - 16 * j;   // bytes of this word group that lie before eg
+            if (r <= 0) continue;
+            unsigned long long lo = ((unsigned long long)v.y << 32 | v.x) & 0x0101010101010101ull;
+            unsigned long long hi = ((unsigned long long)v.w << 32 | v.z) & 0x0101010101010101ull;
+            if (r < 8) {
+                lo &= (1ull << (8 * r)) - 1;
+                hi = 0;
+            } else if (r < 16) {
+                hi &= r == 8 ? 0ull : (1ull << (8 * (r - 8))) - 1;
+            }
+            pos += __popcll(lo) + __popcll(hi);
+        }
+        if (pos >= capacity) continue;
+        apds_keypoint kp;
+        kp.x = __uint_as_float(rx);
+        kp.y = ref[3 * (size_t)i + 1];
+        kp.size = (T.esigma[lvl] * 1.5f) * 2.0f;
+        kp.angle = 0.0f;
+        kp.response = ref[3 * (size_t)i + 2];
+        kp.octave = T.octave[lvl];
+        kp.class_id = lvl;
+        kps[pos] = kp;
+    }
+}
+
 static constexpr int SCAN_BLOCK = 1024;
 
 // flags[lo, hi) = the masks of a run of consecutive levels (a stage); block b covers the 16 KiB from (lo & ~15) + b * 16 KiB. Bytes
@@ -1059,8 +1193,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         total_pix += (long long)e.w * e.h;
     }
     const int nblocks = ceil_div(total_pix, KP_BYTES_PER_BLOCK);
+    const int n_fine = (int)((total_pix >> FINE_SHIFT) + 1), n_coarse = (int)((total_pix >> COARSE_SHIFT) + 1);
     // zero-initialised head of the slab (one 2-D memset clears it for the whole batch): counters, then keypoint masks and statuses
-    int *list_count, *hist, *pend_count, *block_counts, *kp_base;
+    int *list_count, *hist, *pend_count, *block_counts, *kp_base, *fine_counts, *coarse_counts;
     unsigned int* hmax_bits;
     float *k_oct, *gray, *tmpS, *tmpF, *tmpP;
     uint8_t *mask_all, *status_all;
@@ -1073,7 +1208,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         hist = A.take<int>(300);
         pend_count = A.take<int>(3 * AKAZE_MAX_LEVELS * PEND_PITCH);
         kp_base = A.take<int>(8);                 // kp_base[k] = keypoints of the stages before stage k (kp_base[0] stays 0)
-        mask_all = A.take<uint8_t>((size_t)total_pix);
+        fine_counts = A.take<int>(n_fine + 1024);      // ranked compaction: keypoints per 128-byte chunk of the masks (then their prefix)
+        coarse_counts = A.take<int>((size_t)n_coarse * COARSE_PITCH);
+        mask_all = A.take<uint8_t>((size_t)total_pix + 128);   // (+ a line: the last chunk is read whole)
         status_all = A.take<uint8_t>((size_t)total_pix);
         zero_bytes = A.off;
         k_oct = A.take<float>(8);
@@ -1182,6 +1319,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         T.mask[i] = A.mask[i] = mask_all + e.pix_offset;
         A.status[i] = status_all + e.pix_offset;
         T.list[i] = A.list[i] = lists[i];
+        T.ref[i] = reinterpret_cast<float*>(pend[i]);   // the pending lists are idle once the suppression passes are done
         A.pend_cap[i] = ((e.w + 1) / 2) * ((e.h + 1) / 2);
         A.pend[i] = pend[i];
     }
@@ -1223,14 +1361,25 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             run_passes(1, std::max(prev_m, 0), std::min(m, L - 1) - 1, prev_m + 1, m);      // phase 1
         }
         const int a = prev_m + 1;
-        hipLaunchKernelGGL(subpixel_filter_kernel, dim3(B > 1 ? 16 : 64, m - a + 1, B), dim3(256), 0, s_kp, T, (const int*)list_count, a);
-        const long long lo = T.pix_offset[a], hi = T.pix_offset[m + 1];
-        const int nb = ceil_div(hi - (lo & ~15ll), KP_BYTES_PER_BLOCK);
         int* base_k = kp_base + n_stage;
-        hipLaunchKernelGGL(kp_block_counts_kernel, dim3(nb, 1, B), dim3(SCAN_BLOCK), 0, s_kp, (const uint8_t*)mask_all, lo, hi, block_counts, slab);
-        hipLaunchKernelGGL(kp_scan_offsets_kernel, dim3(1, 1, B), dim3(1024), 0, s_kp, block_counts, nb, base_k, slab);
-        hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nb, 1, B), dim3(SCAN_BLOCK), 0, s_kp, T, (const uint8_t*)mask_all, lo, hi, (const int*)block_counts,
-                           (const int*)base_k, kps_out, capacity, kp_bstride);
+        static const int ranked_env = getenv("APDS_KP_RANKED") ? atoi(getenv("APDS_KP_RANKED")) : 1;
+        if (ranked_env && prev_m < 0 && m == L - 1) {
+            // all levels in one stage: the candidates count and place themselves (no pass over the masks)
+            const dim3 cgrid(B > 1 ? 16 : 128, L, B);
+            hipLaunchKernelGGL(subpixel_count_kernel, cgrid, dim3(256), 0, s_kp, T, (const int*)list_count, 0, fine_counts, coarse_counts);
+            hipLaunchKernelGGL(kp_scan_fine_kernel, dim3(ceil_div(n_fine, 1024), 1, B), dim3(1024), 0, s_kp, fine_counts, (const int*)coarse_counts, n_fine,
+                               base_k, slab);
+            hipLaunchKernelGGL(emit_ranked_kernel, cgrid, dim3(256), 0, s_kp, T, (const int*)list_count, 0, (const uint8_t*)mask_all, (const int*)fine_counts,
+                               kps_out, capacity, kp_bstride);
+        } else {
+            hipLaunchKernelGGL(subpixel_filter_kernel, dim3(B > 1 ? 16 : 64, m - a + 1, B), dim3(256), 0, s_kp, T, (const int*)list_count, a);
+            const long long lo = T.pix_offset[a], hi = T.pix_offset[m + 1];
+            const int nb = ceil_div(hi - (lo & ~15ll), KP_BYTES_PER_BLOCK);
+            hipLaunchKernelGGL(kp_block_counts_kernel, dim3(nb, 1, B), dim3(SCAN_BLOCK), 0, s_kp, (const uint8_t*)mask_all, lo, hi, block_counts, slab);
+            hipLaunchKernelGGL(kp_scan_offsets_kernel, dim3(1, 1, B), dim3(1024), 0, s_kp, block_counts, nb, base_k, slab);
+            hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nb, 1, B), dim3(SCAN_BLOCK), 0, s_kp, T, (const uint8_t*)mask_all, lo, hi,
+                               (const int*)block_counts, (const int*)base_k, kps_out, capacity, kp_bstride);
+        }
         // ---- a1.8 / a1.9 over the stage's keypoints [kp_base[k], kp_base[k + 1]), capped at the output capacity
         hipLaunchKernelGGL(orientation_kernel, dim3(kp_blocks, 1, B), dim3(256), 0, s_kp, T, kps_out, (const int*)base_k, std::min(capacity, max_points),
                            kp_bstride, ang_step, nkeys);
