@@ -1201,13 +1201,14 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     uint8_t *mask_all, *status_all;
     std::vector<uint32_t*> lists(L), pend(L);
     std::vector<float*> lsm(L);
-    size_t zero_bytes = 0;
+    size_t zero_bytes = 0, small_zero_bytes = 0;
     auto layout = [&](Arena& A) {
         list_count = A.take<int>(AKAZE_MAX_LEVELS);
         hmax_bits = A.take<unsigned int>(1);
         hist = A.take<int>(300);
         pend_count = A.take<int>(3 * AKAZE_MAX_LEVELS * PEND_PITCH);
         kp_base = A.take<int>(8);                 // kp_base[k] = keypoints of the stages before stage k (kp_base[0] stays 0)
+        small_zero_bytes = A.off;                 // (a multiple of 256)
         fine_counts = A.take<int>(n_fine + 1024);      // ranked compaction: keypoints per 128-byte chunk of the masks (then their prefix)
         coarse_counts = A.take<int>((size_t)n_coarse * COARSE_PITCH);
         mask_all = A.take<uint8_t>((size_t)total_pix + 128);   // (+ a line: the last chunk is read whole)
@@ -1242,9 +1243,29 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     bt.n = B;
     bt.stride = slab;
     bt.img_stride = img_bstride;
+    if (fork_doh && c.fork_open) {   // an earlier call failed between fork and join: its side-stream kernels may still use the workspace
+        HIP_CHECK(hipStreamSynchronize(c.side_stream()));
+        if (c.side2) HIP_CHECK(hipStreamSynchronize(c.side2));
+        c.fork_open = false;
+    }
     // (the runtime's fill kernel clears the 44 MB of a 4096^2 frame at 1.7 TB/s; 16-byte stores from a wide grid are quicker)
-    hipLaunchKernelGGL(zero_slab_heads_kernel, dim3((unsigned)std::min<size_t>(B > 1 ? 1024 : 4096, (zero_bytes / 16 + 255) / 256), 1, B), dim3(256), 0, s,
-                       reinterpret_cast<uint4*>(real.base), zero_bytes, slab);
+    auto zero_range = [&](size_t from, size_t to, hipStream_t zs) {
+        const size_t bytes = to - from;
+        hipLaunchKernelGGL(zero_slab_heads_kernel, dim3((unsigned)std::min<size_t>(B > 1 ? 1024 : 4096, (bytes / 16 + 255) / 256), 1, B), dim3(256), 0, zs,
+                           reinterpret_cast<uint4*>(real.base + from), bytes, slab);
+    };
+    // A large frame's masks, statuses and chunk counters (178 MB at 4096^2) are first touched by the level-0 Hessian kernel, which
+    // runs on the side stream: they are cleared there, beside the base stage, and only the few counters the main chain needs at once
+    // are cleared in front of it. (Nothing of the previous call is in flight on either stream: every call ends with a read-back.)
+    static const int zero_side_env = getenv("APDS_ZERO_SIDE") ? atoi(getenv("APDS_ZERO_SIDE")) : 0;   // (measured: no gain, the base stage is bandwidth-bound itself)
+    const bool zero_on_side = zero_side_env && fork_doh && zero_bytes - small_zero_bytes >= ((size_t)8 << 20);
+    if (zero_on_side) {
+        zero_range(0, small_zero_bytes, s);
+        c.fork_open = true;
+        zero_range(small_zero_bytes, zero_bytes, c.side_stream());
+    } else {
+        zero_range(0, zero_bytes, s);
+    }
     int* counts_dev = B > 1 ? c.alloc_n<int>(B) : nullptr;
 
     // ---- a1.1 / a1.2 / a1.3
@@ -1292,11 +1313,6 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     const bool staged = fork_doh && stages_mode && n_oct >= 3 && ((size_t)W * H * B >= ((size_t)1 << 23) || stages_mode == 2);
     const int early_trigger = staged ? 4 * (n_oct - 2) : -1;   // the level whose Hessian launch releases the early stage
     hipStream_t s_kp = staged ? c.side_stream2() : s;
-    if (fork_doh && c.fork_open) {   // an earlier call failed between fork and join: its side-stream kernels may still use the workspace
-        HIP_CHECK(hipStreamSynchronize(s_doh));
-        if (c.side2) HIP_CHECK(hipStreamSynchronize(c.side2));
-        c.fork_open = false;
-    }
     // ---- level tables for the keypoint kernels (pointers of image 0; kernels add blockIdx.z * slab)
     LevelTable T{};
     SuppressArgs A{};
@@ -1482,7 +1498,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         }
     }
     if (fork_doh) {   // join: everything after this point reads what the Hessian kernels wrote
-        if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, hipEventDisableTiming));
+        if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, stream_event_flags()));
         HIP_CHECK(hipEventRecord(c.join_event, s_doh));
         HIP_CHECK(hipStreamWaitEvent(s, c.join_event, 0));
         c.fork_open = false;

@@ -89,6 +89,7 @@ std::atomic<int>& live_contexts();   // host threads that currently own a stream
 // wait for a stream: poll for a bounded time (a blocking wait costs tens of microseconds to wake up, which is a tenth of a small
 // tile's extraction), then block
 void stream_wait(hipStream_t s);
+unsigned stream_event_flags();   // flags for events that only order GPU streams of one device
 
 inline hipStream_t pick_stream(void* s) { return s ? static_cast<hipStream_t>(s) : ctx().stream; }
 

@@ -107,10 +107,20 @@ void ThreadCtx::drop_side() {
     fork_open = false;
 }
 
+// Events that order one GPU stream after another of the same device: no timing and no system-scope fence when the event completes.
+// The default event makes the producer's data host-visible (cache write-back + invalidate in front of the next kernel: ~3 us per
+// event, 40 us per 4096^2 frame with its 17 fork / join events); a stream-to-stream dependency on one device is covered by the
+// agent-scope release / acquire every kernel dispatch carries (the parity tests at every tile size run with this setting: a plane
+// that was not written back would be stale as a whole for the small tiles). APDS_EVENT_SCOPE=1: the runtime's default event.
+unsigned stream_event_flags() {
+    static const int scope = getenv("APDS_EVENT_SCOPE") ? atoi(getenv("APDS_EVENT_SCOPE")) : 2;
+    return hipEventDisableTiming | (scope == 2 ? (unsigned)hipEventDisableSystemFence : scope == 0 ? (unsigned)hipEventReleaseToDevice : 0u);
+}
+
 hipEvent_t ThreadCtx::fork_event(size_t i) {
     while (fork_events.size() <= i) {
         hipEvent_t e = nullptr;
-        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&e, stream_event_flags()));
         fork_events.push_back(e);
     }
     return fork_events[i];
