@@ -1246,6 +1246,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     if (fork_doh && c.fork_open) {   // an earlier call failed between fork and join: its side-stream kernels may still use the workspace
         HIP_CHECK(hipStreamSynchronize(c.side_stream()));
         if (c.side2) HIP_CHECK(hipStreamSynchronize(c.side2));
+        if (c.side3) HIP_CHECK(hipStreamSynchronize(c.side3));
         c.fork_open = false;
     }
     // (the runtime's fill kernel clears the 44 MB of a 4096^2 frame at 1.7 TB/s; 16-byte stores from a wide grid are quicker)
@@ -1295,6 +1296,11 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // before the suppression): it goes to a second stream, so the latency-bound launches of the small octaves overlap the
     // smoothing and diffusion launches of the levels that follow. Lsmooth then needs a plane per level instead of a shared one.
     hipStream_t s_doh = fork_doh ? c.side_stream() : s;
+    // The Hessian kernels of the small levels (latency-bound, ~10 us each) queue up behind the large levels' (throughput-bound, ~100 us
+    // each, slowed further by the level chain they share the GPU with) and finish long after the level chain: they get a stream of
+    // their own, beside the large ones. (Not in staged mode, whose early stage is released by an event on one Hessian stream.)
+    static const int doh_split = getenv("APDS_DOH_SPLIT") ? atoi(getenv("APDS_DOH_SPLIT")) : 0;   // (measured: no gain, 1.867 vs 1.854 ms; kept as a switch)
+    hipStream_t s_doh_small = s_doh;   // assigned below, once `staged` is known
     // Keypoint stages. Levels 0 .. m are FINAL (cross-level suppression done) once the Hessian of level m + 1 exists (see run_stage).
     // The last two octaves are a chain of short, latency-bound launches that leaves the GPU almost idle, and the large octaves before
     // them hold nearly all keypoints: the EARLY stage = suppression passes + sub-pixel filter + ordered compaction + orientation +
@@ -1313,6 +1319,8 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     const bool staged = fork_doh && stages_mode && n_oct >= 3 && ((size_t)W * H * B >= ((size_t)1 << 23) || stages_mode == 2);
     const int early_trigger = staged ? 4 * (n_oct - 2) : -1;   // the level whose Hessian launch releases the early stage
     hipStream_t s_kp = staged ? c.side_stream2() : s;
+    const bool split_doh = fork_doh && doh_split && !staged && (size_t)W * H * B > ((size_t)1 << 20);
+    if (split_doh) s_doh_small = c.side_stream3();
     // ---- level tables for the keypoint kernels (pointers of image 0; kernels add blockIdx.z * slab)
     LevelTable T{};
     SuppressArgs A{};
@@ -1404,6 +1412,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         n_stage++;
     };
     int stage_prev_m = -1;
+    auto doh_stream = [&](int lvl) { return split_doh && (size_t)ev[lvl].w * ev[lvl].h * B <= ((size_t)1 << 20) ? s_doh_small : s_doh; };
     // ---- a1.4 / a1.5 per level: Lsmooth -> (Lx, Ly, Ldet) and flow; FED steps ping-pong into Lt[i]
     for (int i = 0; i < L; i++) {
         LevelDesc& e = ev[i];
@@ -1445,14 +1454,34 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             float st[32];
             // the last level's Hessian kernel is on the critical path (nothing follows to hide it): its Lsmooth comes from a separate
             // smoothing pass, so that it runs beside the level's FED steps
-            const bool smooth_first = !fused_level || (fork_doh && i == L - 1);
-            if (smooth_first) launch_smooth_flow(P, lsm[i], tmpF, e.w, e.h, g10, k_oct + e.octave, s, bt);   // Lsmooth and the conductivity in one pass
             smooth = lsm[i];
             auto fork_here = [&]() {   // Lsmooth of this level exists from here on
                 if (!fork_doh) return;
                 HIP_CHECK(hipEventRecord(c.fork_event(i), s));
-                HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(i), 0));
+                HIP_CHECK(hipStreamWaitEvent(doh_stream(i), c.fork_event(i), 0));
             };
+            // large levels: the smoothing pass and the first group of FED steps in one pass over register strips (level_strip_kernel)
+            static const int level_strip = getenv("APDS_LEVEL_STRIP") ? atoi(getenv("APDS_LEVEL_STRIP")) : 1;
+            bool strip_done = false;
+            // (1 .. 8 Mpx by default: on the largest levels the Hessian kernel beside it is VALU-bound and the strips' recomputed halos
+            // cost more issue slots than the saved traffic returns: 4096^2 frame 1.83 ms without, 1.85 with; 2048^2 0.82 / 0.79.
+            // APDS_LEVEL_STRIP=3: every level of at least 1 Mpx, 2: every level, 0: never)
+            const size_t lpx = (size_t)e.w * e.h * B;
+            if (!fused_level && e.nsteps > 0 && level_strip &&
+                (level_strip == 2 || (lpx >= (size_t)1 << 20 && (level_strip == 3 || lpx < (size_t)1 << 23)))) {
+                const int g = (e.nsteps + launches - 1) / launches;
+                float* out = ((launches - 1) % 2 == 0) ? e.Lt : tmpP;
+                for (int j = 0; j < g; j++) st[j] = e.tau[j] * 0.5f;
+                if (g <= 4 && launch_level_strips(P, lsm[i], launches > 1 ? tmpF : nullptr, out, e.w, e.h, g10, k_oct + e.octave, st, g, s, bt)) {
+                    strip_done = true;
+                    k = g;
+                    in = out;
+                    pass = 1;
+                    fork_here();
+                }
+            }
+            const bool smooth_first = !strip_done && (!fused_level || (fork_doh && i == L - 1));
+            if (smooth_first) launch_smooth_flow(P, lsm[i], tmpF, e.w, e.h, g10, k_oct + e.octave, s, bt);   // Lsmooth and the conductivity in one pass
             if (smooth_first) fork_here();
             if (fused_level) {
                 float* out = ((launches - 1) % 2 == 0) ? e.Lt : tmpP;
@@ -1484,10 +1513,10 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         if (fork_doh && i == 0) {   // level 0: Lsmooth is Lt[0], ready after the base stage
             c.fork_open = true;
             HIP_CHECK(hipEventRecord(c.fork_event(0), s));
-            HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
+            HIP_CHECK(hipStreamWaitEvent(doh_stream(0), c.fork_event(0), 0));
         }
         launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i,
-                         s_doh, bt);
+                         doh_stream(i), bt);
         if (i == early_trigger) {
             // the Hessian of this level exists once the launch above is done: all levels below can be finished. (The stage also
             // reads Lt / Lxy of its own levels: complete before this level's smoothing pass, which the launch above follows.)
@@ -1501,6 +1530,11 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, stream_event_flags()));
         HIP_CHECK(hipEventRecord(c.join_event, s_doh));
         HIP_CHECK(hipStreamWaitEvent(s, c.join_event, 0));
+        if (split_doh) {
+            if (!c.join_event3) HIP_CHECK(hipEventCreateWithFlags(&c.join_event3, stream_event_flags()));
+            HIP_CHECK(hipEventRecord(c.join_event3, s_doh_small));
+            HIP_CHECK(hipStreamWaitEvent(s, c.join_event3, 0));
+        }
         c.fork_open = false;
     }
     HIP_CHECK(hipGetLastError());

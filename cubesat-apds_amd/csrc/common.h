@@ -74,6 +74,9 @@ struct ThreadCtx {
     int* pinned_ints(size_t n);                 // valid until the next call with a larger n
     hipStream_t side_stream();                  // created on first use
     hipStream_t side_stream2();
+    hipStream_t side3 = nullptr;                // akaze: the Hessian kernels of the small levels (normal priority)
+    hipStream_t side_stream3();
+    hipEvent_t join_event3 = nullptr;
     void drop_side();
     hipEvent_t fork_event(size_t i);            // i-th reusable event (no timing)
 

@@ -89,12 +89,17 @@ void stream_wait(hipStream_t s) {
     HIP_CHECK(hipStreamSynchronize(s));
 }
 
+hipStream_t ThreadCtx::side_stream3() {
+    if (!side3) HIP_CHECK(hipStreamCreateWithPriority(&side3, hipStreamNonBlocking, 0));
+    return side3;
+}
+
 // side streams, their events and the join event: dropped with the thread's stream (release, device change)
 void ThreadCtx::drop_side() {
     if (host_ints) (void)hipHostFree(host_ints);
     host_ints = nullptr;
     host_ints_cap = 0;
-    for (hipStream_t* st : {&side, &side2})
+    for (hipStream_t* st : {&side, &side2, &side3})
         if (*st) {
             (void)hipStreamSynchronize(*st);
             (void)hipStreamDestroy(*st);
@@ -104,6 +109,8 @@ void ThreadCtx::drop_side() {
     fork_events.clear();
     if (join_event) (void)hipEventDestroy(join_event);
     join_event = nullptr;
+    if (join_event3) (void)hipEventDestroy(join_event3);
+    join_event3 = nullptr;
     fork_open = false;
 }
 

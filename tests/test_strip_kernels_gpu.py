@@ -20,3 +20,28 @@ def test_akaze_parity_with_strips_forced_on_every_level(gpu_pkg):
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def _rerun(env_extra):
+    env = dict(os.environ, **env_extra)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_akaze_gpu.py"),
+                        os.path.join("tests", "test_fuzz_gpu.py") + "::test_akaze_random_shapes", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_akaze_parity_with_level_strips_on_every_level(gpu_pkg):
+    """level_strip_kernel (smoothing + conductivity + FED steps on register strips, borders included) normally serves levels of
+    1 .. 8 Mpx: here it serves every level of every test image, so its border waves meet the small and odd-sized ones."""
+    _rerun({"APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0"})
+
+
+def test_akaze_parity_with_lds_fused_levels_on_every_level(gpu_pkg):
+    """level_fused_kernel (one launch per level, register patches exchanging through LDS) normally serves levels up to 1 Mpx."""
+    _rerun({"APDS_LEVEL_FUSE": "2", "APDS_LEVEL_STRIP": "0"})
+
+
+def test_akaze_parity_on_the_unfused_level_path_and_mask_scan_compaction(gpu_pkg):
+    """the round-1 path: separate smoothing / FED launches per level, keypoints placed by two passes over the masks"""
+    _rerun({"APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STRIP": "0", "APDS_KP_RANKED": "0", "APDS_EVENT_SCOPE": "1"})
