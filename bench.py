@@ -48,6 +48,27 @@ def detect_algorithmic_bytes(w, h):
     return total
 
 
+def _debug_solo(tag, frames, T, L, check, pl, dev, torch):
+    """APDS_BENCH_DEBUG_SOLO=1: stand-alone extraction time at this point of the setup (stderr)."""
+    if os.environ.get("APDS_BENCH_DEBUG_SOLO") != "1":
+        return
+    cap = (1 << 18) - 1
+    kps = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+    desc = torch.empty((cap, 64), dtype=torch.uint8, device=dev)
+    st = torch.cuda.Stream(dev)
+    n = C.c_int(0)
+    with torch.cuda.stream(st):
+        def go(reps):
+            for rep in range(reps):
+                f = frames[rep % len(frames)]
+                check(L.apds_dev_akaze_extract(f.data_ptr(), T, T, f.shape[2], f.stride(0), cap, kps.data_ptr(), desc.data_ptr(), cap, C.byref(n), pl.torch_stream()))
+            torch.cuda.synchronize()
+        go(3)
+        t0 = time.perf_counter()
+        go(10)
+        print(f"[debug solo] {tag}: {(time.perf_counter() - t0) * 100:.3f} ms per extraction", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,6 +145,7 @@ def main():
     shift = (37, 52)   # (dy, dx): DB images are np.roll'ed frames, so the true homography is a translation
     frames_np = [synth.make_tile(T, T, frame_index=rank * args.frames + i) for i in range(args.frames)]
     frames = [torch.from_numpy(f).to(dev) for f in frames_np]
+    _debug_solo('after frames', frames, T, L, check, pl, dev, torch)
     cap = pkg.feature_extraction.MAX_POINTS
     kps = torch.empty((cap, 7), dtype=torch.float32, device=dev)
     desc = torch.empty((cap, 64), dtype=torch.uint8, device=dev)
@@ -139,6 +161,7 @@ def main():
         planted_rows.append(desc[:n.value].clone())
         planted_xy.append(kps[:n.value, 0:2].clone())
     mine_rows, mine_xy = torch.cat(planted_rows), torch.cat(planted_xy)
+    _debug_solo('after planting', frames, T, L, check, pl, dev, torch)
     if world > 1:
         cnt_t = torch.zeros(world, dtype=torch.int64, device=dev)
         pl._gather_into(dist, group, cnt_t, torch.tensor([mine_rows.shape[0]], dtype=torch.int64, device=dev))
@@ -204,6 +227,31 @@ def main():
         perm = torch.randperm(NDB, device=dev, generator=gperm)
         db_local, db_xy = db_local[perm].contiguous(), db_xy[perm].contiguous()
     torch.cuda.synchronize()
+    _debug_solo('after DB build', frames, T, L, check, pl, dev, torch)
+    # stand-alone extraction time (no other stage on the GPU) for the detect roofline: BEFORE the pipeline and its streams exist. (The
+    # runtime maps streams onto a few hardware queues; once the pipeline's eight streams are around, the extraction's side stream shares
+    # a queue with its main stream and the same call takes 2.2 ms instead of 1.9: measured both ways, profiles/r02.)
+    solo = pl.FramePipeline(db_local[:4096].contiguous(), db_xy, index_base=0, group=None, device=str(dev))
+    with torch.cuda.stream(solo.stream):
+        nk = C.c_int(0)
+
+        def extract_once(rep):
+            f = frames[rep % len(frames)]
+            check(L.apds_dev_akaze_extract(f.data_ptr(), T, T, f.shape[2], f.stride(0), solo.cap, solo.kps.data_ptr(), solo.desc.data_ptr(), solo.cap,
+                                           C.byref(nk), pl.torch_stream()))
+        for rep in range(3):
+            extract_once(rep)
+        torch.cuda.synchronize()
+        akaze_solo_n = 10
+
+        def timed_solo():
+            ts = time.perf_counter()
+            for rep in range(akaze_solo_n):
+                extract_once(rep)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - ts) * 1e3
+        akaze_solo_ms = timed_solo()
+    del solo
     if args.serial:
         pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
     else:
@@ -246,24 +294,6 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    # stand-alone extraction time (no other stage on the GPU) for the detect roofline; outside the timed region
-    solo = pl.FramePipeline(db_local[:4096].contiguous(), db_xy, index_base=0, group=None, device=str(dev))
-    with torch.cuda.stream(solo.stream):
-        nk = C.c_int(0)
-
-        def extract_once(rep):
-            f = frames[rep % len(frames)]
-            check(L.apds_dev_akaze_extract(f.data_ptr(), T, T, f.shape[2], f.stride(0), solo.cap, solo.kps.data_ptr(), solo.desc.data_ptr(), solo.cap,
-                                           C.byref(nk), pl.torch_stream()))
-        for rep in range(3):
-            extract_once(rep)
-        torch.cuda.synchronize()
-        akaze_solo_n = 10
-        ts = time.perf_counter()
-        for rep in range(akaze_solo_n):
-            extract_once(rep)
-        torch.cuda.synchronize()
-        akaze_solo_ms = (time.perf_counter() - ts) * 1e3
     topk_ms, topk_n = timers.get("hamming_topk", (0.0, 0))
     sample_ms, sample_n = timers.get("hamming_topk_sample", (0.0, 0))
     akaze_ms, akaze_n = timers.get("akaze_extract", (0.0, 0))
@@ -337,7 +367,8 @@ def main():
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": detect_algorithmic_bytes(T, T) / (akaze_solo_ms / max(akaze_solo_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS if akaze_solo_n else 0.0,
                                 "ms_standalone": akaze_solo_ms / max(akaze_solo_n, 1),
-                                "note": "whole extraction (incl. orientation, descriptors, the count read-back), 10 back-to-back calls on resident frames timed by the wall clock with nothing else on the GPU, after the timed region, against the detect stages' algorithmic bytes; stages_ms_per_step.akaze_extract is its wall span while overlapped with the match (two frames are extracted concurrently, so the span may exceed the step time)"},
+                                "library_contexts_alive": int(L.apds_live_contexts()),
+                                "note": "whole extraction (incl. orientation, descriptors, the count read-back), 10 back-to-back calls on resident frames timed by the wall clock with nothing else on the GPU, before the pipeline's streams are created, against the detect stages' algorithmic bytes; stages_ms_per_step.akaze_extract is its wall span while overlapped with the match (two frames are extracted concurrently, so the span may exceed the step time)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pkg, frames_np[0], db_local, int(K), args.filter_strength, db_xy, stats[0])

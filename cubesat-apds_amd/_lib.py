@@ -19,7 +19,7 @@ ERR_NOT_IMPLEMENTED = -213
 
 # every symbol include/apds.h declares (checked by tests/test_abi.py)
 SYMBOLS = [
-    "apds_last_error", "apds_free", "apds_device_count", "apds_set_device", "apds_build_info", "apds_thread_release", "apds_release_cached_memory",
+    "apds_last_error", "apds_free", "apds_device_count", "apds_set_device", "apds_build_info", "apds_thread_release", "apds_live_contexts", "apds_release_cached_memory",
     "apds_akaze_extract", "apds_akaze_extract_batch", "apds_dev_akaze_extract_batch", "apds_tile_extract", "apds_tile_extract_batch", "apds_get_knn_matches", "apds_get_bruteforce_matches", "apds_knn_match",
     "apds_get_points_from_matches", "apds_find_homography", "apds_find_homography_ex", "apds_raster_to_mat",
     "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_match_lds_cap", "apds_dev_match_last_launch_lds", "apds_dev_ratio_filter",
@@ -62,6 +62,7 @@ def lib():
             "apds_device_count": (i, []),
             "apds_set_device": (i, [i]),
             "apds_thread_release": (i, []),
+            "apds_live_contexts": (i, []),
             "apds_release_cached_memory": (i, []),
             "apds_build_info": (C.c_char_p, []),
             "apds_akaze_extract": (i, [vp, i, i, i, sz, i, pp, pp, ip, ip]),

@@ -1244,7 +1244,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     bt.stride = slab;
     bt.img_stride = img_bstride;
     if (fork_doh && c.fork_open) {   // an earlier call failed between fork and join: its side-stream kernels may still use the workspace
-        HIP_CHECK(hipStreamSynchronize(c.side_stream()));
+        if (c.side) HIP_CHECK(hipStreamSynchronize(c.side));
+        for (hipStream_t st : c.side_pool)
+            if (st) HIP_CHECK(hipStreamSynchronize(st));
         if (c.side2) HIP_CHECK(hipStreamSynchronize(c.side2));
         if (c.side3) HIP_CHECK(hipStreamSynchronize(c.side3));
         c.fork_open = false;
@@ -1263,7 +1265,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     if (zero_on_side) {
         zero_range(0, small_zero_bytes, s);
         c.fork_open = true;
-        zero_range(small_zero_bytes, zero_bytes, c.side_stream());
+        zero_range(small_zero_bytes, zero_bytes, side_stream_beside(s));
     } else {
         zero_range(0, zero_bytes, s);
     }
@@ -1295,7 +1297,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // The Hessian / extrema kernel of a level hangs off the main chain (it only needs the level's Lsmooth and nothing waits for it
     // before the suppression): it goes to a second stream, so the latency-bound launches of the small octaves overlap the
     // smoothing and diffusion launches of the levels that follow. Lsmooth then needs a plane per level instead of a shared one.
-    hipStream_t s_doh = fork_doh ? c.side_stream() : s;
+    hipStream_t s_doh = fork_doh ? side_stream_beside(s) : s;
     // The Hessian kernels of the small levels (latency-bound, ~10 us each) queue up behind the large levels' (throughput-bound, ~100 us
     // each, slowed further by the level chain they share the GPU with) and finish long after the level chain: they get a stream of
     // their own, beside the large ones. (Not in staged mode, whose early stage is released by an event on one Hessian stream.)
@@ -1463,12 +1465,11 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             // large levels: the smoothing pass and the first group of FED steps in one pass over register strips (level_strip_kernel)
             static const int level_strip = getenv("APDS_LEVEL_STRIP") ? atoi(getenv("APDS_LEVEL_STRIP")) : 1;
             bool strip_done = false;
-            // (1 .. 8 Mpx by default: on the largest levels the Hessian kernel beside it is VALU-bound and the strips' recomputed halos
-            // cost more issue slots than the saved traffic returns: 4096^2 frame 1.83 ms without, 1.85 with; 2048^2 0.82 / 0.79.
-            // APDS_LEVEL_STRIP=3: every level of at least 1 Mpx, 2: every level, 0: never)
+            // (every level of at least 1 Mpx. On the 16 Mpx levels of a 4096^2 frame the gain is within the box-to-box noise: the Hessian
+            // kernel beside them is VALU-bound and the strips' recomputed halos cost issue slots — 1.89 against 1.93 ms in one run, 1.85
+            // against 1.83 in another; 2048^2: 0.79 against 0.82. APDS_LEVEL_STRIP=2: every level whatever its size, 0: never)
             const size_t lpx = (size_t)e.w * e.h * B;
-            if (!fused_level && e.nsteps > 0 && level_strip &&
-                (level_strip == 2 || (lpx >= (size_t)1 << 20 && (level_strip == 3 || lpx < (size_t)1 << 23)))) {
+            if (!fused_level && e.nsteps > 0 && level_strip && (level_strip == 2 || lpx >= (size_t)1 << 20)) {
                 const int g = (e.nsteps + launches - 1) / launches;
                 float* out = ((launches - 1) % 2 == 0) ? e.Lt : tmpP;
                 for (int j = 0; j < g; j++) st[j] = e.tau[j] * 0.5f;

@@ -73,6 +73,9 @@ struct ThreadCtx {
     size_t host_ints_cap = 0;
     int* pinned_ints(size_t n);                 // valid until the next call with a larger n
     hipStream_t side_stream();                  // created on first use
+    // a side stream that really runs beside `caller` (see side_stream_beside in misc.hip); cached per caller stream
+    hipStream_t side_pool[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side_probe_caller = nullptr, side_probe_choice = nullptr;
     hipStream_t side_stream2();
     hipStream_t side3 = nullptr;                // akaze: the Hessian kernels of the small levels (normal priority)
     hipStream_t side_stream3();
@@ -92,6 +95,11 @@ std::atomic<int>& live_contexts();   // host threads that currently own a stream
 // wait for a stream: poll for a bounded time (a blocking wait costs tens of microseconds to wake up, which is a tenth of a small
 // tile's extraction), then block
 void stream_wait(hipStream_t s);
+// A stream of the calling thread whose kernels run CONCURRENTLY with kernels on `caller`. The runtime maps streams onto a few
+// hardware queues in creation order; two streams on one queue serialise, and which queue the caller's stream sits on cannot be
+// asked. So: four candidates (consecutive creations: different queues), each timed once with a spinning one-wave kernel on it and one
+// on `caller`; the candidate whose pair finishes first does not share the caller's queue. ~0.3 ms, once per (thread, caller stream).
+hipStream_t side_stream_beside(hipStream_t caller);
 unsigned stream_event_flags();   // flags for events that only order GPU streams of one device
 
 inline hipStream_t pick_stream(void* s) { return s ? static_cast<hipStream_t>(s) : ctx().stream; }

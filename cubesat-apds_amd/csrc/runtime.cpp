@@ -99,7 +99,8 @@ void ThreadCtx::drop_side() {
     if (host_ints) (void)hipHostFree(host_ints);
     host_ints = nullptr;
     host_ints_cap = 0;
-    for (hipStream_t* st : {&side, &side2, &side3})
+    side_probe_caller = side_probe_choice = nullptr;
+    for (hipStream_t* st : {&side, &side2, &side3, &side_pool[0], &side_pool[1], &side_pool[2], &side_pool[3]})
         if (*st) {
             (void)hipStreamSynchronize(*st);
             (void)hipStreamDestroy(*st);
@@ -280,6 +281,8 @@ int apds_release_cached_memory(void) {
         c.free.clear();
     });
 }
+
+int apds_live_contexts(void) { return live_contexts().load(); }
 
 int apds_thread_release(void) {
     return guarded([&] {

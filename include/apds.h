@@ -255,6 +255,9 @@ int apds_stream_destroy(void* stream);
  * otherwise live as long as the thread; nothing is freed from thread-exit destructors, which may run after the HIP runtime has
  * shut down). Call it before a worker thread that used the library exits; the thread may use the library again afterwards. */
 int apds_thread_release(void);
+/* Host threads that currently hold a library context (stream + workspace): a lone caller lets the extraction use side streams
+ * (apds_dev_akaze_extract forks its Hessian kernels only then). Diagnostic. */
+int apds_live_contexts(void);
 /* apds_thread_release keeps the thread's device workspace in a process-wide cache (a later thread reuses it instead of allocating);
  * this frees everything in that cache. */
 int apds_release_cached_memory(void);
