@@ -817,7 +817,7 @@ __constant__ MldbLut c_mldb = make_mldb_lut();
 // by all 64 lanes (they were gathered 1241 times, once per grid), then 29 lanes, one per cell of any grid, add their cell's
 // samples in the reference's order (k-major, l-minor; float sums are order dependent), and the 486 comparisons are done 32
 // per lane.
-__global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, const int* __restrict__ range, int n_cap, size_t kp_bstride,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, const int* __restrict__ range, int n_cap, size_t kp_bstride,
                                                    uint32_t* __restrict__ desc64, size_t desc_bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     const int begin = range ? bofs(range, T.bstride)[0] : 0;
@@ -825,12 +825,32 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
     kps = bofs(kps, kp_bstride);
     desc64 = bofs(desc64, desc_bstride);
     constexpr int LW = 21;                     // lattice width: offsets -10 .. 10
-    __shared__ float4 s_samp[4][LW * LW + 7];   // (ri, rrx, rry, valid) per lattice point
+    // per wave: the three sampled values of every lattice point as separate planes (an invalid point holds zeros) and the validity bitmap.
+    // A plane has 25 rows (+): the cell loops below run over a fixed 10 x 10 window whatever the cell's size and mask what lies outside it.
+    constexpr int PL = 25 * LW + 6;            // plane pitch (odd: the three planes of a point sit in different banks); the last window read is 24 * 21 + 24
+    __shared__ float s_samp[4][3 * PL];
+    __shared__ uint32_t s_bits[4][16];
     __shared__ int s_val[4][88];
     __shared__ uint8_t s_lut[976];              // c_mldb: a[488] then b[488]
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // the comparison table goes to LDS once per block (lane-indexed reads of __constant__ data are global loads)
     for (int i = threadIdx.x; i < 244; i += 256) reinterpret_cast<uint32_t*>(s_lut)[i] = reinterpret_cast<const uint32_t*>(&c_mldb)[i];
+    for (int i = lane; i < 3 * PL; i += 64) s_samp[wv][i] = 0.0f;   // the rows past the lattice stay zero
+    if (lane < 16) s_bits[wv][lane] = 0;
+    __syncthreads();
+    // chain = (cell, component): cells 0..3 the 2x2 grid (10 x 10 samples each), 4..12 the 3x3 grid (7 x 7), 13..28 the 4x4 grid (5 x 5);
+    // 87 chains: lanes take chains 0..63 in a first pass (all sizes), chains 64..86 (4x4 cells only) in a second
+    auto chain_geometry = [](int chain, int& step, int& base) {
+        const int cell_all = chain / 3, comp = chain - 3 * cell_all;
+        const int g = cell_all < 4 ? 0 : (cell_all < 13 ? 1 : 2);
+        const int cell = cell_all - (g == 0 ? 0 : (g == 1 ? 4 : 13));
+        const int side = g + 2;
+        step = g == 0 ? 10 : (g == 1 ? 7 : 5);
+        base = comp * PL + ((cell / side) * step) * LW + (cell % side) * step;
+    };
+    int step1, base1, step2, base2;
+    chain_geometry(lane, step1, base1);
+    chain_geometry(min(64 + lane, 86), step2, base2);
     for (int kb = begin + (int)blockIdx.x * 4; kb < n; kb += (int)gridDim.x * 4) {   // block-uniform trip count
     const int ki = kb + wv;
     const bool live = ki < n;
@@ -867,60 +887,78 @@ __global__ __launch_bounds__(256) void mldb_kernel(LevelTable T, const apds_keyp
 #pragma unroll
         for (int j = 0; j < NS; j++) {
             const int sidx = lane + 64 * j;
-            if (sidx < LW * LW) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool in = sidx < LW * LW;
+            const unsigned long long m = __ballot(in && ok[j]);
+            if (lane == 0) {
+                s_bits[wv][2 * j] = (uint32_t)m;
+                s_bits[wv][2 * j + 1] = (uint32_t)(m >> 32);
+            }
+            if (in) {
+                float vi = 0.f, vx = 0.f, vy = 0.f;
                 if (ok[j]) {
                     const float rx = d[j].x, ry = d[j].y;
-                    v.x = li[j];
-                    v.y = -rx * si + ry * co;   // rrx
-                    v.z = rx * co + ry * si;    // rry
-                    v.w = 1.0f;
+                    vi = li[j];
+                    vx = -rx * si + ry * co;   // rrx
+                    vy = rx * co + ry * si;    // rry
                 }
-                s_samp[wv][sidx] = v;
+                s_samp[wv][sidx] = vi;
+                s_samp[wv][PL + sidx] = vx;
+                s_samp[wv][2 * PL + sidx] = vy;
             }
         }
     }
     __syncthreads();
-    if (lane < 29) {   // lanes 0..3: the 2x2 grid, 4..12: 3x3, 13..28: 4x4; values land at s_val[3 * lane ..]
-        const int g = lane < 4 ? 0 : (lane < 13 ? 1 : 2);
-        const int cell = lane - (g == 0 ? 0 : (g == 1 ? 4 : 13));
-        const int side = g + 2;
-        const int step = g == 0 ? 10 : (g == 1 ? 7 : 5);
-        const int k0 = (cell / side) * step, l0 = (cell % side) * step;
-        float di = 0.0f, dx = 0.0f, dy = 0.0f;
+    // Cell sums in the reference's order (row-major over the cell's samples, one running sum per value). An invalid sample contributes
+    // +0: a running sum that starts at +0 is never -0 (x + y is -0 only if both are), so adding +0 never changes it — the reference
+    // skips those samples. The loops run over a fixed 10 x 10 window with static LDS offsets; a chain masks what is outside its cell.
+    {
+        float acc1 = 0.0f, acc2 = 0.0f;
+        const float* p1 = &s_samp[wv][base1];
+        const float* p2 = &s_samp[wv][base2];
+#pragma unroll 1
+        for (int a = 0; a < 10; a++) {      // (a row at a time: fully unrolled, the compiler hoists all hundred loads and spills)
+            const float* row = p1 + a * LW;
+            const bool row_in = a < step1;
+#pragma unroll
+            for (int b = 0; b < 10; b++) {
+                const float v = row[b];
+                acc1 += (row_in && b < step1) ? v : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int b = 0; b < 5; b++) acc2 += p2[a * LW + b];
+        // the number of valid samples of a cell, from the validity bitmap (lane = cell)
         int nsamples = 0;
-        for (int a = 0; a < step; a++) {
-            const float4* p = &s_samp[wv][(k0 + a) * LW + l0];
-            for (int b = 0; b < step; b++) {
-                const float4 v = p[b];
-                if (v.w != 0.0f) {
-                    di += v.x;
-                    dx += v.y;
-                    dy += v.z;
-                    nsamples++;
-                }
+        if (lane < 29) {
+            int st, bs;
+            chain_geometry(3 * lane, st, bs);
+            for (int a = 0; a < st; a++) {
+                const int pos = bs + a * LW;          // (component 0: bs is the cell's first lattice index)
+                const unsigned long long two = (unsigned long long)s_bits[wv][(pos >> 5) + 1] << 32 | s_bits[wv][pos >> 5];
+                nsamples += __popcll((two >> (pos & 31)) & ((1ull << st) - 1));
             }
         }
-        if (nsamples > 0) {
-            const float inv = 1.0f / nsamples;
-            di *= inv;
-            dx *= inv;
-            dy *= inv;
-        }
-        const int v0 = __float_as_int(di), v1 = __float_as_int(dx), v2 = __float_as_int(dy);
-        s_val[wv][3 * lane + 0] = v0 ^ (v0 < 0 ? 0x7fffffff : 0);   // CV_TOGGLE_FLT: int order == float order
-        s_val[wv][3 * lane + 1] = v1 ^ (v1 < 0 ? 0x7fffffff : 0);
-        s_val[wv][3 * lane + 2] = v2 ^ (v2 < 0 ? 0x7fffffff : 0);
+        // chain c's cell count sits in lane c / 3
+        const int n1 = __shfl(nsamples, lane / 3), n2 = __shfl(nsamples, min(64 + lane, 86) / 3);
+        if (n1 > 0) acc1 *= 1.0f / n1;
+        if (n2 > 0) acc2 *= 1.0f / n2;
+        const int v1 = __float_as_int(acc1), v2 = __float_as_int(acc2);
+        s_val[wv][lane] = v1 ^ (v1 < 0 ? 0x7fffffff : 0);   // CV_TOGGLE_FLT: int order == float order
+        if (lane < 23) s_val[wv][64 + lane] = v2 ^ (v2 < 0 ? 0x7fffffff : 0);
     }
     __syncthreads();
-    if (live && lane < 16) {
-        uint32_t word = 0;
-#pragma unroll 4
-        for (int b = 0; b < 32; b++) {
-            const int pos = lane * 32 + b;
-            if (pos < 486 && s_val[wv][s_lut[pos]] > s_val[wv][s_lut[488 + pos]]) word |= 1u << b;
+    // 486 comparisons: lane tests bits lane, lane + 64, ...; a ballot is two words of the descriptor
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int pos = 64 * j + lane;
+        const bool bit = pos < 486 && s_val[wv][s_lut[min(pos, 487)]] > s_val[wv][s_lut[488 + min(pos, 487)]];
+        const unsigned long long m = __ballot(bit);
+        if (live && lane == 0) {
+            desc64[(size_t)ki * 16 + 2 * j] = (uint32_t)m;      // 61 payload bytes + 3 zero bytes per 64-byte row
+            desc64[(size_t)ki * 16 + 2 * j + 1] = (uint32_t)(m >> 32);
         }
-        desc64[(size_t)ki * 16 + lane] = word;   // 61 payload bytes + 3 zero bytes per 64-byte row
     }
     __syncthreads();   // the next keypoint reuses the wave's LDS slices
     }
