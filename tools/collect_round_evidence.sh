@@ -20,4 +20,6 @@ python3 tools/extract_threads_probe.py > $O/extract_threads_probe.log 2>&1
 python3 tools/tile_throughput.py > $O/tile_throughput.log 2>&1
 python3 tools/match_probe.py > $O/match_probe.log 2>&1
 python3 tools/extract_sweep.py > $O/extract_sweep.json 2> $O/extract_sweep.err
+bash tools/trace_extract.sh 4096 > $O/trace_extract.log 2>&1
+cp gpurun_out/trace_extract/timeline.txt $O/extract_timeline.txt
 ls -la $O
