@@ -100,6 +100,9 @@ void stream_wait(hipStream_t s);
 // asked. So: four candidates (consecutive creations: different queues), each timed once with a spinning one-wave kernel on it and one
 // on `caller`; the candidate whose pair finishes first does not share the caller's queue. ~0.3 ms, once per (thread, caller stream).
 hipStream_t side_stream_beside(hipStream_t caller);
+// the candidate streams of released threads, per device (creating and destroying four streams per short-lived thread costs milliseconds)
+bool take_cached_side_stream(int device, hipStream_t& out);
+void cache_side_stream(int device, hipStream_t st);
 unsigned stream_event_flags();   // flags for events that only order GPU streams of one device
 
 inline hipStream_t pick_stream(void* s) { return s ? static_cast<hipStream_t>(s) : ctx().stream; }

@@ -68,7 +68,7 @@ hipStream_t side_stream_beside(hipStream_t caller) {
     static const int probe_env = getenv("APDS_SIDE_PROBE") ? atoi(getenv("APDS_SIDE_PROBE")) : 1;
     if (!probe_env) return c.side_stream();
     for (hipStream_t& st : c.side_pool)
-        if (!st) HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, 0));
+        if (!st && !take_cached_side_stream(c.device, st)) HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, 0));
     HIP_CHECK(hipStreamSynchronize(caller));
     const long long spin = 60000;   // ~25 us of the 2.4 GHz shader clock (s_memtime counts at 100 MHz on some parts: then longer, still bounded)
     double best = 1e30;

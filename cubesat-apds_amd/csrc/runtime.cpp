@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include <mutex>
+#include <vector>
 
 #include <atomic>
 
@@ -63,6 +64,25 @@ hipStream_t ThreadCtx::side_stream2() {
     return side2;
 }
 
+namespace {
+std::mutex g_side_cache_mutex;
+std::vector<std::pair<int, hipStream_t>> g_side_cache;
+}  // namespace
+bool take_cached_side_stream(int device, hipStream_t& out) {
+    std::lock_guard<std::mutex> g(g_side_cache_mutex);
+    for (size_t i = 0; i < g_side_cache.size(); i++)
+        if (g_side_cache[i].first == device) {
+            out = g_side_cache[i].second;
+            g_side_cache.erase(g_side_cache.begin() + i);
+            return true;
+        }
+    return false;
+}
+void cache_side_stream(int device, hipStream_t st) {
+    std::lock_guard<std::mutex> g(g_side_cache_mutex);
+    g_side_cache.emplace_back(device, st);
+}
+
 int* ThreadCtx::pinned_ints(size_t n) {
     if (n > host_ints_cap) {
         if (host_ints) (void)hipHostFree(host_ints);
@@ -100,7 +120,13 @@ void ThreadCtx::drop_side() {
     host_ints = nullptr;
     host_ints_cap = 0;
     side_probe_caller = side_probe_choice = nullptr;
-    for (hipStream_t* st : {&side, &side2, &side3, &side_pool[0], &side_pool[1], &side_pool[2], &side_pool[3]})
+    for (hipStream_t& st : side_pool)
+        if (st) {
+            (void)hipStreamSynchronize(st);
+            cache_side_stream(device, st);
+            st = nullptr;
+        }
+    for (hipStream_t* st : {&side, &side2, &side3})
         if (*st) {
             (void)hipStreamSynchronize(*st);
             (void)hipStreamDestroy(*st);

@@ -17,9 +17,9 @@ imgs = [np.ascontiguousarray(pkg.synth.make_tile(T, T, frame_index=i)) for i in 
 reps = 24
 
 
-def worker(k, out):
-    for r in range(reps + 2):
-        if r == 2:
+def worker(k, out, ends):
+    for r in range(reps + 4):
+        if r == 4:
             barrier.wait()
             out[k] = time.perf_counter()
         img = imgs[(k + r) % 4]
@@ -27,16 +27,18 @@ def worker(k, out):
         pkg._lib.check(L.apds_akaze_extract(img.ctypes.data, T, T, 4, img.strides[0], 0, C.byref(kps), C.byref(desc), C.byref(n), C.byref(nb)))
         L.apds_free(kps)
         L.apds_free(desc)
+    ends[k] = time.perf_counter()   # (the thread's release — stream teardown, workspace to the cache — is not extraction time)
     L.apds_thread_release()
 
 
 for nthreads in (1, 2, 4, 8):
     barrier = threading.Barrier(nthreads)
     starts = [0.0] * nthreads
-    ts = [threading.Thread(target=worker, args=(k, starts)) for k in range(nthreads)]
+    ends = [0.0] * nthreads
+    ts = [threading.Thread(target=worker, args=(k, starts, ends)) for k in range(nthreads)]
     for t in ts:
         t.start()
     for t in ts:
         t.join()
-    dt = time.perf_counter() - min(starts)
+    dt = max(ends) - min(starts)
     print(f"tile {T}^2, {nthreads} threads: {nthreads * reps / dt:8.1f} extractions/s ({dt / reps * 1e3:.3f} ms per extraction per thread)", flush=True)
