@@ -1154,32 +1154,32 @@ static constexpr int DW = 128, DH = 32;   // wide tiles: the halo costs ~1.4x in
 #define APDS_DOH_THREADS 1024
 #endif
 static constexpr int DNT = APDS_DOH_THREADS;
-static constexpr int DCAND = 1024;        // strict 3x3 maxima are never adjacent: at most a quarter of the 4096 tile pixels
+// (candidates of a tile: strict 3x3 maxima are never adjacent, so at most a quarter of the tile pixels — the room behind the determinant plane)
 
 // S = sigma_size as a compile-time constant (2, 3, 4 are all the reference's AKAZE parameters produce): constant LDS strides turn
 // the index divisions into multiplies and let the tile loads be issued together; S = 0 takes it at run time.
-template <int S, int NT>
+template <int S, int NT, int TW>
 __device__ __forceinline__ void doh_tile_generic(const float* __restrict__ Lsmooth, float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h, int s_rt,
                                                  float kside, float kmid, float sq, int border, float thr, uint8_t* __restrict__ mask,
                                                  uint32_t* __restrict__ list, int* __restrict__ list_count) {
     extern __shared__ float smem[];
     __shared__ int s_n, s_base;
     const int s = S ? S : s_rt;
-    const int SW = DW + 4 * s + 2, SH = DH + 4 * s + 2;   // Lsmooth tile, halo 2s + 1
-    const int MW = DW + 2 * s + 2, MH = DH + 2 * s + 2;   // first derivatives, halo s + 1
-    constexpr int EW = DW + 2, EH = DH + 2;               // determinant, halo 1
+    const int SW = TW + 4 * s + 2, SH = DH + 4 * s + 2;   // Lsmooth tile, halo 2s + 1
+    const int MW = TW + 2 * s + 2, MH = DH + 2 * s + 2;   // first derivatives, halo s + 1
+    constexpr int EW = TW + 2, EH = DH + 2;               // determinant, halo 1
     float* s_src = smem;
     float* s_mx = s_src + SW * SH;
     float* s_my = s_mx + MW * MH;
     float* s_det = s_src;                                 // reuses the Lsmooth tile once the first derivatives exist
     uint32_t* s_cand = reinterpret_cast<uint32_t*>(s_src + EW * EH);
-    const int x0 = blockIdx.x * DW, y0 = blockIdx.y * DH;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * DH;
     const int ox = x0 - 2 * s - 1, oy = y0 - 2 * s - 1;   // global coordinate of s_src[0]
     if (threadIdx.x == 0) s_n = 0;
     // the tile with its 2s+1 halo inside the image (all but the outermost tiles, block-uniform): no reflected coordinates, no tests
     const bool inside = ox >= 0 && oy >= 0 && ox + SW <= w && oy + SH <= h;
     if constexpr (S > 0) {
-        constexpr int CSW = DW + 4 * S + 2, CSH = DH + 4 * S + 2, NL = (CSW * CSH + NT - 1) / NT;
+        constexpr int CSW = TW + 4 * S + 2, CSH = DH + 4 * S + 2, NL = (CSW * CSH + NT - 1) / NT;
         float v[NL];
 #pragma unroll
         for (int k = 0; k < NL; k++) {   // all of the tile's loads in flight before the first LDS store
@@ -1242,7 +1242,7 @@ __device__ __forceinline__ void doh_tile_generic(const float* __restrict__ Lsmoo
         const float lyy = rsy2 - rsy0;
         const float det = (lxx * lyy - lxy * lxy) * sq;
         s_det[i] = det;
-        if (ex >= 1 && ex <= DW && ey >= 1 && ey <= DH) {   // the tile itself
+        if (ex >= 1 && ex <= TW && ey >= 1 && ey <= DH) {   // the tile itself
             const size_t o = (size_t)gy * w + gx;
             Lxy[o] = make_float2(s_mx[c], s_my[c]);   // interleaved: orientation and M-LDB gather both with one 8-byte load
             Ldet[o] = det;
@@ -1251,8 +1251,8 @@ __device__ __forceinline__ void doh_tile_generic(const float* __restrict__ Lsmoo
     __syncthreads();
     if (border < 0) return;   // level too small for any extremum (block-uniform)
     const unsigned span_x = (unsigned)(w - 2 * border), span_y = (unsigned)(h - 2 * border);   // (positive: checked by the launcher)
-    for (int i = threadIdx.x; i < DW * DH; i += NT) {
-        const int ly = i / DW, lx = i - ly * DW;
+    for (int i = threadIdx.x; i < TW * DH; i += NT) {
+        const int ly = i / TW, lx = i - ly * TW;
         const int gx = x0 + lx, gy = y0 + ly;
         const float* p = &s_det[(ly + 1) * EW + lx + 1];
         const float v = p[0];
@@ -1273,10 +1273,10 @@ __device__ __forceinline__ void doh_tile_generic(const float* __restrict__ Lsmoo
     for (int i = threadIdx.x; i < n; i += NT) list[s_base + i] = s_cand[i];
 }
 
-template <int S>
-__global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict__ Lsmooth, float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h,
-                                                        int s_rt, float kside, float kmid, float sq, int border, float thr, uint8_t* __restrict__ mask,
-                                                        uint32_t* __restrict__ list, int* __restrict__ list_count, size_t bstride) {
+template <int S, int NT, int TW>
+__global__ __launch_bounds__(NT) void doh_fused_kernel(const float* __restrict__ Lsmooth, float2* __restrict__ Lxy, float* __restrict__ Ldet, int w, int h,
+                                                       int s_rt, float kside, float kmid, float sq, int border, float thr, uint8_t* __restrict__ mask,
+                                                       uint32_t* __restrict__ list, int* __restrict__ list_count, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     APDS_BOFS(Lsmooth);
     APDS_BOFS(Lxy);
@@ -1284,7 +1284,7 @@ __global__ __launch_bounds__(DNT) void doh_fused_kernel(const float* __restrict_
     APDS_BOFS(mask);
     APDS_BOFS(list);
     APDS_BOFS(list_count);
-    doh_tile_generic<S, DNT>(Lsmooth, Lxy, Ldet, w, h, s_rt, kside, kmid, sq, border, thr, mask, list, list_count);
+    doh_tile_generic<S, NT, TW>(Lsmooth, Lxy, Ldet, w, h, s_rt, kside, kmid, sq, border, thr, mask, list, list_count);
 }
 
 // (Measured and not adopted, round 2: "column runs" — a thread owns a column of a stage and walks K consecutive rows, so that the row
@@ -1440,21 +1440,43 @@ void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, co
 }
 void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
                       uint32_t* list, int* list_count, hipStream_t s, const Batch& b) {
-    const size_t lds = (size_t)((DW + 4 * sc + 2) * (DH + 4 * sc + 2) + 2 * (DW + 2 * sc + 2) * (DH + 2 * sc + 2)) * sizeof(float);
-    APDS_REQUIRE((size_t)(DW + 2) * (DH + 2) + DCAND <= (size_t)(DW + 4 * sc + 2) * (DH + 4 * sc + 2), APDS_ERR_INTERNAL, "doh_fused: LDS aliasing needs sigma_size >= 2");
+    // tile width: 128 x 32 tiles on 1024 threads (halo 1.4x, two blocks per CU) or 64 x 32 tiles on 512 threads (halo 1.75x, four blocks
+    // per CU: the kernel is four barrier-separated phases, and more independent blocks per CU hide their latencies better)
+    static const int tile_env = getenv("APDS_DOH_TILE") ? atoi(getenv("APDS_DOH_TILE")) : 64;
+    const int tw = tile_env == 64 ? 64 : (tile_env == 32 ? 32 : DW);
+    const size_t lds = (size_t)((tw + 4 * sc + 2) * (DH + 4 * sc + 2) + 2 * (tw + 2 * sc + 2) * (DH + 2 * sc + 2)) * sizeof(float);
+    APDS_REQUIRE((size_t)(tw + 2) * (DH + 2) + (size_t)tw * DH / 4 <= (size_t)(tw + 4 * sc + 2) * (DH + 4 * sc + 2), APDS_ERR_INTERNAL, "doh_fused: LDS aliasing needs sigma_size >= 2");
     // the extrema test of a level that is too small for its border is skipped (border < 0 in the kernel)
     const bool none = border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0;
-    auto go = [&](auto kernel) {
+    auto go = [&](auto kernel, int nt) {
         if (lds > 64 * 1024)   // above the default dynamic-LDS limit: opt in (idempotent)
             HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
-        hipLaunchKernelGGL(kernel, dim3(ceil_div(w, DW), ceil_div(h, DH), b.n), dim3(DNT), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
+        hipLaunchKernelGGL(kernel, dim3(ceil_div(w, tw), ceil_div(h, DH), b.n), dim3(nt), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
                            (float)(sc * sc * sc * sc), none ? -1 : border, thr, mask, list, list_count, b.stride);
     };
+    if (tw == 32) {
+        switch (sc) {
+            case 2: go(&doh_fused_kernel<2, 256, 32>, 256); break;
+            case 3: go(&doh_fused_kernel<3, 256, 32>, 256); break;
+            case 4: go(&doh_fused_kernel<4, 256, 32>, 256); break;
+            default: go(&doh_fused_kernel<0, 256, 32>, 256); break;
+        }
+        return;
+    }
+    if (tw == 64) {
+        switch (sc) {
+            case 2: go(&doh_fused_kernel<2, 512, 64>, 512); break;
+            case 3: go(&doh_fused_kernel<3, 512, 64>, 512); break;
+            case 4: go(&doh_fused_kernel<4, 512, 64>, 512); break;
+            default: go(&doh_fused_kernel<0, 512, 64>, 512); break;
+        }
+        return;
+    }
     switch (sc) {
-        case 2: go(&doh_fused_kernel<2>); break;
-        case 3: go(&doh_fused_kernel<3>); break;
-        case 4: go(&doh_fused_kernel<4>); break;
-        default: go(&doh_fused_kernel<0>); break;
+        case 2: go(&doh_fused_kernel<2, DNT, DW>, DNT); break;
+        case 3: go(&doh_fused_kernel<3, DNT, DW>, DNT); break;
+        case 4: go(&doh_fused_kernel<4, DNT, DW>, DNT); break;
+        default: go(&doh_fused_kernel<0, DNT, DW>, DNT); break;
     }
 }
 
