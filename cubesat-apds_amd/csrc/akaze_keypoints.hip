@@ -1239,14 +1239,13 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     uint8_t *mask_all, *status_all;
     std::vector<uint32_t*> lists(L), pend(L);
     std::vector<float*> lsm(L);
-    size_t zero_bytes = 0, small_zero_bytes = 0;
+    size_t zero_bytes = 0;
     auto layout = [&](Arena& A) {
         list_count = A.take<int>(AKAZE_MAX_LEVELS);
         hmax_bits = A.take<unsigned int>(1);
         hist = A.take<int>(300);
         pend_count = A.take<int>(3 * AKAZE_MAX_LEVELS * PEND_PITCH);
         kp_base = A.take<int>(8);                 // kp_base[k] = keypoints of the stages before stage k (kp_base[0] stays 0)
-        small_zero_bytes = A.off;                 // (a multiple of 256)
         fine_counts = A.take<int>(n_fine + 1024);      // ranked compaction: keypoints per 128-byte chunk of the masks (then their prefix)
         coarse_counts = A.take<int>((size_t)n_coarse * COARSE_PITCH);
         mask_all = A.take<uint8_t>((size_t)total_pix + 128);   // (+ a line: the last chunk is read whole)
@@ -1286,7 +1285,6 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         for (hipStream_t st : c.side_pool)
             if (st) HIP_CHECK(hipStreamSynchronize(st));
         if (c.side2) HIP_CHECK(hipStreamSynchronize(c.side2));
-        if (c.side3) HIP_CHECK(hipStreamSynchronize(c.side3));
         c.fork_open = false;
     }
     // (the runtime's fill kernel clears the 44 MB of a 4096^2 frame at 1.7 TB/s; 16-byte stores from a wide grid are quicker)
@@ -1295,18 +1293,8 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         hipLaunchKernelGGL(zero_slab_heads_kernel, dim3((unsigned)std::min<size_t>(B > 1 ? 1024 : 4096, (bytes / 16 + 255) / 256), 1, B), dim3(256), 0, zs,
                            reinterpret_cast<uint4*>(real.base + from), bytes, slab);
     };
-    // A large frame's masks, statuses and chunk counters (178 MB at 4096^2) are first touched by the level-0 Hessian kernel, which
-    // runs on the side stream: they are cleared there, beside the base stage, and only the few counters the main chain needs at once
-    // are cleared in front of it. (Nothing of the previous call is in flight on either stream: every call ends with a read-back.)
-    static const int zero_side_env = getenv("APDS_ZERO_SIDE") ? atoi(getenv("APDS_ZERO_SIDE")) : 0;   // (measured: no gain, the base stage is bandwidth-bound itself)
-    const bool zero_on_side = zero_side_env && fork_doh && zero_bytes - small_zero_bytes >= ((size_t)8 << 20);
-    if (zero_on_side) {
-        zero_range(0, small_zero_bytes, s);
-        c.fork_open = true;
-        zero_range(small_zero_bytes, zero_bytes, side_stream_beside(s));
-    } else {
-        zero_range(0, zero_bytes, s);
-    }
+    // (clearing the masks on the side stream, beside the base stage, was measured: no gain — the base stage is bandwidth-bound itself)
+    zero_range(0, zero_bytes, s);
     int* counts_dev = B > 1 ? c.alloc_n<int>(B) : nullptr;
 
     // ---- a1.1 / a1.2 / a1.3
@@ -1336,11 +1324,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // before the suppression): it goes to a second stream, so the latency-bound launches of the small octaves overlap the
     // smoothing and diffusion launches of the levels that follow. Lsmooth then needs a plane per level instead of a shared one.
     hipStream_t s_doh = fork_doh ? side_stream_beside(s) : s;
-    // The Hessian kernels of the small levels (latency-bound, ~10 us each) queue up behind the large levels' (throughput-bound, ~100 us
-    // each, slowed further by the level chain they share the GPU with) and finish long after the level chain: they get a stream of
-    // their own, beside the large ones. (Not in staged mode, whose early stage is released by an event on one Hessian stream.)
-    static const int doh_split = getenv("APDS_DOH_SPLIT") ? atoi(getenv("APDS_DOH_SPLIT")) : 0;   // (measured: no gain, 1.867 vs 1.854 ms; kept as a switch)
-    hipStream_t s_doh_small = s_doh;   // assigned below, once `staged` is known
+    // (a stream of their own for the small levels' Hessian kernels, which queue up behind the large levels' on this one: measured, no gain)
     // Keypoint stages. Levels 0 .. m are FINAL (cross-level suppression done) once the Hessian of level m + 1 exists (see run_stage).
     // The last two octaves are a chain of short, latency-bound launches that leaves the GPU almost idle, and the large octaves before
     // them hold nearly all keypoints: the EARLY stage = suppression passes + sub-pixel filter + ordered compaction + orientation +
@@ -1359,8 +1343,6 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     const bool staged = fork_doh && stages_mode && n_oct >= 3 && ((size_t)W * H * B >= ((size_t)1 << 23) || stages_mode == 2);
     const int early_trigger = staged ? 4 * (n_oct - 2) : -1;   // the level whose Hessian launch releases the early stage
     hipStream_t s_kp = staged ? c.side_stream2() : s;
-    const bool split_doh = fork_doh && doh_split && !staged && (size_t)W * H * B > ((size_t)1 << 20);
-    if (split_doh) s_doh_small = c.side_stream3();
     // ---- level tables for the keypoint kernels (pointers of image 0; kernels add blockIdx.z * slab)
     LevelTable T{};
     SuppressArgs A{};
@@ -1405,7 +1387,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // finishes the chains without any host check.
     constexpr int WIDE_ROUNDS = 3;
     int n_stage = 0;
-    auto run_stage = [&](int prev_m, int m) {
+    auto suppress_stage = [&](int prev_m, int m, hipStream_t s_kp) {
         const int D = std::min(m + 1, L - 1), prev_D = prev_m < 0 ? 0 : std::min(prev_m + 1, L - 1);
         const dim3 lblock(256);
         auto run_passes = [&](int phase, int lo, int hi, int snap_lo, int snap_hi) {
@@ -1426,6 +1408,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             run_passes(0, prev_D + 1, D, prev_D + 1, D);                                   // phase 0: each pass snapshots its own level
             run_passes(1, std::max(prev_m, 0), std::min(m, L - 1) - 1, prev_m + 1, m);      // phase 1
         }
+    };
+    // sub-pixel filter, ordered compaction, orientation and descriptors of levels (prev_m, m], whose suppression passes are done
+    auto emit_stage = [&](int prev_m, int m, hipStream_t s_kp) {
         const int a = prev_m + 1;
         int* base_k = kp_base + n_stage;
         static const int ranked_env = getenv("APDS_KP_RANKED") ? atoi(getenv("APDS_KP_RANKED")) : 1;
@@ -1453,8 +1438,13 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
                            std::min(capacity, max_points), kp_bstride, reinterpret_cast<uint32_t*>(desc64_out), desc_bstride);
         n_stage++;
     };
+    auto run_stage = [&](int prev_m, int m) {
+        suppress_stage(prev_m, m, s_kp);
+        emit_stage(prev_m, m, s_kp);
+    };
+    // (Running only the suppression passes of the large octaves' levels early, on a third stream under the small-octave chain, was built
+    // and measured as well: bit-identical, 1.844 against 1.825 ms — the passes' scattered loads slow the chain by more than they hide.)
     int stage_prev_m = -1;
-    auto doh_stream = [&](int lvl) { return split_doh && (size_t)ev[lvl].w * ev[lvl].h * B <= ((size_t)1 << 20) ? s_doh_small : s_doh; };
     // ---- a1.4 / a1.5 per level: Lsmooth -> (Lx, Ly, Ldet) and flow; FED steps ping-pong into Lt[i]
     for (int i = 0; i < L; i++) {
         LevelDesc& e = ev[i];
@@ -1500,7 +1490,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             auto fork_here = [&]() {   // Lsmooth of this level exists from here on
                 if (!fork_doh) return;
                 HIP_CHECK(hipEventRecord(c.fork_event(i), s));
-                HIP_CHECK(hipStreamWaitEvent(doh_stream(i), c.fork_event(i), 0));
+                HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(i), 0));
             };
             // large levels: the smoothing pass and the first group of FED steps in one pass over register strips (level_strip_kernel)
             static const int level_strip = getenv("APDS_LEVEL_STRIP") ? atoi(getenv("APDS_LEVEL_STRIP")) : 1;
@@ -1554,10 +1544,10 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         if (fork_doh && i == 0) {   // level 0: Lsmooth is Lt[0], ready after the base stage
             c.fork_open = true;
             HIP_CHECK(hipEventRecord(c.fork_event(0), s));
-            HIP_CHECK(hipStreamWaitEvent(doh_stream(0), c.fork_event(0), 0));
+            HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
         }
         launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i,
-                         doh_stream(i), bt);
+                         s_doh, bt);
         if (i == early_trigger) {
             // the Hessian of this level exists once the launch above is done: all levels below can be finished. (The stage also
             // reads Lt / Lxy of its own levels: complete before this level's smoothing pass, which the launch above follows.)
@@ -1571,11 +1561,6 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, stream_event_flags()));
         HIP_CHECK(hipEventRecord(c.join_event, s_doh));
         HIP_CHECK(hipStreamWaitEvent(s, c.join_event, 0));
-        if (split_doh) {
-            if (!c.join_event3) HIP_CHECK(hipEventCreateWithFlags(&c.join_event3, stream_event_flags()));
-            HIP_CHECK(hipEventRecord(c.join_event3, s_doh_small));
-            HIP_CHECK(hipStreamWaitEvent(s, c.join_event3, 0));
-        }
         c.fork_open = false;
     }
     HIP_CHECK(hipGetLastError());
@@ -1618,7 +1603,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         hipLaunchKernelGGL(gather_slab_ints_kernel, dim3(ceil_div(B, 256)), dim3(256), 0, s, (const int*)(kp_base + n_stage), 1, slab, B, counts_dev);
         HIP_CHECK(hipMemcpyAsync(K, counts_dev, (size_t)B * sizeof(int), hipMemcpyDeviceToHost, s));
     }
-    stream_wait(s);
+    HIP_CHECK(hipStreamSynchronize(s));
     int kmax = 0;
     bool over = false;
     for (int bi = 0; bi < B; bi++) {

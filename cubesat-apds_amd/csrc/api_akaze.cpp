@@ -31,7 +31,7 @@ static void extract_to_host(ThreadCtx& c, hipStream_t s, const uint8_t* dimg, in
             HIP_CHECK(hipMemcpyAsync(hk, dk, (size_t)K * sizeof(apds_keypoint), hipMemcpyDeviceToHost, s));
             HIP_CHECK(hipMemcpyAsync(hd, d61, (size_t)K * APDS_DESC_BYTES, hipMemcpyDeviceToHost, s));
         }
-        stream_wait(s);
+        HIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {
         std::free(hk);
         std::free(hd);
@@ -133,7 +133,7 @@ static void batch_results_to_host(ThreadCtx& c, hipStream_t s, const apds_keypoi
             off += (size_t)K;
         }
         if (total) HIP_CHECK(hipMemcpyAsync(hd, d61, total * APDS_DESC_BYTES, hipMemcpyDeviceToHost, s));
-        stream_wait(s);
+        HIP_CHECK(hipStreamSynchronize(s));
     } catch (...) {
         std::free(hk);
         std::free(hd);

@@ -77,9 +77,6 @@ struct ThreadCtx {
     hipStream_t side_pool[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t side_probe_caller = nullptr, side_probe_choice = nullptr;
     hipStream_t side_stream2();
-    hipStream_t side3 = nullptr;                // akaze: the Hessian kernels of the small levels (normal priority)
-    hipStream_t side_stream3();
-    hipEvent_t join_event3 = nullptr;
     void drop_side();
     hipEvent_t fork_event(size_t i);            // i-th reusable event (no timing)
 
@@ -92,9 +89,6 @@ struct ThreadCtx {
 ThreadCtx& ctx();
 std::atomic<int>& live_contexts();   // host threads that currently own a stream + workspace
 
-// wait for a stream: poll for a bounded time (a blocking wait costs tens of microseconds to wake up, which is a tenth of a small
-// tile's extraction), then block
-void stream_wait(hipStream_t s);
 // A stream of the calling thread whose kernels run CONCURRENTLY with kernels on `caller`. The runtime maps streams onto a few
 // hardware queues in creation order; two streams on one queue serialise, and which queue the caller's stream sits on cannot be
 // asked. So: four candidates (consecutive creations: different queues), each timed once with a spinning one-wave kernel on it and one

@@ -95,25 +95,6 @@ int* ThreadCtx::pinned_ints(size_t n) {
     return host_ints;
 }
 
-void stream_wait(hipStream_t s) {
-    static const int spin_us = getenv("APDS_SPIN_US") ? atoi(getenv("APDS_SPIN_US")) : 0;   // (measured: no gain over the runtime's own wait on this box; kept as a switch)
-    if (spin_us > 0) {
-        const auto t0 = std::chrono::steady_clock::now();
-        for (;;) {
-            const hipError_t e = hipStreamQuery(s);
-            if (e == hipSuccess) return;
-            if (e != hipErrorNotReady) HIP_CHECK(e);
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us)) break;
-        }
-    }
-    HIP_CHECK(hipStreamSynchronize(s));
-}
-
-hipStream_t ThreadCtx::side_stream3() {
-    if (!side3) HIP_CHECK(hipStreamCreateWithPriority(&side3, hipStreamNonBlocking, 0));
-    return side3;
-}
-
 // side streams, their events and the join event: dropped with the thread's stream (release, device change)
 void ThreadCtx::drop_side() {
     if (host_ints) (void)hipHostFree(host_ints);
@@ -126,7 +107,7 @@ void ThreadCtx::drop_side() {
             cache_side_stream(device, st);
             st = nullptr;
         }
-    for (hipStream_t* st : {&side, &side2, &side3})
+    for (hipStream_t* st : {&side, &side2})
         if (*st) {
             (void)hipStreamSynchronize(*st);
             (void)hipStreamDestroy(*st);
@@ -136,8 +117,6 @@ void ThreadCtx::drop_side() {
     fork_events.clear();
     if (join_event) (void)hipEventDestroy(join_event);
     join_event = nullptr;
-    if (join_event3) (void)hipEventDestroy(join_event3);
-    join_event3 = nullptr;
     fork_open = false;
 }
 
