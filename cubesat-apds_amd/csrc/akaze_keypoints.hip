@@ -694,24 +694,42 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
     }
     __syncthreads();
     // counting sort, identical to idx[--cum[b]] = i for ascending i: within a bin the larger sample index comes first. Every lane
-    // holds the bins of its samples lane and lane + 64; one ballot per bin gives the bin's population (prefix -> its start) and,
-    // masked to the higher lanes, how many same-bin samples with a larger index precede a sample (the 218 dependent LDS reads per lane
-    // that the two counting loops used to make were most of this kernel's time).
+    // holds the bins of its samples lane and lane + 64. Which samples share a lane's bin comes from six bit-sliced ballots per sample
+    // set (a bin is six bits: the lanes whose bin equals mine are the AND, over the bits, of the ballot or its complement) instead
+    // of one ballot pair per bin (43 iterations): the masked population counts give a sample's place inside its bin and the bin's
+    // size; the bins' sizes go through LDS (every sample of a bin writes the same number) to a 42-lane prefix scan -> the bins' starts.
     {
         const int bin0 = s_bin[wv][lane];
-        const int bin1 = lane + 64 < 109 ? (int)s_bin[wv][lane + 64] : -1;
-        const unsigned long long higher = ~((2ull << lane) - 1);   // lanes above this one (none for lane 63)
-        int acc = 0, st_mine = 0, pos0 = 0, pos1 = 0;
-        for (int b = 0; b < 43; b++) {                              // b == 42: no sample, st_mine becomes the total
-            const unsigned long long m0 = __ballot(bin0 == b), m1 = __ballot(bin1 == b);
-            if (lane == b) st_mine = acc;
-            if (bin0 == b) pos0 = acc + __popcll(m0 & higher) + __popcll(m1);   // every sample lane' + 64 has a larger index
-            if (bin1 == b) pos1 = acc + __popcll(m1 & higher);
-            acc += __popcll(m0) + __popcll(m1);
+        const int bin1 = lane + 64 < 109 ? (int)s_bin[wv][lane + 64] : 63;   // 63: no sample (equal to no bin: they are < 42)
+        unsigned long long eq00 = ~0ull, eq01 = ~0ull, eq10 = ~0ull, eq11 = ~0ull;   // eqXY: the lanes of set Y whose bin equals my binX
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const unsigned long long b0 = __ballot((bin0 >> k) & 1), b1 = __ballot((bin1 >> k) & 1);
+            const unsigned long long n0 = ((bin0 >> k) & 1) ? 0ull : ~0ull, n1 = ((bin1 >> k) & 1) ? 0ull : ~0ull;   // complement unless my bit is set
+            eq00 &= b0 ^ n0;
+            eq01 &= b1 ^ n0;
+            eq10 &= b0 ^ n1;
+            eq11 &= b1 ^ n1;
         }
-        if (lane < 43) s_start[wv][lane] = st_mine;
-        s_sorted[wv][pos0] = (uint8_t)lane;
-        if (bin1 >= 0) s_sorted[wv][pos1] = (uint8_t)(lane + 64);
+        const unsigned long long higher = ~((2ull << lane) - 1);   // lanes above this one (none for lane 63)
+        const int in0 = __popcll(eq00 & higher) + __popcll(eq01);  // same-bin samples with a larger index: every sample lane' + 64 has one
+        const int in1 = __popcll(eq11 & higher);
+        if (lane < 44) s_start[wv][lane] = 0;
+        __syncthreads();
+        s_start[wv][bin0] = __popcll(eq00) + __popcll(eq01);       // the bin's size (the same number from every sample of the bin)
+        if (bin1 < 42) s_start[wv][bin1] = __popcll(eq10) + __popcll(eq11);
+        __syncthreads();
+        int incl = lane < 42 ? s_start[wv][lane] : 0;
+        const int mine = incl;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        __syncthreads();
+        if (lane < 43) s_start[wv][lane] = incl - mine;            // exclusive prefix: bin 42 (no sample) holds the total
+        __syncthreads();
+        s_sorted[wv][s_start[wv][bin0] + in0] = (uint8_t)lane;
+        if (bin1 < 42) s_sorted[wv][s_start[wv][bin1] + in1] = (uint8_t)(lane + 64);
     }
     __syncthreads();
     float sumX = 0.0f, sumY = 0.0f, norm = -1.0f;
