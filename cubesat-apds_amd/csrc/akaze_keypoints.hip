@@ -647,7 +647,8 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
     const int n = range ? min(bofs(range, T.bstride)[1], n_cap) : n_cap;
     kps = bofs(kps, kp_bstride);
     __shared__ float s_x[4][112], s_y[4][112];
-    __shared__ uint8_t s_bin[4][112], s_sorted[4][112];
+    __shared__ float s_xs[4][112], s_ys[4][112];   // the same, in sorted order
+    __shared__ uint8_t s_bin[4][112];
     __shared__ int s_start[4][44];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     for (int kb = begin + (int)blockIdx.x * 4; kb < n; kb += (int)gridDim.x * 4) {   // block-uniform trip count
@@ -728,8 +729,15 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
         __syncthreads();
         if (lane < 43) s_start[wv][lane] = incl - mine;            // exclusive prefix: bin 42 (no sample) holds the total
         __syncthreads();
-        s_sorted[wv][s_start[wv][bin0] + in0] = (uint8_t)lane;
-        if (bin1 < 42) s_sorted[wv][s_start[wv][bin1] + in1] = (uint8_t)(lane + 64);
+        // the samples' values go straight to their sorted places: the window sums below then read consecutive elements
+        const int p0 = s_start[wv][bin0] + in0;
+        s_xs[wv][p0] = s_x[wv][lane];
+        s_ys[wv][p0] = s_y[wv][lane];
+        if (bin1 < 42) {
+            const int p1 = s_start[wv][bin1] + in1;
+            s_xs[wv][p1] = s_x[wv][lane + 64];
+            s_ys[wv][p1] = s_y[wv][lane + 64];
+        }
     }
     __syncthreads();
     float sumX = 0.0f, sumY = 0.0f, norm = -1.0f;
@@ -738,21 +746,18 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
         const int* st = s_start[wv];
         if (sn <= slices - win) {
             for (int i = st[sn]; i < st[sn + win]; i++) {
-                const int idx = s_sorted[wv][i];
-                sumX += s_x[wv][idx];
-                sumY += s_y[wv][idx];
+                sumX += s_xs[wv][i];
+                sumY += s_ys[wv][i];
             }
         } else {
             const int remain = sn + win - slices;
             for (int i = st[sn]; i < st[slices]; i++) {
-                const int idx = s_sorted[wv][i];
-                sumX += s_x[wv][idx];
-                sumY += s_y[wv][idx];
+                sumX += s_xs[wv][i];
+                sumY += s_ys[wv][i];
             }
             for (int i = st[0]; i < st[remain]; i++) {
-                const int idx = s_sorted[wv][i];
-                sumX += s_x[wv][idx];
-                sumY += s_y[wv][idx];
+                sumX += s_xs[wv][i];
+                sumY += s_ys[wv][i];
             }
         }
         norm = sumX * sumX + sumY * sumY;
