@@ -1423,8 +1423,8 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
                                std::max(np, 0));
             if (np <= 0) return;
             for (int round = 0; round < WIDE_ROUNDS; round++)
-                // (a wider grid for the first round, which visits every candidate, is slower: 512 blocks 59 us, 1024 blocks 69 us against 51 us —
-                // the round is bound by the memory system's rate of scattered byte loads, not by a wave's chain of them)
+                // (a wider grid for the first round, which visits every candidate, is slower: 512 blocks 59 us, 1024 blocks 69 us against 51 us
+                // with 256: more waves in flight do not help, and neither do fewer loads per candidate — see suppress_round_body)
                 hipLaunchKernelGGL(suppress_round_kernel, dim3(B > 1 ? 64 : 256, np, B), lblock, 0, s_kp, A, lo, (uint8_t)(round % 253 + 1),
                                    round == 0 ? -1 : (round - 1) % 3, round % 3, (round + 1) % 3);
             hipLaunchKernelGGL(suppress_tail_kernel, dim3(1, np, B), dim3(1024), 0, s_kp, A, lo, WIDE_ROUNDS);
