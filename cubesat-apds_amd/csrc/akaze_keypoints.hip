@@ -13,6 +13,7 @@
 #include <atomic>
 #include <cstdlib>
 
+#include <chrono>
 #include "akaze.h"
 
 namespace apds {
@@ -1207,6 +1208,8 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     if (max_points <= 0) max_points = APDS_MAX_POINTS;
     ThreadCtx& c = ctx();
     KernelTimer whole("akaze_extract", s);   // whole extraction (all kernels + the count read-backs), for bench.py
+    static const int host_time_env = getenv("APDS_DEBUG_HOST_TIME") ? atoi(getenv("APDS_DEBUG_HOST_TIME")) : 0;
+    const auto host_t0 = std::chrono::steady_clock::now();
     const int W = cols, H = rows, B = n_img;
     const float soffset = 1.6f, derivative_factor = 1.5f, dthreshold = 0.001f;
 
@@ -1246,6 +1249,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // 4 threads reach 2400 tiles/s of 1024^2 when no thread ever forked, 1240 - 1320 when some did. So a thread forks only while it
     // is the ONLY host thread holding a library context (apds_thread_release drops one); APDS_AKAZE_FORK = 0 never, 2 always.
     static const int fork_env = getenv("APDS_AKAZE_FORK") ? atoi(getenv("APDS_AKAZE_FORK")) : 1;
+    // (A call costs the host ~3.5 us per launch, event record or stream wait, ~90 of them: a 512^2 tile's 0.32 ms is mostly that. Not
+    // forking below 0.5 Mpx saves 30 of those calls and was measured both ways: 0.355 against 0.367 ms in tools/ab_probe.py, 0.36 against
+    // 0.32 in tools/extract_probe.py — no threshold.)
     const bool fork_doh = fork_env == 2 || (fork_env == 1 && live_contexts().load() <= 1);
 
     // ---- one image's workspace slab (all images of the batch: the same layout, `slab` bytes apart)
@@ -1410,6 +1416,8 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // Level j is final after phase-0 pass j+1 and phase-1 pass j-1; both are in this stage or an earlier one for j <= m. Each pass:
     // a snapshot / counter-reset launch, WIDE_ROUNDS wide rounds (most candidates are ready at once), then suppress_tail_kernel
     // finishes the chains without any host check.
+    // (fewer wide rounds for small tiles — whose calls are bound by the host's enqueue time — were measured: the tail kernel's one block
+    // per level then walks every candidate, 512^2 0.32 -> 0.37 ms)
     constexpr int WIDE_ROUNDS = 3;
     int n_stage = 0;
     auto suppress_stage = [&](int prev_m, int m, hipStream_t s_kp) {
@@ -1620,6 +1628,15 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         dbg.armed = false;
     }
 
+    if (host_time_env) {   // diagnostic: the host's share of a call (everything up to here is enqueue work; the GPU may still be running)
+        static thread_local double acc = 0;
+        static thread_local int calls = 0;
+        acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - host_t0).count();
+        if (++calls % host_time_env == 0) {
+            fprintf(stderr, "[apds] akaze_extract %dx%d x%d: %.1f us of host enqueue time per call\n", W, H, B, acc / host_time_env * 1e6);
+            acc = 0;
+        }
+    }
     // ---- the only read-back of the call: every image's keypoint count
     int* K = c.pinned_ints(B);
     if (B == 1) {
