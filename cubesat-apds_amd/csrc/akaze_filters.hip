@@ -1258,8 +1258,10 @@ __device__ __forceinline__ void doh_tile_generic(const float* __restrict__ Lsmoo
         const float v = p[0];
         // all nine tests evaluated (no short-circuit branches: a strict maximum is rare, the branches were most of this loop);
         // "reject if v <= neighbour" exactly as written in the reference, hence the negated comparisons
-        const bool keep = ((unsigned)(gx - border) < span_x) & ((unsigned)(gy - border) < span_y) & !(v <= thr) & !(v <= p[-EW]) & !(v <= p[EW]) &
-                          !(v <= p[-1]) & !(v <= p[1]) & !(v <= p[-EW - 1]) & !(v <= p[-EW + 1]) & !(v <= p[EW - 1]) & !(v <= p[EW + 1]);
+        // "v <= x for some neighbour x" is "v <= the largest neighbour": fmaxf ignores a NaN operand exactly as the comparison v <= NaN
+        // is false, and !(v <= m) keeps a NaN v as the reference's chain of comparisons does (three v_max3_f32 instead of eight compares)
+        const float m = fmaxf(fmaxf(fmaxf(fmaxf(p[-EW - 1], p[-EW]), p[-EW + 1]), fmaxf(p[-1], p[1])), fmaxf(fmaxf(p[EW - 1], p[EW]), p[EW + 1]));
+        const bool keep = ((unsigned)(gx - border) < span_x) & ((unsigned)(gy - border) < span_y) & !(v <= thr) & !(v <= m);
         if (keep) {
             mask[(size_t)gy * w + gx] = 1;
             s_cand[atomicAdd(&s_n, 1)] = (uint32_t)gx | ((uint32_t)gy << 16);
