@@ -55,7 +55,7 @@ void rgba_to_bgra_device(const uint8_t* rgba, size_t n_pixels, uint8_t* bgra, hi
 __global__ void spin_kernel(long long cycles, int* sink) {
     const long long t0 = __builtin_readcyclecounter();
     long long t = t0;
-    while (t - t0 < cycles) {
+    for (int it = 0; it < 20000 && t - t0 < cycles; it++) {   // bounded whatever the counter does: the wave always ends
         __builtin_amdgcn_s_sleep(8);
         t = __builtin_readcyclecounter();
     }
