@@ -1293,7 +1293,9 @@ __global__ __launch_bounds__(NT) void doh_fused_kernel(const float* __restrict__
 // terms rd(r) = L[r][x+s] - L[r][x-s], rs(r) = kmid L[r][x] + kside (L[r][x-s] + L[r][x+s]) are computed once per row and shared by
 // the outputs that use the row as their upper, middle or lower one. Bit-identical, ~12 % fewer instructions, and slower: K = 10 on
 // 576 threads ran one block per CU (4096^2 extraction 2.26 ms against 1.93), K = 6 on 1024 threads at 64 registers 1.98 - 2.12 ms.
-// This kernel is bound by the latency of its four barrier-separated phases at two blocks per CU, not by its instruction count.)
+// Two horizontally adjacent outputs per item with packed-f32 arithmetic (v_pk_add_f32 / v_pk_mul_f32, pairs read with one LDS
+// instruction) was tried again on the 64 x 32 tiles: bit-identical, 1.824 against 1.782 ms — v_pk_add / v_pk_mul issue at half the rate
+// of their scalar forms (tools/valu_calib.py), so they save index arithmetic only, and the unaligned pair reads cost more than that.)
 
 // ---- host launchers -------------------------------------------------------------------------------------
 // grid of a persistent tile kernel with two 1024-thread blocks per CU: a multiple of 8 (one slice per XCD), at most 2 x 256 blocks
