@@ -69,6 +69,36 @@ def _debug_solo(tag, frames, T, L, check, pl, dev, torch):
         print(f"[debug solo] {tag}: {(time.perf_counter() - t0) * 100:.3f} ms per extraction", file=sys.stderr, flush=True)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>`
+    as a child process (one rank per GPU, rendezvous on 127.0.0.1, a free port), pass rank 0's JSON line through and return the child's exit
+    code. The parent never imports torch or touches HIP."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in proc.stdout:
+        if line.lstrip().startswith("{"):          # the contract: ONE JSON line on stdout; anything else a rank printed goes to stderr
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print(f"bench.py: the ranks exited 0 but printed {lines} JSON lines", file=sys.stderr)
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,7 +119,16 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs masked out of the match stream so the other stages overlap it")
     ap.add_argument("--serial", action="store_true", help="one frame at a time (no cross-frame overlap of the three stages)")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="additionally time the streamed pipeline with every step's frame coming from pinned HOST memory (hipMemcpyAsync on the "
+                         "extraction stream): reported as value_host_frames next to the resident `value` (the reference's bench times Mat "
+                         "construction + extraction, benchmarks/benches/feature_extraction.rs:35-45)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started bare (`python bench.py --gpus N`): this process becomes the launcher. Nothing has touched the GPU yet (no torch import,
+        # no HIP call), the ranks are CHILD processes (never exec from a process that initialised the GPU), rank 0's JSON line is relayed.
+        return spawn_ranks(args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -97,7 +136,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world} (start it bare, or with torch.distributed.run --nproc-per-node {args.gpus})")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     backend = os.environ.get("APDS_BENCH_BACKEND", "nccl")      # "gloo" = single-GPU rehearsal of the multi-rank path
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
@@ -290,10 +330,28 @@ def main():
         stats, timers = pipe.run(frames, args.steps, filter_strength=args.filter_strength, timing=True)
         fence()
         elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    elapsed_host = None
+    if args.host_frames and not args.serial:
+        # the same K steps with every frame coming from pinned host memory: the extraction worker uploads it (hipMemcpyAsync on its own
+        # stream, into a per-slot device buffer) in front of the extraction, so frame i+1's PCIe copy travels under frame i's match
+        host_frames = [torch.from_numpy(f).pin_memory() for f in frames_np]
+        pipe.run(host_frames, max(args.warmup, 2), filter_strength=args.filter_strength)
+        fence()
+        t0 = time.perf_counter()
+        stats_host, _ = pipe.run(host_frames, args.steps, filter_strength=args.filter_strength)
+        fence()
+        elapsed_host = time.perf_counter() - t0
+        assert [s["n_keypoints"] for s in stats_host] == [s["n_keypoints"] for s in stats], "host-frame run differs from the resident run"
+
+    def max_over_ranks(v):
+        if world == 1:
+            return v
+        tt = torch.tensor([v], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
+    elapsed = max_over_ranks(elapsed)
+    if elapsed_host is not None:
+        elapsed_host = max_over_ranks(elapsed_host)
     topk_ms, topk_n = timers.get("hamming_topk", (0.0, 0))
     sample_ms, sample_n = timers.get("hamming_topk_sample", (0.0, 0))
     akaze_ms, akaze_n = timers.get("akaze_extract", (0.0, 0))
@@ -314,7 +372,7 @@ def main():
         topk_ms_step = topk_ms / max(args.steps, 1)
         peak = C.c_double(0)
         check(L.apds_dev_valu_popcount_peak(C.byref(peak)))
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -322,6 +380,8 @@ def main():
                 # the PMC profile was taken on the default workload on one GPU: it says nothing about other DB / tile sizes
                 if (tj.get("db_rows_per_gpu", 1_000_000), tj.get("tile", 4096)) == (rows_local, args.tile) and args.db == "mixed":
                     traffic = tj.get("hamming_topk_hbm_bytes_per_launch")
+                    # not measured in this run: rocprofv3 --pmc passes (tools/profile_bench.sh) wrote the file; say which commit's
+                    traffic_source = f"profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh; collected at {tj.get('commit', 'an earlier commit')})"
             except Exception:
                 traffic = None
         bytes_per_launch = match_bytes / max(launches_per_step, 1e-9)
@@ -344,6 +404,9 @@ def main():
                        "match_stream_gaps_ms_first16": ([round(float(g), 2) for g in pipe.gap_log[:16]] if getattr(pipe, "gap_log", None) else None),
                        "keypoints_per_frame": K, "matches_per_frame": float(np.mean([s["n_matches"] for s in stats])),
                        "inliers_per_frame": float(np.mean([s["n_inliers"] for s in stats])), "homography_found": all(s["H"] is not None for s in stats)},
+            "collectives": collectives_info(torch, dist, world, backend, meta_group),
+            "value_host_frames": (world * args.steps / elapsed_host) if elapsed_host else None,
+            "ms_per_step_host_frames": (elapsed_host / args.steps * 1e3) if elapsed_host else None,
             "mmatches_per_s": world * K * args.steps / elapsed / 1e6,
             "gpairs_per_s": world * Q_step * rows_local * args.steps / elapsed / 1e9,
             # The binding bound of the dominant kernel is integer-VALU issue, so that is what `roofline` carries:
@@ -353,7 +416,7 @@ def main():
             # profiles/r02/valu_calib_*.log). north_star's "% of HBM" is the sub-object `hbm`.
             "roofline": {"kernel": f"hamming_topk_kernel<{4 if Q_step >= 16384 else (2 if Q_step >= 8192 else 1)},2>", "bound": "int32-valu",
                          "achieved": achieved_tops, "peak": peak.value / 1e12, "unit": "T lane-op/s", "frac": achieved_tops / (peak.value / 1e12) if peak.value else 0.0,
-                         "traffic": traffic, "launches_per_step": launches_per_step, "avg_launch_ms": avg_launch_ms,
+                         "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": launches_per_step, "avg_launch_ms": avg_launch_ms,
                          "algorithmic_lane_ops_per_launch": match_ops / max(launches_per_step, 1e-9), "algorithmic_bytes_per_launch": bytes_per_launch,
                          "tpairs_per_s": Q_step * rows_main / (topk_ms_step * 1e-3) / 1e12 if topk_ms_step else 0.0,
                          "peak_spec_fp32_rate": VALU_FP32_LANE_RATE_SPEC,
@@ -371,11 +434,33 @@ def main():
                                 "note": "whole extraction (incl. orientation, descriptors, the count read-back), 10 back-to-back calls on resident frames timed by the wall clock with nothing else on the GPU, before the pipeline's streams are created, against the detect stages' algorithmic bytes; stages_ms_per_step.akaze_extract is its wall span while overlapped with the match (two frames are extracted concurrently, so the span may exceed the step time)"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pkg, frames_np[0], db_local, int(K), args.filter_strength, db_xy, stats[0])
+            # the GPU's keypoints and descriptors of frame 0, for the baseline's equality check against the oracle's
+            n0 = C.c_int(0)
+            with torch.cuda.stream(setup_stream):
+                check(L.apds_dev_akaze_extract(frames[0].data_ptr(), T, T, frames[0].shape[2], frames[0].stride(0), cap, kps.data_ptr(), desc.data_ptr(), cap,
+                                               C.byref(n0), pl.torch_stream()))
+                torch.cuda.synchronize()
+            gpu_kps = kps[:n0.value].cpu().numpy()
+            gpu_desc = desc[:n0.value, :61].cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(pkg, frames_np[0], db_local, int(K), args.filter_strength, db_xy, gpu_kps, gpu_desc)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def collectives_info(torch, dist, world, backend, meta_group):
+    """What carried the exchange step of this run: ranks, backend, and the RCCL build torch links (so a SCALE record shows that RCCL
+    itself saw N ranks, not the gloo rehearsal)."""
+    try:
+        v = torch.cuda.nccl.version()
+        rccl = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:   # noqa: BLE001
+        rccl = None
+    return {"world": world, "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else "none (one rank, no exchange step)",
+            "rccl_version": rccl, "ranks_in_group": dist.get_world_size() if world > 1 else 1,
+            "count_exchange": "gloo host group" if meta_group is not None else ("device-side gather" if world > 1 else None),
+            "exchange": "all-gather of query rows + all-to-all of per-shard top-2 keys + u64-min merge" if world > 1 else None}
 
 
 def bench_l2(args, pkg, pl, torch, dev, world):
@@ -442,7 +527,7 @@ def bench_l2(args, pkg, pl, torch, dev, world):
         "roofline": roof}), flush=True)
 
 
-def cpu_baseline(pkg, frame, db_local, K, fs, db_xy, ref_stats):
+def cpu_baseline(pkg, frame, db_local, K, fs, db_xy, gpu_kps, gpu_desc):
     """The oracle ("port": this repo's scalar/OpenMP C++ restatement) on the host cores, same frame and DB, built
     on this host with -O3 -march=native. Reported at ALL host cores (`value`, `cores`) and at ONE thread (`one_thread`). The match
     runs the full query set when a probe says it fits in 60 s, otherwise a stated sample (`sampled_queries`, `scale`)."""
@@ -510,8 +595,10 @@ def cpu_baseline(pkg, frame, db_local, K, fs, db_xy, ref_stats):
                            "sample": f"1 thread: detect+describe of the central {frame.shape[1] // 2}x{frame.shape[0] // 2} window x{d_scale:.0f}, "
                                      f"match of {nq1} of the {nq} queries ({t1_match_sample:.2f} s, x{nq / nq1:.1f})",
                            "sampled_queries": nq1, "scale": nq / nq1},
-            "keypoints_equal_gpu": int(nq) == int(ref_stats["n_keypoints"])}
+            # every keypoint field (x, y, size, angle, response as f32 bits; octave, class_id) and every descriptor byte of frame 0
+            "keypoints_equal_gpu": bool(len(gpu_kps) == nq and np.array_equal(gpu_kps.view(np.uint32).reshape(-1, 7), ex.keypoints.view(np.uint32).reshape(-1, 7))
+                                        and np.array_equal(gpu_desc, ex.descriptors))}
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -141,6 +141,7 @@ class ShardedMatcher:
     def make_buffers(self, max_queries=None, k=None):
         """Exchange buffers for frames of at most `max_queries` queries per rank (one set per frame in flight)."""
         pad = max(self.pad_rows, int(max_queries or 0))
+        pad = -(-pad // self.msg_round) * self.msg_round          # whole messages: gather_queries sends multiples of msg_round rows
         return GatheredQueries(self.world, pad, k or self.kmax, self.rows.device)
 
     def gather_queries(self, q_rows64, counts, buf):
@@ -150,7 +151,10 @@ class ShardedMatcher:
         buf.counts, buf.total, buf.nq = list(counts), int(sum(counts)), nq
         buf.mine[:nq].copy_(q_rows64)
         # message size of this frame: the largest count, rounded up (the buffers are sized for the capacity, the wire is not)
-        rows = min(buf.pad, max(self.msg_round, -(-max(counts) // self.msg_round) * self.msg_round))
+        # a function of `counts` alone (identical on every rank, whatever each rank's buffer capacity is): a message size taken from the
+        # rank-local buffer would make the collective's sizes differ between ranks, which RCCL answers with a hang, not an error
+        rows = max(self.msg_round, -(-max(counts) // self.msg_round) * self.msg_round)
+        assert rows <= buf.pad, f"exchange buffer holds {buf.pad} rows per rank, this frame needs {rows}: make_buffers(max_queries) rounds up to {self.msg_round}"
         gathered = buf.gathered[:self.world * rows * 64].view(self.world, rows, 64)
         _gather_into(self.dist, self.group, gathered, buf.mine[:rows])
         off = 0
@@ -428,6 +432,13 @@ class StreamedFramePipeline:
                         if s is None:
                             return
                         f = frames[i % len(frames)]
+                        if not f.is_cuda:
+                            # a host frame (pinned memory): upload it on THIS worker's stream in front of the extraction, into the slot's own
+                            # device buffer; the other extraction worker and the match run meanwhile, so the PCIe copy is overlapped
+                            if s.get("frame") is None or s["frame"].shape != f.shape:
+                                s["frame"] = torch.empty(f.shape, dtype=f.dtype, device=self.dev)
+                            s["frame"].copy_(f, non_blocking=True)
+                            f = s["frame"]
                         ch = 1 if f.dim() == 2 else f.shape[2]
                         n = C.c_int(0)
                         check(L.apds_dev_akaze_extract(f.data_ptr(), f.shape[0], f.shape[1], ch, f.stride(0), self.cap, s["kps"].data_ptr(),
