@@ -341,13 +341,15 @@ __device__ __forceinline__ Refined refine(const float* __restrict__ ldet, int co
     const float Dxx = ldet[c + 1] + ldet[c - 1] - 2.0f * ldet[c];
     const float Dyy = ldet[c + cols] + ldet[c - cols] - 2.0f * ldet[c];
     const float Dxy = 0.25f * (ldet[c + cols + 1] + ldet[c - cols - 1] - ldet[c - cols + 1] - ldet[c + cols - 1]);
+    // cv::solve(Matx22f, Vec2f, dst, DECOMP_LU): lapack.cpp's 2 x 2 CV_32F branch - determinant (`det2`) and both numerators in
+    // double (products of two floats are exact there), one rounding to float per unknown
     float dx = 0.0f, dy = 0.0f;
-    float det = Dxx * Dyy - Dxy * Dxy;
-    if (det != 0) {
-        det = 1 / det;
+    double det = (double)Dxx * (double)Dyy - (double)Dxy * (double)Dxy;
+    if (det != 0.) {
+        det = 1. / det;
         const float b0 = -Dx, b1 = -Dy;
-        dx = (b0 * Dyy - b1 * Dxy) * det;
-        dy = (b1 * Dxx - b0 * Dxy) * det;
+        dx = (float)(((double)b0 * (double)Dyy - (double)b1 * (double)Dxy) * det);
+        dy = (float)(((double)b1 * (double)Dxx - (double)b0 * (double)Dxy) * det);
     }
     Refined r;
     r.ok = !(fabsf(dx) > 1.0f || fabsf(dy) > 1.0f);
@@ -1311,7 +1313,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     bt.n = B;
     bt.stride = slab;
     bt.img_stride = img_bstride;
-    if (fork_doh && c.fork_open) {   // an earlier call failed between fork and join: its side-stream kernels may still use the workspace
+    if (c.fork_open) {   // an earlier call failed between fork and join (whether or not THIS call forks): its side-stream kernels may still use the workspace
         if (c.side) HIP_CHECK(hipStreamSynchronize(c.side));
         for (hipStream_t st : c.side_pool)
             if (st) HIP_CHECK(hipStreamSynchronize(st));
@@ -1686,6 +1688,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
                                reinterpret_cast<uint32_t*>(desc64_out + (size_t)bi * desc_bstride), (size_t)0);
         }
         HIP_CHECK(hipGetLastError());
+        // these kernels read the calling thread's workspace (kps_all, masks, planes): the same thread's NEXT call, possibly on another
+        // stream (apds_dev_* take one), starts by re-using that memory, so the rare over-capacity path ends synchronously like the main one
+        HIP_CHECK(hipStreamSynchronize(s));
     }
     return kmax;
 }

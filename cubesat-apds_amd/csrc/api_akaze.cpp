@@ -110,6 +110,17 @@ int apds_akaze_debug_plane(const uint8_t* img, int rows, int cols, int channels,
     return rc;
 }
 
+// Output rows per image of a batched extraction: the rule of the single-image call (capacity = max_points) unless the image cannot hold
+// that many. Strict 3x3 maxima are never adjacent, so a level of w x h pixels has at most ceil(w/2) * ceil(h/2) of them; summed over every
+// level of every octave (four levels per octave; octaves as the detector builds them: halved until width < 80 or height < 40). A bound
+// below the true ceiling would fail a whole batch on a dense image that extracts fine alone.
+static int batch_capacity(int rows, int cols, int max_points) {
+    long long bound = 0;
+    for (int o = 0, w = cols, h = rows; o < 4 && (o == 0 || (w >= 80 && h >= 40)); o++, w >>= 1, h >>= 1)
+        bound += 4LL * ((w + 1) / 2) * ((h + 1) / 2);
+    return (int)std::min<long long>(max_points, std::max<long long>(bound, 64));
+}
+
 // device results of a batch (capacity rows per image) -> malloc'ed host arrays holding the images' rows back to back
 static void batch_results_to_host(ThreadCtx& c, hipStream_t s, const apds_keypoint* dk, const uint8_t* dd, int capacity, int n_images, const int* counts,
                                   apds_keypoint** kps, uint8_t** desc) {
@@ -172,8 +183,7 @@ int apds_tile_extract_batch(const float* const* red, const float* const* green, 
             }
         uint8_t* dimg = c.alloc_n<uint8_t>(all * 4);
         band_merger_device(bands, bands + all, bands + 2 * all, all, minmax6, /*bgra=*/1, dimg, s);
-        const long long bound = (long long)((cols + 1) / 2) * ((rows + 1) / 2) * 2;
-        const int capacity = (int)std::min<long long>(max_points, std::max<long long>(bound, 64));
+        const int capacity = batch_capacity(rows, cols, max_points);
         apds_keypoint* dk = c.alloc_n<apds_keypoint>((size_t)capacity * n_tiles);
         uint8_t* dd = c.alloc_n<uint8_t>((size_t)capacity * 64 * n_tiles);
         akaze_extract_batch_device(dimg, n_tiles, px * 4, rows, cols, 4, (size_t)cols * 4, max_points, dk, dd, capacity, counts, s);
@@ -208,9 +218,7 @@ int apds_akaze_extract_batch(const uint8_t* imgs, int n_images, size_t image_str
             for (int i = 0; i < n_images; i++)
                 HIP_CHECK(hipMemcpy2DAsync(dimg + i * dimg_bytes, dstride, imgs + i * image_stride, stride, row_bytes, rows, hipMemcpyHostToDevice, s));
         }
-        // capacity per image: strict 3x3 maxima are never adjacent -> at most a quarter of the pixel-levels; and never more than max_points
-        const long long bound = (long long)((cols + 1) / 2) * ((rows + 1) / 2) * 2;
-        const int capacity = (int)std::min<long long>(max_points, std::max<long long>(bound, 64));
+        const int capacity = batch_capacity(rows, cols, max_points);
         apds_keypoint* dk = c.alloc_n<apds_keypoint>((size_t)capacity * n_images);
         uint8_t* dd = c.alloc_n<uint8_t>((size_t)capacity * 64 * n_images);
         akaze_extract_batch_device(dimg, n_images, dimg_bytes, rows, cols, channels, dstride, max_points, dk, dd, capacity, counts, s);

@@ -323,16 +323,24 @@ int find_homography_rho_device(const float* src_dev, const float* dst_dev, int n
     std::vector<int> slot(max_batch);          // row of the iteration's model in `models` / `bits`, or -1 (no model: rejected sample)
 
     float bestH[9] = {0};
-    std::vector<unsigned long long> bestRow(words, 0);
+    // rho.cpp keeps two inlier arrays, `curr.inl` and `best.inl`, and SWAPS them when a model becomes the best one. evaluateModelSPRT writes
+    // only the flags of the points it tested, so behind an early SPRT stop an array still holds what an earlier model left there. The two
+    // bit rows below are those arrays (zero at the start of a run), prefix writes and swap included: a model that the SPRT rejected can
+    // still become the best one (isBestModel() compares the counts only), and then the stale flags are part of the state (the
+    // non-randomness walk, the refinement and the returned mask read them).
+    std::vector<unsigned long long> curRow(words, 0), bestRow(words, 0);
     unsigned bestCount = 0;
     unsigned it = 0;
     bool first = true;
-    while (it < maxI) {
+    // rho.cpp: `for(ctrl.i = 0; ctrl.i < arg.maxI || ctrl.i < 100; ctrl.i++)` - never fewer than 100 iterations, however far the
+    // confidence bound has pulled maxI down
+    auto limit = [&]() { return std::max(maxI, 100u); };
+    while (it < limit()) {
         // ---- speculate the samples of iterations it .. it + B - 1 under the current pool limit
         const int Bcap = first ? first_batch : max_batch;
         first = false;
         int B = 0, rows = 0;
-        for (; B < Bcap && it + B < maxI; B++) {
+        for (; B < Bcap && it + B < limit(); B++) {
             before[B] = ps;
             const unsigned i = it + B;
             if (i >= ps.phEndI && ps.phNum < phMax) {
@@ -367,7 +375,7 @@ int find_homography_rho_device(const float* src_dev, const float* dst_dev, int n
         // ---- replay rho.cpp's loop over the speculated iterations
         int b = 0;
         bool redraw = false;
-        for (; b < B && it < maxI; b++, it++) {
+        for (; b < B && it < limit(); b++, it++) {
             if (slot[b] < 0) continue;
             const unsigned long long* row = &bits[(size_t)slot[b] * words];
             // SPRT walk over the points in order
@@ -380,41 +388,53 @@ int find_homography_rho_device(const float* src_dev, const float* dst_dev, int n
                 lambda *= in ? sprt.onInlier : sprt.onOutlier;
                 good = lambda <= sprt.A;
             }
+            {   // curr.inl[0 .. tested) = this model's flags; the rest keeps its old content
+                const unsigned full = tested >> 6, rest = tested & 63;
+                std::memcpy(curRow.data(), row, (size_t)full * sizeof(unsigned long long));
+                if (rest) {
+                    const unsigned long long m = (1ull << rest) - 1;
+                    curRow[full] = (curRow[full] & ~m) | (row[full] & m);
+                }
+            }
+            // updateSPRT()
             if (good) {
                 if (count > bestCount) {
                     sprt.eps = (double)count / N;
                     sprt.design();
-                    std::memcpy(bestH, &models[(size_t)slot[b] * 9], sizeof(bestH));
-                    std::memcpy(bestRow.data(), row, (size_t)words * sizeof(unsigned long long));
-                    bestCount = count;
-                    // non-randomness: the shortest prefix of the (quality-ordered) points whose inlier share beats the whole set's
-                    unsigned best_n = N, bestInl = bestCount, testInl = bestCount;
-                    for (unsigned test_n = N; test_n > 20 && testInl; test_n--) {
-                        if ((uint64_t)testInl * best_n > (uint64_t)bestInl * test_n) {
-                            if (testInl < nonRandom[test_n]) break;
-                            best_n = test_n;
-                            bestInl = testInl;
-                        }
-                        testInl -= bit(bestRow.data(), (int)test_n - 1) ? 1 : 0;
-                    }
-                    if ((uint64_t)bestInl * phMax > (uint64_t)phNumInl * best_n) {
-                        if (phMax != best_n) redraw = true;   // the samples after this iteration were drawn under another pool limit
-                        phMax = best_n;
-                        phNumInl = bestInl;
-                        maxI = iteration_bound(confidence, (double)phNumInl / phMax, 4, maxI);
-                    }
-                    maxI = iteration_bound(confidence, (double)bestCount / N, 4, maxI);
-                    if (redraw) {
-                        b++;
-                        it++;
-                        break;
-                    }
                 }
             } else {
                 const double nd = (double)count / tested;
                 if (nd > 0 && std::fabs(sprt.delta - nd) / sprt.delta > 0.1) {
                     sprt.delta = nd;
                     sprt.design();
+                }
+            }
+            // isBestModel(): the counts alone decide, accepted by the SPRT or not
+            if (count > bestCount) {
+                std::memcpy(bestH, &models[(size_t)slot[b] * 9], sizeof(bestH));
+                curRow.swap(bestRow);
+                bestCount = count;
+                maxI = iteration_bound(confidence, (double)bestCount / N, 4, maxI);   // updateBounds()
+                // nStarOptimize(): the shortest prefix of the (quality-ordered) points whose inlier share beats the whole set's
+                unsigned best_n = N, bestInl = bestCount, testInl = bestCount;
+                for (unsigned test_n = N; test_n > 20 && testInl; test_n--) {
+                    if ((uint64_t)testInl * best_n > (uint64_t)bestInl * test_n) {
+                        if (testInl < nonRandom[test_n]) break;
+                        best_n = test_n;
+                        bestInl = testInl;
+                    }
+                    testInl -= bit(bestRow.data(), (int)test_n - 1) ? 1 : 0;
+                }
+                if ((uint64_t)bestInl * phMax > (uint64_t)phNumInl * best_n) {
+                    if (phMax != best_n) redraw = true;   // the samples after this iteration were drawn under another pool limit
+                    phMax = best_n;
+                    phNumInl = bestInl;
+                    maxI = iteration_bound(confidence, (double)phNumInl / phMax, 4, maxI);
+                }
+                if (redraw) {
+                    b++;
+                    it++;
+                    break;
                 }
             }
         }

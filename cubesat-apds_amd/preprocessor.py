@@ -86,8 +86,14 @@ def downscale_from_lod(table, images, dataset, amount_lod, lod, workers=1, fused
     barrier = threading.Barrier(workers)
 
     def release():
-        barrier.wait()
-        lib().apds_thread_release()
+        # generous, but finite: if one of the `workers` release tasks never reaches the barrier (a pool thread that could not start, an
+        # exception in front of the wait) the others must not block the pool's shutdown for ever; the thread's context is released either way
+        try:
+            barrier.wait(timeout=120.0)
+        except threading.BrokenBarrierError:
+            pass
+        finally:
+            lib().apds_thread_release()
 
     out, pending = [], []
     with ThreadPoolExecutor(max_workers=workers) as pool:

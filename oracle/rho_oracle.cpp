@@ -5,7 +5,10 @@
 // Laganiere: "A fast and robust homography scheme for real-time planar target detection"): PROSAC sampling, SPRT verification,
 // the non-randomness bound on the iteration count, and a final Levenberg-Marquardt refinement, all in binary32. That file is not
 // in /root/reference and OpenCV is not installed: restated from the published algorithm and from memory of rho.cpp's structure.
-// PARITY UNPINNED. Known deviation: the 4-point solve is a generic Gauss-Jordan elimination with partial pivoting on the 8 x 9
+// PARITY UNPINNED: "equal to the oracle" means equal to THIS restatement, not to cv::findHomography(RHO). Controller points restated
+// from rho.cpp as recalled (round 3, after review): the loop runs `i < maxI || i < 100` (a floor of 100 iterations); verify() is
+// evaluateModelSPRT -> updateSPRT -> if (curr.numInl > best.numInl) {saveBestModel (array SWAP); updateBounds; nStarOptimize}, i.e.
+// the best-model test ignores the SPRT verdict and a rejected model's inlier array keeps stale flags behind its last tested point. Known deviation: the 4-point solve is a generic Gauss-Jordan elimination with partial pivoting on the 8 x 9
 // system (rho.cpp's hFuncRefC eliminates a hand-reduced form of it): the same homography up to binary32 rounding, which only
 // decides inlier flags of points that lie on the threshold.
 //
@@ -356,7 +359,8 @@ struct Rho {
             for (unsigned n = SMPL + 1; n < (unsigned)N + 1; n++) nrTbl[n] = (unsigned)std::ceil(SMPL + n * beta + std::sqrt((double)n) * bb);
         }
         design_sprt();
-        for (it = 0; it < maxI; it++) {
+        // rho.cpp: `for(ctrl.i = 0; ctrl.i < arg.maxI || ctrl.i < 100; ctrl.i++)`: at least 100 iterations whatever the confidence bound says
+        for (it = 0; it < maxI || it < 100; it++) {
             if (it >= phEndI && phNum < phMax) {   // next PROSAC phase: one more (lower-ranked) point enters the pool
                 phNum++;
                 const double next = (phEndFpI * phNum) / (phNum - SMPL);
@@ -374,12 +378,17 @@ struct Rho {
             if (!solve4(pk, curH)) continue;
             evaluate_sprt();
             update_sprt();
-            if (good && curNum > bestNum) {
+            // rho.cpp verify(): evaluateModelSPRT(); updateSPRT(); if (isBestModel()) { saveBestModel(); updateBounds(); nStarOptimize(); } with
+            // isBestModel() = curr.numInl > best.numInl - the SPRT's verdict is NOT part of it, so a model rejected after `nTested` points
+            // becomes the best one if the inliers counted that far beat the best count. saveBestModel() swaps the two inlier arrays and
+            // evaluateModelSPRT() writes only the first nTested flags, so the tail of such a model's array holds whatever an earlier
+            // evaluation left there (both arrays start zeroed): curInl / bestInl reproduce exactly that (prefix writes, swap).
+            if (curNum > bestNum) {
                 std::memcpy(bestH, curH, sizeof(curH));
                 bestInl.swap(curInl);
                 bestNum = curNum;
-                nstar_optimize();
                 maxI = iter_bound(cfd, (double)bestNum / N, SMPL, maxI);
+                nstar_optimize();
             }
         }
         const bool ok = bestNum >= minInl;
