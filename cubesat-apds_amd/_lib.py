@@ -27,7 +27,27 @@ SYMBOLS = [
     "apds_dev_valu_popcount_peak", "apds_dev_valu_peak", "apds_dev_valu_peak_modes", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane", "apds_stream_create", "apds_stream_destroy",
     "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective", "apds_pnp_solver_ransac", "apds_pnp_hypotheses", "apds_get_world_coordinates", "apds_l2_knn_match", "apds_dev_l2_topk", "apds_dev_l2_topk_ex",
     "apds_db_create", "apds_db_destroy", "apds_db_rows", "apds_db_insert_image", "apds_db_select", "apds_db_view", "apds_db_view_download", "apds_db_knn_match",
+    "apds_comm_id_create", "apds_shard_create", "apds_shard_destroy", "apds_shard_info", "apds_shard_counts", "apds_shard_knn", "apds_shard_slot_create",
+    "apds_shard_slot_destroy", "apds_shard_gather", "apds_shard_scan", "apds_shard_exchange_merge", "apds_db_shard",
+    "apds_dev_alloc", "apds_dev_release", "apds_dev_upload", "apds_dev_download", "apds_stream_synchronize",
 ]
+
+# multi-GPU sharded matcher (include/apds.h: apds_comm_id, apds_host_transport)
+TRANSPORT_RCCL, TRANSPORT_LOOPBACK, TRANSPORT_HOST = 0, 1, 2
+COMM_ID_BYTES = 128
+
+
+class CommId(C.Structure):
+    _fields_ = [("bytes", C.c_char * COMM_ID_BYTES)]
+
+
+HOST_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+HOST_ALL_TO_ALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
+                              C.POINTER(C.c_size_t))
+
+
+class HostTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", HOST_ALL_GATHER), ("all_to_all", HOST_ALL_TO_ALL)]
 
 
 class ApdsError(RuntimeError):
@@ -112,6 +132,23 @@ def lib():
             "apds_db_view": (i, [vp, pp, pp, pp, pp, ip]),
             "apds_db_view_download": (i, [vp, vp, vp, vp, vp]),
             "apds_db_knn_match": (i, [vp, vp, i, i, i, vp, vp]),
+            "apds_comm_id_create": (i, [i, C.POINTER(CommId)]),
+            "apds_shard_create": (i, [pp, i, i, i, C.POINTER(CommId), C.POINTER(HostTransport), vp, i64, u32]),
+            "apds_shard_destroy": (i, [vp]),
+            "apds_shard_info": (i, [vp, ip, ip, C.POINTER(i64), C.POINTER(u32), C.POINTER(C.c_char_p), ip]),
+            "apds_shard_counts": (i, [vp, i, ip, vp]),
+            "apds_shard_knn": (i, [vp, vp, i, ip, i, vp, vp]),
+            "apds_shard_slot_create": (i, [vp, i, i, pp]),
+            "apds_shard_slot_destroy": (i, [vp, vp]),
+            "apds_shard_gather": (i, [vp, vp, vp, i, ip, vp]),
+            "apds_shard_scan": (i, [vp, vp, i, vp]),
+            "apds_shard_exchange_merge": (i, [vp, vp, i, vp, vp]),
+            "apds_db_shard": (i, [vp, i, i, i, C.POINTER(CommId), C.POINTER(HostTransport), pp]),
+            "apds_dev_alloc": (i, [sz, pp]),
+            "apds_dev_release": (i, [vp]),
+            "apds_dev_upload": (i, [vp, vp, sz, vp]),
+            "apds_dev_download": (i, [vp, vp, sz, vp]),
+            "apds_stream_synchronize": (i, [vp]),
         }
         for name, (rt, at) in sig.items():
             fn = getattr(L, name)

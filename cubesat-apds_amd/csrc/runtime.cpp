@@ -271,6 +271,43 @@ int apds_stream_destroy(void* stream) {
     });
 }
 
+// Device memory and copies for hosts that keep buffers resident (the apds_dev_* / apds_shard_* entry points) without binding the HIP
+// runtime themselves: a Rust or C host needs nothing but this header.
+int apds_dev_alloc(size_t bytes, void** ptr) {
+    return guarded([&] {
+        APDS_REQUIRE(ptr, APDS_ERR_BAD_ARG, "null output");
+        *ptr = nullptr;
+        ctx();   // the calling thread's device
+        HIP_CHECK(hipMalloc(ptr, std::max<size_t>(bytes, 256)));
+    });
+}
+
+int apds_dev_release(void* ptr) {
+    return guarded([&] {
+        if (ptr) HIP_CHECK(hipFree(ptr));
+    });
+}
+
+int apds_dev_upload(void* dst_dev, const void* src_host, size_t bytes, void* stream) {
+    return guarded([&] {
+        APDS_REQUIRE((dst_dev && src_host) || bytes == 0, APDS_ERR_BAD_ARG, "null pointer");
+        if (bytes) HIP_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, pick_stream(stream)));
+    });
+}
+
+int apds_dev_download(void* dst_host, const void* src_dev, size_t bytes, void* stream) {
+    return guarded([&] {
+        APDS_REQUIRE((dst_host && src_dev) || bytes == 0, APDS_ERR_BAD_ARG, "null pointer");
+        hipStream_t s = pick_stream(stream);
+        if (bytes) HIP_CHECK(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+        HIP_CHECK(hipStreamSynchronize(s));
+    });
+}
+
+int apds_stream_synchronize(void* stream) {
+    return guarded([&] { HIP_CHECK(hipStreamSynchronize(pick_stream(stream))); });
+}
+
 int apds_dev_timing_enable(int on) {
     return guarded([&] { ctx().timing = on != 0; });
 }

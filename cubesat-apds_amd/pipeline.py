@@ -8,11 +8,12 @@ module is the composed pipeline the north-star metric (frames/s) is measured on.
 Multi-GPU (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm):
   * the descriptor DB is row-sharded: rank r holds rows [base_r, base_r + n_r) resident in its HBM;
   * frames are data-parallel: every rank extracts its own frame;
-  * the only exchange is in the match step: all-gather of the ranks' query descriptors (padded to a fixed row
-    count), local top-k of ALL queries against the local shard, all-gather of the per-shard top-k keys
+  * the only exchange is in the match step, and it lives behind the C ABI (apds_shard_*, csrc/shard_core.h): all-gather of the
+    ranks' query descriptors, local top-k of ALL queries against the local shard, all-to-all of the per-shard top-k keys
     (packed u64 = distance << 32 | global row), then each rank merges the candidates of its own queries.
     u64 min-merge reproduces the single-GPU result exactly, including the lowest-index tie break.
-torch is used for device buffers, streams and the collectives only; every compute step is a libapds_hip kernel.
+torch is used for device buffers and streams only; every compute step is a libapds_hip kernel and the collectives are the library's
+(RCCL; or the host-callback transport over a gloo group when several ranks share one GPU).
 """
 import ctypes as C
 import time
@@ -36,27 +37,9 @@ def torch_stream():
     return C.c_void_p(h)
 
 
-class HipBackend:
-    """Local compute through the C ABI (device pointers of torch tensors, launched on torch's current stream)."""
-
-    def topk(self, q_rows64, train_rows64, index_base, k, out=None):
-        nq, nt = q_rows64.shape[0], train_rows64.shape[0]
-        if out is None:
-            out = torch.empty((nq, k), dtype=torch.int64, device=q_rows64.device)
-        check(lib().apds_dev_hamming_topk(q_rows64.data_ptr(), nq, train_rows64.data_ptr(), nt, int(index_base), k, out.data_ptr(), torch_stream()))
-        return out
-
-    def merge(self, parts, k, out=None):
-        """parts: [P, Q, k] int64 (contiguous) -> [Q, k]"""
-        p, q = parts.shape[0], parts.shape[1]
-        if out is None:
-            out = torch.empty((q, k), dtype=torch.int64, device=parts.device)
-        check(lib().apds_dev_merge_topk(parts.data_ptr(), p, q, k, out.data_ptr(), torch_stream()))
-        return out
-
-
 def _gather_into(dist, group, dst, src):
-    """all_gather_into_tensor that also works for the gloo rehearsal backend with device tensors (staged through the host)."""
+    """all_gather_into_tensor that also works for the gloo rehearsal backend with device tensors (staged through the host). Used by
+    bench.py's SETUP only (building the shared DB); the per-frame exchange is the C ABI's (apds_shard_*)."""
     if dist.get_backend(group) == "gloo" and src.is_cuda:
         d, s = torch.empty(dst.shape, dtype=dst.dtype), src.cpu()
         dist.all_gather_into_tensor(d.view(-1), s.view(-1), group=group)
@@ -65,58 +48,91 @@ def _gather_into(dist, group, dst, src):
         dist.all_gather_into_tensor(dst.view(-1), src.view(-1), group=group)
 
 
-def _all_to_all_into(dist, group, dst, src, out_splits, in_splits):
-    """all_to_all_single on flat tensors (gloo rehearsal with device tensors: staged through the host)."""
-    if dist.get_backend(group) == "gloo" and src.is_cuda:
-        d, s = torch.empty(dst.shape, dtype=dst.dtype), src.cpu()
-        dist.all_to_all_single(d, s, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
-        dst.copy_(d)
-    else:
-        dist.all_to_all_single(dst, src, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+def host_transport_from_group(dist, group):
+    """apds_host_transport (include/apds.h) over a torch.distributed process group whose collectives take HOST tensors (gloo): the two
+    callbacks wrap the library's staging buffers as tensors without copying. This is what carries the exchange step when several ranks
+    share one GPU (the one-GPU rehearsal of bench.py, APDS_BENCH_BACKEND=gloo) and in the CPU tests. Returns the ctypes struct; it keeps
+    the callback objects alive."""
+    world = dist.get_world_size(group)
+
+    def view(addr, n):
+        if not n:
+            return torch.empty(0, dtype=torch.uint8)
+        return torch.from_numpy(np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_uint8)), shape=(int(n),)))
+
+    def all_gather(_user, send, recv, nbytes):
+        try:
+            dist.all_gather_into_tensor(view(recv, nbytes * world), view(send, nbytes), group=group)
+            return 0
+        except Exception:   # noqa: BLE001 - an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def all_to_all(_user, send, soff, sbytes, recv, roff, rbytes):
+        try:
+            so, sb, ro, rb = ([int(a[p]) for p in range(world)] for a in (soff, sbytes, roff, rbytes))
+            # all_to_all_single wants the blocks back to back in rank order, which is how the matcher lays them out
+            assert all(so[p] == sum(sb[:p]) for p in range(world)) and all(ro[p] == sum(rb[:p]) for p in range(world)), "blocks are not contiguous"
+            dist.all_to_all_single(view(recv, sum(rb)), view(send, sum(sb)), output_split_sizes=rb, input_split_sizes=sb, group=group)
+            return 0
+        except Exception:   # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    ht = _lib.HostTransport(None, _lib.HOST_ALL_GATHER(all_gather), _lib.HOST_ALL_TO_ALL(all_to_all))
+    ht._keep = (all_gather, all_to_all)
+    return ht
 
 
 class GatheredQueries:
-    """One frame's query exchange buffers (allocated once, reused every frame that goes through the same slot):
-    `mine` = this rank's rows padded to the common row count, `gathered` = every rank's padded rows, `all_q` = the ranks' rows
-    back to back without padding (what the local shard is scanned with), `local` = this shard's top-k of all of them,
-    `recv` = every shard's top-k of THIS rank's queries, `merged` = their u64-min merge."""
+    """One frame's exchange slot of a shard handle (apds_shard_slot_create): the buffers live in the library; `merged` is where
+    exchange_merge leaves the keys when the caller passes no output tensor."""
 
-    def __init__(self, world, pad, kmax, device):
-        self.world, self.pad, self.kmax = world, pad, kmax          # pad = capacity in rows per rank
-        self.mine = torch.zeros((pad, 64), dtype=torch.uint8, device=device)
-        self.gathered = torch.empty(world * pad * 64, dtype=torch.uint8, device=device)
-        self.all_q = torch.empty((world * pad, 64), dtype=torch.uint8, device=device)
-        self.local = torch.empty(world * pad * kmax, dtype=torch.int64, device=device)
-        self.recv = torch.empty(world * pad * kmax, dtype=torch.int64, device=device)
-        self.merged = torch.empty(pad * kmax, dtype=torch.int64, device=device)
+    def __init__(self, matcher, max_queries, kmax):
+        self.matcher, self.kmax = matcher, kmax
+        self.handle = C.c_void_p()
+        check(lib().apds_shard_slot_create(matcher.handle, int(max_queries), int(kmax), C.byref(self.handle)))
+        self.pad = -(-max(int(max_queries), 1) // 1024) * 1024
+        self.merged = torch.empty((self.pad, kmax), dtype=torch.int64, device=matcher.rows.device)
         self.counts, self.total, self.nq = None, 0, 0
-        self.event = torch.cuda.Event() if torch.device(device).type == "cuda" else None
+
+    def close(self):
+        h, self.handle = self.handle, None
+        if h and self.matcher.handle:
+            lib().apds_shard_slot_destroy(self.matcher.handle, h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
 
 
 class ShardedMatcher:
-    """Hamming k-NN of per-rank query sets against a row-sharded resident DB.
+    """Hamming k-NN of per-rank query sets against a row-sharded resident DB: a thin front of the C ABI's apds_shard_* (csrc/shard.cpp,
+    csrc/shard_core.h), which owns the whole choreography - all-gather of the ranks' query rows, local top-k of all of them against the
+    local shard with global row indices, all-to-all of the keys, u64-min merge (= the single-GPU result, lowest-index tie-break
+    included). What this class adds is the choice of transport from the torch process group it is given:
+      * no group / one rank: no exchange step, the scan is called directly;
+      * a "nccl" group: the library's RCCL transport (its own communicator; rank 0's id travels through the torch group once);
+      * a "gloo" group: the host-callback transport over that group (several ranks on one GPU: rehearsal).
+    The three steps are separate calls (gather_queries / scan_gathered / exchange_merge) so that a pipeline can issue frame i+1's query
+    gather on another stream BEFORE frame i's key exchange. All collective calls must come from ONE thread in the same order on every
+    rank. No per-frame allocations."""
 
-    Per frame: (1) all-gather of the ranks' query rows (fixed pad, so the message size never changes); (2) local top-k of ALL
-    queries against the local shard, keys carry global row indices; (3) all-to-all of the keys: rank r sends rank s the
-    [counts[s], k] block of s's queries and receives [counts[r], k] from every shard (1/world of what an all-gather of the
-    keys moves); (4) u64-min merge of the `world` candidate lists per query = the single-GPU result, lowest-index tie-break
-    included. The three steps are separate calls (gather_queries / scan_gathered / exchange_merge) so that a pipeline can issue
-    frame i+1's query gather on another stream BEFORE frame i's key exchange: it then runs under frame i's scan. All collectives
-    use ONE communicator and must be issued by ONE thread in the same order on every rank (torch serialises them on the process
-    group's internal stream; two communicators driven from two threads could be launched in different orders on different ranks
-    and dead-lock). No per-frame allocations."""
-
-    def __init__(self, local_rows64, index_base, group=None, backend=None, pad_rows=32768, meta_group=None, kmax=2, always_exchange=False):
-        self.rows = local_rows64
+    def __init__(self, local_rows64, index_base, group=None, pad_rows=32768, meta_group=None, kmax=2, always_exchange=False):
+        self.rows = local_rows64            # borrowed by the shard handle for its whole life
         self.index_base = int(index_base)
         self.group = group
         self.meta_group = meta_group      # optional host-side (gloo) group for the per-frame query counts
-        self.backend = backend or HipBackend()
-        self.pad_rows = pad_rows          # smallest buffer capacity (rows per rank)
-        self.msg_round = 1024             # the query all-gather's row count is the frame's largest count rounded up to this
+        self.pad_rows = pad_rows          # smallest slot capacity (rows per rank)
         self.kmax = kmax
         self.always_exchange = always_exchange   # run the collectives even with one rank (RCCL self-test on a one-GPU box)
-        self._own = None                  # buffers of the plain knn() form
+        self._own = None                  # slot of the plain knn() form
+        self.handle = None
+        self.transport = "none"
         if group is not None:
             import torch.distributed as dist
             self.dist = dist
@@ -124,12 +140,56 @@ class ShardedMatcher:
             self.rank = dist.get_rank(group)
         else:
             self.dist, self.world, self.rank = None, 1, 0
+        if self.world == 1 and not (always_exchange and self.dist is not None):
+            return
+        L, dist = lib(), self.dist
+        backend = dist.get_backend(group)
+        h = C.c_void_p()
+        n_rows = int(local_rows64.shape[0])
+        if backend == "nccl":
+            # rank 0 creates the RCCL id; 128 bytes through the torch group; every rank then joins the library's own communicator
+            cid = _lib.CommId()
+            if self.rank == 0:
+                check(L.apds_comm_id_create(_lib.TRANSPORT_RCCL, C.byref(cid)))
+            t = torch.frombuffer(bytearray(bytes(cid)), dtype=torch.uint8).to(local_rows64.device)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if hasattr(dist, "get_global_rank") else 0, group=group)
+            C.memmove(C.byref(cid), bytes(t.cpu().numpy().tobytes()), _lib.COMM_ID_BYTES)
+            check(L.apds_shard_create(C.byref(h), self.rank, self.world, _lib.TRANSPORT_RCCL, C.byref(cid), None, local_rows64.data_ptr(), n_rows, self.index_base))
+            self.transport = "rccl"
+        else:
+            self._host_transport = host_transport_from_group(dist, group)
+            check(L.apds_shard_create(C.byref(h), self.rank, self.world, _lib.TRANSPORT_HOST, None, C.byref(self._host_transport), local_rows64.data_ptr(), n_rows,
+                                      self.index_base))
+            self.transport = "host-callbacks (%s)" % backend
+        self.handle = h
+
+    def close(self):
+        if self._own is not None:
+            self._own.close()
+            self._own = None
+        h, self.handle = self.handle, None
+        if h:
+            lib().apds_shard_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
+
+    def info(self):
+        """{rank, world, rows, index_base, transport, rccl_version} as the library reports them."""
+        if not self.handle:
+            return dict(rank=0, world=1, rows=int(self.rows.shape[0]), index_base=self.index_base, transport="none (one rank)", rccl_version=None)
+        r, w, ver, n, base, name = C.c_int(), C.c_int(), C.c_int(), C.c_int64(), C.c_uint32(), C.c_char_p()
+        check(lib().apds_shard_info(self.handle, C.byref(r), C.byref(w), C.byref(n), C.byref(base), C.byref(name), C.byref(ver)))
+        return dict(rank=r.value, world=w.value, rows=n.value, index_base=base.value, transport=name.value.decode(), rccl_version=ver.value)
 
     def exchange_counts(self, nq):
         """Every rank's query count for one frame, as host ints, through the host-side group: no device work and no stream
         synchronisation, so the thread that later issues the match keeps queueing kernels ahead of the GPU. Must be called
         once per frame, in frame order, by the same thread on every rank."""
-        if self.world == 1 and not self.always_exchange:
+        if self.handle is None:
             return [int(nq)]
         if self.meta_group is None:
             return None
@@ -139,49 +199,29 @@ class ShardedMatcher:
         return [int(v) for v in o.tolist()]
 
     def make_buffers(self, max_queries=None, k=None):
-        """Exchange buffers for frames of at most `max_queries` queries per rank (one set per frame in flight)."""
-        pad = max(self.pad_rows, int(max_queries or 0))
-        pad = -(-pad // self.msg_round) * self.msg_round          # whole messages: gather_queries sends multiples of msg_round rows
-        return GatheredQueries(self.world, pad, k or self.kmax, self.rows.device)
+        """An exchange slot for frames of at most `max_queries` queries per rank (one per frame in flight)."""
+        return GatheredQueries(self, max(self.pad_rows, int(max_queries or 0)), k or self.kmax)
+
+    @staticmethod
+    def _counts_arg(counts):
+        return (C.c_int * len(counts))(*[int(c) for c in counts])
 
     def gather_queries(self, q_rows64, counts, buf):
-        """Step (1) on the CURRENT stream, into `buf`: after it `buf.all_q[:buf.total]` holds every rank's queries."""
-        nq = q_rows64.shape[0]
-        assert counts[self.rank] == nq and max(counts) <= buf.pad and buf.world == self.world
+        """Step (1) on the CURRENT stream (collective): afterwards the slot holds every rank's queries."""
+        nq = int(q_rows64.shape[0])
         buf.counts, buf.total, buf.nq = list(counts), int(sum(counts)), nq
-        buf.mine[:nq].copy_(q_rows64)
-        # message size of this frame: the largest count, rounded up (the buffers are sized for the capacity, the wire is not)
-        # a function of `counts` alone (identical on every rank, whatever each rank's buffer capacity is): a message size taken from the
-        # rank-local buffer would make the collective's sizes differ between ranks, which RCCL answers with a hang, not an error
-        rows = max(self.msg_round, -(-max(counts) // self.msg_round) * self.msg_round)
-        assert rows <= buf.pad, f"exchange buffer holds {buf.pad} rows per rank, this frame needs {rows}: make_buffers(max_queries) rounds up to {self.msg_round}"
-        gathered = buf.gathered[:self.world * rows * 64].view(self.world, rows, 64)
-        _gather_into(self.dist, self.group, gathered, buf.mine[:rows])
-        off = 0
-        for r, c in enumerate(counts):          # drop the padding: `world` slice copies into the preallocated block
-            if c:
-                buf.all_q[off:off + c].copy_(gathered[r, :c])
-            off += c
-        if buf.event is not None:
-            buf.event.record()
+        check(lib().apds_shard_gather(self.handle, buf.handle, q_rows64.data_ptr() if nq else None, nq, self._counts_arg(counts), torch_stream()))
         return buf
 
     def scan_gathered(self, buf, k=2):
-        """Step (2) on the CURRENT stream: this shard's top-k of every gathered query (no collective)."""
-        assert k <= buf.kmax
-        if buf.event is not None:
-            torch.cuda.current_stream().wait_event(buf.event)
-        if buf.total:
-            self.backend.topk(buf.all_q[:buf.total], self.rows, self.index_base, k, out=buf.local[:buf.total * k].view(buf.total, k))
+        """Step (2) on the CURRENT stream: this shard's top-k of every gathered query (no collective; waits for the gather's event)."""
+        check(lib().apds_shard_scan(self.handle, buf.handle, k, torch_stream()))
 
     def exchange_merge(self, buf, k=2, out=None):
-        """Steps (3)-(4) on the CURRENT stream (the one scan_gathered ran on): all-to-all of the keys, then the per-query merge."""
-        world, nq, total = self.world, buf.nq, buf.total
-        recv = buf.recv[:world * nq * k]
-        _all_to_all_into(self.dist, self.group, recv, buf.local[:total * k], [nq * k] * world, [c * k for c in buf.counts])
-        dst = out[:nq] if out is not None else buf.merged[:nq * k].view(nq, k)
-        if nq:
-            self.backend.merge(recv.view(world, nq, k), k, out=dst)
+        """Steps (3)-(4) on the CURRENT stream (the one scan_gathered ran on; collective): all-to-all of the keys, then the per-query merge."""
+        nq = buf.nq
+        dst = out[:nq] if out is not None else buf.merged[:nq, :k] if k == buf.kmax else torch.empty((nq, k), dtype=torch.int64, device=self.rows.device)
+        check(lib().apds_shard_exchange_merge(self.handle, buf.handle, k, dst.data_ptr() if nq else None, torch_stream()))
         return dst
 
     def match_gathered(self, buf, k=2, out=None):
@@ -191,23 +231,15 @@ class ShardedMatcher:
 
     def knn(self, q_rows64, k=2, out=None, counts=None):
         """q_rows64: this rank's queries [Q_r, 64] u8. Returns [Q_r, k] int64 keys over the WHOLE DB. `counts`: every rank's
-        query count (exchange_counts); without it the counts are gathered on the device, which costs a host synchronisation.
-        Without `out` the result is a view of an internal buffer, valid until the next call."""
-        be = self.backend
-        if self.world == 1 and not (self.always_exchange and self.dist is not None):
-            if out is not None:
-                return be.topk(q_rows64, self.rows, self.index_base, k, out=out[:q_rows64.shape[0]])
-            return be.topk(q_rows64, self.rows, self.index_base, k)
-        dist, dev = self.dist, q_rows64.device
-        nq = q_rows64.shape[0]
-        if counts is None:
-            cnt = torch.zeros(self.world, dtype=torch.int64, device=dev)
-            _gather_into(dist, self.group, cnt, torch.tensor([nq], dtype=torch.int64, device=dev))
-            counts = [int(c) for c in cnt.tolist()]
-        if self._own is None or self._own.pad < max(counts) or self._own.kmax < k:
-            self._own = self.make_buffers(max(counts), max(k, self.kmax))
-        self.gather_queries(q_rows64, counts, self._own)
-        return self.match_gathered(self._own, k, out=out)
+        query count (exchange_counts); without it the library exchanges them first, which costs a host synchronisation."""
+        nq = int(q_rows64.shape[0])
+        dst = out[:nq] if out is not None else torch.empty((nq, k), dtype=torch.int64, device=q_rows64.device)
+        if self.handle is None:
+            check(lib().apds_dev_hamming_topk(q_rows64.data_ptr(), nq, self.rows.data_ptr(), int(self.rows.shape[0]), self.index_base, k, dst.data_ptr(), torch_stream()))
+            return dst
+        check(lib().apds_shard_knn(self.handle, q_rows64.data_ptr() if nq else None, nq, self._counts_arg(counts) if counts is not None else None, k,
+                                   dst.data_ptr() if nq else None, torch_stream()))
+        return dst
 
 
 class FramePipeline:

@@ -201,6 +201,58 @@ int apds_db_view_download(void* db, apds_keypoint* kps, uint8_t* desc61, int32_t
 /* knnMatch (k in {1,2}) of host query descriptors against the current view; idx = position in the view (= trainIdx of the Vec the reference would hold) */
 int apds_db_knn_match(void* db, const uint8_t* query_desc, int n_query, int desc_bytes, int k, int32_t* idx, int32_t* dist);
 
+/* ---- multi-GPU: the descriptor DB row-sharded over the GPUs of one node (BASELINE config 5) -------------------------------
+ * No counterpart upstream: the reference matches on one CPU (feature_extraction/src/lib.rs:94-126) against whatever train set
+ * feature_database/src/keypointdb.rs:50-90 returned, and its only parallelism is the preprocessor's rayon pool
+ * (preprocessor/src/main.rs:86-89,227-245). Here one rank (a process, or a thread) drives each GPU; rank r keeps rows
+ * [index_base, index_base + n_rows) of the train set resident, every rank brings its own frame's queries, and apds_shard_knn returns to
+ * every rank the top-k of ITS queries over the WHOLE train set: all-gather of the query rows -> local scan -> all-to-all of the
+ * per-shard keys -> u64-min merge. The result equals apds_dev_hamming_topk over the unsharded rows bit for bit (ties to the lower
+ * global row). All ranks must issue the collective calls (create, counts, knn, gather, exchange_merge, destroy) in the same order.
+ *
+ * Transports: APDS_TRANSPORT_RCCL (one rank per GPU; the id comes from apds_comm_id_create on rank 0 and reaches the other ranks by any
+ * host-side means - a file, MPI, the parent process), APDS_TRANSPORT_LOOPBACK (the ranks are threads of one process, any number per
+ * GPU: the identical choreography on a one-GPU box), APDS_TRANSPORT_HOST (the host program's communicator as two callbacks on HOST
+ * buffers, e.g. gloo or MPI; device data is staged around them, so it synchronises with the host). */
+#define APDS_COMM_ID_BYTES 128
+typedef struct apds_comm_id {
+    char bytes[APDS_COMM_ID_BYTES];
+} apds_comm_id;
+enum { APDS_TRANSPORT_RCCL = 0, APDS_TRANSPORT_LOOPBACK = 1, APDS_TRANSPORT_HOST = 2 };
+typedef struct apds_host_transport {
+    void* user;
+    /* recv = every rank's bytes_per_rank bytes, rank-major; return 0 on success */
+    int (*all_gather)(void* user, const void* send, void* recv, size_t bytes_per_rank);
+    /* to rank p: send[send_off[p] .. + send_bytes[p]); from rank p: recv_bytes[p] bytes to recv + recv_off[p] */
+    int (*all_to_all)(void* user, const void* send, const size_t* send_off, const size_t* send_bytes, void* recv, const size_t* recv_off,
+                      const size_t* recv_bytes);
+} apds_host_transport;
+/* A fresh communicator id for `transport` (RCCL: ncclGetUniqueId; loopback: a process-unique name; host: zeros). Called by ONE rank. */
+int apds_comm_id_create(int transport, apds_comm_id* id);
+/* Collective. The shard lives on the calling thread's device (apds_set_device first). rows64_dev: n_rows x 64-byte rows, borrowed for
+ * the life of the handle. index_base = global index of the shard's first row. id: RCCL / loopback; host: the host transport's callbacks. */
+int apds_shard_create(void** shard, int rank, int world, int transport, const apds_comm_id* id, const apds_host_transport* host,
+                      const void* rows64_dev, int64_t n_rows, uint32_t index_base);
+int apds_shard_destroy(void* shard);
+/* any output may be NULL; *rccl_version = ncclGetVersion() of the RCCL this library runs on */
+int apds_shard_info(const void* shard, int* rank, int* world, int64_t* n_rows, uint32_t* index_base, const char** transport_name, int* rccl_version);
+/* Collective: every rank's query count of one frame, as host ints (counts[world]). Synchronises `stream` on the RCCL transport. */
+int apds_shard_counts(void* shard, int n_query, int* counts, void* stream);
+/* Collective: out_keys_dev = n_query x k uint64 ((distance << 32) | global row; 0xFFFF... when absent) for THIS rank's queries over the
+ * whole train set. counts: every rank's n_query (apds_shard_counts), or NULL to exchange them inside the call. 1 <= k <= 16. */
+int apds_shard_knn(void* shard, const void* q_rows64_dev, int n_query, const int* counts, int k, void* out_keys_dev, void* stream);
+/* The same in three steps on per-frame exchange slots, for pipelines that keep two frames in flight: frame i+1's gather (collective) may be
+ * issued - on another stream - before frame i's exchange_merge (collective), so it travels under frame i's scan (no collective). */
+int apds_shard_slot_create(void* shard, int max_queries_per_rank, int kmax, void** slot);
+int apds_shard_slot_destroy(void* shard, void* slot);
+int apds_shard_gather(void* shard, void* slot, const void* q_rows64_dev, int n_query, const int* counts, void* stream);
+int apds_shard_scan(void* shard, void* slot, int k, void* stream);
+int apds_shard_exchange_merge(void* shard, void* slot, int k, void* out_keys_dev, void* stream);
+/* SURVEY §8(b) "apds_db_create / append / shard / destroy": this rank's block of the resident keypoint table's current view (every rank
+ * holds the same table and selection; rank r keeps rows [r n / world, (r + 1) n / world) of the view) as a shard; train indices stay the
+ * positions in the view, i.e. what apds_db_knn_match returns. */
+int apds_db_shard(void* db, int rank, int world, int transport, const apds_comm_id* id, const apds_host_transport* host, void** shard);
+
 /* ---- device-resident API ------------------------------------------------------------------- */
 /* All pointers below are HIP device pointers. stream: hipStream_t or NULL (the thread's own stream).
  * Calls are asynchronous on that stream unless they return a count to the host. */
@@ -250,6 +302,15 @@ int apds_dev_find_homography(const void* input_xy, const void* reference_xy, int
  * (hipExtStreamCreateWithCUMask); priority 0 normal, -1 high (ignored when a mask is given). */
 int apds_stream_create(int priority, const uint32_t* cu_mask, int cu_mask_words, void** stream);
 int apds_stream_destroy(void* stream);
+
+/* Device memory and copies on the calling thread's device, so that a host which keeps buffers resident (apds_dev_*, apds_shard_*) needs
+ * no HIP binding of its own. upload is asynchronous on `stream` (the host buffer must stay valid until the stream has passed it; pinned
+ * memory makes it a true async copy); download returns when the bytes are in dst_host. stream NULL = the thread's own stream. */
+int apds_dev_alloc(size_t bytes, void** ptr);
+int apds_dev_release(void* ptr);
+int apds_dev_upload(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int apds_dev_download(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int apds_stream_synchronize(void* stream);
 
 /* Releases the calling thread's HIP stream and device workspace (they are created lazily by the first call on a thread and
  * otherwise live as long as the thread; nothing is freed from thread-exit destructors, which may run after the HIP runtime has

@@ -32,9 +32,11 @@ with torch.cuda.stream(torch.cuda.Stream(dev)):
     rows = torch.from_numpy(db64).to(dev)
     qd = torch.from_numpy(q64).to(dev)
     direct = pl.ShardedMatcher(rows, 0).knn(qd, 2).cpu().numpy().view(np.uint64)          # no collectives
-    # the collective path of the multi-GPU matcher on ONE rank: RCCL all_gather_into_tensor of the queries, the scan,
-    # RCCL all_to_all_single of the keys (unequal-split form), the merge; first in one call, then in the split form the pipeline uses
+    # the collective path of the multi-GPU matcher on ONE rank, through the C ABI (apds_shard_*): ncclAllGather of the queries, the scan,
+    # the send/recv group of the keys, the merge; first in one call, then in the split form the pipeline uses
     m = pl.ShardedMatcher(rows, 0, group=dist.group.WORLD, meta_group=meta, always_exchange=True)
+    info = m.info()
+    assert info["transport"] == "rccl" and info["world"] == 1 and info["rccl_version"] > 0, info
     cnt = m.exchange_counts(len(q))
     one_call = m.knn(qd, 2, counts=cnt).cpu().numpy().view(np.uint64).copy()
     bufs = [m.make_buffers(len(q)), m.make_buffers(len(q))]
@@ -53,4 +55,5 @@ planted = src >= 0
 assert np.array_equal((direct[planted, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64), src[planted])
 dist.barrier()
 dist.destroy_process_group()
-print("nccl selftest OK: RCCL world-1 all_gather_into_tensor + all_to_all_single between library kernels (one-call and split forms), gloo meta group, barrier")
+print(f"nccl selftest OK: the library's RCCL transport (rccl {info['rccl_version']}) at world 1 - ncclAllGather of the queries + send/recv group of the keys between "
+      "library kernels, one-call and split forms - under a torch nccl group with a gloo meta group beside it, barrier")
