@@ -76,6 +76,12 @@ void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, co
 void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
                       uint32_t* list, int* list_count, hipStream_t s, const Batch& b);
 
+// akaze_doh_strips.hip: the streaming form of the same stage for the large levels; it also writes the mask and the suppression status of
+// every pixel of the level (so neither needs clearing). false = not a level for it (the caller launches doh_fused instead).
+bool doh_strips_eligible(int w, int h, int sc, int batch);
+bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
+                       uint8_t* status, uint32_t* list, int* list_count, hipStream_t s, const Batch& b);
+
 // Test hook: when armed (per thread) the next akaze_extract_device copies one intermediate plane to the host.
 // which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet (f32), 7 keypoint mask after cross-level suppression (u8), 8 kcontrast (1 float)
 struct AkazeDebugRequest {

@@ -1164,10 +1164,13 @@ AkazeDebugRequest& akaze_debug_request() {
 
 // Zero the first `bytes` (a multiple of 16) of every image's slab: one launch for the batch. (hipMemset2DAsync / hipMemcpy2DAsync take a
 // slow, serialising path in the runtime: with them N host threads extracting concurrently stopped scaling, 2200 -> 880 tiles/s.)
-__global__ void zero_slab_heads_kernel(uint4* __restrict__ base, size_t bytes, size_t bstride) {
+struct ZeroRanges {
+    size_t from[3], bytes[3];   // 16-byte aligned offsets into the slab; blockIdx.y picks the range
+};
+__global__ void zero_slab_heads_kernel(char* __restrict__ base, ZeroRanges r, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
-    uint4* p = reinterpret_cast<uint4*>(reinterpret_cast<char*>(base) + (size_t)blockIdx.z * bstride);
-    const size_t n = bytes / 16;
+    uint4* p = reinterpret_cast<uint4*>(base + (size_t)blockIdx.z * bstride + r.from[blockIdx.y]);
+    const size_t n = r.bytes[blockIdx.y] / 16;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
 }
 
@@ -1272,7 +1275,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     uint8_t *mask_all, *status_all;
     std::vector<uint32_t*> lists(L), pend(L);
     std::vector<float*> lsm(L);
-    size_t zero_bytes = 0;
+    size_t zero_bytes = 0, mask_off = 0, status_off = 0;
     auto layout = [&](Arena& A) {
         list_count = A.take<int>(AKAZE_MAX_LEVELS);
         hmax_bits = A.take<unsigned int>(1);
@@ -1281,7 +1284,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         kp_base = A.take<int>(8);                 // kp_base[k] = keypoints of the stages before stage k (kp_base[0] stays 0)
         fine_counts = A.take<int>(n_fine + 1024);      // ranked compaction: keypoints per 128-byte chunk of the masks (then their prefix)
         coarse_counts = A.take<int>((size_t)n_coarse * COARSE_PITCH);
+        mask_off = A.off;
         mask_all = A.take<uint8_t>((size_t)total_pix + 128);   // (+ a line: the last chunk is read whole)
+        status_off = A.off;
         status_all = A.take<uint8_t>((size_t)total_pix);
         zero_bytes = A.off;
         k_oct = A.take<float>(8);
@@ -1320,14 +1325,25 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         if (c.side2) HIP_CHECK(hipStreamSynchronize(c.side2));
         c.fork_open = false;
     }
-    // (the runtime's fill kernel clears the 44 MB of a 4096^2 frame at 1.7 TB/s; 16-byte stores from a wide grid are quicker)
-    auto zero_range = [&](size_t from, size_t to, hipStream_t zs) {
-        const size_t bytes = to - from;
-        hipLaunchKernelGGL(zero_slab_heads_kernel, dim3((unsigned)std::min<size_t>(B > 1 ? 1024 : 4096, (bytes / 16 + 255) / 256), 1, B), dim3(256), 0, zs,
-                           reinterpret_cast<uint4*>(real.base + from), bytes, slab);
-    };
-    // (clearing the masks on the side stream, beside the base stage, was measured: no gain — the base stage is bandwidth-bound itself)
-    zero_range(0, zero_bytes, s);
+    // The streaming Hessian kernel (akaze_doh_strips.hip) writes the keypoint-mask byte and the suppression-status byte of EVERY pixel of
+    // its level, so those levels - the large ones, a prefix of the level list - need no clearing: what is zeroed is the counters at the head
+    // of the slab and the masks / statuses of the remaining (small) levels. (Round 2 cleared all of it: 181 MB per 4096^2 frame.)
+    int n_strip_levels = 0;
+    while (n_strip_levels < L && doh_strips_eligible(ev[n_strip_levels].w, ev[n_strip_levels].h, ev[n_strip_levels].sigma_size, B)) n_strip_levels++;
+    {
+        const size_t first = n_strip_levels < L ? (size_t)ev[n_strip_levels].pix_offset : (size_t)total_pix;
+        ZeroRanges zr{};
+        zr.from[0] = 0;
+        zr.bytes[0] = mask_off;                                                   // counters (all planes start on 256-byte boundaries)
+        zr.from[1] = mask_off + (first & ~(size_t)15);
+        zr.bytes[1] = (status_off - zr.from[1]) & ~(size_t)15;                    // masks of the remaining levels + the padding line behind the last one
+        zr.from[2] = status_off + (first & ~(size_t)15);
+        zr.bytes[2] = (zero_bytes - zr.from[2]) & ~(size_t)15;
+        const size_t most = std::max(zr.bytes[0], std::max(zr.bytes[1], zr.bytes[2]));
+        // (the runtime's fill kernel reaches 1.7 TB/s; 16-byte stores from a wide grid are quicker)
+        hipLaunchKernelGGL(zero_slab_heads_kernel, dim3((unsigned)std::min<size_t>(B > 1 ? 1024 : 4096, (most / 16 + 255) / 256), 3, B), dim3(256), 0, s,
+                           real.base, zr, slab);
+    }
     int* counts_dev = B > 1 ? c.alloc_n<int>(B) : nullptr;
 
     // ---- a1.1 / a1.2 / a1.3
@@ -1581,8 +1597,10 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             HIP_CHECK(hipEventRecord(c.fork_event(0), s));
             HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
         }
-        launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i,
-                         s_doh, bt);
+        if (!(i < n_strip_levels && launch_doh_strips(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset,
+                                                       status_all + e.pix_offset, lists[i], list_count + i, s_doh, bt)))
+            launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i,
+                             s_doh, bt);
         if (i == early_trigger) {
             // the Hessian of this level exists once the launch above is done: all levels below can be finished. (The stage also
             // reads Lt / Lxy of its own levels: complete before this level's smoothing pass, which the launch above follows.)

@@ -45,3 +45,17 @@ def test_akaze_parity_with_lds_fused_levels_on_every_level(gpu_pkg):
 def test_akaze_parity_on_the_unfused_level_path_and_mask_scan_compaction(gpu_pkg):
     """the round-1 path: separate smoothing / FED launches per level, keypoints placed by two passes over the masks"""
     _rerun({"APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STRIP": "0", "APDS_KP_RANKED": "0", "APDS_EVENT_SCOPE": "1"})
+
+
+def test_akaze_parity_with_the_streaming_hessian_kernel_on_every_level(gpu_pkg):
+    """doh_strip_kernel (akaze_doh_strips.hip: determinant of the Hessian + extrema walking down 64-column strips, the masks written for
+    every pixel instead of cleared) normally serves levels of 1 Mpx and more: here it serves every level of at least 64 x 64 pixels of
+    every test image - top / bottom bands with reflected rows, first / last strips with reflected columns, partial last bands - with band
+    heights of 16 rows, and once more with tall bands."""
+    _rerun({"APDS_DOH_STRIP": "2", "APDS_DOH_STRIP_ROWS": "16"})
+    _rerun({"APDS_DOH_STRIP": "2", "APDS_DOH_STRIP_ROWS": "112"})
+
+
+def test_akaze_parity_without_the_streaming_hessian_kernel(gpu_pkg):
+    """the LDS-tile Hessian kernel on every level (round 2's path), masks cleared by the zeroing kernel"""
+    _rerun({"APDS_DOH_STRIP": "0"})
