@@ -30,6 +30,7 @@ SYMBOLS = [
     "apds_comm_id_create", "apds_shard_create", "apds_shard_destroy", "apds_shard_info", "apds_shard_counts", "apds_shard_knn", "apds_shard_slot_create",
     "apds_shard_slot_destroy", "apds_shard_gather", "apds_shard_scan", "apds_shard_exchange_merge", "apds_db_shard",
     "apds_dev_alloc", "apds_dev_release", "apds_dev_upload", "apds_dev_download", "apds_stream_synchronize",
+    "apds_dev_topk_state_create", "apds_dev_topk_state_destroy", "apds_dev_topk_prepass", "apds_dev_topk_scan", "apds_dev_topk_merge",
 ]
 
 # multi-GPU sharded matcher (include/apds.h: apds_comm_id, apds_host_transport)
@@ -149,6 +150,11 @@ def lib():
             "apds_dev_upload": (i, [vp, vp, sz, vp]),
             "apds_dev_download": (i, [vp, vp, sz, vp]),
             "apds_stream_synchronize": (i, [vp]),
+            "apds_dev_topk_state_create": (i, [pp]),
+            "apds_dev_topk_state_destroy": (i, [vp]),
+            "apds_dev_topk_prepass": (i, [vp, vp, i, vp, i64, u32, i, vp]),
+            "apds_dev_topk_scan": (i, [vp, vp, vp, vp]),
+            "apds_dev_topk_merge": (i, [vp, u32, vp, vp]),
         }
         for name, (rt, at) in sig.items():
             fn = getattr(L, name)

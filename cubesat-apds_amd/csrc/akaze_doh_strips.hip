@@ -255,7 +255,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 bool doh_strips_eligible(int w, int h, int sc, int batch) {
     static const int mode = getenv("APDS_DOH_STRIP") ? atoi(getenv("APDS_DOH_STRIP")) : 1;
     if (mode == 0 || sc < 2 || sc > 4 || w < 64 || h < 64) return false;
-    return mode == 2 || (size_t)w * h * batch >= ((size_t)1 << 20);
+    // 8 Mpx and more (the first octave of a 4096^2 frame): below that a level has too few 64-column strips to fill the chip with bands of
+    // a useful height (2048^2: 41 strips; bands of 16 rows spend half their walk on the 4 s + 2 warm-up rows) and the LDS tiles are quicker
+    return mode == 2 || (long long)w * h * batch >= (1ll << 23);
 }
 
 bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
@@ -263,11 +265,12 @@ bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, in
     if (!doh_strips_eligible(w, h, sc, b.n)) return false;
     const int vw = 64 - 4 * sc - 2;
     const int strips = ceil_div(w, vw);
-    // band height: enough waves to fill the chip a few times over (the walk costs 4 s + 2 extra rows per band), at most 128 rows
+    // band height (APDS_DOH_STRIP_ROWS: test hook): 64 rows - a walk of 64 + 4 s + 2 rows - while that still gives every SIMD four waves,
+    // else shorter bands. Measured at 4096^2, stand-alone extraction: 32 rows 1.854 ms, 64 rows 1.813, 128 rows 1.89 - 2.3.
     static const int rb_env = getenv("APDS_DOH_STRIP_ROWS") ? atoi(getenv("APDS_DOH_STRIP_ROWS")) : 0;
-    int rb = rb_env > 0 ? rb_env : 128;
+    int rb = rb_env > 0 ? rb_env : 64;
     if (rb_env <= 0)
-        while (rb > 16 && (long long)strips * ceil_div(h, rb) * b.n < 6144) rb /= 2;
+        while (rb > 16 && (long long)strips * ceil_div(h, rb) * b.n < 4096) rb /= 2;
     const bool none = border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0;
     DohStripArgs a{Lsmooth, Lxy, Ldet, mask, status, w, h, none ? -1 : border, kside, kmid, (float)(sc * sc * sc * sc), thr, strips,
                    ceil_div(h, rb), rb};

@@ -1373,6 +1373,11 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // before the suppression): it goes to a second stream, so the latency-bound launches of the small octaves overlap the
     // smoothing and diffusion launches of the levels that follow. Lsmooth then needs a plane per level instead of a shared one.
     hipStream_t s_doh = fork_doh ? side_stream_beside(s) : s;
+    // (Round 3, measured and removed: holding the first octave's four big Hessian kernels back until the level chain has left that octave, on
+    // a stream of their own, so that they run under the latency-bound chains of the later octaves instead of beside the first octave's
+    // bandwidth-bound ones: 1.828 against 1.807 ms at 4096^2 - they are off the critical path either way, which is the level chain
+    // followed by the keypoint tail, and beside the small octaves' kernels they delay those. Lowest priority for the side streams: no
+    // difference. profiles/r03/doh_ab.txt)
     // (a stream of their own for the small levels' Hessian kernels, which queue up behind the large levels' on this one: measured, no gain)
     // Keypoint stages. Levels 0 .. m are FINAL (cross-level suppression done) once the Hessian of level m + 1 exists (see run_stage).
     // The last two octaves are a chain of short, latency-bound launches that leaves the GPU almost idle, and the large octaves before
@@ -1597,10 +1602,14 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             HIP_CHECK(hipEventRecord(c.fork_event(0), s));
             HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
         }
-        if (!(i < n_strip_levels && launch_doh_strips(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset,
-                                                       status_all + e.pix_offset, lists[i], list_count + i, s_doh, bt)))
-            launch_doh_fused(smooth, e.Lxy, e.Ldet, e.w, e.h, e.sigma_size, kside, kmid, e.border, dthreshold, mask_all + e.pix_offset, lists[i], list_count + i,
-                             s_doh, bt);
+        auto launch_hessian = [&](hipStream_t st) {
+            const LevelDesc& le = ev[i];
+            if (!(i < n_strip_levels && launch_doh_strips(smooth, le.Lxy, le.Ldet, le.w, le.h, le.sigma_size, kside, kmid, le.border, dthreshold,
+                                                           mask_all + le.pix_offset, status_all + le.pix_offset, lists[i], list_count + i, st, bt)))
+                launch_doh_fused(smooth, le.Lxy, le.Ldet, le.w, le.h, le.sigma_size, kside, kmid, le.border, dthreshold, mask_all + le.pix_offset, lists[i],
+                                 list_count + i, st, bt);
+        };
+        launch_hessian(s_doh);
         if (i == early_trigger) {
             // the Hessian of this level exists once the launch above is done: all levels below can be finished. (The stage also
             // reads Lt / Lxy of its own levels: complete before this level's smoothing pass, which the launch above follows.)

@@ -185,6 +185,29 @@ int apds_dev_hamming_topk(const void* q, int nq, const void* t, int64_t nt, uint
     });
 }
 
+int apds_dev_topk_state_create(void** state) {
+    return guarded([&] {
+        APDS_REQUIRE(state, APDS_ERR_BAD_ARG, "null output");
+        *state = topk_split_create();
+    });
+}
+
+int apds_dev_topk_state_destroy(void* state) {
+    return guarded([&] { topk_split_destroy(state); });
+}
+
+int apds_dev_topk_prepass(void* state, const void* q, int nq, const void* t, int64_t nt, uint32_t index_base, int k, void* stream) {
+    return guarded([&] { topk_split_prepass(state, q, nq, t, nt, index_base, k, pick_stream(stream)); });
+}
+
+int apds_dev_topk_scan(void* state, const void* q, const void* t, void* stream) {
+    return guarded([&] { topk_split_scan(state, q, t, pick_stream(stream)); });
+}
+
+int apds_dev_topk_merge(void* state, uint32_t index_base, void* out_keys, void* stream) {
+    return guarded([&] { topk_split_merge(state, index_base, static_cast<uint64_t*>(out_keys), pick_stream(stream)); });
+}
+
 int apds_dev_match_lds_cap(int bytes, int* previous) {
     return guarded([&] {
         APDS_REQUIRE(bytes >= 0 && bytes <= 64 * 1024, APDS_ERR_BAD_ARG, "cap must be 0 .. 65536 bytes");

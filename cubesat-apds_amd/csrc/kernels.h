@@ -8,6 +8,12 @@ namespace apds {
 // match_hamming.hip
 void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s);
 void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_t* out, hipStream_t s);
+// the scan of hamming_topk_device in three separately launched steps on a per-frame state object (k = 1, 2)
+void* topk_split_create();
+void topk_split_destroy(void* state);
+void topk_split_prepass(void* state, const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, hipStream_t s);
+void topk_split_scan(void* state, const void* q, const void* t, hipStream_t s);
+void topk_split_merge(void* state, uint32_t index_base, uint64_t* out, hipStream_t s);
 void pack_rows_device(const void* src, long long n, int desc_bytes, long long src_stride, void* dst, hipStream_t s);
 int* scan_flags_device(const uint8_t* flags, int n, int** total_dev, hipStream_t s);
 int ratio_filter_device(const uint64_t* keys, int nq, int k, float fs, apds_dmatch* out, hipStream_t s);

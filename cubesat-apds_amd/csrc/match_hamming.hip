@@ -913,6 +913,115 @@ static void topk_device_k(const void* q, int nq, const void* t, long long nt, ui
     HIP_CHECK(hipGetLastError());
 }
 
+// ---- the same scan in three separately launched steps, for pipelines that overlap consecutive frames ---------------------------------
+// topk_device_k runs threshold pre-pass -> main scan -> merge back to back on one stream: per frame ~0.6 ms of pre-pass, ~0.2 ms of
+// merge and four dependent-launch gaps sit between two main scans. With the intermediate buffers owned by a per-frame state object
+// (instead of the calling thread's workspace, which the next call reuses), frame i + 1's pre-pass can run on a second stream while
+// frame i's main scan is on the GPU and frame i - 1's merge on a third: the main scans then follow each other directly.
+struct TopkSplitState {
+    int device = 0;
+    char* buf = nullptr;
+    size_t cap = 0;
+    // layout of the current frame (offsets into buf), filled by the pre-pass
+    size_t off_sparts = 0, off_sample_keys = 0, off_thr = 0, off_parts = 0;
+    int nq = 0, k = 0;
+    long long nt = 0, sample = 0;
+    ChunkPlan sp{}, p{};
+};
+
+static long long split_sample_rows(long long nt) {
+    static const int sample_rows = env_int("APDS_MATCH_SAMPLE", 16384);
+    return (sample_rows > 0 && nt >= 32768) ? std::min<long long>(sample_rows, (nt / 16) & ~1023ll) : 0;
+}
+
+template <int K>
+static void split_prepass_k(TopkSplitState& st, const void* q, int nq, const void* t, long long nt, uint32_t index_base, hipStream_t s) {
+    st.nq = nq;
+    st.k = K;
+    st.nt = nt;
+    st.sample = split_sample_rows(nt);
+    st.p = plan_chunks(nq, nt - st.sample, false, false);
+    size_t need = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = need;
+        need += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    if (st.sample) {
+        st.sp = plan_chunks(nq, st.sample, true, false);
+        st.off_sparts = take(record_words<K>(nq, st.sp) * 4);
+        st.off_sample_keys = take((size_t)nq * K * 8);
+        st.off_thr = take((size_t)nq * 4);
+    }
+    st.off_parts = take(record_words<K>(nq, st.p) * 4);
+    if (need > st.cap) {   // grow-only; a frame still using the old buffer is finished first (rare: the first frames of a run)
+        HIP_CHECK(hipDeviceSynchronize());
+        if (st.buf) (void)hipFree(st.buf);
+        st.buf = nullptr;
+        st.cap = 0;
+        const size_t want = need + need / 4;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.buf), want));
+        st.cap = want;
+    }
+    if (!st.sample) return;
+    uint32_t* sparts = reinterpret_cast<uint32_t*>(st.buf + st.off_sparts);
+    uint64_t* sample_keys = reinterpret_cast<uint64_t*>(st.buf + st.off_sample_keys);
+    launch_topk<K>(q, nq, t, st.sample, nullptr, sparts, st.sp, s, "hamming_topk_sample");
+    merge_records_launch<K>(sparts, st.sp, index_base, nullptr, nq, sample_keys, s);
+    hipLaunchKernelGGL(thr_from_keys_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, sample_keys, nq, K, reinterpret_cast<int*>(st.buf + st.off_thr));
+    HIP_CHECK(hipGetLastError());
+}
+
+template <int K>
+static void split_scan_k(TopkSplitState& st, const void* q, const void* t, hipStream_t s) {
+    const char* rest = static_cast<const char*>(t) + (size_t)st.sample * 64;
+    launch_topk<K>(q, st.nq, rest, st.nt - st.sample, st.sample ? reinterpret_cast<const int*>(st.buf + st.off_thr) : nullptr,
+                   reinterpret_cast<uint32_t*>(st.buf + st.off_parts), st.p, s);
+}
+
+template <int K>
+static void split_merge_k(TopkSplitState& st, uint32_t index_base, uint64_t* out, hipStream_t s) {
+    merge_records_launch<K>(reinterpret_cast<const uint32_t*>(st.buf + st.off_parts), st.p, index_base + (uint32_t)st.sample,
+                            st.sample ? reinterpret_cast<const uint64_t*>(st.buf + st.off_sample_keys) : nullptr, st.nq, out, s);
+    HIP_CHECK(hipGetLastError());
+}
+
+void* topk_split_create() {
+    TopkSplitState* st = new TopkSplitState();
+    st->device = ctx().device;
+    return st;
+}
+void topk_split_destroy(void* h) {
+    TopkSplitState* st = static_cast<TopkSplitState*>(h);
+    if (!st) return;
+    (void)hipSetDevice(st->device);
+    (void)hipDeviceSynchronize();
+    if (st->buf) (void)hipFree(st->buf);
+    delete st;
+}
+void topk_split_prepass(void* h, const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, hipStream_t s) {
+    APDS_REQUIRE(h, APDS_ERR_BAD_ARG, "null scan state");
+    APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "the split scan serves k = 1 and k = 2 (what the crate surface consumes, lib.rs:107-111)");
+    APDS_REQUIRE(nq > 0 && nt > 0 && nt < (1ll << 31), APDS_ERR_ASSERT, "the split scan needs queries and train rows");
+    TopkSplitState& st = *static_cast<TopkSplitState*>(h);
+    if (k == 1) split_prepass_k<1>(st, q, nq, t, nt, index_base, s);
+    else split_prepass_k<2>(st, q, nq, t, nt, index_base, s);
+}
+void topk_split_scan(void* h, const void* q, const void* t, hipStream_t s) {
+    APDS_REQUIRE(h, APDS_ERR_BAD_ARG, "null scan state");
+    TopkSplitState& st = *static_cast<TopkSplitState*>(h);
+    APDS_REQUIRE(st.nq > 0, APDS_ERR_ASSERT, "scan before pre-pass");
+    if (st.k == 1) split_scan_k<1>(st, q, t, s);
+    else split_scan_k<2>(st, q, t, s);
+}
+void topk_split_merge(void* h, uint32_t index_base, uint64_t* out, hipStream_t s) {
+    APDS_REQUIRE(h && out, APDS_ERR_BAD_ARG, "null scan state / output");
+    TopkSplitState& st = *static_cast<TopkSplitState*>(h);
+    APDS_REQUIRE(st.nq > 0, APDS_ERR_ASSERT, "merge before pre-pass");
+    if (st.k == 1) split_merge_k<1>(st, index_base, out, s);
+    else split_merge_k<2>(st, index_base, out, s);
+}
+
 // Full top-k of nq queries over nt train rows (device, 64-byte rows). out: nq*k keys. k <= 16; k in {1,2} is the tuned path
 // (the reference only ever consumes the two nearest, lib.rs:107-111); other k run with one query per lane.
 void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out,

@@ -343,6 +343,7 @@ class StreamedFramePipeline:
                      keys=torch.empty((self.cap, 2), dtype=torch.int64, device=self.dev), keys_view=None,
                      ev_extract=torch.cuda.Event(), ev_match=torch.cuda.Event(), K=0, M=0, index=0,
                      ev_mstart=torch.cuda.Event(enable_timing=True), ev_mend=torch.cuda.Event(enable_timing=True),
+                     ev_pre=torch.cuda.Event(), ev_scan=torch.cuda.Event(), topk_state=None,
                      owner=len(self.slots) % self.extract_workers,
                      gq=self.matcher.make_buffers(self.cap) if self.matcher.world > 1 else None)
             self.slots.append(s)
@@ -362,6 +363,18 @@ class StreamedFramePipeline:
         self.debug_extract_delay = float(os.environ.get("APDS_DEBUG_EXTRACT_DELAY_MS", "0")) * 1e-3
         self.match_workers = 2 if (group is None and os.environ.get("APDS_MATCH_WORKERS", "1") == "2") else 1
         self.gather_stream = torch.cuda.Stream(self.dev, priority=hp) if self.matcher.world > 1 else None
+        # One GPU: the scan of a frame is issued as three launches groups on three streams (apds_dev_topk_prepass / _scan / _merge on a
+        # per-slot state object): frame i + 1's threshold pre-pass and frame i - 1's record merge run beside frame i's main scan, so the
+        # main scans follow each other on their stream without the ~0.8 ms of pre-pass, merge and dependent-launch gaps between them.
+        # Per-launch event timing stays on the main kernel only (its stream carries nothing else). APDS_MATCH_SPLIT=0: one call per frame.
+        self.split_match = self.matcher.world == 1 and os.environ.get("APDS_MATCH_SPLIT", "1") != "0" and self.match_workers == 1
+        if self.split_match:
+            self.pre_stream = torch.cuda.Stream(self.dev, priority=0)
+            self.merge_stream = torch.cuda.Stream(self.dev, priority=hp)
+            for s in self.slots:
+                h = C.c_void_p()
+                check(lib().apds_dev_topk_state_create(C.byref(h)))
+                s["topk_state"] = h
         if reserve_cus > 0:
             # keep `reserve_cus` CUs (spread evenly over the CU index space) out of the MATCH stream only
             words = (n_cus + 31) // 32
@@ -394,6 +407,10 @@ class StreamedFramePipeline:
         if h is not None:
             torch.cuda.synchronize()
             lib().apds_stream_destroy(h)
+        for s in getattr(self, "slots", []):
+            st, s["topk_state"] = s.get("topk_state"), None
+            if st:
+                lib().apds_dev_topk_state_destroy(st)
 
     def __del__(self):
         try:
@@ -567,13 +584,33 @@ class StreamedFramePipeline:
                         if s is None:
                             q1.put(None)            # let the other match worker see the end marker too
                             break
-                        stream.wait_event(s["ev_extract"])
-                        if watch:
-                            s["ev_mstart"].record(stream)
-                        s["keys_view"] = self.matcher.knn(s["desc"][:s["K"]], 2, out=s["keys"], counts=s["counts"])
-                        s["ev_match"].record(stream)
-                        if watch:
-                            s["ev_mend"].record(stream)
+                        if self.split_match and s["K"] > 0:
+                            m, K = self.matcher, s["K"]
+                            with torch.cuda.stream(self.pre_stream):        # threshold pre-pass: beside the previous frame's main scan
+                                self.pre_stream.wait_event(s["ev_extract"])
+                                check(L.apds_dev_topk_prepass(s["topk_state"], s["desc"].data_ptr(), K, m.rows.data_ptr(), int(m.rows.shape[0]), m.index_base, 2,
+                                                              torch_stream()))
+                                s["ev_pre"].record(self.pre_stream)
+                            stream.wait_event(s["ev_pre"])
+                            if watch:
+                                s["ev_mstart"].record(stream)
+                            check(L.apds_dev_topk_scan(s["topk_state"], s["desc"].data_ptr(), m.rows.data_ptr(), torch_stream()))
+                            s["ev_scan"].record(stream)
+                            if watch:
+                                s["ev_mend"].record(stream)
+                            with torch.cuda.stream(self.merge_stream):      # record merge: beside the next frame's main scan
+                                self.merge_stream.wait_event(s["ev_scan"])
+                                check(L.apds_dev_topk_merge(s["topk_state"], m.index_base, s["keys"].data_ptr(), torch_stream()))
+                                s["ev_match"].record(self.merge_stream)
+                            s["keys_view"] = s["keys"][:K]
+                        else:
+                            stream.wait_event(s["ev_extract"])
+                            if watch:
+                                s["ev_mstart"].record(stream)
+                            s["keys_view"] = self.matcher.knn(s["desc"][:s["K"]], 2, out=s["keys"], counts=s["counts"])
+                            s["ev_match"].record(stream)
+                            if watch:
+                                s["ev_mend"].record(stream)
                             if prev is not None and s["index"] >= 4:           # the first frames are the pipeline filling up
                                 pending.append((prev["ev_mend"], s["ev_mstart"]))
                             prev = s

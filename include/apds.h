@@ -265,6 +265,17 @@ int apds_dev_pack_descriptors(const void* src_rows, int64_t n, int desc_bytes, i
  * Ordering equals BFMatcher's: by distance, ties to the lower train index. */
 int apds_dev_hamming_topk(const void* query_rows64, int n_query, const void* train_rows64, int64_t n_train,
                           uint32_t index_base, int k, void* out_keys, void* stream);
+/* apds_dev_hamming_topk in three separately launched steps (k = 1 or 2), for pipelines that keep several frames in flight: the threshold
+ * pre-pass over the first train rows, the main scan, and the merge of its per-chunk records. The intermediate buffers live in a state
+ * object (one per frame in flight; grow-only device memory) instead of the calling thread's workspace, so frame i + 1's pre-pass may run
+ * on another stream while frame i's scan is on the GPU. Order per frame: prepass -> scan -> merge, each after the previous one on the GPU
+ * (same stream, or events); q / t / n as given to the pre-pass must stay valid until the merge has run. Result == apds_dev_hamming_topk. */
+int apds_dev_topk_state_create(void** state);
+int apds_dev_topk_state_destroy(void* state);
+int apds_dev_topk_prepass(void* state, const void* query_rows64, int n_query, const void* train_rows64, int64_t n_train, uint32_t index_base, int k,
+                          void* stream);
+int apds_dev_topk_scan(void* state, const void* query_rows64, const void* train_rows64, void* stream);
+int apds_dev_topk_merge(void* state, uint32_t index_base, void* out_keys, void* stream);
 /* Merge `parts` candidate lists (each n_query*k keys, e.g. gathered from DB shards) into the global top-k. */
 int apds_dev_merge_topk(const void* keys_parts, int parts, int n_query, int k, void* out_keys, void* stream);
 /* Occupancy cap of the main Hamming scan, process-wide: the kernel requests `bytes` of (unused) dynamic LDS per workgroup, which bounds

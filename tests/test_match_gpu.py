@@ -180,3 +180,46 @@ def test_config5_db_size_10m_rows(gpu_pkg, oracle_mod):
     sel = np.arange(0, len(q), 32)
     oi, od = oracle_mod.knn_hamming(q[sel], db, 2)
     assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od)
+
+
+@pytest.mark.parametrize("nq,nt,k", [(3000, 200000, 2), (20000, 60000, 2), (500, 5000, 2), (9000, 70000, 1)])
+def test_split_scan_equals_the_one_call_scan(gpu_pkg, nq, nt, k):
+    # apds_dev_topk_prepass / _scan / _merge on a state object, each step on ITS OWN stream with events between them and two frames in
+    # flight (the second frame's pre-pass is issued before the first frame's merge, as the streamed pipeline does), against
+    # apds_dev_hamming_topk on the same rows: identical keys
+    import ctypes as C
+    import torch
+    L, check = gpu_pkg.lib(), gpu_pkg._lib.check
+    dev = torch.device("cuda:0")
+    db = gpu_pkg.synth.make_descriptor_db(nt, seed=0x44420001 + nt)
+    qa, _ = gpu_pkg.synth.make_queries(db, nq, seed=0x51550001 + nq)
+    qb = np.ascontiguousarray(qa[::-1])
+    pad = lambda a: torch.from_numpy(np.concatenate([a, np.zeros((len(a), 3), np.uint8)], 1)).to(dev)   # noqa: E731
+    rows, da, dbq = pad(db), pad(qa), pad(qb)
+    want = torch.empty((nq, k), dtype=torch.int64, device=dev)
+    st_pre, st_main, st_merge = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    torch.cuda.synchronize()
+    check(L.apds_dev_hamming_topk(da.data_ptr(), nq, rows.data_ptr(), nt, 7, k, want.data_ptr(), C.c_void_p(st_main.cuda_stream)))
+    st_main.synchronize()
+    states = [C.c_void_p(), C.c_void_p()]
+    outs = [torch.empty((nq, k), dtype=torch.int64, device=dev) for _ in range(2)]
+    ev_pre, ev_scan = [torch.cuda.Event() for _ in range(2)], [torch.cuda.Event() for _ in range(2)]
+    for s in states:
+        check(L.apds_dev_topk_state_create(C.byref(s)))
+    try:
+        for rep in range(2):      # second round: the state buffers are reused
+            for f, q in enumerate((da, dbq)):
+                check(L.apds_dev_topk_prepass(states[f], q.data_ptr(), nq, rows.data_ptr(), nt, 7, k, C.c_void_p(st_pre.cuda_stream)))
+                ev_pre[f].record(st_pre)
+                st_main.wait_event(ev_pre[f])
+                check(L.apds_dev_topk_scan(states[f], q.data_ptr(), rows.data_ptr(), C.c_void_p(st_main.cuda_stream)))
+                ev_scan[f].record(st_main)
+            for f in range(2):
+                st_merge.wait_event(ev_scan[f])
+                check(L.apds_dev_topk_merge(states[f], 7, outs[f].data_ptr(), C.c_void_p(st_merge.cuda_stream)))
+            torch.cuda.synchronize()
+            assert torch.equal(outs[0], want)
+            assert torch.equal(outs[1], torch.flip(want, dims=(0,)))
+    finally:
+        for s in states:
+            check(L.apds_dev_topk_state_destroy(s))

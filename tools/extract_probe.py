@@ -18,7 +18,7 @@ dev = torch.device("cuda:0")
 cap = (1 << 18) - 1
 kps = torch.empty((cap, 7), dtype=torch.float32, device=dev)
 desc = torch.empty((cap, 64), dtype=torch.uint8, device=dev)
-for T in (512, 1024, 2048, 4096):
+for T in ([int(a) for a in sys.argv[1:]] or [512, 1024, 2048, 4096]):
     frames = [torch.from_numpy(pkg.synth.make_tile(T, T, frame_index=i)).to(dev) for i in range(2)]
     n = C.c_int(0)
     st = torch.cuda.Stream(dev)
