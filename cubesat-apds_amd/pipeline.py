@@ -611,6 +611,7 @@ class StreamedFramePipeline:
                             s["ev_match"].record(stream)
                             if watch:
                                 s["ev_mend"].record(stream)
+                        if watch:
                             if prev is not None and s["index"] >= 4:           # the first frames are the pipeline filling up
                                 pending.append((prev["ev_mend"], s["ev_mstart"]))
                             prev = s
