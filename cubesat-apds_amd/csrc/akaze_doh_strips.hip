@@ -24,6 +24,7 @@
 // taps swap places: a + b == b + a), and Ly of a virtual row needs its operands swapped (rs(v-s) - rs(v+s): the mirror's upper tap is this
 // row's lower one). Interior bands carry none of this (VEDGE = false).
 #include "akaze.h"
+#include "config.h"
 
 namespace apds {
 
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // true: the level's (Lx, Ly), det, keypoint mask, suppression status (every pixel of the level: no zero fill needed) and candidate list are
 // on their way on `s`. false: not a level for this kernel (the caller takes doh_fused_kernel and clears mask / status itself).
 bool doh_strips_eligible(int w, int h, int sc, int batch) {
-    static const int mode = getenv("APDS_DOH_STRIP") ? atoi(getenv("APDS_DOH_STRIP")) : 1;
+    const int mode = config().doh_strip;
     if (mode == 0 || sc < 2 || sc > 4 || w < 64 || h < 64) return false;
     // 8 Mpx and more (the first octave of a 4096^2 frame): below that a level has too few 64-column strips to fill the chip with bands of
     // a useful height (2048^2: 41 strips; bands of 16 rows spend half their walk on the 4 s + 2 warm-up rows) and the LDS tiles are quicker
@@ -267,7 +268,7 @@ bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, in
     const int strips = ceil_div(w, vw);
     // band height (APDS_DOH_STRIP_ROWS: test hook): 64 rows - a walk of 64 + 4 s + 2 rows - while that still gives every SIMD four waves,
     // else shorter bands. Measured at 4096^2, stand-alone extraction: 32 rows 1.854 ms, 64 rows 1.813, 128 rows 1.89 - 2.3.
-    static const int rb_env = getenv("APDS_DOH_STRIP_ROWS") ? atoi(getenv("APDS_DOH_STRIP_ROWS")) : 0;
+    const int rb_env = config().doh_strip_rows;
     int rb = rb_env > 0 ? rb_env : 64;
     if (rb_env <= 0)
         while (rb > 16 && (long long)strips * ceil_div(h, rb) * b.n < 4096) rb /= 2;

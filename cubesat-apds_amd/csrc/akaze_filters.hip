@@ -12,6 +12,7 @@
 // binary32 operation per source operation, no FMA contraction (-ffp-contract=off), correctly rounded
 // division; symmetric taps as  acc = k0*c; acc += k1*(lo1+hi1); ...  antisymmetric taps as  hi - lo.
 #include "akaze.h"
+#include "config.h"
 
 namespace apds {
 
@@ -1149,11 +1150,7 @@ __global__ void area_resize_kernel(const float* __restrict__ src, int sw, float*
 // derivatives and the determinant on the tile + 1 ring (kept in LDS), then the strict 3x3 maxima of the tile above the
 // threshold and inside the level's border -> keypoint mask + candidate list (block-aggregated append). Lsmooth is read once,
 // Ldet is not read back for the extrema test, and two launches per level disappear.
-static constexpr int DW = 128, DH = 32;   // wide tiles: the halo costs ~1.4x instead of ~2x at s = 4
-#ifndef APDS_DOH_THREADS
-#define APDS_DOH_THREADS 1024
-#endif
-static constexpr int DNT = APDS_DOH_THREADS;
+static constexpr int DH = 32;             // tile height (the width is the kernel's TW parameter)
 // (candidates of a tile: strict 3x3 maxima are never adjacent, so at most a quarter of the tile pixels — the room behind the determinant plane)
 
 // S = sigma_size as a compile-time constant (2, 3, 4 are all the reference's AKAZE parameters produce): constant LDS strides turn
@@ -1300,8 +1297,7 @@ __global__ __launch_bounds__(NT) void doh_fused_kernel(const float* __restrict__
 // ---- host launchers -------------------------------------------------------------------------------------
 // grid of a persistent tile kernel with two 1024-thread blocks per CU: a multiple of 8 (one slice per XCD), at most 2 x 256 blocks
 static int persistent_grid(int ntiles) {
-    static const int cap = getenv("APDS_PERSISTENT_BLOCKS") ? atoi(getenv("APDS_PERSISTENT_BLOCKS")) : 512;
-    return std::min((ntiles + 7) & ~7, std::max(8, cap & ~7));
+    return std::min((ntiles + 7) & ~7, 512);
 }
 void launch_gray(const void* img, int rows, int cols, int channels, size_t stride, float* out, hipStream_t s, const Batch& b) {
     hipLaunchKernelGGL(gray_kernel, dim3(ceil_div(cols, 256), rows, b.n), dim3(256), 0, s, static_cast<const uint8_t*>(img), rows, cols, channels, stride, out,
@@ -1319,7 +1315,7 @@ static size_t deriv_lds_bytes(int s) { return (size_t)((TH + 2 * s) * (TW + 2 * 
 void launch_smooth_flow(const float* src, float* smooth, float* flow, int w, int h, const GaussTaps& taps, const float* kptr, hipStream_t s, const Batch& b) {
     const int tiles_x = ceil_div(w, FW), tiles_y = ceil_div(h, FH), ntiles = tiles_x * tiles_y;
     // tiles [1, txi) x [1, tyi) lie inside the image with their 3-pixel halo: register strips; the frame around them: LDS tiles
-    static const int strip_mode = getenv("APDS_SF_STRIP") ? atoi(getenv("APDS_SF_STRIP")) : 1;
+    const int strip_mode = config().sf_strip;
     const int txi = w >= FW + 67 ? (w - 67) / FW + 1 : 1, tyi = h >= FH + 35 ? (h - 35) / FH + 1 : 1;
     // the strips pay once the launch has enough pixels to be throughput-bound: a batch counts as a whole
     const bool strips_on = strip_mode && txi > 1 && tyi > 1 && (size_t)w * h < ((size_t)1 << 29) && ((size_t)w * h * b.n >= ((size_t)1 << 21) || strip_mode == 2);
@@ -1352,7 +1348,7 @@ void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsign
 // false when the image is too small to pay (the launch-bound small tiles keep the separate kernels) or does not fit 32-bit offsets.
 bool launch_base_strips(const void* img, int rows, int cols, int channels, size_t stride, const GaussTaps& g16, const GaussTaps& g10, float* Lt0, float* modg,
                         unsigned int* hmax_bits, bool want_modg, hipStream_t s, const Batch& b) {
-    static const int strip_mode = getenv("APDS_BASE_STRIP") ? atoi(getenv("APDS_BASE_STRIP")) : 1;
+    const int strip_mode = config().base_strip;
     const size_t px = (size_t)rows * cols;
     if (!strip_mode || (px * b.n < ((size_t)1 << 21) && strip_mode != 2) || px >= ((size_t)1 << 29) || (size_t)rows * stride >= ((size_t)1 << 31)) return false;
     if (channels == 4 && ((reinterpret_cast<uintptr_t>(img) | stride | b.img_stride) & 3)) return false;   // dword loads of the BGRA pixels
@@ -1369,11 +1365,8 @@ bool launch_base_strips(const void* img, int rows, int cols, int channels, size_
 template <int S>
 static void nld_multi_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s, const Batch& b) {
     // 1024 threads per 64x32 tile: each step is ~3 short dependent LDS passes, so what matters is waves in flight per CU
-    static const int nt = getenv("APDS_NLD_THREADS") ? atoi(getenv("APDS_NLD_THREADS")) : 1024;
     const dim3 grid(ceil_div(w, T2W), ceil_div(h, T2H), b.n);
-    if (nt == 256) hipLaunchKernelGGL((nld_multi_kernel<S, 256>), grid, dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, b.stride);
-    else if (nt == 512) hipLaunchKernelGGL((nld_multi_kernel<S, 512>), grid, dim3(512), 0, s, Lt, Lf, Lnew, w, h, st, b.stride);
-    else hipLaunchKernelGGL((nld_multi_kernel<S, 1024>), grid, dim3(1024), 0, s, Lt, Lf, Lnew, w, h, st, b.stride);
+    hipLaunchKernelGGL((nld_multi_kernel<S, 1024>), grid, dim3(1024), 0, s, Lt, Lf, Lnew, w, h, st, b.stride);
 }
 template <int S>
 static void nld_strip_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s, const Batch& b) {
@@ -1387,7 +1380,7 @@ void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int 
     // register strips for the throughput-bound launches (up to 4 steps on launches of at least 1 Mpx, a batch counted as a whole);
     // the LDS tiles keep the deeply fused launches of the small, latency-bound octaves (their unrolled strip code would not fit the
     // instruction cache)
-    static const int strip_mode = getenv("APDS_NLD_STRIP") ? atoi(getenv("APDS_NLD_STRIP")) : 1;
+    const int strip_mode = config().nld_strip;
     if (strip_mode && nsteps <= 4 && ((size_t)w * h * b.n >= ((size_t)1 << 20) || strip_mode == 2) && (size_t)w * h < ((size_t)1 << 29)) {   // 32-bit byte offsets
         switch (nsteps) {
             case 1: nld_strip_launch<1>(Lt, Lf, Lnew, w, h, st, s, b); return;
@@ -1428,8 +1421,7 @@ void launch_level_fused(const float* src, float* smooth, float* flow_out, const 
     }
     const dim3 grid(ceil_div(w, LFT), ceil_div(h, LFT), b.n);
     // several tiles per CU: 512-thread blocks, so that three or four of them share a CU; otherwise all the threads one tile can use
-    static const int nt_env = getenv("APDS_LEVEL_FUSE_THREADS") ? atoi(getenv("APDS_LEVEL_FUSE_THREADS")) : 0;
-    const bool small_blocks = nsteps <= LF_MAX_STEPS_512 && (nt_env ? nt_env == 512 : (size_t)grid.x * grid.y * grid.z >= 512);
+    const bool small_blocks = nsteps <= LF_MAX_STEPS_512 && (size_t)grid.x * grid.y * grid.z >= 512;
     if (small_blocks)
         hipLaunchKernelGGL((level_fused_kernel<512>), grid, dim3(512), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride);
     else
@@ -1444,10 +1436,10 @@ void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, co
 }
 void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
                       uint32_t* list, int* list_count, hipStream_t s, const Batch& b) {
-    // tile width: 128 x 32 tiles on 1024 threads (halo 1.4x, two blocks per CU) or 64 x 32 tiles on 512 threads (halo 1.75x, four blocks
-    // per CU: the kernel is four barrier-separated phases, and more independent blocks per CU hide their latencies better)
-    static const int tile_env = getenv("APDS_DOH_TILE") ? atoi(getenv("APDS_DOH_TILE")) : 64;
-    const int tw = tile_env == 64 ? 64 : (tile_env == 32 ? 32 : DW);
+    // 64 x 32 tiles on 512 threads (halo 1.75x, four blocks per CU: the kernel is four barrier-separated phases, and more independent
+    // blocks per CU hide their latencies better than the 128 x 32 / 1024-thread tiles of round 1 or 32-pixel tiles on 256 threads did:
+    // 1.82 against 1.91 and 1.98 ms per 4096^2 extraction; those variants are gone)
+    constexpr int tw = 64;
     const size_t lds = (size_t)((tw + 4 * sc + 2) * (DH + 4 * sc + 2) + 2 * (tw + 2 * sc + 2) * (DH + 2 * sc + 2)) * sizeof(float);
     APDS_REQUIRE((size_t)(tw + 2) * (DH + 2) + (size_t)tw * DH / 4 <= (size_t)(tw + 4 * sc + 2) * (DH + 4 * sc + 2), APDS_ERR_INTERNAL, "doh_fused: LDS aliasing needs sigma_size >= 2");
     // the extrema test of a level that is too small for its border is skipped (border < 0 in the kernel)
@@ -1458,29 +1450,11 @@ void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int
         hipLaunchKernelGGL(kernel, dim3(ceil_div(w, tw), ceil_div(h, DH), b.n), dim3(nt), lds, s, Lsmooth, Lxy, Ldet, w, h, sc, kside, kmid,
                            (float)(sc * sc * sc * sc), none ? -1 : border, thr, mask, list, list_count, b.stride);
     };
-    if (tw == 32) {
-        switch (sc) {
-            case 2: go(&doh_fused_kernel<2, 256, 32>, 256); break;
-            case 3: go(&doh_fused_kernel<3, 256, 32>, 256); break;
-            case 4: go(&doh_fused_kernel<4, 256, 32>, 256); break;
-            default: go(&doh_fused_kernel<0, 256, 32>, 256); break;
-        }
-        return;
-    }
-    if (tw == 64) {
-        switch (sc) {
-            case 2: go(&doh_fused_kernel<2, 512, 64>, 512); break;
-            case 3: go(&doh_fused_kernel<3, 512, 64>, 512); break;
-            case 4: go(&doh_fused_kernel<4, 512, 64>, 512); break;
-            default: go(&doh_fused_kernel<0, 512, 64>, 512); break;
-        }
-        return;
-    }
     switch (sc) {
-        case 2: go(&doh_fused_kernel<2, DNT, DW>, DNT); break;
-        case 3: go(&doh_fused_kernel<3, DNT, DW>, DNT); break;
-        case 4: go(&doh_fused_kernel<4, DNT, DW>, DNT); break;
-        default: go(&doh_fused_kernel<0, DNT, DW>, DNT); break;
+        case 2: go(&doh_fused_kernel<2, 512, 64>, 512); break;
+        case 3: go(&doh_fused_kernel<3, 512, 64>, 512); break;
+        case 4: go(&doh_fused_kernel<4, 512, 64>, 512); break;
+        default: go(&doh_fused_kernel<0, 512, 64>, 512); break;
     }
 }
 

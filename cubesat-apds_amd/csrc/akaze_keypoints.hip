@@ -15,6 +15,7 @@
 
 #include <chrono>
 #include "akaze.h"
+#include "config.h"
 
 namespace apds {
 
@@ -1213,7 +1214,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     if (max_points <= 0) max_points = APDS_MAX_POINTS;
     ThreadCtx& c = ctx();
     KernelTimer whole("akaze_extract", s);   // whole extraction (all kernels + the count read-backs), for bench.py
-    static const int host_time_env = getenv("APDS_DEBUG_HOST_TIME") ? atoi(getenv("APDS_DEBUG_HOST_TIME")) : 0;
+    const int host_time_env = config().debug_host_time;
     const auto host_t0 = std::chrono::steady_clock::now();
     const int W = cols, H = rows, B = n_img;
     const float soffset = 1.6f, derivative_factor = 1.5f, dthreshold = 0.001f;
@@ -1253,7 +1254,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // streams share the few hardware queues and the threads serialise each other — even an idle side stream shifts the mapping:
     // 4 threads reach 2400 tiles/s of 1024^2 when no thread ever forked, 1240 - 1320 when some did. So a thread forks only while it
     // is the ONLY host thread holding a library context (apds_thread_release drops one); APDS_AKAZE_FORK = 0 never, 2 always.
-    static const int fork_env = getenv("APDS_AKAZE_FORK") ? atoi(getenv("APDS_AKAZE_FORK")) : 1;
+    const int fork_env = config().akaze_fork;
     // (A call costs the host ~3.5 us per launch, event record or stream wait, ~90 of them: a 512^2 tile's 0.32 ms is mostly that. Not
     // forking below 0.5 Mpx saves 30 of those calls and was measured both ways: 0.355 against 0.367 ms in tools/ab_probe.py, 0.36 against
     // 0.32 in tools/extract_probe.py — no threshold.)
@@ -1322,7 +1323,6 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         if (c.side) HIP_CHECK(hipStreamSynchronize(c.side));
         for (hipStream_t st : c.side_pool)
             if (st) HIP_CHECK(hipStreamSynchronize(st));
-        if (c.side2) HIP_CHECK(hipStreamSynchronize(c.side2));
         c.fork_open = false;
     }
     // The streaming Hessian kernel (akaze_doh_strips.hip) writes the keypoint-mask byte and the suppression-status byte of EVERY pixel of
@@ -1379,24 +1379,11 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // followed by the keypoint tail, and beside the small octaves' kernels they delay those. Lowest priority for the side streams: no
     // difference. profiles/r03/doh_ab.txt)
     // (a stream of their own for the small levels' Hessian kernels, which queue up behind the large levels' on this one: measured, no gain)
-    // Keypoint stages. Levels 0 .. m are FINAL (cross-level suppression done) once the Hessian of level m + 1 exists (see run_stage).
-    // The last two octaves are a chain of short, latency-bound launches that leaves the GPU almost idle, and the large octaves before
-    // them hold nearly all keypoints: the EARLY stage = suppression passes + sub-pixel filter + ordered compaction + orientation +
-    // descriptors of all octaves but the last two, on a third (lowest-priority) stream, issued as soon as the first level of the
-    // second-to-last octave has its Hessian, runs under that chain instead of after it. (Starting earlier, per octave, only moves
-    // the work under the throughput-bound large levels, where it takes the time away from the chain: measured slower.) Output order
-    // is level-major, so the stages append in order. One stage (all levels, after the join) when the Hessian kernels are not forked,
-    // with fewer than three octaves, or unless APDS_AKAZE_STAGES asks for it.
-    // OFF by default: inside the streamed pipeline (bench.py) the extra stream and launches cost more than the overlap returns
-    // (42.5 frames/s without, 41.2 with; stand-alone 4096^2: 2.18 ms without, 2.14 with). APDS_AKAZE_STAGES=1 turns it on for the
-    // largest frames, =2 for every size (the parity tests run both ways).
-    static const int stages_mode = getenv("APDS_AKAZE_STAGES") ? atoi(getenv("APDS_AKAZE_STAGES")) : 0;
-    // (measured, tools/extract_probe.py: 4096^2 2.18 -> 2.14 ms staged, but 2048^2 1.03 -> 1.10 and 1024^2 0.74 -> 0.77: the
-    // descriptor kernel of the early stage fills the CUs and the chain's 1024-thread blocks wait for room whatever the stream
-    // priorities say (profiles/r02/extract_timeline_staged.txt) - so only the largest frames are staged)
-    const bool staged = fork_doh && stages_mode && n_oct >= 3 && ((size_t)W * H * B >= ((size_t)1 << 23) || stages_mode == 2);
-    const int early_trigger = staged ? 4 * (n_oct - 2) : -1;   // the level whose Hessian launch releases the early stage
-    hipStream_t s_kp = staged ? c.side_stream2() : s;
+    // Keypoint stage: once every level has its Hessian, ONE stage makes all levels final and emits them (suppress_stage / emit_stage below
+    // take a level range because round 2 also ran the large octaves' levels early, on a third stream under the small octaves' chain -
+    // "staged" mode: 2.14 against 2.18 ms stand-alone then, 1.91 against 1.83 in round 3, and slower inside the streamed pipeline: the
+    // per-keypoint kernels fill every CU and the chain's blocks wait for room whatever the priorities or occupancy caps; removed).
+    hipStream_t s_kp = s;
     // ---- level tables for the keypoint kernels (pointers of image 0; kernels add blockIdx.z * slab)
     LevelTable T{};
     SuppressArgs A{};
@@ -1469,7 +1456,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     auto emit_stage = [&](int prev_m, int m, hipStream_t s_kp) {
         const int a = prev_m + 1;
         int* base_k = kp_base + n_stage;
-        static const int ranked_env = getenv("APDS_KP_RANKED") ? atoi(getenv("APDS_KP_RANKED")) : 1;
+        const int ranked_env = config().kp_ranked;
         if (ranked_env && prev_m < 0 && m == L - 1) {
             // all levels in one stage: the candidates count and place themselves (no pass over the masks)
             const dim3 cgrid(B > 1 ? 16 : 128, L, B);
@@ -1500,7 +1487,6 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     };
     // (Running only the suppression passes of the large octaves' levels early, on a third stream under the small-octave chain, was built
     // and measured as well: bit-identical, 1.844 against 1.825 ms — the passes' scattered loads slow the chain by more than they hide.)
-    int stage_prev_m = -1;
     // ---- a1.4 / a1.5 per level: Lsmooth -> (Lx, Ly, Ldet) and flow; FED steps ping-pong into Lt[i]
     for (int i = 0; i < L; i++) {
         LevelDesc& e = ev[i];
@@ -1512,11 +1498,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             const float* P;   // the level's starting image
             // FED steps are issued in fused groups of up to `fuse` steps (temporal blocking in LDS): `launches` passes ping-pong
             // between e.Lt and tmpP and must end in e.Lt. Deeper fusion for the small octaves, whose launches are latency-bound.
-            static const int fuse_big = getenv("APDS_NLD_FUSE_BIG") ? atoi(getenv("APDS_NLD_FUSE_BIG")) : 4;
-            static const int fuse_small = getenv("APDS_NLD_FUSE_SMALL") ? atoi(getenv("APDS_NLD_FUSE_SMALL")) : 8;
-            const int fuse = std::min(8, std::max(1, (size_t)e.w * e.h * B <= (size_t)1 << 20 ? fuse_small : fuse_big));
+            const int fuse = (size_t)e.w * e.h * B <= (size_t)1 << 20 ? 8 : 4;
             // small levels: Lsmooth, conductivity and the first (usually all) FED steps in ONE launch (level_fused_kernel)
-            static const int level_fuse = getenv("APDS_LEVEL_FUSE") ? atoi(getenv("APDS_LEVEL_FUSE")) : 1;
+            const int level_fuse = config().level_fuse;
             const bool fused_level = e.nsteps > 0 && level_fuse && ((size_t)e.w * e.h * B <= (size_t)1 << 20 || level_fuse == 2);
             const int head = fused_level ? std::min(e.nsteps, level_fused_max_steps()) : 0;
             const int launches = (e.nsteps - head + fuse - 1) / fuse + (fused_level ? 1 : 0);
@@ -1549,7 +1533,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
                 HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(i), 0));
             };
             // large levels: the smoothing pass and the first group of FED steps in one pass over register strips (level_strip_kernel)
-            static const int level_strip = getenv("APDS_LEVEL_STRIP") ? atoi(getenv("APDS_LEVEL_STRIP")) : 1;
+            const int level_strip = config().level_strip;
             bool strip_done = false;
             // (every level of at least 1 Mpx. On the 16 Mpx levels of a 4096^2 frame the gain is within the box-to-box noise: the Hessian
             // kernel beside them is VALU-bound and the strips' recomputed halos cost issue slots — 1.89 against 1.93 ms in one run, 1.85
@@ -1610,14 +1594,6 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
                                  list_count + i, st, bt);
         };
         launch_hessian(s_doh);
-        if (i == early_trigger) {
-            // the Hessian of this level exists once the launch above is done: all levels below can be finished. (The stage also
-            // reads Lt / Lxy of its own levels: complete before this level's smoothing pass, which the launch above follows.)
-            HIP_CHECK(hipEventRecord(c.fork_event(AKAZE_MAX_LEVELS + n_stage), s_doh));
-            HIP_CHECK(hipStreamWaitEvent(s_kp, c.fork_event(AKAZE_MAX_LEVELS + n_stage), 0));
-            run_stage(stage_prev_m, i - 1);
-            stage_prev_m = i - 1;
-        }
     }
     if (fork_doh) {   // join: everything after this point reads what the Hessian kernels wrote
         if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, stream_event_flags()));
@@ -1626,16 +1602,8 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         c.fork_open = false;
     }
     HIP_CHECK(hipGetLastError());
-    // ---- last stage: the remaining levels (all of them when not staged), after the join
-    if (staged) {
-        HIP_CHECK(hipEventRecord(c.fork_event(AKAZE_MAX_LEVELS + n_stage), s));
-        HIP_CHECK(hipStreamWaitEvent(s_kp, c.fork_event(AKAZE_MAX_LEVELS + n_stage), 0));
-    }
-    run_stage(stage_prev_m, L - 1);
-    if (staged) {   // back to the caller's stream
-        HIP_CHECK(hipEventRecord(c.fork_event(AKAZE_MAX_LEVELS + 8), s_kp));
-        HIP_CHECK(hipStreamWaitEvent(s, c.fork_event(AKAZE_MAX_LEVELS + 8), 0));
-    }
+    // ---- the keypoint stage (all levels), after the join
+    run_stage(-1, L - 1);
     HIP_CHECK(hipGetLastError());
 
     AkazeDebugRequest& dbg = akaze_debug_request();

@@ -67,7 +67,6 @@ struct ThreadCtx {
     int akaze_first_batch[2] = {8, 8};          // suppression rounds to launch before the first host check, per phase (adaptive)
     int akaze_batch_streak[2] = {0, 0};
     bool fork_open = false;                     // side-stream work was issued and not yet joined (only after an error in between)
-    hipStream_t side2 = nullptr;                // akaze: keypoint stages of the finished octaves
     int akaze_kp_estimate = 0;                  // keypoints of this thread's previous image (grid size of the per-keypoint kernels)
     int* host_ints = nullptr;                   // pinned host memory for count read-backs (a pageable target makes the copy a staged, blocking one)
     size_t host_ints_cap = 0;
@@ -76,7 +75,6 @@ struct ThreadCtx {
     // a side stream that really runs beside `caller` (see side_stream_beside in misc.hip); cached per caller stream
     hipStream_t side_pool[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t side_probe_caller = nullptr, side_probe_choice = nullptr;
-    hipStream_t side_stream2();
     void drop_side();
     hipEvent_t fork_event(size_t i);            // i-th reusable event (no timing)
 

@@ -1,0 +1,37 @@
+// csrc/config.h — every run-time switch of the library, read ONCE per process from the environment (first use) into one struct.
+// The defaults are the measured best; every switch keeps results bit-identical (the parity tests run the forced variants:
+// tests/test_strip_kernels_gpu.py). Round 3 folded 38 scattered getenv sites into this table and deleted the variants that had lost every
+// measurement: the persistent-grid match kernel, the staged keypoint pipeline, the 32- and 128-pixel Hessian tiles, and the tuning knobs
+// of the match's work-item plan (now constants in match_hamming.hip).
+#pragma once
+
+namespace apds {
+
+struct Config {
+    // ---- AKAZE extraction: which kernel family serves a level (1 = by level size (default), 0 = never, 2 = every level: tests)
+    int nld_strip;        // APDS_NLD_STRIP    FED steps on register strips (unfused path)
+    int sf_strip;         // APDS_SF_STRIP     smoothing + conductivity on register strips (unfused path)
+    int base_strip;       // APDS_BASE_STRIP   image -> gray -> Lt[0] + gradient magnitude in one pass
+    int level_strip;      // APDS_LEVEL_STRIP  smoothing + conductivity + first FED steps of a level on register strips (levels >= 1 Mpx)
+    int level_fuse;       // APDS_LEVEL_FUSE   one launch per level through LDS (levels <= 1 Mpx)
+    int doh_strip;        // APDS_DOH_STRIP    streaming Hessian / extrema kernel (levels >= 8 Mpx)
+    int doh_strip_rows;   // APDS_DOH_STRIP_ROWS  band height of that kernel (0 = chosen by level size); test hook
+    int kp_ranked;        // APDS_KP_RANKED    1: candidates place themselves (default); 0: two passes over the masks
+    // ---- AKAZE extraction: scheduling
+    int akaze_fork;       // APDS_AKAZE_FORK   Hessian kernels on a side stream: 1 when the caller is the only library thread, 0 never, 2 always
+    int side_probe;       // APDS_SIDE_PROBE   1: pick the side stream by a one-time concurrency probe; 0: the first stream created
+    int event_scope;      // APDS_EVENT_SCOPE  2: fork / join events without the system-scope fence (default); 1: the runtime's default event
+    int debug_host_time;  // APDS_DEBUG_HOST_TIME  N > 0: print the host's enqueue time per extraction call every N calls (stderr)
+    // ---- Hamming match
+    int match_lds_cap;    // APDS_MATCH_LDS_CAP  initial occupancy cap of the main scan (bytes of unused LDS per workgroup; apds_dev_match_lds_cap)
+    int match_sample;     // APDS_MATCH_SAMPLE   rows of the threshold pre-pass (16384; 0 = no pre-pass)
+    // ---- homography / PnP / L2
+    int ransac_coop;      // APDS_RANSAC_COOP  1: 16 lanes per 4-point sample in the hypothesis kernel (default); 0: one thread per sample
+    int ransac_batch;     // APDS_RANSAC_BATCH first speculated batch of RANSAC hypotheses (512)
+    int pnp_batch;        // APDS_PNP_BATCH    hypotheses per PnP batch (2048)
+    int l2_sample_div;    // APDS_L2_SAMPLE_DIV  the bf16 screen's threshold sample = rows / this (12)
+};
+
+const Config& config();
+
+}  // namespace apds

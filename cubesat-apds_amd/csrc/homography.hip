@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "config.h"
 #include "kernels.h"
 
 namespace apds {
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const P2* __restric
 namespace {
 
 void launch_hypotheses(const P2* M, const P2* m, const int* idx_dev, int B, double* models_dev, uint8_t* valid_dev, hipStream_t s) {
-    static const bool coop = !(getenv("APDS_RANSAC_COOP") && atoi(getenv("APDS_RANSAC_COOP")) == 0);
+    const bool coop = config().ransac_coop != 0;
     if (coop)
         hipLaunchKernelGGL(hypothesis_coop_kernel, dim3(ceil_div(B, COOP_PER_BLOCK)), dim3(COOP_LANES * COOP_PER_BLOCK), 0, s, M, m, idx_dev, B, models_dev,
                            valid_dev);
@@ -1072,7 +1073,7 @@ int find_homography_device(const float* src, const float* dst, int n, int method
     } else {
         fetch_points();
         RNG rng((uint64_t)-1);
-        static const int batch_env = getenv("APDS_RANSAC_BATCH") ? atoi(getenv("APDS_RANSAC_BATCH")) : 512;
+        const int batch_env = config().ransac_batch;
         double best_model[9] = {0};
 
         if (method == APDS_HOMOGRAPHY_RANSAC) {

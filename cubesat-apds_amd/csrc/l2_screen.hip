@@ -30,6 +30,7 @@
 // column, so the running top-2 (or the threshold) lives in the lane and insertions / appends are rare.
 #include <cmath>
 
+#include "config.h"
 #include "kernels.h"
 
 namespace apds {
@@ -339,7 +340,7 @@ bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt,
     // pass A runs over a sample of the rows: the first n_sample (whole tiles)
     // (a threshold taken from a fraction f of the rows admits ~2 / f rows of the whole set, times ~2.5 for the 2 eps margin: pass A
     // costs f of a pass, the re-rank ~0.36 ms per candidate per query at config 3 => the sum is flat around f = 1/8 .. 1/16)
-    static const int sample_div = getenv("APDS_L2_SAMPLE_DIV") ? std::max(1, atoi(getenv("APDS_L2_SAMPLE_DIV"))) : 12;
+    const int sample_div = config().l2_sample_div;
     const long long n_sample = std::min<long long>(nt, std::max<long long>(8192, (nt / sample_div + SC_TM - 1) / SC_TM * SC_TM));
     const int s_tiles = ceil_div(n_sample, SC_TM);
     int s_splits = std::max(1, std::min(s_tiles, ceil_div(256 * 2, q_tiles)));

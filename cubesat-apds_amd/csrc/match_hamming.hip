@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "common.h"
+#include "config.h"
 
 namespace apds {
 
@@ -251,25 +252,8 @@ __global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restr
     hamming_topk_item<T, K>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, chunk, qblock);
 }
 
-// Persistent form: a fixed number of resident workgroups pull (chunk, query tile) items from an atomic counter.
-// Every wave leaves the loop when the counter passes the item count, so the grid always drains.
-template <int T, int K>
-__global__ __launch_bounds__(256) void hamming_topk_persistent_kernel(const u32x16* __restrict__ train, int n_train,
-                                                                      const u32x4* __restrict__ queries, int nq, int rows_per_chunk,
-                                                                      const int* __restrict__ init_thr, uint32_t* __restrict__ out,
-                                                                      int qtile_blocks, int n_chunks, int* __restrict__ next_item) {
-    __shared__ int s_item;
-    const int total = qtile_blocks * n_chunks;
-    for (;;) {
-        if (threadIdx.x == 0) s_item = atomicAdd(next_item, 1);
-        __syncthreads();
-        const int item = s_item;
-        __syncthreads();
-        if (item >= total) break;
-        const int chunk = item / qtile_blocks, qblock = item - chunk * qtile_blocks;
-        hamming_topk_item<T, K>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, chunk, qblock);
-    }
-}
+// (A persistent work-queue form of this kernel - resident workgroups pulling items from an atomic counter - was kept through round 2 behind
+// APDS_MATCH_PERSIST; the plain grid was as fast in every sweep (profiles/r01/match_persistent_sweep.log): deleted in round 3.)
 
 // merge `parts` sorted candidate lists per query into the k smallest keys
 template <int K>
@@ -764,10 +748,6 @@ struct ChunkPlan {
     int T, chunks, rows_per_chunk, qtiles_blocks;
 };
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v && *v ? atoi(v) : dflt;
-}
 
 // Occupancy cap of the main scan (bytes of unused dynamic LDS per workgroup; 0 = none), process-wide: APDS_MATCH_LDS_CAP at first
 // use, then apds_dev_match_lds_cap(). See launch_topk.
@@ -778,7 +758,7 @@ std::atomic<int>& last_scan_launch_lds() {
 }
 
 std::atomic<int>& match_lds_cap() {
-    static std::atomic<int> cap{env_int("APDS_MATCH_LDS_CAP", 0)};
+    static std::atomic<int> cap{config().match_lds_cap};
     return cap;
 }
 
@@ -787,16 +767,12 @@ std::atomic<int>& match_lds_cap() {
 // per-chunk candidate lists dominate the merge.
 static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false, bool one_query_per_lane = false) {
     ChunkPlan p;
-    static const int forced_t = env_int("APDS_MATCH_T", 0);
-    static const int target_waves = env_int("APDS_MATCH_TARGET_WAVES", 256 * 4 * 4 * 24);
-    static const int min_rows_main = env_int("APDS_MATCH_MIN_ROWS", 1024);
-    static const int min_rows_sample = env_int("APDS_MATCH_SAMPLE_MIN_ROWS", 256);
-    static const int sample_t = env_int("APDS_MATCH_SAMPLE_T", 1);
-    const int min_rows = sample_pass ? min_rows_sample : min_rows_main;
+    // (the sweeps behind these constants: profiles/r01/match_work_item_sweep.log, match_probe.log; they were environment knobs until round 3)
+    constexpr int target_waves = 256 * 4 * 4 * 24;   // waves per launch: many dispatch rounds deep, so the block scheduler balances the tail
+    const int min_rows = sample_pass ? 256 : 1024;   // shortest row chunk of a work item
     p.T = nq >= 64 * 4 * 64 ? 4 : (nq >= 64 * 2 * 64 ? 2 : 1);
-    if (forced_t == 1 || forced_t == 2 || forced_t == 4) p.T = forced_t;
     // the threshold pre-pass covers few rows: smaller items (T = 1, short chunks) keep all CUs busy
-    if (sample_pass && (sample_t == 1 || sample_t == 2 || sample_t == 4)) p.T = std::min(p.T, sample_t);
+    if (sample_pass) p.T = 1;
     if (one_query_per_lane) p.T = 1;
     const int waves_q = ceil_div(nq, 64 * p.T);
     p.qtiles_blocks = ceil_div(waves_q, 4);
@@ -817,15 +793,13 @@ static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false
 template <int K>
 static void launch_topk(const void* q, int nq, const void* t, long long nt, const int* init_thr, uint32_t* parts, const ChunkPlan& p, hipStream_t s,
                         const char* timer_name = "hamming_topk") {
-    static const int xcd = env_int("APDS_MATCH_XCD", 1);
-    static const int persist = env_int("APDS_MATCH_PERSIST", 0);   // resident workgroups per CU (0 = plain grid)
+    constexpr int xcd = 1;   // XCD-aware chunk placement (profiles/r01/match_xcd_placement_ab.log)
     const u32x16* tr = static_cast<const u32x16*>(t);
     const u32x4* qq = static_cast<const u32x4*>(q);
-    const int items = p.qtiles_blocks * p.chunks;
     // Occupancy cap: the kernels use no LDS, so an (unused) dynamic LDS request of `cap` bytes per workgroup bounds the
     // workgroups resident per CU (160 KB / cap). Two waves per SIMD already issue at full VALU rate; capping there leaves
     // registers, wave slots and the rest of the LDS free, so the short kernels of the other pipeline stages are dispatched
-    // at once instead of waiting for a match wave to retire. Applies to every variant of the scan (all T, all K, persistent).
+    // at once instead of waiting for a match wave to retire. Applies to every variant of the scan (all T, all K).
     const size_t cap = (size_t)std::max(0, match_lds_cap().load(std::memory_order_relaxed));
     last_scan_launch_lds().store((int)cap, std::memory_order_relaxed);
     if (K > 2) {   // larger k keeps K (distance, index) pairs per query in registers: one query per lane
@@ -833,19 +807,6 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, cons
         KernelTimer timer(timer_name, s);
         hipLaunchKernelGGL((hamming_topk_kernel<1, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks,
                            p.chunks, 0);
-        HIP_CHECK(hipGetLastError());
-        return;
-    }
-    if (persist > 0 && items > 256 * persist) {
-        int* counter = ctx().alloc_n<int>(1);
-        HIP_CHECK(hipMemsetAsync(counter, 0, sizeof(int), s));
-        dim3 grid(256 * persist), block(256);
-        KernelTimer timer(timer_name, s);
-        switch (p.T) {
-            case 4: hipLaunchKernelGGL((hamming_topk_persistent_kernel<4, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
-            case 2: hipLaunchKernelGGL((hamming_topk_persistent_kernel<2, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
-            default: hipLaunchKernelGGL((hamming_topk_persistent_kernel<1, K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts, p.qtiles_blocks, p.chunks, counter); break;
-        }
         HIP_CHECK(hipGetLastError());
         return;
     }
@@ -888,7 +849,7 @@ static void topk_device_k(const void* q, int nq, const void* t, long long nt, ui
     // every chunk starts from, so the rare-hit fast path is reached immediately. The sample rows have the
     // lowest indices, hence a later row at equal distance never outranks them: strict '<' stays exact.
     // (1/16 of the rows, at most APDS_MATCH_SAMPLE = 16384, from 32768 rows up: a 125k-row shard of an 8-GPU run still gets one)
-    static const int sample_rows = env_int("APDS_MATCH_SAMPLE", 16384);
+    const int sample_rows = config().match_sample;
     long long sample = 0;
     if (sample_rows > 0 && nt >= 32768) sample = std::min<long long>(sample_rows, (nt / 16) & ~1023ll);
     const int* thr = nullptr;
@@ -930,7 +891,7 @@ struct TopkSplitState {
 };
 
 static long long split_sample_rows(long long nt) {
-    static const int sample_rows = env_int("APDS_MATCH_SAMPLE", 16384);
+    const int sample_rows = config().match_sample;
     return (sample_rows > 0 && nt >= 32768) ? std::min<long long>(sample_rows, (nt / 16) & ~1023ll) : 0;
 }
 

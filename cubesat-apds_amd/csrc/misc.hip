@@ -1,5 +1,6 @@
 // csrc/misc.hip — small byte/gather kernels on the edges of the path.
 #include <chrono>
+#include "config.h"
 #include "kernels.h"
 
 namespace apds {
@@ -65,8 +66,7 @@ __global__ void spin_kernel(long long cycles, int* sink) {
 hipStream_t side_stream_beside(hipStream_t caller) {
     ThreadCtx& c = ctx();
     if (c.side_probe_choice && c.side_probe_caller == caller) return c.side_probe_choice;
-    static const int probe_env = getenv("APDS_SIDE_PROBE") ? atoi(getenv("APDS_SIDE_PROBE")) : 1;
-    if (!probe_env) return c.side_stream();
+    if (!config().side_probe) return c.side_stream();
     for (hipStream_t& st : c.side_pool)
         if (!st && !take_cached_side_stream(c.device, st)) HIP_CHECK(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, 0));
     HIP_CHECK(hipStreamSynchronize(caller));

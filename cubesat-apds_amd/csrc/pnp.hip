@@ -8,6 +8,7 @@
 // points in one launch, and the host replays the sequential accept/shorten logic over the batch's counts; the result is
 // the model and inlier set the sequential loop would have produced. The final EPnP over the inliers runs on the host in
 // the same code (pnp_core.h), as OpenCV does it once, in index order.
+#include "config.h"
 #include "kernels.h"
 #include "pnp_core.h"
 
@@ -238,7 +239,7 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     HIP_CHECK(hipMemcpyAsync(img_dev, ip.data(), ip.size() * sizeof(float), hipMemcpyHostToDevice, s));
 
     // a batch costs about the same wall time up to ~16 k samples (one thread each, latency-bound): speculate deep
-    static const int batch_env = getenv("APDS_PNP_BATCH") ? atoi(getenv("APDS_PNP_BATCH")) : 2048;
+    const int batch_env = config().pnp_batch;
     int niters = std::max(iterations, 1), maxGood = 0, iter = 0;
     const int batch = std::max(PNP_HT, std::min(batch_env, niters));
     const float t = (float)((double)reproj_thr * (double)reproj_thr);

@@ -9,8 +9,39 @@
 #include <atomic>
 
 #include "common.h"
+#include "config.h"
 
 namespace apds {
+
+const Config& config() {
+    static const Config c = [] {
+        auto env = [](const char* name, int dflt) {
+            const char* v = getenv(name);
+            return v && *v ? atoi(v) : dflt;
+        };
+        Config k;
+        k.nld_strip = env("APDS_NLD_STRIP", 1);
+        k.sf_strip = env("APDS_SF_STRIP", 1);
+        k.base_strip = env("APDS_BASE_STRIP", 1);
+        k.level_strip = env("APDS_LEVEL_STRIP", 1);
+        k.level_fuse = env("APDS_LEVEL_FUSE", 1);
+        k.doh_strip = env("APDS_DOH_STRIP", 1);
+        k.doh_strip_rows = env("APDS_DOH_STRIP_ROWS", 0);
+        k.kp_ranked = env("APDS_KP_RANKED", 1);
+        k.akaze_fork = env("APDS_AKAZE_FORK", 1);
+        k.side_probe = env("APDS_SIDE_PROBE", 1);
+        k.event_scope = env("APDS_EVENT_SCOPE", 2);
+        k.debug_host_time = env("APDS_DEBUG_HOST_TIME", 0);
+        k.match_lds_cap = env("APDS_MATCH_LDS_CAP", 0);
+        k.match_sample = env("APDS_MATCH_SAMPLE", 16384);
+        k.ransac_coop = env("APDS_RANSAC_COOP", 1);
+        k.ransac_batch = env("APDS_RANSAC_BATCH", 512);
+        k.pnp_batch = env("APDS_PNP_BATCH", 2048);
+        k.l2_sample_div = std::max(1, env("APDS_L2_SAMPLE_DIV", 12));
+        return k;
+    }();
+    return c;
+}
 
 static thread_local std::string g_last_error;
 static thread_local ThreadCtx g_ctx;
@@ -46,22 +77,9 @@ hipStream_t ThreadCtx::side_stream() {
     if (!side) {
         // normal priority: a high-priority stream, even an idle one, halves the throughput of OTHER host threads' streams on this
         // runtime (4 threads extracting 1024^2 tiles: 1320 /s with one high-priority side stream around, 1880 /s with normal ones)
-        static const int prio = getenv("APDS_SIDE_PRIO") ? atoi(getenv("APDS_SIDE_PRIO")) : 0;
-        HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, prio));
+        HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, 0));
     }
     return side;
-}
-
-// LOWEST priority: the keypoint stages of finished octaves fill the gaps of the level chain (the critical path, on the caller's stream
-// and the high-priority side stream); at equal priority the descriptor kernel of octave 0 held the CUs and the chain's kernels ran
-// 3 - 7x longer (profiles/r02/extract_timeline_*.txt)
-hipStream_t ThreadCtx::side_stream2() {
-    if (!side2) {
-        int least = 0, greatest = 0;
-        HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIP_CHECK(hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, least));
-    }
-    return side2;
 }
 
 namespace {
@@ -107,12 +125,11 @@ void ThreadCtx::drop_side() {
             cache_side_stream(device, st);
             st = nullptr;
         }
-    for (hipStream_t* st : {&side, &side2})
-        if (*st) {
-            (void)hipStreamSynchronize(*st);
-            (void)hipStreamDestroy(*st);
-            *st = nullptr;
-        }
+    if (side) {
+        (void)hipStreamSynchronize(side);
+        (void)hipStreamDestroy(side);
+        side = nullptr;
+    }
     for (hipEvent_t e : fork_events) (void)hipEventDestroy(e);
     fork_events.clear();
     if (join_event) (void)hipEventDestroy(join_event);
@@ -126,7 +143,7 @@ void ThreadCtx::drop_side() {
 // agent-scope release / acquire every kernel dispatch carries (the parity tests at every tile size run with this setting: a plane
 // that was not written back would be stale as a whole for the small tiles). APDS_EVENT_SCOPE=1: the runtime's default event.
 unsigned stream_event_flags() {
-    static const int scope = getenv("APDS_EVENT_SCOPE") ? atoi(getenv("APDS_EVENT_SCOPE")) : 2;
+    const int scope = config().event_scope;
     return hipEventDisableTiming | (scope == 2 ? (unsigned)hipEventDisableSystemFence : scope == 0 ? (unsigned)hipEventReleaseToDevice : 0u);
 }
 

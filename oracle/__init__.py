@@ -51,7 +51,7 @@ def use_native():
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle_native.so" if _NATIVE else "liboracle.so")
+        so = os.environ.get("APDS_ORACLE_LIB") or os.path.join(_HERE, "liboracle_native.so" if _NATIVE else "liboracle.so")   # (override: the sanitizer build, tests)
         if not os.path.exists(so):
             so = build()
         L = C.CDLL(so)
