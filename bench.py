@@ -292,6 +292,45 @@ def main():
             return (time.perf_counter() - ts) * 1e3
         akaze_solo_ms = timed_solo()
     del solo
+    # The same stage as THROUGHPUT: two host threads, each with its own stream and output buffers, extract alternate frames, so one
+    # frame's latency-bound phases (the small octaves' launch chain, the suppression rounds) run beside the other frame's bandwidth-bound
+    # ones - what the streamed pipeline's two extraction workers do. Informational: `frac` stays the one-call-at-a-time figure.
+    akaze_pair_ms = None
+    if not args.serial:
+        import threading
+
+        def pair_worker(tid, reps, errs):
+            try:
+                torch.cuda.set_device(dev_index)
+                check(L.apds_set_device(dev_index))
+                st = torch.cuda.Stream(dev)
+                k2 = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+                d2 = torch.empty((cap, 64), dtype=torch.uint8, device=dev)
+                n2 = C.c_int(0)
+                with torch.cuda.stream(st):
+                    for rep in range(reps):
+                        f = frames[(rep + tid) % len(frames)]
+                        check(L.apds_dev_akaze_extract(f.data_ptr(), T, T, f.shape[2], f.stride(0), cap, k2.data_ptr(), d2.data_ptr(), cap, C.byref(n2),
+                                                       pl.torch_stream()))
+                    st.synchronize()
+            except BaseException as e:   # noqa: BLE001
+                errs.append(e)
+            finally:
+                L.apds_thread_release()
+
+        def run_pair(reps):
+            errs, ts = [], [threading.Thread(target=pair_worker, args=(t, reps, errs)) for t in range(2)]
+            t0p = time.perf_counter()
+            for t in ts:
+                t.start()
+            for t in ts:
+                t.join()
+            if errs:
+                raise errs[0]
+            return (time.perf_counter() - t0p) * 1e3
+        run_pair(3)
+        akaze_pair_ms = run_pair(10) / 20.0
+        torch.cuda.synchronize()
     if args.serial:
         pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
     else:
@@ -453,6 +492,9 @@ def main():
                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                 "frac": detect_algorithmic_bytes(T, T) / (akaze_solo_ms / max(akaze_solo_n, 1) * 1e-3) / 1e9 / HBM_PEAK_GBPS if akaze_solo_n else 0.0,
                                 "ms_standalone": akaze_solo_ms / max(akaze_solo_n, 1),
+                                "two_in_flight": ({"ms_per_frame": akaze_pair_ms, "frac": detect_algorithmic_bytes(T, T) / (akaze_pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                   "note": "throughput form: two host threads / streams extracting alternate frames (20 frames, wall clock); the "
+                                                           "Hessian kernels are not forked to a side stream in this mode"} if akaze_pair_ms else None),
                                 "library_contexts_alive": int(L.apds_live_contexts()),
                                 "note": "whole extraction (incl. orientation, descriptors, the count read-back), 10 back-to-back calls on resident frames timed by the wall clock with nothing else on the GPU, before the pipeline's streams are created, against the detect stages' algorithmic bytes; stages_ms_per_step.akaze_extract is its wall span while overlapped with the match (two frames are extracted concurrently, so the span may exceed the step time)"},
         }
