@@ -204,6 +204,146 @@ bool host_p3p(const T* obj, const T* img, const Camera& cam, double* rvec, doubl
     return true;
 }
 
+// ---- SOLVEPNP_ITERATIVE: the final refinement over the inliers (host; six parameters, a few thousand residuals at most) ---------------
+// solvePnPRansac(flags = SOLVEPNP_ITERATIVE) as recalled for OpenCV >= 4.6: EPnP stays the RANSAC kernel and the final solvePnP starts
+// from the best RANSAC model (useExtrinsicGuess), i.e. cvFindExtrinsicCameraParams2 reduces to its Levenberg-Marquardt refinement:
+// CvLevMarq(6, 2 n, 20 iterations, FLT_EPSILON) around cvProjectPoints2's analytic Jacobian, zero distortion (mod.rs:344).
+struct PoseRefiner {
+    const double* obj;   // n x 3
+    const double* img;   // n x 2
+    int n;
+    Camera cam;
+    std::vector<double> jac, res;   // 2 n x 6, 2 n
+
+    // R and dR/dr (3 x 9) of a rotation vector: cvRodrigues2 with its Jacobian
+    static void rotation_and_derivative(const double* rv, double* R, double* D) {
+        static const double skew_d[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+        static const double eye[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        const double theta = std::sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+        if (theta < DBL_EPSILON) {
+            std::memcpy(R, eye, sizeof(eye));
+            std::memcpy(D, skew_d, sizeof(skew_d));
+            return;
+        }
+        double sn, cs;
+        pnp::sincos_fixed(theta, sn, cs);
+        const double c1 = 1. - cs, itheta = 1. / theta;
+        const double u[3] = {rv[0] * itheta, rv[1] * itheta, rv[2] * itheta};
+        const double outer[9] = {u[0] * u[0], u[0] * u[1], u[0] * u[2], u[0] * u[1], u[1] * u[1], u[1] * u[2], u[0] * u[2], u[1] * u[2], u[2] * u[2]};
+        const double skew[9] = {0, -u[2], u[1], u[2], 0, -u[0], -u[1], u[0], 0};
+        for (int k = 0; k < 9; k++) R[k] = (cs * eye[k] + c1 * outer[k]) + sn * skew[k];
+        const double outer_d[27] = {u[0] + u[0], u[1], u[2], u[1], 0, 0, u[2], 0, 0, 0, u[0], 0, u[0], u[1] + u[1], u[2], 0, u[2], 0,
+                                    0, 0, u[0], 0, 0, u[1], u[0], u[1], u[2] + u[2]};
+        for (int i = 0; i < 3; i++) {
+            const double ui = u[i];
+            const double a0 = -sn * ui, a1 = (sn - 2 * c1 * itheta) * ui, a2 = c1 * itheta, a3 = (cs - sn * itheta) * ui, a4 = sn * itheta;
+            for (int k = 0; k < 9; k++) D[i * 9 + k] = a0 * eye[k] + a1 * outer[k] + a2 * outer_d[i * 9 + k] + a3 * skew[k] + a4 * skew_d[i * 9 + k];
+        }
+    }
+    // residuals (projection - measurement) of pose p and, if asked, their Jacobian
+    void evaluate(const double* p, bool with_jacobian) {
+        double R[9], D[27];
+        rotation_and_derivative(p, R, D);
+        for (int i = 0; i < n; i++) {
+            const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+            double x = R[0] * X + R[1] * Y + R[2] * Z + p[3];
+            double y = R[3] * X + R[4] * Y + R[5] * Z + p[4];
+            double z = R[6] * X + R[7] * Y + R[8] * Z + p[5];
+            z = z ? 1. / z : 1;
+            x *= z;
+            y *= z;
+            res[2 * (size_t)i] = (x * cam.fu + cam.uc) - img[2 * i];
+            res[2 * (size_t)i + 1] = (y * cam.fv + cam.vc) - img[2 * i + 1];
+            if (!with_jacobian) continue;
+            double* ju = &jac[(size_t)(2 * i) * 6];
+            double* jv = ju + 6;
+            const double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
+            for (int j = 0; j < 3; j++) {
+                ju[3 + j] = cam.fu * dxdt[j];
+                jv[3 + j] = cam.fv * dydt[j];
+            }
+            for (int j = 0; j < 3; j++) {
+                const double* d = D + 9 * j;
+                const double dx0 = X * d[0] + Y * d[1] + Z * d[2], dy0 = X * d[3] + Y * d[4] + Z * d[5], dz0 = X * d[6] + Y * d[7] + Z * d[8];
+                ju[j] = cam.fu * (z * (dx0 - x * dz0));
+                jv[j] = cam.fv * (z * (dy0 - y * dz0));
+            }
+        }
+    }
+    static double norm2(const double* v, size_t k) {
+        double s = 0;
+        for (size_t i = 0; i < k; i++) s += v[i] * v[i];
+        return std::sqrt(s);
+    }
+    // cv::solve(A, b, x, DECOMP_SVD) for the 6 x 6 normal equations
+    static void solve6(const double* A, const double* b, double* x) {
+        double At[36], Vt[36], W[6];
+        for (int i = 0; i < 6; i++)
+            for (int k = 0; k < 6; k++) At[i * 6 + k] = A[k * 6 + i];
+        pnp::svd_rows<true>(pnp::Plain<double>{At}, 6, 6, pnp::Plain<double>{W}, pnp::Plain<double>{Vt});
+        double threshold = 0;
+        for (int i = 0; i < 6; i++) threshold += W[i];
+        threshold *= DBL_EPSILON * 2;
+        for (int j = 0; j < 6; j++) x[j] = 0;
+        for (int i = 0; i < 6; i++) {
+            double wi = W[i];
+            if (std::fabs(wi) <= threshold) continue;
+            wi = 1 / wi;
+            double s = 0;
+            for (int j = 0; j < 6; j++) s += At[i * 6 + j] * b[j];
+            s *= wi;
+            for (int j = 0; j < 6; j++) x[j] = x[j] + s * Vt[i * 6 + j];
+        }
+    }
+    // CvLevMarq::update / step; pose: the starting pose in, the refined pose out
+    void run(double* pose) {
+        const size_t m = 2 * (size_t)n;
+        jac.resize(m * 6);
+        res.resize(m);
+        double N[36], g[6], before[6], damped[36], delta[6];
+        int lambda_lg10 = -3, iters = 0;
+        double prev_norm = DBL_MAX;
+        auto take_step = [&]() {
+            const double lambda = std::exp(lambda_lg10 * std::log(10.));
+            std::memcpy(damped, N, sizeof(N));
+            for (int i = 0; i < 6; i++) damped[i * 6 + i] *= 1. + lambda;
+            solve6(damped, g, delta);
+            for (int i = 0; i < 6; i++) pose[i] = before[i] - delta[i];
+        };
+        evaluate(pose, true);
+        for (;;) {
+            for (int a = 0; a < 6; a++)
+                for (int b = a; b < 6; b++) {
+                    double s = 0;
+                    for (size_t k = 0; k < m; k++) s += jac[k * 6 + a] * jac[k * 6 + b];
+                    N[a * 6 + b] = N[b * 6 + a] = s;
+                }
+            for (int a = 0; a < 6; a++) {
+                double s = 0;
+                for (size_t k = 0; k < m; k++) s += jac[k * 6 + a] * res[k];
+                g[a] = s;
+            }
+            std::memcpy(before, pose, sizeof(before));
+            take_step();
+            if (iters == 0) prev_norm = norm2(res.data(), m);
+            evaluate(pose, false);
+            double now;
+            for (;;) {
+                now = norm2(res.data(), m);
+                if (!(now > prev_norm && ++lambda_lg10 <= 16)) break;
+                take_step();
+                evaluate(pose, false);
+            }
+            lambda_lg10 = std::max(lambda_lg10 - 1, -16);
+            double moved[6];
+            for (int i = 0; i < 6; i++) moved[i] = pose[i] - before[i];
+            if (++iters >= 20 || norm2(moved, 6) / norm2(before, 6) < FLT_EPSILON) return;
+            prev_norm = now;
+            evaluate(pose, true);
+        }
+    }
+};
+
 }  // namespace
 
 int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const double* K, int iterations, float reproj_thr, double confidence, int method,
@@ -212,8 +352,8 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     *n_inliers = 0;
     APDS_REQUIRE(obj_xyz && img_xy && K && rvec && tvec && inliers, APDS_ERR_BAD_ARG, "null argument");
     APDS_REQUIRE(n >= 4, APDS_ERR_ASSERT, "solvePnPRansac needs at least 4 correspondences");
-    APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP || method == APDS_SOLVEPNP_P3P, APDS_ERR_NOT_IMPLEMENTED,
-                 "only SOLVEPNP_EPNP (the reference's default) and SOLVEPNP_P3P are implemented");
+    APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP || method == APDS_SOLVEPNP_P3P || method == APDS_SOLVEPNP_ITERATIVE, APDS_ERR_NOT_IMPLEMENTED,
+                 "SOLVEPNP_EPNP (the reference's default), SOLVEPNP_P3P and SOLVEPNP_ITERATIVE are implemented");
     // kernel choice of solvePnPRansac: P3P on 4 points when asked for, or when there are only 4 points; EPnP on 5 otherwise
     const bool p3p = method == APDS_SOLVEPNP_P3P || n == 4;
     const int model_points = p3p ? 4 : 5;
@@ -302,7 +442,15 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
             inliers[cnt++] = i;
         }
     APDS_REQUIRE(cnt == maxGood, APDS_ERR_INTERNAL, "inlier mask disagrees with the scored count");
-    host_epnp<double>(oi.data(), ii.data(), cnt, cam, rvec, tvec);
+    if (method == APDS_SOLVEPNP_ITERATIVE) {   // Levenberg-Marquardt from the best RANSAC model
+        double pose[6];
+        std::memcpy(pose, best, sizeof(pose));
+        PoseRefiner{oi.data(), ii.data(), cnt, cam, {}, {}}.run(pose);
+        std::memcpy(rvec, pose, 3 * sizeof(double));
+        std::memcpy(tvec, pose + 3, 3 * sizeof(double));
+    } else {
+        host_epnp<double>(oi.data(), ii.data(), cnt, cam, rvec, tvec);
+    }
     *n_inliers = cnt;
     return 1;
 }

@@ -726,6 +726,128 @@ void pnp_errors(const float* obj, const float* img, int n, const double* K, cons
     }
 }
 
+// ---- SOLVEPNP_ITERATIVE: the final refinement of solvePnPRansac(..., flags = SOLVEPNP_ITERATIVE) ------------------------------------
+// Reference call site: homographier/src/homographier/mod.rs:327,359-360 (`method: Option<SolvePnPMethod>` handed to solve_pnp_ransac).
+// calib3d/solvepnp.cpp as recalled (OpenCV >= 4.6): the RANSAC kernel stays EPnP on 5 points, and the final solvePnP over the inliers
+// runs with the best RANSAC model as its extrinsic guess (`rvec = _local_model.col(0); useExtrinsicGuess = true`), which in
+// cvFindExtrinsicCameraParams2 (calibration.cpp) skips the DLT / homography initialisation and goes straight to the refinement:
+// CvLevMarq(6 parameters, 2 n residuals, max 20 iterations, eps FLT_EPSILON, completeSymmFlag) around cvProjectPoints2 with its
+// analytic Jacobian (Rodrigues' dR/dr, then d(proj)/d(r, t)). Zero distortion (mod.rs:344). PARITY UNPINNED; what the tests hold it
+// to is first-order optimality and an independent numpy optimiser (tests/test_external_anchors.py).
+void rodrigues_with_jacobian(const double* rv, double* R, double* J /* 3 x 9: row i = dR/dr_i */) {
+    const double theta = std::sqrt(rv[0] * rv[0] + rv[1] * rv[1] + rv[2] * rv[2]);
+    static const double d_r_x[27] = {0, 0, 0, 0, 0, -1, 0, 1, 0, 0, 0, 1, 0, 0, 0, -1, 0, 0, 0, -1, 0, 1, 0, 0, 0, 0, 0};
+    if (theta < DBL_EPSILON) {
+        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
+        for (int i = 0; i < 27; i++) J[i] = d_r_x[i];
+        return;
+    }
+    double s, c;
+    det_sincos(theta, s, c);
+    const double c1 = 1. - c, itheta = 1. / theta;
+    const double r[3] = {rv[0] * itheta, rv[1] * itheta, rv[2] * itheta};
+    const double rrt[9] = {r[0] * r[0], r[0] * r[1], r[0] * r[2], r[0] * r[1], r[1] * r[1], r[1] * r[2], r[0] * r[2], r[1] * r[2], r[2] * r[2]};
+    const double r_x[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    for (int k = 0; k < 9; k++) R[k] = (c * I[k] + c1 * rrt[k]) + s * r_x[k];
+    const double drrt[27] = {r[0] + r[0], r[1], r[2], r[1], 0, 0, r[2], 0, 0, 0, r[0], 0, r[0], r[1] + r[1], r[2], 0, r[2], 0,
+                             0, 0, r[0], 0, 0, r[1], r[0], r[1], r[2] + r[2]};
+    for (int i = 0; i < 3; i++) {
+        const double ri = r[i];
+        const double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta, a3 = (c - s * itheta) * ri, a4 = s * itheta;
+        for (int k = 0; k < 9; k++) J[i * 9 + k] = a0 * I[k] + a1 * rrt[k] + a2 * drrt[i * 9 + k] + a3 * r_x[k] + a4 * d_r_x[i * 9 + k];
+    }
+}
+
+// cvProjectPoints2 without distortion: err[2 i .. ] = projection - measurement; Jm (2 n x 6, row major: d/dr then d/dt) if wanted
+void project_residuals(const double* obj, const double* img, int n, const Camera& cam, const double* param, double* err, double* Jm) {
+    double R[9], dRdr[27];
+    rodrigues_with_jacobian(param, R, dRdr);
+    const double* t = param + 3;
+    for (int i = 0; i < n; i++) {
+        const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+        double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+        double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+        double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+        z = z ? 1. / z : 1;
+        x *= z;
+        y *= z;
+        err[2 * i] = (x * cam.fu + cam.uc) - img[2 * i];
+        err[2 * i + 1] = (y * cam.fv + cam.vc) - img[2 * i + 1];
+        if (!Jm) continue;
+        double* jr0 = Jm + (size_t)(2 * i) * 6;
+        double* jr1 = jr0 + 6;
+        const double dxdt[3] = {z, 0, -x * z}, dydt[3] = {0, z, -y * z};
+        for (int j = 0; j < 3; j++) {
+            jr0[3 + j] = cam.fu * dxdt[j];
+            jr1[3 + j] = cam.fv * dydt[j];
+        }
+        for (int j = 0; j < 3; j++) {
+            const double* d = dRdr + 9 * j;
+            const double dx0 = X * d[0] + Y * d[1] + Z * d[2], dy0 = X * d[3] + Y * d[4] + Z * d[5], dz0 = X * d[6] + Y * d[7] + Z * d[8];
+            jr0[j] = cam.fu * (z * (dx0 - x * dz0));
+            jr1[j] = cam.fv * (z * (dy0 - y * dz0));
+        }
+    }
+}
+
+double l2_norm(const double* v, int n) {
+    double s = 0;
+    for (int i = 0; i < n; i++) s += v[i] * v[i];
+    return std::sqrt(s);
+}
+
+// CvLevMarq::update()'s state machine, unrolled into straight code; param: in = the initial pose (rvec, tvec), out = the refined one
+void refine_pose_lm(const double* obj, const double* img, int n, const Camera& cam, double* param) {
+    const int max_iter = 20, m = 2 * n;
+    std::vector<double> J((size_t)m * 6), err(m);
+    double JtJ[36], JtErr[6], prev[6], A[36], step[6];
+    int lambdaLg10 = -3, iters = 0;
+    double prevErrNorm = DBL_MAX;
+    auto lm_step = [&]() {
+        const double lambda = std::exp(lambdaLg10 * std::log(10.));
+        std::memcpy(A, JtJ, sizeof(A));
+        for (int i = 0; i < 6; i++) A[i * 6 + i] *= 1. + lambda;
+        svd_solve(A, 6, 6, JtErr, step);
+        for (int i = 0; i < 6; i++) param[i] = prev[i] - step[i];
+    };
+    project_residuals(obj, img, n, cam, param, err.data(), J.data());        // STARTED -> CALC_J
+    for (;;) {
+        // CALC_J
+        for (int a = 0; a < 6; a++)
+            for (int b = a; b < 6; b++) {
+                double s = 0;
+                for (int k = 0; k < m; k++) s += J[(size_t)k * 6 + a] * J[(size_t)k * 6 + b];
+                JtJ[a * 6 + b] = JtJ[b * 6 + a] = s;
+            }
+        for (int a = 0; a < 6; a++) {
+            double s = 0;
+            for (int k = 0; k < m; k++) s += J[(size_t)k * 6 + a] * err[k];
+            JtErr[a] = s;
+        }
+        std::memcpy(prev, param, sizeof(prev));
+        lm_step();
+        if (iters == 0) prevErrNorm = l2_norm(err.data(), m);
+        project_residuals(obj, img, n, cam, param, err.data(), nullptr);      // -> CHECK_ERR
+        double errNorm;
+        for (;;) {
+            errNorm = l2_norm(err.data(), m);
+            if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) {
+                lm_step();
+                project_residuals(obj, img, n, cam, param, err.data(), nullptr);
+                continue;
+            }
+            break;
+        }
+        lambdaLg10 = std::max(lambdaLg10 - 1, -16);
+        double diff[6];
+        for (int i = 0; i < 6; i++) diff[i] = param[i] - prev[i];
+        if (++iters >= max_iter || l2_norm(diff, 6) / l2_norm(prev, 6) < FLT_EPSILON) return;   // DONE
+        prevErrNorm = errNorm;
+        project_residuals(obj, img, n, cam, param, err.data(), J.data());     // -> CALC_J
+    }
+}
+
 // ---- p3p.cpp (Gao, Hou, Tang, Cheng 2003) + polynom_solver.cpp --------------------------------------------------------
 // cube root with a fixed evaluation order (OpenCV calls pow(x, 1/3.)): bit-level first guess + 6 Newton steps, x > 0
 double det_cbrt(double x) {
@@ -1176,7 +1298,7 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
                             double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers) {
     *n_inliers = 0;
     if (n < 4 || !obj_xyz || !img_xy || !K) return -215;          // CV_Assert(npoints >= 4 && ...)
-    if (method != 1 /* SOLVEPNP_EPNP */ && method != 2 /* SOLVEPNP_P3P */) return -213;   // AP3P, ITERATIVE, ...: not restated
+    if (method != 0 /* SOLVEPNP_ITERATIVE */ && method != 1 /* SOLVEPNP_EPNP */ && method != 2 /* SOLVEPNP_P3P */) return -213;   // AP3P, SQPNP, ...: not restated
     // kernel choice of solvePnPRansac: P3P on 4 points when asked for, or when there are only 4 points; EPnP on 5 otherwise
     const bool p3p = method == 2 || n == 4;
     const int modelPoints = p3p ? 4 : 5;
@@ -1240,7 +1362,14 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
             for (int c = 0; c < 2; c++) ii.push_back((double)ip[2 * (size_t)i + c]);
             inliers[cnt++] = i;
         }
-    solve_pnp_epnp<double>(oi.data(), ii.data(), cnt, K, rvec, tvec);
+    if (method == 0) {   // SOLVEPNP_ITERATIVE: Levenberg-Marquardt from the best RANSAC model over the inliers
+        double param[6] = {best_r[0], best_r[1], best_r[2], best_t[0], best_t[1], best_t[2]};
+        refine_pose_lm(oi.data(), ii.data(), cnt, Camera{K[0], K[4], K[2], K[5]}, param);
+        std::memcpy(rvec, param, 3 * sizeof(double));
+        std::memcpy(tvec, param + 3, 3 * sizeof(double));
+    } else {
+        solve_pnp_epnp<double>(oi.data(), ii.data(), cnt, K, rvec, tvec);
+    }
     *n_inliers = cnt;
     return 1;
 }

@@ -155,7 +155,62 @@ def check_pnp_solver(solve, synth):
     assert np.allclose(R, rodrigues(rvec), atol=2e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.0)
 
 
+def pose_residual_jacobian(rvec, tvec, obj, img, K, eps=1e-6):
+    """reprojection residuals (2n) of a pose and their Jacobian wrt (rvec, tvec) by central differences - nothing analytic shared with
+    either implementation"""
+    def res(p):
+        return (project(obj, rodrigues(p[:3]), p[3:], K) - img).ravel()
+    p0 = np.concatenate([rvec, tvec]).astype(np.float64)
+    J = np.empty((2 * len(obj), 6))
+    for k in range(6):
+        d = np.zeros(6)
+        d[k] = eps * max(1.0, abs(p0[k]))
+        J[:, k] = (res(p0 + d) - res(p0 - d)) / (2 * d[k])
+    return res(p0), J
+
+
+def check_iterative_pnp_solver(solve, synth):
+    """SOLVEPNP_ITERATIVE: the final pose is a Levenberg-Marquardt refinement over the inliers, so it must sit at a minimum of the
+    reprojection error: (a) the gradient vanishes, (b) an independent Gauss-Newton iteration (numerical Jacobian, run to convergence from
+    the reported pose) cannot lower the objective by more than 1e-6 relative and stays at the same pose, (c) it fits the inliers at
+    least as well as EPnP's pose does."""
+    obj, img, K, rvec, tvec, flag = synth.make_pnp_set(3000, seed=31, inlier_frac=0.7, noise=0.4)
+    ok, r, t, idx = solve(obj, img, K, 500, 3.0, 0.99, 0)          # 0 = SOLVEPNP_ITERATIVE
+    ok_e, re, te, idx_e = solve(obj, img, K, 500, 3.0, 0.99, 1)    # 1 = SOLVEPNP_EPNP: same RANSAC kernel, hence the same inliers
+    assert ok and ok_e and np.array_equal(idx, idx_e)
+    o, i = obj[idx].astype(np.float32).astype(np.float64), img[idx].astype(np.float32).astype(np.float64)   # the solver sees float copies
+    res, J = pose_residual_jacobian(r, t, o, i, K)
+    f = res @ res
+    g = J.T @ res
+    scale = np.sqrt(np.diag(J.T @ J)) * np.sqrt(f)
+    assert np.all(np.abs(g) <= 1e-5 * scale), (np.abs(g) / scale)                       # (a) first-order optimality
+    p = np.concatenate([r, t]).astype(np.float64)
+    for _ in range(30):                                                               # (b) independent Gauss-Newton
+        rr, JJ = pose_residual_jacobian(p[:3], p[3:], o, i, K)
+        step = np.linalg.lstsq(JJ, -rr, rcond=None)[0]
+        p = p + step
+        if np.linalg.norm(step) < 1e-13 * max(1.0, np.linalg.norm(p)):
+            break
+    rr, _ = pose_residual_jacobian(p[:3], p[3:], o, i, K)
+    assert f <= (rr @ rr) * (1 + 1e-6)
+    assert np.allclose(np.concatenate([r, t]), p, rtol=1e-5, atol=1e-5)
+    res_e, _ = pose_residual_jacobian(re, te, o, i, K)
+    assert f <= res_e @ res_e * (1 + 1e-9)                                              # (c) no worse than EPnP over the same inliers
+    assert np.allclose(rodrigues(r), rodrigues(rvec), atol=2e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.0)
+    # noise-free data: the refinement must not move a perfect pose away
+    obj, img, K, rvec, tvec, _ = synth.make_pnp_set(400, seed=33, inlier_frac=1.1, noise=0.0)
+    ok, r, t, idx = solve(obj, img, K, 100, 2.0, 0.99, 0)
+    assert ok and len(idx) == 400 and np.abs(project(obj, rodrigues(r), t, K) - img).max() < 1e-4
+
+
 # ---------------------------------------------------------------------------------------------------------------- oracle (CPU)
+def test_oracle_iterative_pnp_against_external_anchors(pkg, oracle_mod):
+    def solve(obj, img, K, iters, thr, conf, method):
+        rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, iters, thr, conf, method=method)
+        return rc == 1, r, t, idx
+    check_iterative_pnp_solver(solve, pkg.synth)
+
+
 def test_oracle_homography_against_external_anchors(pkg, oracle_mod):
     def find(src, dst, method, thr):
         ok, H, mask = oracle_mod.find_homography(src, dst, method, thr)
@@ -195,3 +250,16 @@ def test_gpu_pnp_against_external_anchors(gpu_pkg):
             return False, None, None, None
         return True, sol.rvec.mat.ravel(), sol.tvec.mat.ravel(), sol.inliers.mat.ravel()
     check_pnp_solver(solve, gpu_pkg.synth)
+
+
+@pytest.mark.gpu
+def test_gpu_iterative_pnp_against_external_anchors(gpu_pkg):
+    hg = gpu_pkg.homographier
+
+    def solve(obj, img, K, iters, thr, conf, method):
+        corr = [hg.ImgObjCorrespondence(o, i) for o, i in zip(obj, img)]
+        sol = hg.pnp_solver_ransac(corr, hg.Cmat(np.ascontiguousarray(K, np.float64), np.float64), iters, thr, conf, None, hg.SolvePnPMethod(method))
+        if sol is None:
+            return False, None, None, None
+        return True, sol.rvec.mat.ravel(), sol.tvec.mat.ravel(), sol.inliers.mat.ravel()
+    check_iterative_pnp_solver(solve, gpu_pkg.synth)
