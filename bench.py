@@ -319,7 +319,8 @@ def main():
                 L.apds_thread_release()
 
         def run_pair(reps):
-            errs, ts = [], [threading.Thread(target=pair_worker, args=(t, reps, errs)) for t in range(2)]
+            errs = []
+            ts = [threading.Thread(target=pair_worker, args=(t, reps, errs)) for t in range(2)]
             t0p = time.perf_counter()
             for t in ts:
                 t.start()

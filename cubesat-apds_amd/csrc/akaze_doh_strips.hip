@@ -222,6 +222,9 @@ __device__ __forceinline__ void doh_strip_rows(const DohStripArgs& a, uint32_t* 
     if (ncand) flush_candidates(list, list_count, cand, ncand, lane);
 }
 
+}  // namespace
+
+// (outside the anonymous namespace: the profilers' kernel names stay readable)
 template <int S>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void doh_strip_kernel(DohStripArgs a, uint32_t* __restrict__ list, int* __restrict__ list_count, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
@@ -248,8 +251,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     if (vedge) doh_strip_rows<S, true>(a, list, list_count, strip, band, s_l[wv], s_xy[wv], s_cand[wv]);
     else doh_strip_rows<S, false>(a, list, list_count, strip, band, s_l[wv], s_xy[wv], s_cand[wv]);
 }
-
-}  // namespace
 
 // true: the level's (Lx, Ly), det, keypoint mask, suppression status (every pixel of the level: no zero fill needed) and candidate list are
 // on their way on `s`. false: not a level for this kernel (the caller takes doh_fused_kernel and clears mask / status itself).

@@ -44,6 +44,7 @@ static void extract_to_host(ThreadCtx& c, hipStream_t s, const uint8_t* dimg, in
 
 int apds_akaze_extract(const uint8_t* img, int rows, int cols, int channels, size_t stride, int max_points, apds_keypoint** kps, uint8_t** desc,
                        int* n, int* desc_bytes) {
+    APDS_RANGE("apds_akaze_extract");
     return guarded([&] {
         APDS_REQUIRE(kps && desc && n && desc_bytes, APDS_ERR_BAD_ARG, "null output");
         *kps = nullptr;
@@ -69,6 +70,7 @@ int apds_akaze_extract(const uint8_t* img, int rows, int cols, int channels, siz
 // writes BGRA (geotiff_extractor mod.rs:346-378 fused with homographier raster_to_mat mod.rs:183-197) and AKAZE reads it on the device.
 int apds_tile_extract(const float* red, const float* green, const float* blue, int rows, int cols, size_t row_stride, const double* minmax6,
                       int max_points, apds_keypoint** kps, uint8_t** desc, int* n, int* desc_bytes) {
+    APDS_RANGE("apds_tile_extract");
     return guarded([&] {
         APDS_REQUIRE(kps && desc && n && desc_bytes, APDS_ERR_BAD_ARG, "null output");
         *kps = nullptr;
@@ -159,6 +161,7 @@ static void batch_results_to_host(ThreadCtx& c, hipStream_t s, const apds_keypoi
 // every kernel once for all of them. red / green / blue: n_tiles pointers each (windows of one size, row_stride elements between rows).
 int apds_tile_extract_batch(const float* const* red, const float* const* green, const float* const* blue, int n_tiles, int rows, int cols, size_t row_stride,
                             const double* minmax6, int max_points, apds_keypoint** kps, uint8_t** desc, int* counts, int* desc_bytes) {
+    APDS_RANGE("apds_tile_extract_batch");
     return guarded([&] {
         APDS_REQUIRE(kps && desc && counts && desc_bytes, APDS_ERR_BAD_ARG, "null output");
         *kps = nullptr;
@@ -195,6 +198,7 @@ int apds_tile_extract_batch(const float* const* red, const float* const* green, 
 // Outputs: concatenated keypoints / 61-byte descriptors (image 0's rows first), counts[i] rows per image.
 int apds_akaze_extract_batch(const uint8_t* imgs, int n_images, size_t image_stride, int rows, int cols, int channels, size_t stride, int max_points,
                              apds_keypoint** kps, uint8_t** desc, int* counts, int* desc_bytes) {
+    APDS_RANGE("apds_akaze_extract_batch");
     return guarded([&] {
         APDS_REQUIRE(kps && desc && counts && desc_bytes, APDS_ERR_BAD_ARG, "null output");
         *kps = nullptr;
@@ -228,6 +232,7 @@ int apds_akaze_extract_batch(const uint8_t* imgs, int n_images, size_t image_str
 
 int apds_dev_akaze_extract_batch(const void* imgs, int n_images, size_t image_stride, int rows, int cols, int channels, size_t stride, int max_points,
                                  void* kps, void* desc64, int capacity, int* counts, void* stream) {
+    APDS_RANGE("apds_dev_akaze_extract_batch");
     return guarded([&] {
         APDS_REQUIRE(counts && kps && desc64, APDS_ERR_BAD_ARG, "null output");
         ctx().ws_reset();
@@ -238,6 +243,7 @@ int apds_dev_akaze_extract_batch(const void* imgs, int n_images, size_t image_st
 
 int apds_dev_akaze_extract(const void* img, int rows, int cols, int channels, size_t stride, int max_points, void* kps, void* desc64, int capacity,
                            int* n, void* stream) {
+    APDS_RANGE("apds_dev_akaze_extract");
     return guarded([&] {
         APDS_REQUIRE(n && kps && desc64, APDS_ERR_BAD_ARG, "null output");
         ctx().ws_reset();

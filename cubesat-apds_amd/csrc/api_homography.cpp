@@ -28,6 +28,7 @@ extern "C" {
 
 int apds_find_homography_ex(const float* src, const float* dst, int n, int method, double thr, int max_iters, double confidence, double* H,
                             uint8_t* mask) {
+    APDS_RANGE("apds_find_homography_ex");
     return guarded([&] {
         const int found = find_h(src, dst, n, method, thr, max_iters, confidence, H, mask);
         if (!found) fail(APDS_ERR_EMPTY, "no homography found (empty model)");
@@ -40,6 +41,7 @@ int apds_find_homography(const float* src, const float* dst, int n, int method, 
 
 int apds_dev_find_homography(const void* src, const void* dst, int n, int method, double thr, int max_iters, double confidence, double* H,
                              void* mask_dev, void* stream) {
+    APDS_RANGE("apds_dev_find_homography");
     return guarded([&] {
         ctx().ws_reset();
         const int found = find_homography_device(static_cast<const float*>(src), static_cast<const float*>(dst), n, method, thr, max_iters, confidence, H,

@@ -37,6 +37,7 @@ T* host_alloc(size_t n) {
 extern "C" {
 
 int apds_knn_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_bytes, int k, int32_t* idx, int32_t* dist) {
+    APDS_RANGE("apds_knn_match");
     return guarded([&] {
         check_desc_args(q, nq, t, nt, desc_bytes);
         APDS_REQUIRE(k >= 1, APDS_ERR_ASSERT, "k must be >= 1");
@@ -66,6 +67,7 @@ int apds_knn_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_
 
 int apds_get_knn_matches(const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_bytes, int k, float filter_strength,
                          apds_dmatch** matches, int* n_matches) {
+    APDS_RANGE("apds_get_knn_matches");
     return guarded([&] {
         APDS_REQUIRE(matches && n_matches, APDS_ERR_BAD_ARG, "null output");
         *matches = nullptr;
@@ -96,6 +98,7 @@ int apds_get_knn_matches(const uint8_t* q, int nq, const uint8_t* t, int nt, int
 }
 
 int apds_get_bruteforce_matches(const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_bytes, apds_dmatch** matches, int* n_matches) {
+    APDS_RANGE("apds_get_bruteforce_matches");
     return guarded([&] {
         APDS_REQUIRE(matches && n_matches, APDS_ERR_BAD_ARG, "null output");
         *matches = nullptr;
@@ -178,6 +181,7 @@ int apds_dev_pack_descriptors(const void* src, int64_t n, int desc_bytes, int64_
 }
 
 int apds_dev_hamming_topk(const void* q, int nq, const void* t, int64_t nt, uint32_t index_base, int k, void* out_keys, void* stream) {
+    APDS_RANGE("apds_dev_hamming_topk");
     return guarded([&] {
         APDS_REQUIRE(nq >= 0 && nt >= 0, APDS_ERR_ASSERT, "negative row count");
         ctx().ws_reset();
@@ -197,14 +201,17 @@ int apds_dev_topk_state_destroy(void* state) {
 }
 
 int apds_dev_topk_prepass(void* state, const void* q, int nq, const void* t, int64_t nt, uint32_t index_base, int k, void* stream) {
+    APDS_RANGE("apds_dev_topk_prepass");
     return guarded([&] { topk_split_prepass(state, q, nq, t, nt, index_base, k, pick_stream(stream)); });
 }
 
 int apds_dev_topk_scan(void* state, const void* q, const void* t, void* stream) {
+    APDS_RANGE("apds_dev_topk_scan");
     return guarded([&] { topk_split_scan(state, q, t, pick_stream(stream)); });
 }
 
 int apds_dev_topk_merge(void* state, uint32_t index_base, void* out_keys, void* stream) {
+    APDS_RANGE("apds_dev_topk_merge");
     return guarded([&] { topk_split_merge(state, index_base, static_cast<uint64_t*>(out_keys), pick_stream(stream)); });
 }
 
@@ -228,6 +235,7 @@ int apds_dev_merge_topk(const void* parts, int nparts, int nq, int k, void* out_
 }
 
 int apds_dev_ratio_filter(const void* keys, int nq, int k, float fs, void* out_matches, int* n_matches, void* stream) {
+    APDS_RANGE("apds_dev_ratio_filter");
     return guarded([&] {
         APDS_REQUIRE(k >= 2, APDS_ERR_OUT_OF_RANGE, "ratio test needs two neighbours");
         APDS_REQUIRE(n_matches, APDS_ERR_BAD_ARG, "null output");

@@ -7,6 +7,7 @@ extern "C" {
 
 int apds_pnp_solver_ransac(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, int iter_count, float reproj_thres,
                            double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers, int* found) {
+    APDS_RANGE("apds_pnp_solver_ransac");
     return guarded([&] {
         APDS_REQUIRE(found, APDS_ERR_BAD_ARG, "null argument");
         *found = 0;

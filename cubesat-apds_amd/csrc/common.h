@@ -118,6 +118,17 @@ struct KernelTimer {
     }
 };
 
+// A named ROCTx range around a stage of the path (visible in `rocprofv3 --marker-trace` timelines; SURVEY section 5 asks for them). The
+// marker library (librocprofiler-sdk-roctx.so, or the older libroctx64.so) is looked up once with dlopen: the library does not depend on
+// a profiler being installed, and without one a range is a null-pointer test.
+struct TraceRange {
+    explicit TraceRange(const char* name);
+    ~TraceRange();
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
+#define APDS_RANGE(name) ::apds::TraceRange apds_trace_range_(name)
+
 // Wrap an entry-point body: map exceptions to status codes + last_error text.
 template <class F>
 int guarded(F&& f) {

@@ -1,5 +1,6 @@
 // csrc/runtime.cpp — library-level entry points and the per-thread runtime (stream, workspace, timing).
 #include <chrono>
+#include <dlfcn.h>
 #include <cstdlib>
 #include <cstring>
 
@@ -41,6 +42,34 @@ const Config& config() {
         return k;
     }();
     return c;
+}
+
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            void* h = dlopen(lib, RTLD_LAZY | RTLD_LOCAL);
+            if (!h) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(h, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr;
+            pop = nullptr;
+        }
+    }
+};
+const Roctx& roctx() {
+    static const Roctx r;
+    return r;
+}
+}  // namespace
+TraceRange::TraceRange(const char* name) {
+    if (roctx().push) roctx().push(name);
+}
+TraceRange::~TraceRange() {
+    if (roctx().pop) roctx().pop();
 }
 
 static thread_local std::string g_last_error;

@@ -337,6 +337,7 @@ int apds_shard_counts(void* shard, int n_query, int* counts, void* stream) {
 }
 
 int apds_shard_knn(void* shard, const void* q_rows64_dev, int n_query, const int* counts, int k, void* out_keys_dev, void* stream) {
+    APDS_RANGE("apds_shard_knn");
     return shard_guarded([&] {
         APDS_REQUIRE(n_query >= 0 && (q_rows64_dev || n_query == 0), APDS_ERR_ASSERT, "bad query rows");
         APDS_REQUIRE(out_keys_dev || n_query == 0, APDS_ERR_BAD_ARG, "null output");
@@ -363,6 +364,7 @@ int apds_shard_slot_destroy(void* shard, void* slot) {
 }
 
 int apds_shard_gather(void* shard, void* slot, const void* q_rows64_dev, int n_query, const int* counts, void* stream) {
+    APDS_RANGE("apds_shard_gather");
     return shard_guarded([&] {
         APDS_REQUIRE(slot && counts, APDS_ERR_BAD_ARG, "null slot / counts");
         APDS_REQUIRE(n_query >= 0 && (q_rows64_dev || n_query == 0), APDS_ERR_ASSERT, "bad query rows");
@@ -371,6 +373,7 @@ int apds_shard_gather(void* shard, void* slot, const void* q_rows64_dev, int n_q
 }
 
 int apds_shard_scan(void* shard, void* slot, int k, void* stream) {
+    APDS_RANGE("apds_shard_scan");
     return shard_guarded([&] {
         APDS_REQUIRE(slot, APDS_ERR_BAD_ARG, "null slot");
         handle(shard)->m->scan(*static_cast<Slot*>(slot), k, stream);
@@ -378,6 +381,7 @@ int apds_shard_scan(void* shard, void* slot, int k, void* stream) {
 }
 
 int apds_shard_exchange_merge(void* shard, void* slot, int k, void* out_keys_dev, void* stream) {
+    APDS_RANGE("apds_shard_exchange_merge");
     return shard_guarded([&] {
         APDS_REQUIRE(slot, APDS_ERR_BAD_ARG, "null slot");
         handle(shard)->m->exchange_merge(*static_cast<Slot*>(slot), k, out_keys_dev, stream);
