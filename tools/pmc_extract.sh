@@ -21,7 +21,7 @@ for sub in ("a", "b"):
     by = collections.defaultdict(list)
     for (name, _), c in disp.items():
         by[name].append(c)
-    for name in ("doh_fused_kernel<3", "doh_fused_kernel<4", "level_strip_kernel<3", "level_strip_kernel<4", "level_fused_kernel<512", "level_fused_kernel<1024",
+    for name in ("doh_strip_kernel<3", "doh_strip_kernel<4", "doh_fused_kernel<3", "doh_fused_kernel<4", "level_strip_kernel<3", "level_strip_kernel<4", "level_fused_kernel<512", "level_fused_kernel<1024",
                  "nld_strip_kernel<3", "mldb_kernel", "orientation_kernel", "suppress_round_kernel", "base_strip_kernel"):
         ds = [c for k, v in by.items() if k.startswith(name) for c in v]   # every instantiation whose name starts so
         if not ds:
