@@ -119,10 +119,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs masked out of the match stream so the other stages overlap it")
     ap.add_argument("--serial", action="store_true", help="one frame at a time (no cross-frame overlap of the three stages)")
-    ap.add_argument("--host-frames", action="store_true",
-                    help="additionally time the streamed pipeline with every step's frame coming from pinned HOST memory (hipMemcpyAsync on the "
-                         "extraction stream): reported as value_host_frames next to the resident `value` (the reference's bench times Mat "
+    ap.add_argument("--host-frames", action="store_true", default=True,
+                    help="(default) additionally time the streamed pipeline with every step's frame coming from pinned HOST memory (hipMemcpyAsync on "
+                         "the extraction stream): reported as value_host_frames next to the resident `value` (the reference's bench times Mat "
                          "construction + extraction, benchmarks/benches/feature_extraction.rs:35-45)")
+    ap.add_argument("--no-host-frames", dest="host_frames", action="store_false", help="skip the host-frames leg")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libapds_hip.so")
+LIB_PATH = os.environ.get("APDS_LIB_PATH") or os.path.join(_HERE, "libapds_hip.so")   # (override: A/B runs of differently built libraries)
 _LIB = None
 
 KEYPOINT_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),

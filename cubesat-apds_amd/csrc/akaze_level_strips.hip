@@ -28,6 +28,9 @@ struct NldSteps {
 #ifndef APDS_STRIP_RB
 #define APDS_STRIP_RB 16
 #endif
+#ifndef APDS_STRIP_WIDE_FROM
+#define APDS_STRIP_WIDE_FROM 3   // level_strip_kernel<S> with S >= this may use up to 168 VGPRs (three waves per SIMD) instead of spilling at 128
+#endif
 
 // ---- a whole level step on register strips (the large levels) ---------------------------------------------------------------------
 // smooth_flow_strip_kernel and nld_strip_kernel in one pass: Lsmooth = Gaussian(Lt_prev), conductivity = g2(Scharr(Lsmooth)) and the
@@ -164,7 +167,7 @@ __device__ __forceinline__ void level_strip(const float* __restrict__ src, float
 }
 
 template <int S, int RB, bool FLOW_OUT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_WAVES, 8)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S >= APDS_STRIP_WIDE_FROM ? 3 : APDS_STRIP_WAVES, 8)))
 void level_strip_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow_out, float* __restrict__ Lnew, int w, int h,
                         GaussTaps taps, const float* __restrict__ kptr, NldSteps steps, int strips, int nwaves, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
