@@ -67,6 +67,8 @@ bool launch_base_strips(const void* img, int rows, int cols, int channels, size_
 void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b);
 bool launch_level_strips(const float* src, float* smooth, float* flow_out, float* Lnew, int w, int h, const GaussTaps& taps, const float* kptr,
                          const float* step_sizes, int nsteps, hipStream_t s, const Batch& b);
+bool launch_level_stream(const float* src, float* smooth, float* flow_out, float* Lnew, int w, int h, const GaussTaps& taps, const float* kptr,
+                         const float* step_sizes, int nsteps, hipStream_t s, const Batch& b);
 int level_fused_max_steps();
 void launch_level_fused(const float* src, float* smooth, float* flow_out, const float* flow_in, float* Lnew, int w, int h, const GaussTaps& taps,
                         const float* kptr, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b);
@@ -81,6 +83,22 @@ void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int
 bool doh_strips_eligible(int w, int h, int sc, int batch);
 bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
                        uint8_t* status, uint32_t* list, int* list_count, hipStream_t s, const Batch& b);
+
+// Band height of a streaming kernel (a wave walks a band of rows of one 64-column strip; 256-thread blocks = four waves): the waves of a
+// launch should fill the resident wave slots a WHOLE number of times - 5248 waves on 5120 slots run as two rounds, the second one 2.5 %
+// full (the first measurements of both streaming kernels had exactly that). Asks the runtime how many blocks of `kernel` fit a CU, takes
+// bands of about `want_rows` rows and then stretches them so that the last round is (just) full.
+long long stream_wave_slots(const void* kernel);   // resident waves of a 256-thread-block kernel on the current device (cached per kernel)
+template <class K>
+inline int stream_band_rows(K kernel, int strips, int h, int batch, int want_rows, int min_rows) {
+    const long long slots = stream_wave_slots(reinterpret_cast<const void*>(kernel));
+    const long long lanes = (long long)strips * batch;                              // waves per band row
+    long long bands = (h + want_rows - 1) / want_rows;
+    const long long rounds = std::max<long long>(1, (lanes * bands + slots / 2) / slots);
+    bands = std::max<long long>(1, rounds * slots / lanes);                          // as many bands as fill `rounds` rounds, not one more
+    const int rb = (int)((h + bands - 1) / bands);
+    return std::max(rb, min_rows);
+}
 
 // Test hook: when armed (per thread) the next akaze_extract_device copies one intermediate plane to the host.
 // which: 0 Lt, 2 Lx, 3 Ly, 4 Ldet (f32), 7 keypoint mask after cross-level suppression (u8), 8 kcontrast (1 float)

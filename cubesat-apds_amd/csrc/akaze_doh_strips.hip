@@ -23,6 +23,9 @@
 // reflect(u); rd / rs of a virtual row are those of its mirror image, Lx of a virtual row comes out right by itself (its two outer
 // taps swap places: a + b == b + a), and Ly of a virtual row needs its operands swapped (rs(v-s) - rs(v+s): the mirror's upper tap is this
 // row's lower one). Interior bands carry none of this (VEDGE = false).
+#include <map>
+#include <mutex>
+
 #include "akaze.h"
 #include "config.h"
 
@@ -252,6 +255,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     else doh_strip_rows<S, false>(a, list, list_count, strip, band, s_l[wv], s_xy[wv], s_cand[wv]);
 }
 
+long long stream_wave_slots(const void* kernel) {
+    static std::mutex m;
+    static std::map<std::pair<int, const void*>, long long> cache;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(m);
+    auto it = cache.find({dev, kernel});
+    if (it != cache.end()) return it->second;
+    int blocks_per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) != hipSuccess || blocks_per_cu < 1) {
+        (void)hipGetLastError();
+        blocks_per_cu = 4;
+    }
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+        (void)hipGetLastError();
+        cus = 256;
+    }
+    const long long slots = (long long)blocks_per_cu * cus * 4;
+    cache[{dev, kernel}] = slots;
+    return slots;
+}
+
 // true: the level's (Lx, Ly), det, keypoint mask, suppression status (every pixel of the level: no zero fill needed) and candidate list are
 // on their way on `s`. false: not a level for this kernel (the caller takes doh_fused_kernel and clears mask / status itself).
 bool doh_strips_eligible(int w, int h, int sc, int batch) {
@@ -267,12 +293,11 @@ bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, in
     if (!doh_strips_eligible(w, h, sc, b.n)) return false;
     const int vw = 64 - 4 * sc - 2;
     const int strips = ceil_div(w, vw);
-    // band height (APDS_DOH_STRIP_ROWS: test hook): 64 rows - a walk of 64 + 4 s + 2 rows - while that still gives every SIMD four waves,
-    // else shorter bands. Measured at 4096^2, stand-alone extraction: 32 rows 1.854 ms, 64 rows 1.813, 128 rows 1.89 - 2.3.
+    // band height (APDS_DOH_STRIP_ROWS: test hook): about 64 rows - a walk of 64 + 4 s + 2 rows - stretched so that the launch's waves fill the
+    // resident wave slots a whole number of times (akaze.h: stream_band_rows)
     const int rb_env = config().doh_strip_rows;
-    int rb = rb_env > 0 ? rb_env : 64;
-    if (rb_env <= 0)
-        while (rb > 16 && (long long)strips * ceil_div(h, rb) * b.n < 4096) rb /= 2;
+    auto rows_for = [&](auto kernel) { return rb_env > 0 ? rb_env : stream_band_rows(kernel, strips, h, b.n, 64, 16); };
+    const int rb = sc == 2 ? rows_for(&doh_strip_kernel<2>) : sc == 3 ? rows_for(&doh_strip_kernel<3>) : rows_for(&doh_strip_kernel<4>);
     const bool none = border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0;
     DohStripArgs a{Lsmooth, Lxy, Ldet, mask, status, w, h, none ? -1 : border, kside, kmid, (float)(sc * sc * sc * sc), thr, strips,
                    ceil_div(h, rb), rb};

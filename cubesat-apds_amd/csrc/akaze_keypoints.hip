@@ -1543,7 +1543,8 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
                 const int g = (e.nsteps + launches - 1) / launches;
                 float* out = ((launches - 1) % 2 == 0) ? e.Lt : tmpP;
                 for (int j = 0; j < g; j++) st[j] = e.tau[j] * 0.5f;
-                if (g <= 4 && launch_level_strips(P, lsm[i], launches > 1 ? tmpF : nullptr, out, e.w, e.h, g10, k_oct + e.octave, st, g, s, bt)) {
+                if (g <= 4 && (launch_level_stream(P, lsm[i], launches > 1 ? tmpF : nullptr, out, e.w, e.h, g10, k_oct + e.octave, st, g, s, bt) ||
+                               launch_level_strips(P, lsm[i], launches > 1 ? tmpF : nullptr, out, e.w, e.h, g10, k_oct + e.octave, st, g, s, bt))) {
                     strip_done = true;
                     k = g;
                     in = out;

@@ -14,6 +14,8 @@ struct Config {
     int base_strip;       // APDS_BASE_STRIP   image -> gray -> Lt[0] + gradient magnitude in one pass
     int level_strip;      // APDS_LEVEL_STRIP  smoothing + conductivity + first FED steps of a level on register strips (levels >= 1 Mpx)
     int level_fuse;       // APDS_LEVEL_FUSE   one launch per level through LDS (levels <= 1 Mpx)
+    int level_stream;     // APDS_LEVEL_STREAM the same level step as a streaming kernel (levels >= 8 Mpx); APDS_LEVEL_STREAM_ROWS: its band height (test hook)
+    int level_stream_rows;
     int doh_strip;        // APDS_DOH_STRIP    streaming Hessian / extrema kernel (levels >= 8 Mpx)
     int doh_strip_rows;   // APDS_DOH_STRIP_ROWS  band height of that kernel (0 = chosen by level size); test hook
     int kp_ranked;        // APDS_KP_RANKED    1: candidates place themselves (default); 0: two passes over the masks

@@ -26,6 +26,8 @@ const Config& config() {
         k.base_strip = env("APDS_BASE_STRIP", 1);
         k.level_strip = env("APDS_LEVEL_STRIP", 1);
         k.level_fuse = env("APDS_LEVEL_FUSE", 1);
+        k.level_stream = env("APDS_LEVEL_STREAM", 1);
+        k.level_stream_rows = env("APDS_LEVEL_STREAM_ROWS", 0);
         k.doh_strip = env("APDS_DOH_STRIP", 1);
         k.doh_strip_rows = env("APDS_DOH_STRIP_ROWS", 0);
         k.kp_ranked = env("APDS_KP_RANKED", 1);
