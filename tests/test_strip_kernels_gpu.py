@@ -66,6 +66,6 @@ def test_akaze_parity_with_the_streaming_level_kernel_on_every_level(gpu_pkg):
     64-column strips with register rings) normally serves levels of 8 Mpx and more: here every level of at least 64 x 32 pixels of every
     test image - clamped / reflected edge strips and bands, partial last bands - with 16-row bands and with 100-row bands; and once with
     both streaming kernels off (round 2's kernels on every level)."""
-    _rerun({"APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "16", "APDS_LEVEL_FUSE": "0"})
-    _rerun({"APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "100", "APDS_DOH_STRIP": "2"})
+    _rerun({"APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "16", "APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0"})
+    _rerun({"APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "100", "APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0", "APDS_DOH_STRIP": "2"})
     _rerun({"APDS_LEVEL_STREAM": "0", "APDS_DOH_STRIP": "0"})
