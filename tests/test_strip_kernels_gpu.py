@@ -34,7 +34,7 @@ def _rerun(env_extra):
 def test_akaze_parity_with_level_strips_on_every_level(gpu_pkg):
     """level_strip_kernel (smoothing + conductivity + FED steps on register strips, borders included) normally serves levels of
     1 .. 8 Mpx: here it serves every level of every test image, so its border waves meet the small and odd-sized ones."""
-    _rerun({"APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0"})
+    _rerun({"APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STREAM": "0"})
 
 
 def test_akaze_parity_with_lds_fused_levels_on_every_level(gpu_pkg):
@@ -42,30 +42,17 @@ def test_akaze_parity_with_lds_fused_levels_on_every_level(gpu_pkg):
     _rerun({"APDS_LEVEL_FUSE": "2", "APDS_LEVEL_STRIP": "0"})
 
 
-def test_akaze_parity_on_the_unfused_level_path_and_mask_scan_compaction(gpu_pkg):
-    """the round-1 path: separate smoothing / FED launches per level, keypoints placed by two passes over the masks"""
-    _rerun({"APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STRIP": "0", "APDS_KP_RANKED": "0", "APDS_EVENT_SCOPE": "1"})
+def test_akaze_parity_on_the_round_2_path(gpu_pkg):
+    """separate smoothing / FED launches per level, keypoints placed by two passes over the masks, the LDS-tile Hessian kernel on every
+    level with the masks cleared by the zeroing kernel, default events: none of round 3's streaming kernels"""
+    _rerun({"APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STRIP": "0", "APDS_KP_RANKED": "0", "APDS_EVENT_SCOPE": "1", "APDS_DOH_STRIP": "0", "APDS_LEVEL_STREAM": "0"})
 
 
-def test_akaze_parity_with_the_streaming_hessian_kernel_on_every_level(gpu_pkg):
-    """doh_strip_kernel (akaze_doh_strips.hip: determinant of the Hessian + extrema walking down 64-column strips, the masks written for
-    every pixel instead of cleared) normally serves levels of 1 Mpx and more: here it serves every level of at least 64 x 64 pixels of
-    every test image - top / bottom bands with reflected rows, first / last strips with reflected columns, partial last bands - with band
-    heights of 16 rows, and once more with tall bands."""
-    _rerun({"APDS_DOH_STRIP": "2", "APDS_DOH_STRIP_ROWS": "16"})
-    _rerun({"APDS_DOH_STRIP": "2", "APDS_DOH_STRIP_ROWS": "112"})
-
-
-def test_akaze_parity_without_the_streaming_hessian_kernel(gpu_pkg):
-    """the LDS-tile Hessian kernel on every level (round 2's path), masks cleared by the zeroing kernel"""
-    _rerun({"APDS_DOH_STRIP": "0"})
-
-
-def test_akaze_parity_with_the_streaming_level_kernel_on_every_level(gpu_pkg):
-    """level_stream_kernel (akaze_level_stream.hip: Gaussian, Scharr, conductivity and the first FED steps of a level walking down
-    64-column strips with register rings) normally serves levels of 8 Mpx and more: here every level of at least 64 x 32 pixels of every
-    test image - clamped / reflected edge strips and bands, partial last bands - with 16-row bands and with 100-row bands; and once with
-    both streaming kernels off (round 2's kernels on every level)."""
-    _rerun({"APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "16", "APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0"})
-    _rerun({"APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "100", "APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0", "APDS_DOH_STRIP": "2"})
-    _rerun({"APDS_LEVEL_STREAM": "0", "APDS_DOH_STRIP": "0"})
+def test_akaze_parity_with_the_streaming_kernels_on_every_level(gpu_pkg):
+    """Round 3's streaming kernels - doh_strip_kernel (akaze_doh_strips.hip: determinant of the Hessian + extrema walking down 64-column
+    strips, the masks written for every pixel instead of cleared) and level_stream_kernel (akaze_level_stream.hip: Gaussian, Scharr,
+    conductivity and the first FED steps of a level, the same way) - normally serve levels of 8 Mpx and more. Here they serve every level
+    of at least 64 pixels of every test image: top / bottom bands with reflected or clamped rows, first / last strips with reflected or
+    clamped columns, partial last bands; once with 16-row bands and once with tall ones."""
+    _rerun({"APDS_DOH_STRIP": "2", "APDS_DOH_STRIP_ROWS": "16", "APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "16", "APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0"})
+    _rerun({"APDS_DOH_STRIP": "2", "APDS_DOH_STRIP_ROWS": "112", "APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "100", "APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0"})
