@@ -88,10 +88,10 @@ bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, in
 // launch should fill the resident wave slots a WHOLE number of times - 5248 waves on 5120 slots run as two rounds, the second one 2.5 %
 // full (the first measurements of both streaming kernels had exactly that). Asks the runtime how many blocks of `kernel` fit a CU, takes
 // bands of about `want_rows` rows and then stretches them so that the last round is (just) full.
-long long stream_wave_slots(const void* kernel);   // resident waves of a 256-thread-block kernel on the current device (cached per kernel)
+long long stream_wave_slots(const void* kernel, int dynamic_lds = 0);   // resident waves of a 256-thread-block kernel on the current device (cached)
 template <class K>
-inline int stream_band_rows(K kernel, int strips, int h, int batch, int want_rows, int min_rows) {
-    const long long slots = stream_wave_slots(reinterpret_cast<const void*>(kernel));
+inline int stream_band_rows(K kernel, int strips, int h, int batch, int want_rows, int min_rows, int dynamic_lds = 0) {
+    const long long slots = stream_wave_slots(reinterpret_cast<const void*>(kernel), dynamic_lds);
     const long long lanes = (long long)strips * batch;                              // waves per band row
     long long bands = (h + want_rows - 1) / want_rows;
     const long long rounds = std::max<long long>(1, (lanes * bands + slots / 2) / slots);

@@ -255,21 +255,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     else doh_strip_rows<S, false>(a, list, list_count, strip, band, s_l[wv], s_xy[wv], s_cand[wv]);
 }
 
-long long stream_wave_slots(const void* kernel) {
+long long stream_wave_slots(const void* kernel, int dynamic_lds) {
     static std::mutex m;
     static std::map<std::pair<int, const void*>, long long> cache;
     int dev = 0;
     (void)hipGetDevice(&dev);
+    dev = dev * 1024 + dynamic_lds / 1024;   // (cache key: device and LDS request in KiB)
     std::lock_guard<std::mutex> g(m);
     auto it = cache.find({dev, kernel});
     if (it != cache.end()) return it->second;
     int blocks_per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, 0) != hipSuccess || blocks_per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, kernel, 256, (size_t)dynamic_lds) != hipSuccess || blocks_per_cu < 1) {
         (void)hipGetLastError();
         blocks_per_cu = 4;
     }
     int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev / 1024) != hipSuccess || cus < 1) {
         (void)hipGetLastError();
         cus = 256;
     }
@@ -296,16 +297,19 @@ bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, in
     // band height (APDS_DOH_STRIP_ROWS: test hook): about 64 rows - a walk of 64 + 4 s + 2 rows - stretched so that the launch's waves fill the
     // resident wave slots a whole number of times (akaze.h: stream_band_rows)
     const int rb_env = config().doh_strip_rows;
-    auto rows_for = [&](auto kernel) { return rb_env > 0 ? rb_env : stream_band_rows(kernel, strips, h, b.n, 64, 16); };
+    // (An occupancy cap - unused dynamic LDS, so that the kernel's long-lived waves leave registers to the level chain it runs beside - was
+    // measured at 4 / 3 / 2 blocks per CU: 1.71 - 1.76 ms per 4096^2 extraction in every setting, profiles/r03/level_ab.txt. No cap.)
+    constexpr int lds_pad = 0;
+    auto rows_for = [&](auto kernel) { return rb_env > 0 ? rb_env : stream_band_rows(kernel, strips, h, b.n, 64, 16, lds_pad); };
     const int rb = sc == 2 ? rows_for(&doh_strip_kernel<2>) : sc == 3 ? rows_for(&doh_strip_kernel<3>) : rows_for(&doh_strip_kernel<4>);
     const bool none = border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0;
     DohStripArgs a{Lsmooth, Lxy, Ldet, mask, status, w, h, none ? -1 : border, kside, kmid, (float)(sc * sc * sc * sc), thr, strips,
                    ceil_div(h, rb), rb};
     const dim3 grid(ceil_div((long long)a.strips * a.bands, 4), 1, b.n);
     switch (sc) {
-        case 2: hipLaunchKernelGGL(doh_strip_kernel<2>, grid, dim3(256), 0, s, a, list, list_count, b.stride); break;
-        case 3: hipLaunchKernelGGL(doh_strip_kernel<3>, grid, dim3(256), 0, s, a, list, list_count, b.stride); break;
-        default: hipLaunchKernelGGL(doh_strip_kernel<4>, grid, dim3(256), 0, s, a, list, list_count, b.stride); break;
+        case 2: hipLaunchKernelGGL(doh_strip_kernel<2>, grid, dim3(256), lds_pad, s, a, list, list_count, b.stride); break;
+        case 3: hipLaunchKernelGGL(doh_strip_kernel<3>, grid, dim3(256), lds_pad, s, a, list, list_count, b.stride); break;
+        default: hipLaunchKernelGGL(doh_strip_kernel<4>, grid, dim3(256), lds_pad, s, a, list, list_count, b.stride); break;
     }
     return true;
 }
