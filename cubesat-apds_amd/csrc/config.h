@@ -1,6 +1,6 @@
 // csrc/config.h — every run-time switch of the library, read ONCE per process from the environment (first use) into one struct.
 // The defaults are the measured best; every switch keeps results bit-identical (the parity tests run the forced variants:
-// tests/test_strip_kernels_gpu.py). Round 3 folded 38 scattered getenv sites into this table and deleted the variants that had lost every
+// tests/test_strip_kernels_gpu.py). Round 3 folded 38 scattered getenv sites into this table (20 switches) and deleted the variants that had lost every
 // measurement: the persistent-grid match kernel, the staged keypoint pipeline, the 32- and 128-pixel Hessian tiles, and the tuning knobs
 // of the match's work-item plan (now constants in match_hamming.hip).
 #pragma once
