@@ -772,6 +772,7 @@ static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false
     const int min_rows = sample_pass ? 256 : 1024;   // shortest row chunk of a work item
     p.T = nq >= 64 * 4 * 64 ? 4 : (nq >= 64 * 2 * 64 ? 2 : 1);
     // the threshold pre-pass covers few rows: smaller items (T = 1, short chunks) keep all CUs busy
+    // (round 3, with the pre-pass running beside the previous frame's main scan: T = 2 / 4 for it measured again, no difference)
     if (sample_pass) p.T = 1;
     if (one_query_per_lane) p.T = 1;
     const int waves_q = ceil_div(nq, 64 * p.T);
