@@ -76,8 +76,13 @@ struct RcclTransport final : Transport {
         ncclUniqueId uid;
         static_assert(sizeof(uid) == APDS_COMM_ID_BYTES, "apds_comm_id must hold an ncclUniqueId");
         std::memcpy(&uid, id.bytes, sizeof(uid));
-        NCCL_CHECK(ncclCommInitRank(&comm, world, uid, rank));
         HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&counts_dev), (size_t)(world + 1) * sizeof(int)));
+        try {
+            NCCL_CHECK(ncclCommInitRank(&comm, world, uid, rank));
+        } catch (...) {   // (a constructor that throws runs no destructor)
+            (void)hipFree(counts_dev);
+            throw;
+        }
     }
     ~RcclTransport() override {
         if (counts_dev) (void)hipFree(counts_dev);
@@ -162,11 +167,17 @@ struct LoopbackTransport final : Transport {
             hub = h;
             hub->attached++;
         }
-        Hub::Post& me = hub->posts[(size_t)rank];
-        if (me.ready) throw ShardError(APDS_ERR_BAD_ARG, "loopback rank attached twice");
-        HIP_CHECK(hipEventCreateWithFlags(&me.ready, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&me.done, hipEventDisableTiming));
-        hub->barrier();   // every rank's events exist before the first collective reads them
+        try {
+            Hub::Post& me = hub->posts[(size_t)rank];
+            if (me.ready) throw ShardError(APDS_ERR_BAD_ARG, "loopback rank attached twice");
+            HIP_CHECK(hipEventCreateWithFlags(&me.ready, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&me.done, hipEventDisableTiming));
+            hub->barrier();   // every rank's events exist before the first collective reads them
+        } catch (...) {       // (a constructor that throws runs no destructor: leave the hub as it was found)
+            std::lock_guard<std::mutex> g(g_hubs_mutex);
+            if (--hub->attached == 0) g_hubs.erase(key);
+            throw;
+        }
     }
     ~LoopbackTransport() override {
         Hub::Post& me = hub->posts[(size_t)rank];
