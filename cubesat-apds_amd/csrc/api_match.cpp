@@ -41,7 +41,6 @@ int apds_knn_match(const uint8_t* q, int nq, const uint8_t* t, int nt, int desc_
     return guarded([&] {
         check_desc_args(q, nq, t, nt, desc_bytes);
         APDS_REQUIRE(k >= 1, APDS_ERR_ASSERT, "k must be >= 1");
-        APDS_REQUIRE(k <= 16, APDS_ERR_ASSERT, "k > 16 is not implemented (the reference only consumes the two nearest, lib.rs:107-111)");
         APDS_REQUIRE(idx && dist, APDS_ERR_BAD_ARG, "null output");
         if (nq == 0) return;
         ThreadCtx& c = ctx();

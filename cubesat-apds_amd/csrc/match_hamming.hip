@@ -88,13 +88,22 @@ __device__ __forceinline__ void row_distances(const u32x16 row, const uint32_t (
     }
 }
 
-template <int T, int K>
+// Paged scans (k > 16, see hamming_topk_device) look for the best K keys ABOVE a per-query floor key (the last key of the page before):
+// FLOOR adds that one comparison to the rare hit path - the rows at or below the floor are the query's best, so they all reach it, but
+// there are only 16 per page of them.
+struct KeyFloor {
+    uint32_t dist, index;   // the floor key (distance << 32 | global row index), split
+    uint32_t base;          // global index of row 0 of the scanned array
+};
+
+template <int T, int K, bool FLOOR = false>
 __device__ __forceinline__ void insert_hits(const int (&acc)[T], const int (&nthr_old)[T], const uint32_t (&q)[T][16], uint32_t row15, uint32_t r,
-                                            int (&bd)[T][K], uint32_t (&bi)[T][K]) {
+                                            int (&bd)[T][K], uint32_t (&bi)[T][K], const KeyFloor (&fl)[T]) {
 #pragma unroll
     for (int t = 0; t < T; t++) {
         if (acc[t] < 0) {   // the 480-bit bound is below the threshold this pair was screened with: finish the distance
             const int d = acc[t] - nthr_old[t] + __popc(q[t][15] ^ row15);
+            if (FLOOR && !((uint32_t)d > fl[t].dist || ((uint32_t)d == fl[t].dist && r + fl[t].base > fl[t].index))) continue;
             if (d < bd[t][K - 1]) {
                 // insertion with strict '<': a later row never moves ahead of an equal earlier one
                 bool placed = false;
@@ -121,10 +130,10 @@ __device__ __forceinline__ void insert_hits(const int (&acc)[T], const int (&nth
 }
 
 // One work item = (64*T queries per wave, 4 waves) x (one chunk of train rows).
-template <int T, int K>
+template <int T, int K, bool FLOOR = false>
 __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ train, int n_train, const u32x4* __restrict__ queries, int nq,
                                                   int rows_per_chunk, const int* __restrict__ init_thr, uint32_t* __restrict__ out, int chunk,
-                                                  int qblock) {
+                                                  int qblock, const uint64_t* __restrict__ floor_keys = nullptr, uint32_t floor_base = 0) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int qbase = (qblock * 4 + wave) * (64 * T);
@@ -135,9 +144,16 @@ __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ tra
     int bd[T][K];
     uint32_t bi[T][K];
     int nthr[T];
+    KeyFloor fl[T];
 #pragma unroll
     for (int t = 0; t < T; t++) {
         const int qi = min(qbase + t * 64 + lane, nq - 1);
+        if (FLOOR) {   // the last key of the query's previous page (all ones when that page was not full: nothing is above it)
+            const uint64_t f = floor_keys[(size_t)qi * K + (K - 1)];
+            fl[t].dist = (uint32_t)(f >> 32);
+            fl[t].index = (uint32_t)f;
+            fl[t].base = floor_base;
+        }
 #pragma unroll
         for (int v = 0; v < 4; v++) {
             const u32x4 x = queries[(size_t)qi * 4 + v];
@@ -169,8 +185,8 @@ __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ tra
             int nthr_old[T];
 #pragma unroll
             for (int t = 0; t < T; t++) nthr_old[t] = nthr[t];
-            insert_hits<T, K>(acc0, nthr_old, q, a0[15], (uint32_t)r, bd, bi);
-            insert_hits<T, K>(acc1, nthr_old, q, a1[15], (uint32_t)(r + 1), bd, bi);
+            insert_hits<T, K, FLOOR>(acc0, nthr_old, q, a0[15], (uint32_t)r, bd, bi, fl);
+            insert_hits<T, K, FLOOR>(acc1, nthr_old, q, a1[15], (uint32_t)(r + 1), bd, bi, fl);
 #pragma unroll
             for (int t = 0; t < T; t++) nthr[t] = -bd[t][K - 1];
         }
@@ -200,7 +216,7 @@ __device__ __forceinline__ void hamming_topk_item(const u32x16* __restrict__ tra
         const u32x16 a0 = train[r];
         int acc0[T];
         row_distances<T>(a0, q, nthr, acc0);
-        insert_hits<T, K>(acc0, nthr, q, a0[15], (uint32_t)r, bd, bi);
+        insert_hits<T, K, FLOOR>(acc0, nthr, q, a0[15], (uint32_t)r, bd, bi, fl);
 #pragma unroll
         for (int t = 0; t < T; t++) nthr[t] = -bd[t][K - 1];
     }
@@ -250,6 +266,17 @@ __global__ __launch_bounds__(256) void hamming_topk_kernel(const u32x16* __restr
     }
     if (chunk >= n_chunks) return;   // block-uniform
     hamming_topk_item<T, K>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, chunk, qblock);
+}
+
+// One page of a paged scan: the K best keys above floor_keys[query][K - 1] (one query per lane, plain chunk-major grid).
+template <int K>
+__global__ __launch_bounds__(256) void hamming_topk_page_kernel(const u32x16* __restrict__ train, int n_train, const u32x4* __restrict__ queries, int nq,
+                                                                int rows_per_chunk, const int* __restrict__ init_thr, uint32_t* __restrict__ out,
+                                                                int qtile_blocks, int n_chunks, const uint64_t* __restrict__ floor_keys,
+                                                                uint32_t floor_base) {
+    const int chunk = blockIdx.x / qtile_blocks, qblock = blockIdx.x - chunk * qtile_blocks;
+    if (chunk >= n_chunks) return;   // block-uniform
+    hamming_topk_item<1, K, true>(train, n_train, queries, nq, rows_per_chunk, init_thr, out, chunk, qblock, floor_keys, floor_base);
 }
 
 // (A persistent work-queue form of this kernel - resident workgroups pulling items from an atomic counter - was kept through round 2 behind
@@ -793,7 +820,7 @@ static ChunkPlan plan_chunks(int nq, long long n_train, bool sample_pass = false
 
 template <int K>
 static void launch_topk(const void* q, int nq, const void* t, long long nt, const int* init_thr, uint32_t* parts, const ChunkPlan& p, hipStream_t s,
-                        const char* timer_name = "hamming_topk") {
+                        const char* timer_name = "hamming_topk", const uint64_t* floor_keys = nullptr, uint32_t floor_base = 0) {
     constexpr int xcd = 1;   // XCD-aware chunk placement (profiles/r01/match_xcd_placement_ab.log)
     const u32x16* tr = static_cast<const u32x16*>(t);
     const u32x4* qq = static_cast<const u32x4*>(q);
@@ -803,6 +830,16 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, cons
     // at once instead of waiting for a match wave to retire. Applies to every variant of the scan (all T, all K).
     const size_t cap = (size_t)std::max(0, match_lds_cap().load(std::memory_order_relaxed));
     last_scan_launch_lds().store((int)cap, std::memory_order_relaxed);
+    if constexpr (K == 16) {
+        if (floor_keys) {   // one page of a paged scan
+            dim3 grid((unsigned)(p.chunks * p.qtiles_blocks)), block(256);
+            KernelTimer timer(timer_name, s);
+            hipLaunchKernelGGL((hamming_topk_page_kernel<K>), grid, block, cap, s, tr, (int)nt, qq, nq, p.rows_per_chunk, init_thr, parts,
+                               p.qtiles_blocks, p.chunks, floor_keys, floor_base);
+            HIP_CHECK(hipGetLastError());
+            return;
+        }
+    }
     if (K > 2) {   // larger k keeps K (distance, index) pairs per query in registers: one query per lane
         dim3 grid((unsigned)(ceil_div(p.chunks, 8) * 8 * p.qtiles_blocks)), block(256);
         KernelTimer timer(timer_name, s);
@@ -872,6 +909,52 @@ static void topk_device_k(const void* q, int nq, const void* t, long long nt, ui
     launch_topk<K>(q, nq, rest, nrest, thr, parts, p, s);
     // the sample pass's result joins the merge as one more (already expanded) list
     merge_records_launch<K>(parts, p, index_base + (uint32_t)sample, sample_keys, nq, out, s);
+    HIP_CHECK(hipGetLastError());
+}
+
+// k > 16 (BFMatcher::knnMatch takes any k, lib.rs:94-103): pages of 16. Page j is the plain K = 16 scan restricted to the keys above the
+// last key of page j - 1 (keys are unique, so "above the floor" removes exactly the rows already reported); every page is a full pass over
+// the train rows, with its own threshold pre-pass under the same floor. The scratch buffers are shared by the pages (stream order).
+__global__ void gather_pages_kernel(const uint64_t* __restrict__ pages, int nq, int n_pages, int k, uint64_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nq * k) return;
+    const int q = (int)(i / k), c = (int)(i - (long long)q * k);
+    const int page = c >> 4;
+    out[i] = page < n_pages ? pages[((size_t)page * nq + q) * 16 + (c & 15)] : EMPTY_KEY;
+}
+
+static long long split_sample_rows(long long nt);
+
+static void topk_paged_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s) {
+    constexpr int K = 16;
+    ThreadCtx& c = ctx();
+    const int n_pages = (int)std::min<long long>(ceil_div(k, K), ceil_div(nt, K));   // pages past the last train row would be empty
+    const long long sample = split_sample_rows(nt);
+    const ChunkPlan p = plan_chunks(nq, nt - sample, false, true);
+    ChunkPlan sp{};
+    uint32_t* sparts = nullptr;
+    uint64_t* sample_keys = nullptr;
+    int* thr = nullptr;
+    if (sample) {
+        sp = plan_chunks(nq, sample, true, true);
+        sparts = c.alloc_n<uint32_t>(record_words<K>(nq, sp));
+        sample_keys = c.alloc_n<uint64_t>((size_t)nq * K);
+        thr = c.alloc_n<int>(nq);
+    }
+    uint32_t* parts = c.alloc_n<uint32_t>(record_words<K>(nq, p));
+    uint64_t* pages = c.alloc_n<uint64_t>((size_t)n_pages * nq * K);
+    const char* rest = static_cast<const char*>(t) + (size_t)sample * 64;
+    for (int j = 0; j < n_pages; j++) {
+        const uint64_t* floor_keys = j ? pages + (size_t)(j - 1) * nq * K : nullptr;
+        if (sample) {
+            launch_topk<K>(q, nq, t, sample, nullptr, sparts, sp, s, "hamming_topk_sample", floor_keys, index_base);
+            merge_records_launch<K>(sparts, sp, index_base, nullptr, nq, sample_keys, s);
+            hipLaunchKernelGGL(thr_from_keys_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, (const uint64_t*)sample_keys, nq, K, thr);
+        }
+        launch_topk<K>(q, nq, rest, nt - sample, thr, parts, p, s, "hamming_topk", floor_keys, index_base + (uint32_t)sample);
+        merge_records_launch<K>(parts, p, index_base + (uint32_t)sample, sample_keys, nq, pages + (size_t)j * nq * K, s);
+    }
+    hipLaunchKernelGGL(gather_pages_kernel, dim3((unsigned)ceil_div((long long)nq * k, 256)), dim3(256), 0, s, (const uint64_t*)pages, nq, n_pages, k, out);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -984,15 +1067,19 @@ void topk_split_merge(void* h, uint32_t index_base, uint64_t* out, hipStream_t s
     else split_merge_k<2>(st, index_base, out, s);
 }
 
-// Full top-k of nq queries over nt train rows (device, 64-byte rows). out: nq*k keys. k <= 16; k in {1,2} is the tuned path
-// (the reference only ever consumes the two nearest, lib.rs:107-111); other k run with one query per lane.
+// Full top-k of nq queries over nt train rows (device, 64-byte rows). out: nq*k keys. k in {1,2} is the tuned path (the reference only
+// ever consumes the two nearest, lib.rs:107-111); 3 <= k <= 16 run with one query per lane, larger k in pages of 16 (topk_paged_device).
 void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out,
                          hipStream_t s) {
-    APDS_REQUIRE(k >= 1 && k <= 16, APDS_ERR_ASSERT, "top-k supports 1 <= k <= 16");
+    APDS_REQUIRE(k >= 1, APDS_ERR_ASSERT, "top-k needs k >= 1");
     APDS_REQUIRE(nt < (1ll << 31), APDS_ERR_ASSERT, "train set too large for one call; shard it");
     if (nq <= 0) return;
     if (nt <= 0) {
         HIP_CHECK(hipMemsetAsync(out, 0xFF, (size_t)nq * k * 8, s));
+        return;
+    }
+    if (k > 16) {
+        topk_paged_device(q, nq, t, nt, index_base, k, out, s);
         return;
     }
     const int K = k <= 2 ? k : (k <= 4 ? 4 : (k <= 8 ? 8 : 16));

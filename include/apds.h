@@ -96,7 +96,8 @@ int apds_get_knn_matches(const uint8_t* origin_desc, int n_origin, const uint8_t
 int apds_get_bruteforce_matches(const uint8_t* origin_desc, int n_origin, const uint8_t* target_desc, int n_target,
                                 int desc_bytes, apds_dmatch** matches, int* n_matches);
 
-/* BFMatcher::knnMatch itself (lib.rs:103), 1 <= k <= 16: idx/dist are n_query*k, -1 / INT32_MAX where fewer than k exist. */
+/* BFMatcher::knnMatch itself (lib.rs:103), any k >= 1 (k <= 2 is the tuned path; above 16 the scan runs once per 16 neighbours): idx/dist are
+ * n_query*k, -1 / INT32_MAX where fewer than k exist. */
 int apds_knn_match(const uint8_t* query_desc, int n_query, const uint8_t* train_desc, int n_train, int desc_bytes,
                    int k, int32_t* idx, int32_t* dist);
 
@@ -261,7 +262,7 @@ int apds_db_shard(void* db, int rank, int world, int transport, const apds_comm_
 /* Pack n rows of desc_bytes (<= 64) bytes into 64-byte rows (zero padded). */
 int apds_dev_pack_descriptors(const void* src_rows, int64_t n, int desc_bytes, int64_t src_stride, void* dst_rows64, void* stream);
 
-/* Hamming top-k (1 <= k <= 16; k in {1,2} is the tuned path) of n_query rows against n_train rows, both 64-byte pitch.
+/* Hamming top-k (k >= 1; k in {1,2} is the tuned path, above 16 one pass per 16 neighbours) of n_query rows against n_train rows, both 64-byte pitch.
  * out_keys: n_query*k uint64 = (distance << 32) | (train_index + index_base), ascending; 0xFFFF... when absent.
  * Ordering equals BFMatcher's: by distance, ties to the lower train index. */
 int apds_dev_hamming_topk(const void* query_rows64, int n_query, const void* train_rows64, int64_t n_train,

@@ -182,6 +182,27 @@ def test_config5_db_size_10m_rows(gpu_pkg, oracle_mod):
     assert np.array_equal(idx[sel], oi) and np.array_equal(dist[sel], od)
 
 
+@pytest.mark.parametrize("k,nt", [(17, 3000), (32, 150000), (50, 40000), (100, 5000)])
+def test_k_above_16_runs_in_pages(gpu_pkg, oracle_mod, k, nt):
+    """BFMatcher::knnMatch takes any k (lib.rs:94-103): above 16 the scan runs in pages of 16, each page the keys above the last key of the
+    page before. 40 identical train rows make one query's ties straddle the page borders (index order must hold across them); with 150 000
+    rows every page also has its own threshold pre-pass."""
+    db = gpu_pkg.synth.make_descriptor_db(nt, seed=7 + k)
+    twins = np.linspace(10, nt - 1, 40).astype(np.int64)
+    db[twins] = db[10]
+    q, _ = gpu_pkg.synth.make_queries(db, 300, seed=k)
+    q[0] = db[10]
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q, db, k)
+    oracle_mod.set_threads(8)
+    oi, od = oracle_mod.knn_hamming(q, db, k)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi)
+    assert np.array_equal(idx[0, :min(k, 40)], twins[:min(k, 40)]) and (dist[0, :min(k, 40)] == 0).all()
+    few = db[:k - 5]           # fewer train rows than k: the tail is (-1, INT_MAX), also across a page border
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q[:50], few, k)
+    oi, od = oracle_mod.knn_hamming(q[:50], few, k)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi) and (idx[:, -5:] == -1).all()
+
+
 @pytest.mark.parametrize("nq,nt,k", [(3000, 200000, 2), (20000, 60000, 2), (500, 5000, 2), (9000, 70000, 1)])
 def test_split_scan_equals_the_one_call_scan(gpu_pkg, nq, nt, k):
     # apds_dev_topk_prepass / _scan / _merge on a state object, each step on ITS OWN stream with events between them and two frames in
