@@ -150,6 +150,20 @@ def test_2048_frame_equals_oracle(gpu_pkg, oracle_mod):
     _assert_same_extraction(gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(tile, None), oracle_mod.akaze(tile))
 
 
+@pytest.mark.parametrize("h,w", [(2891, 3333), (5003, 2049)])
+def test_odd_large_frames_equal_oracle(gpu_pkg, oracle_mod, h, w):
+    # Frames of 8 Mpx and more take the streaming Hessian / level kernels on their own (csrc/akaze_doh_strips.hip, akaze_level_stream.hip);
+    # the square power-of-two sizes above never leave a partial 62-column strip, a partial row band or an odd half-size behind. Odd sizes do.
+    t = gpu_pkg.synth.make_tile(4096, 4096, frame_index=7, channels=1)
+    img = np.ascontiguousarray(np.block([[t], [t[::-1]]])[:h, :w]) if h > 4096 else np.ascontiguousarray(t[:h, :w])
+    assert img.shape == (h, w) and h * w >= 1 << 23
+    got = gpu_pkg.feature_extraction.akaze_keypoint_descriptor_extraction_def(img, None)
+    oracle_mod.set_threads(16)
+    ref = oracle_mod.akaze(img)
+    assert len(ref.keypoints) > 10000
+    _assert_same_extraction(got, ref)
+
+
 def test_8192_frame_equals_oracle(gpu_pkg, oracle_mod):
     # the largest size of the reference's bench sweep: 8192 x 8192. The image is a 2 x 2 mosaic of one synthetic 4096^2 tile and its three
     # flips (the tile generator needs 15 s per 4096^2 tile). More than 100 k keypoints: also the largest keypoint set of the suite
