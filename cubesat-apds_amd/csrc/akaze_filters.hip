@@ -528,15 +528,16 @@ void base_strip_kernel(const uint8_t* __restrict__ img, int w, int h, int stride
 }
 
 // ---- contrast factor: 300-bin histogram of |grad|/hmax over interior pixels, 70th percentile -----------
-// Eight sub-histograms per block (lane & 7 picks one): gradient magnitudes crowd the low bins, so with one histogram most of a
+// SUB sub-histograms per block (lane & (SUB - 1) picks one): gradient magnitudes crowd the low bins, so with one histogram most of a
 // wave's 64 LDS atomics hit a handful of addresses and serialise; each thread reads four consecutive pixels of a row per step.
+template <int SUB>
 __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __restrict__ modg, int w, int h, const unsigned int* __restrict__ hmax_bits,
                                                               int* __restrict__ hist, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     APDS_BOFS(modg);
     APDS_BOFS(hmax_bits);
     APDS_BOFS(hist);
-    constexpr int SUB = 8, PITCH = 301;                 // odd pitch: the eight copies of a bin sit in different banks
+    constexpr int PITCH = 301;                          // odd pitch: the copies of a bin sit in different banks
     __shared__ int s_hist[SUB * PITCH];
     for (int i = threadIdx.x; i < SUB * PITCH; i += 256) s_hist[i] = 0;
     __syncthreads();
@@ -1108,16 +1109,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_
 }
 
 // ---- resize(INTER_AREA) by exactly 2: mean of 2x2 ---------------------------------------------------------
-__global__ void half_sample_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh, size_t bstride) {
+// One thread = two neighbouring output pixels of HS_ROWS consecutive rows: 16-byte loads, all of a thread's loads issued before the first
+// sum (one output per thread with 8-byte loads ran at 1.5 TB/s on the 4096^2 -> 2048^2 step, which sits on the level chain's critical path).
+static constexpr int HS_ROWS = 4;
+__global__ __launch_bounds__(256) void half_sample_kernel(const float* __restrict__ src, int sw, float* __restrict__ dst, int dw, int dh, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     APDS_BOFS(src);
     APDS_BOFS(dst);
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= dw || y >= dh) return;
-    const float2 a = *reinterpret_cast<const float2*>(&src[(size_t)(2 * y) * sw + 2 * x]);
-    const float2 b = *reinterpret_cast<const float2*>(&src[(size_t)(2 * y + 1) * sw + 2 * x]);
-    dst[(size_t)y * dw + x] = ((a.x + a.y) + (b.x + b.y)) * 0.25f;
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int y0 = blockIdx.y * HS_ROWS;
+    if (x >= dw) return;
+    // 16-byte loads need rows that start on a 16-byte boundary; 8-byte stores an even destination width
+    const bool wide = x + 1 < dw && !(sw & 3) && !(dw & 1) && !((reinterpret_cast<uintptr_t>(src) & 15) | (reinterpret_cast<uintptr_t>(dst) & 7));
+    if (wide) {
+        float4 a[HS_ROWS], b[HS_ROWS];
+#pragma unroll
+        for (int r = 0; r < HS_ROWS; r++) {
+            const int y = min(y0 + r, dh - 1);
+            a[r] = *reinterpret_cast<const float4*>(&src[(size_t)(2 * y) * sw + 2 * x]);
+            b[r] = *reinterpret_cast<const float4*>(&src[(size_t)(2 * y + 1) * sw + 2 * x]);
+        }
+#pragma unroll
+        for (int r = 0; r < HS_ROWS; r++) {
+            const int y = y0 + r;
+            if (y >= dh) break;
+            float2 o;
+            o.x = ((a[r].x + a[r].y) + (b[r].x + b[r].y)) * 0.25f;
+            o.y = ((a[r].z + a[r].w) + (b[r].z + b[r].w)) * 0.25f;
+            *reinterpret_cast<float2*>(&dst[(size_t)y * dw + x]) = o;
+        }
+        return;
+    }
+    for (int r = 0; r < HS_ROWS; r++) {
+        const int y = y0 + r;
+        if (y >= dh) break;
+        for (int xx = x; xx < min(x + 2, dw); xx++) {
+            const float* p0 = &src[(size_t)(2 * y) * sw + 2 * xx];
+            const float* p1 = &src[(size_t)(2 * y + 1) * sw + 2 * xx];
+            dst[(size_t)y * dw + xx] = ((p0[0] + p0[1]) + (p1[0] + p1[1])) * 0.25f;
+        }
+    }
 }
 
 // general INTER_AREA (odd source sizes): per destination pixel, up to 4 taps per axis from host-built tables
@@ -1341,7 +1372,8 @@ void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsign
                            (float*)nullptr, w, h, 1, 3.0f, 10.0f, (const float*)nullptr, hmax_bits, b.stride);
     // the histogram's grid shrinks with the image: 1024 blocks for one large frame, a share of that for each image of a batch
     const int hist_blocks = std::max(8, std::min(1024, ceil_div((long long)w * h, 4096)));
-    hipLaunchKernelGGL(kcontrast_hist_kernel, dim3(hist_blocks, 1, b.n), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist, b.stride);
+    // 16 sub-histograms per block (8: 1.755, 16: 1.739, 32: 1.763 ms per 4096^2 extraction, profiles/r03/half_sample_ab.txt)
+    hipLaunchKernelGGL(kcontrast_hist_kernel<16>, dim3(hist_blocks, 1, b.n), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist, b.stride);
     hipLaunchKernelGGL(kcontrast_finish_kernel, dim3(1, 1, b.n), dim3(64), 0, s, hist, hmax_bits, w, h, k_oct, n_oct, b.stride);
 }
 // image -> Lt[0] (and, if want_modg, |grad| of the sigma = 1 image + its interior maximum) in one pass on register strips. Returns
@@ -1428,7 +1460,7 @@ void launch_level_fused(const float* src, float* smooth, float* flow_out, const 
         hipLaunchKernelGGL((level_fused_kernel<1024>), grid, dim3(1024), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride);
 }
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s, const Batch& b) {
-    hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 256), dh, b.n), dim3(256), 0, s, src, sw, dst, dw, dh, b.stride);
+    hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 512), ceil_div(dh, HS_ROWS), b.n), dim3(256), 0, s, src, sw, dst, dw, dh, b.stride);
 }
 void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, const int* xofs, const float* xw, const int* xcnt, const int* yofs,
                         const float* yw, const int* ycnt, hipStream_t s, const Batch& b) {
