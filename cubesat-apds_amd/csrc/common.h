@@ -54,6 +54,7 @@ struct ThreadCtx {
     hipStream_t stream = nullptr;
     std::vector<std::pair<char*, size_t>> slabs;
     size_t slab_used = 0;   // in slabs.back()
+    size_t call_bytes = 0;  // bytes handed out since the last ws_reset() (what one slab has to hold for the call to need no second one)
     bool timing = false;
     struct Ev {
         hipEvent_t a, b;

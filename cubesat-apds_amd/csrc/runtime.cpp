@@ -221,10 +221,12 @@ void cache_slab(int device, std::pair<char*, size_t> s) {
 void* ThreadCtx::alloc(size_t bytes) {
     bytes = (bytes + 255) & ~size_t(255);
     if (bytes == 0) bytes = 256;
+    call_bytes += bytes;
     if (slabs.empty() || slab_used + bytes > slabs.back().second) {
-        size_t want = bytes;
-        if (!slabs.empty()) want = std::max(want, slabs.back().second * 2);
-        want = std::max(want, size_t(1) << 22);
+        // an additional slab lives until the next ws_reset(), which replaces all of them by one that fits the whole call: it only has to
+        // hold this request and the small ones that usually follow it (doubling here turned the 9 MB request behind an 8192^2 frame's
+        // 5 GB arena into a 10 GB slab, and the next call's consolidation into 1.3 s of hipFree / hipMalloc)
+        const size_t want = std::max(bytes + bytes / 8, size_t(1) << 24);
         std::pair<char*, size_t> got;
         if (take_cached_slab(device, want, got)) {
             slabs.push_back(got);
@@ -242,17 +244,28 @@ void* ThreadCtx::alloc(size_t bytes) {
 
 void ThreadCtx::ws_reset() {
     if (slabs.size() > 1) {
-        size_t total = 0;
-        for (auto& s : slabs) total += s.second;
+        // one slab for everything the last call asked for (+ 1/16), not the sum of the slabs it happened to open
+        const size_t total = call_bytes + call_bytes / 16 + (size_t(1) << 20);
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipDeviceSynchronize());
-        for (auto& s : slabs) (void)hipFree(s.first);
+        size_t big = 0;
+        for (size_t i = 1; i < slabs.size(); i++)
+            if (slabs[i].second > slabs[big].second) big = i;
+        const std::pair<char*, size_t> keep = slabs[big];
+        const bool fits = keep.second >= total;   // the usual case: the slab opened for the call's one large request
+        for (size_t i = 0; i < slabs.size(); i++)
+            if (!fits || i != big) (void)hipFree(slabs[i].first);
         slabs.clear();
-        char* p = nullptr;
-        HIP_CHECK(hipMalloc(&p, total));
-        slabs.emplace_back(p, total);
+        if (fits) {
+            slabs.push_back(keep);
+        } else {
+            char* p = nullptr;
+            HIP_CHECK(hipMalloc(&p, total));
+            slabs.emplace_back(p, total);
+        }
     }
     slab_used = 0;
+    call_bytes = 0;
 }
 
 }  // namespace apds
