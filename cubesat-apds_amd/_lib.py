@@ -1,6 +1,7 @@
 """ctypes binding of libapds_hip.so (C ABI: include/apds.h). Fails loudly when the library is missing."""
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -74,6 +75,13 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise ApdsError(ERR_NO_DEVICE, f"{LIB_PATH} is missing: build it with __graft_entry__.build(); there is no CPU fallback")
+        # torch ships a HIP runtime of its own: a process that loads this library first and torch afterwards ends up with two runtimes, and
+        # the second one to initialise finds no device (-216 from the first call). Loading torch first makes both use the same one.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         vp, i, f, d, sz, i64, u32 = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t, C.c_int64, C.c_uint32
         pp, ip = C.POINTER(C.c_void_p), C.POINTER(C.c_int)
