@@ -1,6 +1,6 @@
 // csrc/config.h — every run-time switch of the library, read ONCE per process from the environment (first use) into one struct.
 // The defaults are the measured best; every switch keeps results bit-identical (the parity tests run the forced variants:
-// tests/test_strip_kernels_gpu.py). Round 3 folded 38 scattered getenv sites into this table (20 switches) and deleted the variants that had lost every
+// tests/test_strip_kernels_gpu.py). Round 3 folded 38 scattered getenv sites into this table (19 switches) and deleted the variants that had lost every
 // measurement: the persistent-grid match kernel, the staged keypoint pipeline, the 32- and 128-pixel Hessian tiles, and the tuning knobs
 // of the match's work-item plan (now constants in match_hamming.hip).
 #pragma once
@@ -28,7 +28,6 @@ struct Config {
     int match_lds_cap;    // APDS_MATCH_LDS_CAP  initial occupancy cap of the main scan (bytes of unused LDS per workgroup; apds_dev_match_lds_cap)
     int match_sample;     // APDS_MATCH_SAMPLE   rows of the threshold pre-pass (16384; 0 = no pre-pass)
     // ---- homography / PnP / L2
-    int ransac_coop;      // APDS_RANSAC_COOP  1: 16 lanes per 4-point sample in the hypothesis kernel (default); 0: one thread per sample
     int ransac_batch;     // APDS_RANSAC_BATCH first speculated batch of RANSAC hypotheses (512)
     int pnp_batch;        // APDS_PNP_BATCH    hypotheses per PnP batch (2048)
     int l2_sample_div;    // APDS_L2_SAMPLE_DIV  the bf16 screen's threshold sample = rows / this (12)

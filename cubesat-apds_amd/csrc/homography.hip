@@ -219,39 +219,13 @@ __host__ __device__ inline int run_kernel_small(const P2* M, const P2* m, int co
 }
 
 // ---- device kernels ------------------------------------------------------------------------------------------
-// One thread per 4-point sample. The 9x9 normal equations, eigenvectors, eigenvalues and pivot indices of every thread
-// live in LDS (171 doubles + 18 ints per thread, element-major): the pivoted Jacobi indexes them dynamically, which
-// would otherwise go through scratch (global) memory at ~1 us per dependent access.
-static constexpr int HYP_THREADS = 32;   // 46 KB of LDS per block (under the 64 KB dynamic-LDS default)
-__global__ __launch_bounds__(HYP_THREADS) void hypothesis_kernel(const P2* __restrict__ M, const P2* __restrict__ m, const int* __restrict__ idx4, int B,
-                                                                 double* __restrict__ models, uint8_t* __restrict__ valid) {
-    APDS_RAISE_WAVE_PRIORITY();
-    extern __shared__ double hyp_lds[];
-    double* base = hyp_lds + threadIdx.x;
-    StridedArr<double, HYP_THREADS> A{base}, V{base + 81 * HYP_THREADS}, W{base + 162 * HYP_THREADS};
-    int* ibase = reinterpret_cast<int*>(hyp_lds + 171 * HYP_THREADS) + threadIdx.x;
-    StridedArr<int, HYP_THREADS> indR{ibase}, indC{ibase + 9 * HYP_THREADS};
-    const int h = blockIdx.x * HYP_THREADS + threadIdx.x;
-    if (h >= B) return;
-    P2 ms1[4], ms2[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int id = idx4[h * 4 + j];
-        ms1[j] = M[id];
-        ms2[j] = m[id];
-    }
-    double H[9];
-    const int ok = run_kernel_small(ms1, ms2, 4, A, W, V, indR, indC, H);
-    valid[h] = (uint8_t)ok;
-    for (int i = 0; i < 9; i++) models[(size_t)h * 9 + i] = ok ? H[i] : 0.0;
-}
-static constexpr size_t HYP_LDS_BYTES = (size_t)171 * HYP_THREADS * sizeof(double) + (size_t)18 * HYP_THREADS * sizeof(int);
-
-// Cooperative form of the same computation: 16 lanes per 4-point sample (four samples per wave). The matrices stay in LDS, but
+// (Round 1 ran one thread per 4-point sample, the 9x9 system of every thread in LDS; the cooperative form below replaced it as the default
+// in round 2 and the old kernel, by then launched by no test, was deleted in round 3.)
+// The 4-point solve, 16 lanes per sample (four samples per wave). The matrices stay in LDS, but
 // the work inside one Jacobi rotation -- the row/column updates, the eigenvector update, the four pivot-index rescans -- is
 // spread over the lanes, and every lane evaluates the (cheap, uniform) pivot scan and rotation parameters itself. Each
-// element goes through exactly the operations of jacobi_eigen<9> in the same order, so the result is bit-identical to the
-// one-thread-per-sample kernel above (and to the host refit). What it cannot change is the rotation COUNT: the stopping rule
+// element goes through exactly the operations of jacobi_eigen<9> in the same order, so the result is bit-identical to one
+// thread running jacobi_eigen<9> alone (the host refit, the oracle). What it cannot change is the rotation COUNT: the stopping rule
 // is |pivot| <= DBL_EPSILON in absolute terms, which the rounding noise of a 9x9 system with O(10) entries rarely reaches, so
 // most samples run the full 9*9*30 = 2430 rotations (as they do in OpenCV); a rotation costs ~0.2 us here against ~0.3 us.
 static constexpr int COOP_LANES = 16, COOP_PER_BLOCK = 16;
@@ -732,12 +706,7 @@ __global__ __launch_bounds__(RED_THREADS) void reduce_kernel(const P2* __restric
 namespace {
 
 void launch_hypotheses(const P2* M, const P2* m, const int* idx_dev, int B, double* models_dev, uint8_t* valid_dev, hipStream_t s) {
-    const bool coop = config().ransac_coop != 0;
-    if (coop)
-        hipLaunchKernelGGL(hypothesis_coop_kernel, dim3(ceil_div(B, COOP_PER_BLOCK)), dim3(COOP_LANES * COOP_PER_BLOCK), 0, s, M, m, idx_dev, B, models_dev,
-                           valid_dev);
-    else
-        hipLaunchKernelGGL(hypothesis_kernel, dim3(ceil_div(B, HYP_THREADS)), dim3(HYP_THREADS), HYP_LDS_BYTES, s, M, m, idx_dev, B, models_dev, valid_dev);
+    hipLaunchKernelGGL(hypothesis_coop_kernel, dim3(ceil_div(B, COOP_PER_BLOCK)), dim3(COOP_LANES * COOP_PER_BLOCK), 0, s, M, m, idx_dev, B, models_dev, valid_dev);
 }
 
 struct RNG {

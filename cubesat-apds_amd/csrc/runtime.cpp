@@ -37,7 +37,6 @@ const Config& config() {
         k.debug_host_time = env("APDS_DEBUG_HOST_TIME", 0);
         k.match_lds_cap = env("APDS_MATCH_LDS_CAP", 0);
         k.match_sample = env("APDS_MATCH_SAMPLE", 16384);
-        k.ransac_coop = env("APDS_RANSAC_COOP", 1);
         k.ransac_batch = env("APDS_RANSAC_BATCH", 512);
         k.pnp_batch = env("APDS_PNP_BATCH", 2048);
         k.l2_sample_div = std::max(1, env("APDS_L2_SAMPLE_DIV", 12));
