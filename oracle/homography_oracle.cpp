@@ -680,13 +680,15 @@ int oracle_find_homography(const float* src_xy, const float* dst_xy, int n, int 
                            double confidence, double* H, uint8_t* mask_out) {
     if (!src_xy || !dst_xy || !H) return -215;
     if (n < 4) return -215;   // StsVecLengthErr in OpenCV; the shim maps any error to MatError::Opencv
-    if (method == 16) {   // RHO: its own estimator and refinement (rho_oracle.cpp); findHomography skips the generic refit for it
+    // RHO: its own estimator and refinement (rho_oracle.cpp); findHomography skips the generic refit for it. With exactly four pairs every
+    // method is the plain 4-point solve: `if( method == 0 || npoints == 4 )` comes first in cv::findHomography (fundam.cpp).
+    if (method == 16 && n > 4) {
         std::vector<uint8_t> m(n, 0);
         const int rc = oracle_rho_homography(src_xy, dst_xy, n, thr, max_iters, confidence, H, m.data());
         if (mask_out) std::memcpy(mask_out, m.data(), n);
         return rc;
     }
-    if (method != 0 && method != 4 && method != 8) return -5;
+    if (method != 0 && method != 4 && method != 8 && method != 16) return -5;
     if (thr <= 0) thr = 3;
     const P2f* src = reinterpret_cast<const P2f*>(src_xy);
     const P2f* dst = reinterpret_cast<const P2f*>(dst_xy);

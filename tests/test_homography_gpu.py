@@ -108,6 +108,17 @@ def test_rho_equals_oracle(gpu_pkg, oracle_mod, n, inl, noise, thr, iters):
         assert np.allclose(H, H_true, rtol=2e-2, atol=1.0)
 
 
+@pytest.mark.parametrize("method", [0, 4, 8, 16])
+def test_exactly_four_pairs_is_the_plain_solve_for_every_method(gpu_pkg, oracle_mod, method):
+    # cv::findHomography: `if( method == 0 || npoints == 4 )` comes before the method dispatch, so four pairs never reach RANSAC / LMEDS /
+    # RHO (found by tools/fuzz_parity.py: the oracle sent RHO with four pairs to the RHO estimator; the GPU path did not)
+    src, dst, _, _ = gpu_pkg.synth.make_ransac_set(4, seed=77, inlier_frac=0.2, noise=1.0)
+    found, H, mask = _check(gpu_pkg, oracle_mod, src, dst, method, 5.0)
+    assert found and mask.all()
+    _, H0, _ = oracle_mod.find_homography(src, dst, 0, 5.0, 2000, 0.995)
+    assert np.array_equal(H, H0.reshape(3, 3))
+
+
 def test_rho_through_the_crate_api(gpu_pkg):
     # the reference's own KAT (mod.rs:437-472) with RHO: identity; no mask for RHO (mod.rs:253-257)
     hg = gpu_pkg.homographier

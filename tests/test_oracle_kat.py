@@ -301,3 +301,9 @@ def test_rho_oracle_on_the_reference_kat_and_on_planted_data(pkg, oracle_mod):
     ok2, H2, mask2 = oracle_mod.find_homography(src, dst, 16, 3.0)
     assert ok and ok2 and np.array_equal(H, H2) and np.array_equal(mask, mask2)
     assert (mask.astype(bool) & flag).sum() >= 0.9 * flag.sum() and np.allclose(H.reshape(3, 3), H_true, rtol=2e-2, atol=1.0)
+    # exactly four pairs: cv::findHomography takes the plain 4-point solve whatever the method (`method == 0 || npoints == 4` comes first)
+    s4, d4, _, _ = pkg.synth.make_ransac_set(4, seed=77, inlier_frac=0.2, noise=1.0)
+    ok0, H0, _ = oracle_mod.find_homography(s4, d4, 0, 5.0)
+    for method in (4, 8, 16):
+        ok, H, mask = oracle_mod.find_homography(s4, d4, method, 5.0)
+        assert ok == ok0 and np.array_equal(H, H0) and mask.all()
