@@ -1,5 +1,5 @@
 """Randomised parity run: HIP path (through the C ABI) against the oracle on shapes and contents no fixed test names.
-    python3 tools/fuzz_parity.py [seconds] [seed]
+    python3 tools/fuzz_parity.py [seconds] [seed] [large]
 Extraction (random sizes / channels / strides / contents / max_points), Hamming k-NN (random shapes, descriptor lengths, k up to 40,
 duplicated rows), Lowe-filtered and cross-checked match lists, findHomography (every method, random inlier shares, degenerate sets),
 pnp_solver_ransac (EPnP / P3P / ITERATIVE, 4 .. 1500 correspondences).
@@ -52,15 +52,31 @@ def image(h, w, ch, kind):
     return np.ascontiguousarray(img)
 
 
+LARGE = len(sys.argv) > 3 and sys.argv[3] == "large"   # only frames of 8 Mpx and more (the streaming kernels' sizes), few cases per minute
+_large_tile = None
+
+
 def case_akaze():
+    global _large_tile
     big = rng.random() < 0.15
     h = int(rng.integers(600, 1400)) if big else int(rng.integers(8, 520))
     w = int(rng.integers(600, 1400)) if big else int(rng.integers(8, 520))
     ch = int(rng.choice([1, 3, 4]))
     kind = int(rng.integers(0, 5))
+    if LARGE:
+        h = int(rng.integers(2050, 3700))
+        w = max(int(rng.integers(2050, 3700)), (1 << 23) // h + 1)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:   # a random crop of one synthetic tile (the generator needs 15 s per 4096^2)
+            if _large_tile is None:
+                _large_tile = pkg.synth.make_tile(4096, 4096, frame_index=3, channels=1)
+            y0, x0 = int(rng.integers(0, 4096 - h + 1)), int(rng.integers(0, 4096 - w + 1))
+            g = _large_tile[y0:y0 + h, x0:x0 + w]
+            ch = int(rng.choice([1, 3]))
+            img0 = np.ascontiguousarray(g if ch == 1 else np.dstack([g, g, g]))
     mp = None if rng.random() < 0.7 else int(rng.integers(1, 400))
     params = dict(h=h, w=w, ch=ch, kind=kind, max_points=mp)
-    img = image(h, w, ch, kind)
+    img = img0 if (LARGE and kind == 0) else image(h, w, ch, kind)
     if rng.random() < 0.3:   # rows with padding behind them
         pad = int(rng.integers(1, 9)) * (1 if ch != 4 else 4)
         wide = np.zeros((h, w * ch + pad), np.uint8)
@@ -170,7 +186,7 @@ def case_pnp():
 
 
 t_end = time.time() + budget
-families = [case_akaze, case_akaze, case_knn, case_lists, case_homography, case_pnp]
+families = [case_akaze] if LARGE else [case_akaze, case_akaze, case_knn, case_lists, case_homography, case_pnp]
 i = 0
 last = time.time()
 while time.time() < t_end:
