@@ -644,6 +644,16 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x) {
     return a;
 }
 
+// The per-keypoint kernels below give every wave its own slices of the block's LDS arrays: what one phase writes, only the same wave reads in
+// the next. The LDS unit executes a wave's instructions in issue order, so a later read sees an earlier write without any wait; all that is
+// needed between two phases is that the compiler does not move LDS accesses across the boundary. (Round 2 used __syncthreads() here: three
+// block-wide rendezvous per keypoint in the descriptor kernel and seven in the orientation kernel tied four independent waves together.
+// Same time either way - the descriptor kernel waits for HBM, see below - but nothing is left that needs the block to move in step.)
+__device__ __forceinline__ void wave_lds_phase() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Keypoints [range[0], min(range[1], n_cap)) of this image (range: two consecutive ints of the image's slab, written by the stage's
 // scan; nullptr: [0, n_cap)): the counts stay on the device, and the blocks stride over the range, so the grid need not match it.
 __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_keypoint* __restrict__ kps, const int* __restrict__ range, int n_cap, size_t kp_bstride,
@@ -699,7 +709,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
             }
         }
     }
-    __syncthreads();
+    wave_lds_phase();
     // counting sort, identical to idx[--cum[b]] = i for ascending i: within a bin the larger sample index comes first. Every lane
     // holds the bins of its samples lane and lane + 64. Which samples share a lane's bin comes from six bit-sliced ballots per sample
     // set (a bin is six bits: the lanes whose bin equals mine are the AND, over the bits, of the ballot or its complement) instead
@@ -722,19 +732,19 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
         const int in0 = __popcll(eq00 & higher) + __popcll(eq01);  // same-bin samples with a larger index: every sample lane' + 64 has one
         const int in1 = __popcll(eq11 & higher);
         if (lane < 44) s_start[wv][lane] = 0;
-        __syncthreads();
+        wave_lds_phase();
         s_start[wv][bin0] = __popcll(eq00) + __popcll(eq01);       // the bin's size (the same number from every sample of the bin)
         if (bin1 < 42) s_start[wv][bin1] = __popcll(eq10) + __popcll(eq11);
-        __syncthreads();
+        wave_lds_phase();
         int incl = lane < 42 ? s_start[wv][lane] : 0;
         const int mine = incl;
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(incl, off);
             if (lane >= off) incl += t;
         }
-        __syncthreads();
+        wave_lds_phase();
         if (lane < 43) s_start[wv][lane] = incl - mine;            // exclusive prefix: bin 42 (no sample) holds the total
-        __syncthreads();
+        wave_lds_phase();
         // the samples' values go straight to their sorted places: the window sums below then read consecutive elements
         const int p0 = s_start[wv][bin0] + in0;
         s_xs[wv][p0] = s_x[wv][lane];
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
             s_ys[wv][p1] = s_y[wv][lane + 64];
         }
     }
-    __syncthreads();
+    wave_lds_phase();
     float sumX = 0.0f, sumY = 0.0f, norm = -1.0f;
     if (lane < 42) {
         const int sn = lane, win = 7, slices = 42;
@@ -782,7 +792,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
         }
     }
     if (live && lane == 0) kps[ki].angle = fast_atan2_deg(sumY, sumX);
-    __syncthreads();   // the next keypoint reuses the wave's LDS slices
+    wave_lds_phase();   // the next keypoint reuses the wave's LDS slices
     }
 }
 
@@ -846,6 +856,12 @@ __constant__ MldbLut c_mldb = make_mldb_lut();
 // by all 64 lanes (they were gathered 1241 times, once per grid), then 29 lanes, one per cell of any grid, add their cell's
 // samples in the reference's order (k-major, l-minor; float sums are order dependent), and the 486 comparisons are done 32
 // per lane.
+// What bounds it (4096^2 frame, 35 k keypoints, 237 us; profiles/r03/mldb_decomposition.txt): with every gather pointed at one cache line
+// the kernel takes 92 us, without the cell sums it still takes 239, with neither 67 - the 145 us are gather misses and everything else
+// hides behind them. The patches of 25 k octave-0 keypoints (42 - 63 pixels square, one sample every 2 - 3 pixels) cover most of the four
+// octave-0 levels, so the kernel reads nearly all of their Lt and Lx/Ly planes (~0.9 GB) once, in scattered 128-byte lines: ~3.8 TB/s of
+// HBM. Walking the lattice in the direction closest to the image's rows for the keypoint's angle (fewer lines per load) changed nothing,
+// and neither did dropping the block-wide barriers: the bytes have to come from HBM whatever the order.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, const int* __restrict__ range, int n_cap, size_t kp_bstride,
                                                    uint32_t* __restrict__ desc64, size_t desc_bstride) {
     APDS_RAISE_WAVE_PRIORITY();
@@ -936,7 +952,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             }
         }
     }
-    __syncthreads();
+    wave_lds_phase();
     // Cell sums in the reference's order (row-major over the cell's samples, one running sum per value). An invalid sample contributes
     // +0: a running sum that starts at +0 is never -0 (x + y is -0 only if both are), so adding +0 never changes it — the reference
     // skips those samples. The loops run over a fixed 10 x 10 window with static LDS offsets; a chain masks what is outside its cell.
@@ -977,7 +993,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
         s_val[wv][lane] = v1 ^ (v1 < 0 ? 0x7fffffff : 0);   // CV_TOGGLE_FLT: int order == float order
         if (lane < 23) s_val[wv][64 + lane] = v2 ^ (v2 < 0 ? 0x7fffffff : 0);
     }
-    __syncthreads();
+    wave_lds_phase();
     // 486 comparisons: lane tests bits lane, lane + 64, ...; a ballot is two words of the descriptor
 #pragma unroll
     for (int j = 0; j < 8; j++) {
@@ -989,7 +1005,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             desc64[(size_t)ki * 16 + 2 * j + 1] = (uint32_t)(m >> 32);
         }
     }
-    __syncthreads();   // the next keypoint reuses the wave's LDS slices
+    wave_lds_phase();   // the next keypoint reuses the wave's LDS slices
     }
 }
 
