@@ -2,7 +2,7 @@
     python3 tools/fuzz_parity.py [seconds] [seed] [large]
 Extraction (random sizes / channels / strides / contents / max_points), Hamming k-NN (random shapes, descriptor lengths, k up to 40,
 duplicated rows), Lowe-filtered and cross-checked match lists, findHomography (every method, random inlier shares, degenerate sets),
-pnp_solver_ransac (EPnP / P3P / ITERATIVE, 4 .. 1500 correspondences).
+pnp_solver_ransac (EPnP / P3P / ITERATIVE, 4 .. 1500 correspondences), batched extraction, band_merger and warp_image_perspective.
 Stops at the first difference with the case's parameters (exit code 1); prints the number of cases per family otherwise."""
 import importlib
 import os
@@ -23,7 +23,7 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 fe, hg, L, ptr = pkg.feature_extraction, pkg.homographier, pkg.lib(), pkg._lib.ptr
 oracle.set_threads(min(16, os.cpu_count() or 1))
-counts = {"akaze": 0, "akaze_keypoints": 0, "knn": 0, "lists": 0, "homography": 0, "pnp": 0}
+counts = {"akaze": 0, "akaze_keypoints": 0, "knn": 0, "lists": 0, "homography": 0, "pnp": 0, "batch": 0, "ingest": 0}
 
 
 def fail(family, params, what):
@@ -185,8 +185,49 @@ def case_pnp():
     counts["pnp"] += 1
 
 
+def case_batch():
+    """apds_akaze_extract_batch: every image of a batch == the oracle on that image alone."""
+    b = int(rng.integers(2, 9))
+    h, w = int(rng.integers(16, 400)), int(rng.integers(16, 400))
+    ch = int(rng.choice([1, 3, 4]))
+    mp = None if rng.random() < 0.7 else int(rng.integers(1, 300))
+    params = dict(batch=b, h=h, w=w, ch=ch, max_points=mp)
+    imgs = np.stack([image(h, w, ch, int(rng.integers(0, 5))) for _ in range(b)])
+    got = fe.akaze_keypoint_descriptor_extraction_batch(list(imgs), mp)
+    for i in range(b):
+        ref = oracle.akaze(np.ascontiguousarray(imgs[i]), mp if mp is not None else (1 << 18) - 1)
+        if len(got[i].keypoints) != len(ref.keypoints) or not np.array_equal(got[i].descriptors, ref.descriptors):
+            fail("batch", dict(params, image=i), f"{len(got[i].keypoints)} keypoints / descriptors, oracle {len(ref.keypoints)}")
+        for f in ("x", "y", "size", "angle", "response", "octave", "class_id"):
+            if not np.array_equal(got[i].keypoints[f], ref.keypoints[f]):
+                fail("batch", dict(params, image=i), f"field {f} differs")
+    counts["batch"] += 1
+
+
+def case_ingest():
+    """band_merger (mod.rs:346-378) and warp_image_perspective (mod.rs:271-300)."""
+    n = int(rng.integers(1, 200000))
+    bands = [rng.uniform(-0.3, 1.4, n).astype(np.float32) for _ in range(3)]
+    for b in bands:
+        b[rng.random(n) < 0.02] = np.nan
+    lo = rng.uniform(-0.2, 0.3, 3)
+    mm = pkg.geotiff_extractor.BandsMinMax(lo[0], lo[0] + rng.uniform(0.1, 1.2), lo[1], lo[1] + rng.uniform(0.1, 1.2), lo[2], lo[2] + rng.uniform(0.1, 1.2))
+    got = pkg.geotiff_extractor.band_merger(bands, mm)
+    if not np.array_equal(got, oracle.band_merger(bands[0], bands[1], bands[2], mm.as_array())):
+        fail("ingest", dict(n=n, minmax=list(mm.as_array())), "band_merger differs")
+    h, w = int(rng.integers(2, 300)), int(rng.integers(2, 300))
+    img = hg.Cmat(rng.integers(0, 256, (h, w, 4), dtype=np.uint8), np.uint8, 4)
+    ang, sc = rng.uniform(-0.6, 0.6), rng.uniform(0.6, 1.6)
+    M = np.array([[sc * np.cos(ang), -sc * np.sin(ang), rng.uniform(-40, 40)], [sc * np.sin(ang), sc * np.cos(ang), rng.uniform(-40, 40)],
+                  [rng.uniform(-5e-4, 5e-4), rng.uniform(-5e-4, 5e-4), rng.uniform(0.8, 1.2)]])
+    out = hg.warp_image_perspective(img, hg.Cmat(M, np.float64), None).mat
+    if not np.array_equal(out, oracle.warp_perspective(img.mat, M)):
+        fail("ingest", dict(h=h, w=w, M=M.tolist()), "warp_image_perspective differs")
+    counts["ingest"] += 1
+
+
 t_end = time.time() + budget
-families = [case_akaze] if LARGE else [case_akaze, case_akaze, case_knn, case_lists, case_homography, case_pnp]
+families = [case_akaze] if LARGE else [case_akaze, case_akaze, case_knn, case_lists, case_homography, case_pnp, case_batch, case_ingest]
 i = 0
 last = time.time()
 while time.time() < t_end:
