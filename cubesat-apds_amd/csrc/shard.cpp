@@ -131,6 +131,15 @@ struct Hub {
     };
     std::vector<Post> posts;
     explicit Hub(int w) : world(w), posts((size_t)w) {}
+    // The events belong to the hub, not to the rank that created them: a rank that has left its last collective may destroy its transport
+    // while a slower peer is still issuing that collective's closing hipStreamWaitEvent on this rank's `done` (found by the randomised
+    // run of tests/cpp/shard_loopback_test.cpp: "invalid resource handle" once in ~900 worlds). They go when the last rank has detached.
+    ~Hub() {
+        for (Post& p : posts) {
+            if (p.ready) (void)hipEventDestroy(p.ready);
+            if (p.done) (void)hipEventDestroy(p.done);
+        }
+    }
     // all `world` threads meet here; a rank that never arrives (it failed) must not hang the others for ever
     void barrier() {
         std::unique_lock<std::mutex> g(m);
@@ -174,18 +183,18 @@ struct LoopbackTransport final : Transport {
             HIP_CHECK(hipEventCreateWithFlags(&me.done, hipEventDisableTiming));
             hub->barrier();   // every rank's events exist before the first collective reads them
         } catch (...) {       // (a constructor that throws runs no destructor: leave the hub as it was found)
+            Hub::Post& me = hub->posts[(size_t)rank];
+            if (me.ready) (void)hipEventDestroy(me.ready);   // no collective has used them yet
+            if (me.done) (void)hipEventDestroy(me.done);
+            me.ready = me.done = nullptr;
             std::lock_guard<std::mutex> g(g_hubs_mutex);
             if (--hub->attached == 0) g_hubs.erase(key);
             throw;
         }
     }
     ~LoopbackTransport() override {
-        Hub::Post& me = hub->posts[(size_t)rank];
-        if (me.ready) (void)hipEventDestroy(me.ready);
-        if (me.done) (void)hipEventDestroy(me.done);
-        me.ready = me.done = nullptr;
         std::lock_guard<std::mutex> g(g_hubs_mutex);
-        if (--hub->attached == 0) g_hubs.erase(key);
+        if (--hub->attached == 0) g_hubs.erase(key);   // (the hub itself, and with it every rank's events, lives until the last transport lets go of it)
     }
     const char* name() const override { return "loopback"; }
     void counts(int mine, int* all, void*) override {
