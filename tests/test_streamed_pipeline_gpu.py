@@ -54,6 +54,31 @@ def test_streamed_results_equal_the_serial_pipeline(gpu_pkg):
         assert abs(a["H"][0, 2] - 23) < 0.5 and abs(a["H"][1, 2] - 19) < 0.5      # the planted translation
 
 
+def test_streamed_pipeline_with_frames_that_find_nothing(gpu_pkg):
+    """A stream is not all good frames: a blank frame (no keypoint, hence no query, no match, no homography), a frame of noise (keypoints
+    but nothing in the DB resembles them: too few matches survive the ratio test) between good ones - the pipeline must report each as
+    the serial pipeline does and carry on with the next frame (split scan, slots and events are per frame: none may be left half-used)."""
+    import torch
+    pl, frames, db, db_xy = _setup(gpu_pkg, T=512, ndb=40000, nframes=2)
+    dev = frames[0].device
+    rng = np.random.default_rng(3)
+    blank = torch.zeros_like(frames[0])
+    blank[..., 3] = 255
+    noise = torch.from_numpy(rng.integers(0, 256, tuple(frames[0].shape), dtype=np.uint8)).to(dev)
+    seq = [frames[0], blank, frames[1], noise, blank, blank, frames[0], noise, frames[1]]
+    serial = pl.FramePipeline(db, db_xy)
+    want = [serial.step(f, filter_strength=0.3) for f in seq]
+    streamed = pl.StreamedFramePipeline(db, db_xy)
+    got, _ = streamed.run(seq, len(seq), filter_strength=0.3)
+    assert len(got) == len(seq)
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert a["n_keypoints"] == b["n_keypoints"] and a["n_matches"] == b["n_matches"] and a["n_inliers"] == b["n_inliers"], (i, a, b)
+        assert (a["H"] is None) == (b["H"] is None) and (a["H"] is None or np.array_equal(a["H"], b["H"])), i
+    assert want[1]["n_keypoints"] == 0 and want[1]["H"] is None
+    assert want[3]["n_keypoints"] > 100 and want[3]["H"] is None
+    assert want[0]["H"] is not None and want[6]["H"] is not None and want[8]["H"] is not None
+
+
 def test_starvation_watch_caps_the_match_kernel(gpu_pkg):
     pl, frames, db, db_xy = _setup(gpu_pkg)
     L, check = gpu_pkg.lib(), gpu_pkg._lib.check
