@@ -82,7 +82,7 @@ void launch_doh_fused(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int
 // every pixel of the level (so neither needs clearing). false = not a level for it (the caller launches doh_fused instead).
 bool doh_strips_eligible(int w, int h, int sc, int batch);
 bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
-                       uint8_t* status, uint32_t* list, int* list_count, hipStream_t s, const Batch& b);
+                       uint8_t* status, uint32_t* list, int* list_count, hipStream_t s, const Batch& b, bool dense_det);
 
 // Band height of a streaming kernel (a wave walks a band of rows of one 64-column strip; 256-thread blocks = four waves): the waves of a
 // launch should fill the resident wave slots a WHOLE number of times - 5248 waves on 5120 slots run as two rounds, the second one 2.5 %

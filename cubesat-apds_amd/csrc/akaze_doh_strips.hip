@@ -70,6 +70,7 @@ struct DohStripArgs {
     int w, h, border;
     float kside, kmid, sq, thr;
     int strips, bands, rb;
+    int dense_det;   // 1: the determinant of every pixel is stored (debug-plane reads); 0: only around the candidates (see the store below)
 };
 
 // a wave's collected candidates -> the level's list (one atomic per flush; the list's order does not matter)
@@ -123,7 +124,7 @@ __device__ __forceinline__ void doh_strip_rows(const DohStripArgs& a, uint32_t* 
     float rd[P], rs[P], rdx[P], rsx[P], rsy[P];
 #pragma unroll
     for (int j = 0; j < P; j++) rd[j] = rs[j] = rdx[j] = rsx[j] = rsy[j] = 0.0f;
-    float d1 = 0.0f, hm0 = 0.0f, hs1 = 0.0f, hm1 = 0.0f;   // det row z - 1; neighbour maxima of rows z - 2 and z - 1
+    float d1 = 0.0f, d0 = 0.0f, hm0 = 0.0f, hs1 = 0.0f, hm1 = 0.0f;   // det rows z - 1 and z - 2; neighbour maxima of rows z - 2 and z - 1
     int ncand = 0;                                          // wave-uniform
     float cur[P], nxt[P];
 #pragma unroll
@@ -182,7 +183,10 @@ __device__ __forceinline__ void doh_strip_rows(const DohStripArgs& a, uint32_t* 
             const float lxy = rsx[j] - rsx[jA];
             const float lyy = rsy[j] - rsy[jA];
             const float d2 = (lxx * lyy - lxy * lxy) * sq;
-            {
+            // The determinant is read again only AT candidates (their response; the suppression compares responses of candidates) and in
+            // the 3 x 3 block around one (sub-pixel fit): with dense_det = 0 nothing is stored here, and a row with candidates stores the
+            // three rows of the candidates' columns and of the columns beside them further down (4 of the stage's 18 bytes per pixel less).
+            if (a.dense_det) {
                 const bool ok = z >= y0 && z < y1;
                 const __amdgpu_buffer_rsrc_t r_det = __builtin_amdgcn_make_buffer_rsrc(a.Ldet, 0, ok ? plane4 : 0, 0x00020000);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d2), r_det, xo4, __builtin_amdgcn_readfirstlane(ok ? z * w * 4 : 0), 0);
@@ -206,6 +210,19 @@ __device__ __forceinline__ void doh_strip_rows(const DohStripArgs& a, uint32_t* 
                 __builtin_amdgcn_raw_buffer_store_b8((unsigned char)0, r_stat, xo1, o, 0);
                 const unsigned long long b = __ballot(keep);
                 if (b) {   // wave-uniform, rare
+                    if (!a.dense_det) {
+                        // rows y - 1, y, y + 1 (= z - 2, z - 1, z; all inside the image: candidates keep `border` >= 1 away from its edges) of
+                        // the candidates' columns and their two neighbours: every lane stores its own column's three values
+                        const unsigned long long near = b | (b << 1) | (b >> 1);
+                        // (x4, not xo4: the column beside a candidate in the wave's first / last output column is a halo lane, whose determinant is
+                        // as valid as the extrema test that just used it; the other lanes store past the buffer, i.e. nothing)
+                        const int vo = ((near >> lane) & 1) ? x4 : DROP;
+                        const __amdgpu_buffer_rsrc_t r_det = __builtin_amdgcn_make_buffer_rsrc(a.Ldet, 0, plane4, 0x00020000);
+                        const int row = __builtin_amdgcn_readfirstlane((y - 1) * w * 4);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d0), r_det, vo, row, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d1), r_det, vo, row + w * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, d2), r_det, vo, row + 2 * w * 4, 0);
+                    }
                     if (keep) cand[ncand + __builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0))] = (uint32_t)x | ((uint32_t)y << 16);
                     ncand += __builtin_popcountll(b);
                     if (ncand > DS_CAND - 32) {
@@ -217,6 +234,7 @@ __device__ __forceinline__ void doh_strip_rows(const DohStripArgs& a, uint32_t* 
             hm0 = hm1;
             hs1 = hs2;
             hm1 = hm2;
+            d0 = d1;
             d1 = d2;
         }
 #pragma unroll
@@ -290,7 +308,7 @@ bool doh_strips_eligible(int w, int h, int sc, int batch) {
 }
 
 bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, int h, int sc, float kside, float kmid, int border, float thr, uint8_t* mask,
-                       uint8_t* status, uint32_t* list, int* list_count, hipStream_t s, const Batch& b) {
+                       uint8_t* status, uint32_t* list, int* list_count, hipStream_t s, const Batch& b, bool dense_det) {
     if (!doh_strips_eligible(w, h, sc, b.n)) return false;
     const int vw = 64 - 4 * sc - 2;
     const int strips = ceil_div(w, vw);
@@ -304,7 +322,7 @@ bool launch_doh_strips(const float* Lsmooth, float2* Lxy, float* Ldet, int w, in
     const int rb = sc == 2 ? rows_for(&doh_strip_kernel<2>) : sc == 3 ? rows_for(&doh_strip_kernel<3>) : rows_for(&doh_strip_kernel<4>);
     const bool none = border + 1 >= h || w - 2 * border <= 0 || h - 2 * border <= 0;
     DohStripArgs a{Lsmooth, Lxy, Ldet, mask, status, w, h, none ? -1 : border, kside, kmid, (float)(sc * sc * sc * sc), thr, strips,
-                   ceil_div(h, rb), rb};
+                   ceil_div(h, rb), rb, dense_det ? 1 : 0};
     const dim3 grid(ceil_div((long long)a.strips * a.bands, 4), 1, b.n);
     switch (sc) {
         case 2: hipLaunchKernelGGL(doh_strip_kernel<2>, grid, dim3(256), lds_pad, s, a, list, list_count, b.stride); break;

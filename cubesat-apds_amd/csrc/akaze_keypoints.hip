@@ -1603,10 +1603,12 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             HIP_CHECK(hipEventRecord(c.fork_event(0), s));
             HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
         }
+        // the determinant plane of a level is stored whole only when somebody asked to see it (apds_akaze_debug_plane)
+        const bool dense_det = akaze_debug_request().armed;
         auto launch_hessian = [&](hipStream_t st) {
             const LevelDesc& le = ev[i];
             if (!(i < n_strip_levels && launch_doh_strips(smooth, le.Lxy, le.Ldet, le.w, le.h, le.sigma_size, kside, kmid, le.border, dthreshold,
-                                                           mask_all + le.pix_offset, status_all + le.pix_offset, lists[i], list_count + i, st, bt)))
+                                                           mask_all + le.pix_offset, status_all + le.pix_offset, lists[i], list_count + i, st, bt, dense_det)))
                 launch_doh_fused(smooth, le.Lxy, le.Ldet, le.w, le.h, le.sigma_size, kside, kmid, le.border, dthreshold, mask_all + le.pix_offset, lists[i],
                                  list_count + i, st, bt);
         };
