@@ -333,6 +333,31 @@ def main():
         run_pair(3)
         akaze_pair_ms = run_pair(10) / 20.0
         torch.cuda.synchronize()
+    # ... and as ONE batched call over four resident frames (apds_dev_akaze_extract_batch: every launch four images wide, so the dependent
+    # launch chain that bounds a single frame is paid once per four). Informational as well; the batch's workspace is given back afterwards.
+    akaze_batch4_ms = None
+    if not args.serial and world == 1 and T * T * 4 * 24 * 4 < 40e9:
+        with torch.cuda.stream(setup_stream):
+            bimgs = torch.stack([frames[i % len(frames)] for i in range(4)]).contiguous()
+            bcap = 1 << 16
+            bk = torch.empty((4, bcap, 7), dtype=torch.float32, device=dev)
+            bd = torch.empty((4, bcap, 64), dtype=torch.uint8, device=dev)
+            bcounts = (C.c_int * 4)()
+            try:
+                for rep in range(4):
+                    torch.cuda.synchronize()
+                    tb = time.perf_counter()
+                    check(L.apds_dev_akaze_extract_batch(bimgs.data_ptr(), 4, bimgs.stride(0), T, T, bimgs.shape[3], bimgs.stride(1), bcap, bk.data_ptr(), bd.data_ptr(),
+                                                         bcap, bcounts, pl.torch_stream()))
+                    torch.cuda.synchronize()
+                    akaze_batch4_ms = (time.perf_counter() - tb) * 1e3 / 4
+            except pkg._lib.ApdsError as e:   # (e.g. more keypoints per frame than the probe's capacity: the line is informational)
+                print(f"[bench] batched extraction probe skipped: {e}", file=sys.stderr, flush=True)
+                akaze_batch4_ms = None
+            del bimgs, bk, bd
+        check(L.apds_thread_release())
+        check(L.apds_release_cached_memory())
+        check(L.apds_set_device(dev_index))
     if args.serial:
         pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
     else:
@@ -497,6 +522,9 @@ def main():
                                 "two_in_flight": ({"ms_per_frame": akaze_pair_ms, "frac": detect_algorithmic_bytes(T, T) / (akaze_pair_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                                                    "note": "throughput form: two host threads / streams extracting alternate frames (20 frames, wall clock); the "
                                                            "Hessian kernels are not forked to a side stream in this mode"} if akaze_pair_ms else None),
+                                "batch_of_4": ({"ms_per_frame": akaze_batch4_ms, "frac": detect_algorithmic_bytes(T, T) / (akaze_batch4_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                                                "note": "throughput form: one apds_dev_akaze_extract_batch call over four resident frames (wall clock / 4)"}
+                                               if akaze_batch4_ms else None),
                                 "library_contexts_alive": int(L.apds_live_contexts()),
                                 "note": "whole extraction (incl. orientation, descriptors, the count read-back), 10 back-to-back calls on resident frames timed by the wall clock with nothing else on the GPU, before the pipeline's streams are created, against the detect stages' algorithmic bytes; stages_ms_per_step.akaze_extract is its wall span while overlapped with the match (two frames are extracted concurrently, so the span may exceed the step time)"},
         }
