@@ -48,27 +48,6 @@ def detect_algorithmic_bytes(w, h):
     return total
 
 
-def _debug_solo(tag, frames, T, L, check, pl, dev, torch):
-    """APDS_BENCH_DEBUG_SOLO=1: stand-alone extraction time at this point of the setup (stderr)."""
-    if os.environ.get("APDS_BENCH_DEBUG_SOLO") != "1":
-        return
-    cap = (1 << 18) - 1
-    kps = torch.empty((cap, 7), dtype=torch.float32, device=dev)
-    desc = torch.empty((cap, 64), dtype=torch.uint8, device=dev)
-    st = torch.cuda.Stream(dev)
-    n = C.c_int(0)
-    with torch.cuda.stream(st):
-        def go(reps):
-            for rep in range(reps):
-                f = frames[rep % len(frames)]
-                check(L.apds_dev_akaze_extract(f.data_ptr(), T, T, f.shape[2], f.stride(0), cap, kps.data_ptr(), desc.data_ptr(), cap, C.byref(n), pl.torch_stream()))
-            torch.cuda.synchronize()
-        go(3)
-        t0 = time.perf_counter()
-        go(10)
-        print(f"[debug solo] {tag}: {(time.perf_counter() - t0) * 100:.3f} ms per extraction", file=sys.stderr, flush=True)
-
-
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>`
     as a child process (one rank per GPU, rendezvous on 127.0.0.1, a free port), pass rank 0's JSON line through and return the child's exit
@@ -186,7 +165,6 @@ def main():
     shift = (37, 52)   # (dy, dx): DB images are np.roll'ed frames, so the true homography is a translation
     frames_np = [synth.make_tile(T, T, frame_index=rank * args.frames + i) for i in range(args.frames)]
     frames = [torch.from_numpy(f).to(dev) for f in frames_np]
-    _debug_solo('after frames', frames, T, L, check, pl, dev, torch)
     cap = pkg.feature_extraction.MAX_POINTS
     kps = torch.empty((cap, 7), dtype=torch.float32, device=dev)
     desc = torch.empty((cap, 64), dtype=torch.uint8, device=dev)
@@ -202,7 +180,6 @@ def main():
         planted_rows.append(desc[:n.value].clone())
         planted_xy.append(kps[:n.value, 0:2].clone())
     mine_rows, mine_xy = torch.cat(planted_rows), torch.cat(planted_xy)
-    _debug_solo('after planting', frames, T, L, check, pl, dev, torch)
     if world > 1:
         cnt_t = torch.zeros(world, dtype=torch.int64, device=dev)
         pl._gather_into(dist, group, cnt_t, torch.tensor([mine_rows.shape[0]], dtype=torch.int64, device=dev))
@@ -268,7 +245,6 @@ def main():
         perm = torch.randperm(NDB, device=dev, generator=gperm)
         db_local, db_xy = db_local[perm].contiguous(), db_xy[perm].contiguous()
     torch.cuda.synchronize()
-    _debug_solo('after DB build', frames, T, L, check, pl, dev, torch)
     # stand-alone extraction time (no other stage on the GPU) for the detect roofline: BEFORE the pipeline and its streams exist. (The
     # runtime maps streams onto a few hardware queues; once the pipeline's eight streams are around, the extraction's side stream shares
     # a queue with its main stream and the same call takes 2.2 ms instead of 1.9: measured both ways, profiles/r02.)
@@ -495,23 +471,27 @@ def main():
             "gpairs_per_s": world * Q_step * rows_local * args.steps / elapsed / 1e9,
             # The binding bound of the dominant kernel is integer-VALU issue, so that is what `roofline` carries:
             # achieved = ALGORITHMIC lane-ops (32 per pair: 16 dword xor + 16 popcount-accumulate) / launch time;
-            # peak = the xor+bcnt pair rate measured on this GPU by the register-only microbenchmark in its best issue order
-            # (apds_dev_valu_popcount_peak; v_xor_b32 issues at the full FP32 rate, v_bcnt_u32_b32 at half of it:
+            # peak = the guide's VALU rate (MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 op every 2 cycles = 128 lanes/clk/CU x 256 CU x
+            # 2.4 GHz = 78.6 T lane-op/s) and frac = achieved / that. mix_ceiling = what THIS instruction mix can reach: the xor + bcnt pair
+            # rate measured on this GPU by the register-only microbenchmark in its best issue order (apds_dev_valu_popcount_peak; v_xor_b32
+            # issues at the full rate, v_bcnt_u32_b32 at half of it: 2 + 4 cycles per dword pair, 52.4 T in theory; calibration
             # profiles/r02/valu_calib_*.log). north_star's "% of HBM" is the sub-object `hbm`.
             "roofline": {"kernel": f"hamming_topk_kernel<{4 if Q_step >= 16384 else (2 if Q_step >= 8192 else 1)},2>", "bound": "int32-valu",
-                         "achieved": achieved_tops, "peak": peak.value / 1e12, "unit": "T lane-op/s", "frac": achieved_tops / (peak.value / 1e12) if peak.value else 0.0,
+                         "achieved": achieved_tops, "peak": VALU_FP32_LANE_RATE_SPEC / 1e12, "unit": "T lane-op/s", "frac": achieved_tops / (VALU_FP32_LANE_RATE_SPEC / 1e12),
+                         "mix_ceiling": peak.value / 1e12, "frac_of_mix_ceiling": achieved_tops / (peak.value / 1e12) if peak.value else None,
+                         "mix_ceiling_source": "apds_dev_valu_popcount_peak in this run (xor at the full VALU rate + half-rate bcnt = 6 issue cycles per dword pair); calibration of every instruction kind: profiles/r02/valu_calib_patterns.log, valu_calib_modes.log",
                          "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": launches_per_step, "avg_launch_ms": avg_launch_ms,
                          "solo": ({"avg_launch_ms": solo_launch_ms, "queries": int(stats[0]["n_keypoints"]),
-                                   "frac": (32.0 * stats[0]["n_keypoints"] * rows_main / (solo_launch_ms * 1e-3) / peak.value) if peak.value and solo_launch_ms else None,
+                                   "frac": (32.0 * stats[0]["n_keypoints"] * rows_main / (solo_launch_ms * 1e-3) / VALU_FP32_LANE_RATE_SPEC) if solo_launch_ms else None,
+                                   "frac_of_mix_ceiling": (32.0 * stats[0]["n_keypoints"] * rows_main / (solo_launch_ms * 1e-3) / peak.value) if peak.value and solo_launch_ms else None,
                                    "note": "the same kernel alone on the GPU after the timed region (frame 0's query count); `achieved` / `frac` above are the "
                                            "LIVE launches of the timed region, which share the GPU with the next frame's threshold pre-pass, the previous "
                                            "frame's merge and the extraction"} if solo_launch_ms else None),
                          "algorithmic_lane_ops_per_launch": match_ops / max(launches_per_step, 1e-9), "algorithmic_bytes_per_launch": bytes_per_launch,
                          "tpairs_per_s": Q_step * rows_main / (topk_ms_step * 1e-3) / 1e12 if topk_ms_step else 0.0,
-                         "peak_spec_fp32_rate": VALU_FP32_LANE_RATE_SPEC,
                          "hbm": {"achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS},
-                         "note": "32 algorithmic lane-ops per pair; the kernel screens on 15 of the 16 dwords (30.6 issued ops per pair), so frac can pass 1.0 slightly. "
-                                 "peak is measured (xor at the full VALU rate + bcnt at half rate = 6 issue cycles per dword pair); peak_spec_fp32_rate = 128 lanes/clk/CU x 256 CU x 2.4 GHz"},
+                         "note": "32 algorithmic lane-ops per pair; peak = 128 lanes/clk/CU x 256 CU x 2.4 GHz (the guide's full-rate VALU figure, which no popcount loop reaches: "
+                                 "v_bcnt_u32_b32 is a half-rate instruction); the kernel screens on 15 of the 16 dwords (30.6 issued ops per pair), so frac_of_mix_ceiling can pass 1.0 slightly"},
             "stages_ms_per_step": {"akaze_extract": akaze_ms / max(args.steps, 1), "hamming_topk": topk_ms_step,
                                    "hamming_topk_sample": sample_ms / max(args.steps, 1), "ransac_score": score_ms / max(args.steps, 1)},
             "detect_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": detect_algorithmic_bytes(T, T),

@@ -28,7 +28,7 @@ SYMBOLS = [
     "apds_dev_valu_popcount_peak", "apds_dev_valu_peak", "apds_dev_valu_peak_modes", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane", "apds_stream_create", "apds_stream_destroy",
     "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective", "apds_pnp_solver_ransac", "apds_pnp_hypotheses", "apds_get_world_coordinates", "apds_l2_knn_match", "apds_dev_l2_topk", "apds_dev_l2_topk_ex",
     "apds_db_create", "apds_db_destroy", "apds_db_rows", "apds_db_insert_image", "apds_db_select", "apds_db_view", "apds_db_view_download", "apds_db_knn_match",
-    "apds_comm_id_create", "apds_shard_create", "apds_shard_destroy", "apds_shard_info", "apds_shard_counts", "apds_shard_knn", "apds_shard_slot_create",
+    "apds_comm_id_create", "apds_shard_create", "apds_shard_destroy", "apds_shard_info", "apds_shard_counts", "apds_shard_knn", "apds_shard_knn_replicated", "apds_shard_slot_create",
     "apds_shard_slot_destroy", "apds_shard_gather", "apds_shard_scan", "apds_shard_exchange_merge", "apds_db_shard",
     "apds_dev_alloc", "apds_dev_release", "apds_dev_upload", "apds_dev_download", "apds_stream_synchronize",
     "apds_dev_topk_state_create", "apds_dev_topk_state_destroy", "apds_dev_topk_prepass", "apds_dev_topk_scan", "apds_dev_topk_merge",
@@ -147,6 +147,7 @@ def lib():
             "apds_shard_info": (i, [vp, ip, ip, C.POINTER(i64), C.POINTER(u32), C.POINTER(C.c_char_p), ip]),
             "apds_shard_counts": (i, [vp, i, ip, vp]),
             "apds_shard_knn": (i, [vp, vp, i, ip, i, vp, vp]),
+            "apds_shard_knn_replicated": (i, [vp, vp, i, i, i, vp, vp]),
             "apds_shard_slot_create": (i, [vp, i, i, pp]),
             "apds_shard_slot_destroy": (i, [vp, vp]),
             "apds_shard_gather": (i, [vp, vp, vp, i, ip, vp]),

@@ -31,6 +31,8 @@ struct Config {
     int ransac_batch;     // APDS_RANSAC_BATCH first speculated batch of RANSAC hypotheses (512)
     int pnp_batch;        // APDS_PNP_BATCH    hypotheses per PnP batch (2048)
     int l2_sample_div;    // APDS_L2_SAMPLE_DIV  the bf16 screen's threshold sample = rows / this (12)
+    // ---- test hooks
+    int loopback_lag_rank, loopback_lag_ms;   // APDS_TEST_LOOPBACK_LAG="rank:ms"  that rank sleeps before the closing waits of every loopback collective
 };
 
 const Config& config();

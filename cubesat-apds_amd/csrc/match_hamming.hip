@@ -282,6 +282,27 @@ __global__ __launch_bounds__(256) void hamming_topk_page_kernel(const u32x16* __
 // (A persistent work-queue form of this kernel - resident workgroups pulling items from an atomic counter - was kept through round 2 behind
 // APDS_MATCH_PERSIST; the plain grid was as fast in every sweep (profiles/r01/match_persistent_sweep.log): deleted in round 3.)
 
+// The same for any k (the sharded matcher above 16 neighbours, and k not a power of two): every list is ascending and all keys are distinct
+// (a key carries its global row), so output j is the smallest key above output j - 1: each lane walks a cursor per list. parts <= 64.
+__global__ void merge_topk_any_kernel(const uint64_t* __restrict__ parts_keys, int parts, int nq, int k, uint64_t* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (qi >= nq) return;
+    uint16_t cur[64];   // cursor of every list
+    for (int p = 0; p < parts; p++) cur[p] = 0;
+    for (int j = 0; j < k; j++) {
+        uint64_t best = EMPTY_KEY;
+        int arg = -1;
+        for (int p = 0; p < parts; p++) {
+            if (cur[p] >= k) continue;
+            const uint64_t v = parts_keys[((size_t)p * nq + qi) * k + cur[p]];
+            if (v < best) best = v, arg = p;
+        }
+        out[(size_t)qi * k + j] = best;
+        if (arg >= 0) cur[arg]++;
+    }
+}
+
 // merge `parts` sorted candidate lists per query into the k smallest keys
 template <int K>
 __global__ void merge_topk_kernel(const uint64_t* __restrict__ parts_keys, int parts, int nq, uint64_t* __restrict__ out) {
@@ -1039,10 +1060,13 @@ void* topk_split_create() {
 void topk_split_destroy(void* h) {
     TopkSplitState* st = static_cast<TopkSplitState*>(h);
     if (!st) return;
+    int previous = -1;   // the caller's device is put back: its thread context (stream, workspace) belongs there
+    if (hipGetDevice(&previous) != hipSuccess) previous = -1;
     (void)hipSetDevice(st->device);
     (void)hipDeviceSynchronize();
     if (st->buf) (void)hipFree(st->buf);
     delete st;
+    if (previous >= 0) (void)hipSetDevice(previous);
 }
 void topk_split_prepass(void* h, const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, hipStream_t s) {
     APDS_REQUIRE(h, APDS_ERR_BAD_ARG, "null scan state");
@@ -1105,7 +1129,9 @@ void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_
         case 4: merge_launch<4>(parts, nparts, nq, out, s); break;
         case 8: merge_launch<8>(parts, nparts, nq, out, s); break;
         case 16: merge_launch<16>(parts, nparts, nq, out, s); break;
-        default: fail(APDS_ERR_ASSERT, "merge supports k in {1,2,4,8,16}");
+        default:
+            APDS_REQUIRE(k >= 1 && k <= 4096 && nparts <= 64, APDS_ERR_ASSERT, "merge supports 1 <= k <= 4096 over at most 64 lists");
+            hipLaunchKernelGGL(merge_topk_any_kernel, dim3(ceil_div(nq, 64)), dim3(64), 0, s, parts, nparts, nq, k, out);
     }
     HIP_CHECK(hipGetLastError());
 }

@@ -40,6 +40,12 @@ const Config& config() {
         k.ransac_batch = env("APDS_RANSAC_BATCH", 512);
         k.pnp_batch = env("APDS_PNP_BATCH", 2048);
         k.l2_sample_div = std::max(1, env("APDS_L2_SAMPLE_DIV", 12));
+        k.loopback_lag_rank = -1;
+        k.loopback_lag_ms = 0;
+        if (const char* lag = getenv("APDS_TEST_LOOPBACK_LAG")) {
+            int r = -1, ms = 0;
+            if (sscanf(lag, "%d:%d", &r, &ms) == 2 && r >= 0 && ms > 0) k.loopback_lag_rank = r, k.loopback_lag_ms = ms;
+        }
         return k;
     }();
     return c;

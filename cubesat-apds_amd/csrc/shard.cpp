@@ -15,7 +15,9 @@
 #include <memory>
 #include <mutex>
 #include <random>
+#include <thread>
 
+#include "config.h"
 #include "kernels.h"
 #include "shard_core.h"
 
@@ -29,6 +31,19 @@ namespace {
         ncclResult_t r_ = (x);                                                                                                          \
         if (r_ != ncclSuccess && r_ != ncclInProgress) throw ShardError(APDS_ERR_INTERNAL, std::string(#x " failed: ") + ncclGetErrorString(r_)); \
     } while (0)
+
+// hipSetDevice(handle's device) for the length of a destroy path, then the caller's device again: a thread bound to GPU A may destroy a
+// handle living on GPU B (a thread-per-GPU host; a finaliser running on an arbitrary thread) and must keep launching on A afterwards.
+struct DeviceGuard {
+    int previous = -1;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&previous) != hipSuccess) previous = -1;
+        (void)hipSetDevice(device);
+    }
+    ~DeviceGuard() {
+        if (previous >= 0) (void)hipSetDevice(previous);
+    }
+};
 
 struct HipDevice final : Device {
     static hipStream_t st(void* s) { return pick_stream(s); }
@@ -70,6 +85,28 @@ struct HipDevice final : Device {
 struct RcclTransport final : Transport {
     ncclComm_t comm = nullptr;
     int* counts_dev = nullptr;
+    bool broken = false;   // a collective failed half-way: the communicator's state is unknown, every later call refuses
+    // ncclGroupEnd on every path out of a group, and the communicator marked broken when a call inside it failed
+    struct Group {
+        RcclTransport& t;
+        bool open = false, ok = false;
+        explicit Group(RcclTransport& t_) : t(t_) {
+            NCCL_CHECK(ncclGroupStart());
+            open = true;
+        }
+        void end() {
+            open = false;
+            NCCL_CHECK(ncclGroupEnd());
+            ok = true;
+        }
+        ~Group() {
+            if (open) (void)ncclGroupEnd();
+            if (!ok) t.broken = true;
+        }
+    };
+    void usable() const {
+        if (broken) throw ShardError(APDS_ERR_INTERNAL, "the RCCL communicator is broken (an earlier collective failed): destroy the shard and create a new one");
+    }
     RcclTransport(int rank_, int world_, const apds_comm_id& id) {
         rank = rank_;
         world = world_;
@@ -90,28 +127,44 @@ struct RcclTransport final : Transport {
     }
     const char* name() const override { return "rccl"; }
     void counts(int mine, int* all, void* s) override {
+        usable();
         hipStream_t st = pick_stream(s);
         HIP_CHECK(hipMemcpyAsync(counts_dev + world, &mine, sizeof(int), hipMemcpyHostToDevice, st));
-        NCCL_CHECK(ncclAllGather(counts_dev + world, counts_dev, 1, ncclInt32, comm, st));
+        collective_call([&] { NCCL_CHECK(ncclAllGather(counts_dev + world, counts_dev, 1, ncclInt32, comm, st)); });
         HIP_CHECK(hipMemcpyAsync(all, counts_dev, (size_t)world * sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_CHECK(hipStreamSynchronize(st));
     }
+    template <class F>
+    void collective_call(F&& f) {
+        try {
+            f();
+        } catch (...) {
+            broken = true;
+            throw;
+        }
+    }
     void all_gather(const void* send, void* recv, size_t bytes, void* s) override {
-        NCCL_CHECK(ncclAllGather(send, recv, bytes, ncclUint8, comm, pick_stream(s)));
+        usable();
+        collective_call([&] { NCCL_CHECK(ncclAllGather(send, recv, bytes, ncclUint8, comm, pick_stream(s))); });
+    }
+    void broadcast(void* buf, size_t bytes, int root, void*, Device&, void* s) override {
+        usable();
+        collective_call([&] { NCCL_CHECK(ncclBroadcast(buf, buf, bytes, ncclUint8, root, comm, pick_stream(s))); });
     }
     void all_to_all(const void* send, const size_t* soff, const size_t* sbytes, void* recv, const size_t* roff, const size_t* rbytes, void* s) override {
+        usable();
         hipStream_t st = pick_stream(s);
         const char* sp = static_cast<const char*>(send);
         char* rp = static_cast<char*>(recv);
         // this rank's own block never touches the network
         if (sbytes[rank]) HIP_CHECK(hipMemcpyAsync(rp + roff[rank], sp + soff[rank], sbytes[rank], hipMemcpyDeviceToDevice, st));
-        NCCL_CHECK(ncclGroupStart());
+        Group g(*this);   // (its destructor closes the group and marks the communicator broken if a call below throws)
         for (int p = 0; p < world; p++) {
             if (p == rank) continue;
             if (sbytes[p]) NCCL_CHECK(ncclSend(sp + soff[p], sbytes[p], ncclUint8, p, comm, st));
             if (rbytes[p]) NCCL_CHECK(ncclRecv(rp + roff[p], rbytes[p], ncclUint8, p, comm, st));
         }
-        NCCL_CHECK(ncclGroupEnd());
+        g.end();
     }
 };
 
@@ -128,6 +181,7 @@ struct Hub {
         std::vector<size_t> soff, sbytes;
         hipEvent_t ready = nullptr, done = nullptr;
         int count = 0;
+        bool owned = false;   // a transport is attached as this rank
     };
     std::vector<Post> posts;
     explicit Hub(int w) : world(w), posts((size_t)w) {}
@@ -173,27 +227,38 @@ struct LoopbackTransport final : Transport {
             auto& h = g_hubs[key];
             if (!h) h = std::make_shared<Hub>(world);
             if (h->world != world) throw ShardError(APDS_ERR_BAD_ARG, "loopback communicator id already used with another world size");
+            // a second attachment of a rank is refused BEFORE anything of the hub is touched: the post, its events and the attachment
+            // count belong to the first, healthy attachment
+            if (h->posts[(size_t)rank].owned) throw ShardError(APDS_ERR_BAD_ARG, "loopback rank attached twice");
             hub = h;
+            hub->posts[(size_t)rank].owned = true;
             hub->attached++;
         }
+        bool made_events = false;   // only events THIS constructor created are taken back when it fails
         try {
             Hub::Post& me = hub->posts[(size_t)rank];
-            if (me.ready) throw ShardError(APDS_ERR_BAD_ARG, "loopback rank attached twice");
-            HIP_CHECK(hipEventCreateWithFlags(&me.ready, hipEventDisableTiming));
-            HIP_CHECK(hipEventCreateWithFlags(&me.done, hipEventDisableTiming));
+            if (!me.ready) {        // (a rank slot that was attached, detached and is attached again keeps its hub-owned events)
+                made_events = true;
+                HIP_CHECK(hipEventCreateWithFlags(&me.ready, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&me.done, hipEventDisableTiming));
+            }
             hub->barrier();   // every rank's events exist before the first collective reads them
         } catch (...) {       // (a constructor that throws runs no destructor: leave the hub as it was found)
             Hub::Post& me = hub->posts[(size_t)rank];
-            if (me.ready) (void)hipEventDestroy(me.ready);   // no collective has used them yet
-            if (me.done) (void)hipEventDestroy(me.done);
-            me.ready = me.done = nullptr;
+            if (made_events) {
+                if (me.ready) (void)hipEventDestroy(me.ready);   // no collective has used them yet
+                if (me.done) (void)hipEventDestroy(me.done);
+                me.ready = me.done = nullptr;
+            }
             std::lock_guard<std::mutex> g(g_hubs_mutex);
+            me.owned = false;
             if (--hub->attached == 0) g_hubs.erase(key);
             throw;
         }
     }
     ~LoopbackTransport() override {
         std::lock_guard<std::mutex> g(g_hubs_mutex);
+        hub->posts[(size_t)rank].owned = false;
         if (--hub->attached == 0) g_hubs.erase(key);   // (the hub itself, and with it every rank's events, lives until the last transport lets go of it)
     }
     const char* name() const override { return "loopback"; }
@@ -218,6 +283,10 @@ struct LoopbackTransport final : Transport {
         }
         HIP_CHECK(hipEventRecord(me.done, st));
         hub->barrier();
+        // test hook (APDS_TEST_LOOPBACK_LAG="rank:ms"): this rank dawdles between the closing barrier and its closing waits, the window in
+        // which a faster peer may already be destroying its shard (the event-lifetime race of round 3, reproduced deterministically by
+        // tests/cpp/shard_loopback_test.cpp `lag`)
+        if (config().loopback_lag_ms > 0 && config().loopback_lag_rank == rank) std::this_thread::sleep_for(std::chrono::milliseconds(config().loopback_lag_ms));
         for (int p = 0; p < world; p++)
             if (p != rank) HIP_CHECK(hipStreamWaitEvent(st, hub->posts[(size_t)p].done, 0));   // my send buffer is free again only after every peer has read it
     }
@@ -225,6 +294,12 @@ struct LoopbackTransport final : Transport {
         hipStream_t st = pick_stream(s);
         collective(send, nullptr, nullptr, st, [&](int p, const Hub::Post& peer) {
             HIP_CHECK(hipMemcpyAsync(static_cast<char*>(recv) + (size_t)p * bytes, peer.send, bytes, hipMemcpyDeviceToDevice, st));
+        });
+    }
+    void broadcast(void* buf, size_t bytes, int root, void*, Device&, void* s) override {
+        hipStream_t st = pick_stream(s);
+        collective(buf, nullptr, nullptr, st, [&](int p, const Hub::Post& peer) {
+            if (p == root && p != rank && bytes) HIP_CHECK(hipMemcpyAsync(buf, peer.send, bytes, hipMemcpyDeviceToDevice, st));
         });
     }
     void all_to_all(const void* send, const size_t* soff, const size_t* sbytes, void* recv, const size_t* roff, const size_t* rbytes, void* s) override {
@@ -326,7 +401,7 @@ int apds_shard_destroy(void* shard) {
     return shard_guarded([&] {
         if (!shard) return;
         ShardHandle* h = static_cast<ShardHandle*>(shard);
-        (void)hipSetDevice(h->device);
+        DeviceGuard on(h->device);
         (void)hipDeviceSynchronize();
         h->m.reset();     // slots first (device buffers), then the communicator
         h->tr.reset();
@@ -361,8 +436,21 @@ int apds_shard_knn(void* shard, const void* q_rows64_dev, int n_query, const int
     return shard_guarded([&] {
         APDS_REQUIRE(n_query >= 0 && (q_rows64_dev || n_query == 0), APDS_ERR_ASSERT, "bad query rows");
         APDS_REQUIRE(out_keys_dev || n_query == 0, APDS_ERR_BAD_ARG, "null output");
-        APDS_REQUIRE(k >= 1 && k <= KMAX, APDS_ERR_ASSERT, "1 <= k <= 16");
+        APDS_REQUIRE(k >= 1 && k <= KMAX, APDS_ERR_ASSERT, "1 <= k <= 4096");
         handle(shard)->m->knn(q_rows64_dev, n_query, counts, k, out_keys_dev, stream);
+    });
+}
+
+int apds_shard_knn_replicated(void* shard, const void* q_rows64_dev, int n_query, int root, int k, void* out_keys_dev, void* stream) {
+    APDS_RANGE("apds_shard_knn_replicated");
+    return shard_guarded([&] {
+        ShardHandle* h = handle(shard);
+        APDS_REQUIRE(n_query >= 0, APDS_ERR_ASSERT, "bad query count");
+        APDS_REQUIRE(root < h->m->world(), APDS_ERR_BAD_ARG, "root outside [0, world)");
+        APDS_REQUIRE(q_rows64_dev || n_query == 0 || (root >= 0 && root != h->m->rank()), APDS_ERR_ASSERT, "this rank has to bring the query rows");
+        APDS_REQUIRE(out_keys_dev || n_query == 0, APDS_ERR_BAD_ARG, "null output");
+        APDS_REQUIRE(k >= 1 && k <= KMAX, APDS_ERR_ASSERT, "1 <= k <= 4096");
+        h->m->knn_replicated(q_rows64_dev, n_query, root, k, out_keys_dev, stream);
     });
 }
 
@@ -377,7 +465,7 @@ int apds_shard_slot_destroy(void* shard, void* slot) {
     return shard_guarded([&] {
         if (!slot) return;
         ShardHandle* h = handle(shard);
-        (void)hipSetDevice(h->device);
+        DeviceGuard on(h->device);
         (void)hipDeviceSynchronize();
         h->m->slot_destroy(static_cast<Slot*>(slot));
     });

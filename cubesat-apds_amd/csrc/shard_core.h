@@ -12,6 +12,10 @@
 //       (1/world of an all-gather's bytes; the result is what north_star's "all-gather of per-shard top-k" gives);
 //   (4) u64-min merge of the `world` candidate lists of every query = the single-GPU answer, lowest-index tie-break included.
 //
+// The strong-scaling (latency) form, SURVEY 8e's literal shape, is Matcher::knn_replicated: ONE frame, the same queries on every rank
+// (each rank extracted the frame itself, or one rank's rows are broadcast first), local top-k per shard, ALL-GATHER of the [nq, k] key
+// lists, u64-min merge on every rank: every rank ends with the whole frame's answer after 1/world of the scan.
+//
 // Matcher is written against two small interfaces so that the SAME text runs in three places: the product (Device = HIP kernels and
 // hipMemcpyAsync, Transport = RCCL), the g++-built loopback test (threads as ranks on one GPU, Transport = pointer exchange inside
 // one process), and the CPU tests (tests/cpp/shard_host.cpp: Device = host memory with the local compute injected by the test,
@@ -29,7 +33,7 @@ namespace apds {
 namespace shard {
 
 constexpr int MSG_ROUND = 1024;   // the query all-gather moves multiples of this many rows per rank
-constexpr int KMAX = 16;
+constexpr int KMAX = 4096;   // per-query neighbours a slot may carry: a bound on the exchange buffers, not on the scan (which serves any k, above 16 in pages of 16)
 
 struct ShardError : std::runtime_error {
     int code;
@@ -63,6 +67,12 @@ struct Transport {
     virtual void all_gather(const void* send, void* recv, size_t bytes, void* stream) = 0;
     // to rank p: send[soff[p] .. +sbytes[p]); from rank p: rbytes[p] bytes to recv + roff[p]
     virtual void all_to_all(const void* send, const size_t* soff, const size_t* sbytes, void* recv, const size_t* roff, const size_t* rbytes, void* stream) = 0;
+    // buf[0 .. bytes) of rank `root` replaces buf on every rank. `scratch` holds world * bytes (used by the default form only: an
+    // all-gather of which block `root` is kept - what a transport without a native broadcast does).
+    virtual void broadcast(void* buf, size_t bytes, int root, void* scratch, Device& dev, void* stream) {
+        all_gather(buf, scratch, bytes, stream);
+        if (bytes) dev.copy(buf, static_cast<char*>(scratch) + (size_t)root * bytes, bytes, stream);
+    }
 };
 
 // A communicator supplied by the host program as two callbacks on HOST buffers (gloo, MPI, a test harness): the device data is
@@ -154,7 +164,7 @@ public:
     const char* transport_name() const { return tr.name(); }
 
     Slot* slot_create(int max_queries, int kmax) {
-        if (kmax < 1 || kmax > KMAX) throw ShardError(-215, "1 <= k <= 16");
+        if (kmax < 1 || kmax > KMAX) throw ShardError(-215, "1 <= k <= 4096");
         Slot* s = new Slot();
         try {
             const size_t w = (size_t)tr.world;
@@ -251,6 +261,38 @@ public:
         tr.all_to_all(s.local, soff.data(), sbytes.data(), s.recv, roff.data(), rbytes.data(), stream);
         if (nq) dev.merge(s.recv, w, nq, k, dst, stream);
         return dst;
+    }
+
+    // Strong-scaling form on slot `s`: every rank holds the SAME nq queries (root < 0), or rank `root`'s rows are broadcast first (the other
+    // ranks' q_rows64 is ignored; nq must be the same number on every rank either way). Every rank scans its own shard, the [nq, k] key lists
+    // are all-gathered and merged: out_keys [nq, k] on EVERY rank = the single-device answer for the whole frame.
+    uint64_t* replicated(Slot& s, const void* q_rows64, int nq, int root, int k, void* out_keys, void* stream) {
+        if (k < 1 || k > s.kmax) throw ShardError(-215, "k outside the slot's range");
+        if (nq < 0 || root >= tr.world) throw ShardError(-215, "bad query count / root");
+        if (round_up(nq) > s.pad) throw ShardError(-215, "exchange slot holds " + std::to_string(s.pad) + " query rows, this frame has " + std::to_string(nq));
+        const int w = tr.world;
+        uint64_t* dst = out_keys ? static_cast<uint64_t*>(out_keys) : s.merged;
+        s.nq = s.total = nq;
+        if (!nq) return dst;
+        const bool exchange = w > 1 || force_exchange;
+        if (root < 0 || tr.rank == root || !exchange) dev.copy(s.all_q, q_rows64, (size_t)nq * 64, stream);
+        if (root >= 0 && exchange) tr.broadcast(s.all_q, (size_t)round_up(nq) * 64, root, s.gathered, dev, stream);
+        dev.topk(s.all_q, nq, rows, n_rows, index_base, k, s.local, stream);
+        if (!exchange) {
+            dev.copy(dst, s.local, (size_t)nq * k * 8, stream);
+            return dst;
+        }
+        tr.all_gather(s.local, s.recv, (size_t)nq * k * 8, stream);   // recv = [world, nq, k]: the layout the merge reads
+        dev.merge(s.recv, w, nq, k, dst, stream);
+        return dst;
+    }
+    uint64_t* knn_replicated(const void* q_rows64, int nq, int root, int k, void* out_keys, void* stream) {
+        if (!own || own->pad < round_up(nq) || own->kmax < k) {
+            if (own) slot_destroy(own);
+            own = nullptr;
+            own = slot_create(nq, std::max(k, 2));
+        }
+        return replicated(*own, q_rows64, nq, root, k, out_keys, stream);
     }
 
     // the one-call form: counts == nullptr exchanges them first (a host synchronisation on most transports)

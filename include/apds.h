@@ -241,8 +241,15 @@ int apds_shard_info(const void* shard, int* rank, int* world, int64_t* n_rows, u
 /* Collective: every rank's query count of one frame, as host ints (counts[world]). Synchronises `stream` on the RCCL transport. */
 int apds_shard_counts(void* shard, int n_query, int* counts, void* stream);
 /* Collective: out_keys_dev = n_query x k uint64 ((distance << 32) | global row; 0xFFFF... when absent) for THIS rank's queries over the
- * whole train set. counts: every rank's n_query (apds_shard_counts), or NULL to exchange them inside the call. 1 <= k <= 16. */
+ * whole train set. counts: every rank's n_query (apds_shard_counts), or NULL to exchange them inside the call. Any k >= 1 the
+ * single-device scan serves (k <= 2 tuned, above 16 in pages of 16); the exchange buffers bound it at 4096. */
 int apds_shard_knn(void* shard, const void* q_rows64_dev, int n_query, const int* counts, int k, void* out_keys_dev, void* stream);
+/* Strong-scaling (latency) form, SURVEY 8e's literal shape. Collective: ONE frame whose n_query queries are the same on every rank -
+ * root < 0: every rank passes them (each extracted the frame itself: ~1.5 ms, no communication); root >= 0: rank `root`'s rows are broadcast
+ * first, the other ranks' q_rows64_dev is ignored (n_query must still be the same number everywhere). Every rank scans its shard (1 / world of
+ * the rows), the [n_query, k] key lists are ALL-GATHERED and merged by u64 min: out_keys_dev = n_query x k keys of the whole frame over the
+ * whole train set on EVERY rank, equal to apds_dev_hamming_topk over the unsharded rows bit for bit. */
+int apds_shard_knn_replicated(void* shard, const void* q_rows64_dev, int n_query, int root, int k, void* out_keys_dev, void* stream);
 /* The same in three steps on per-frame exchange slots, for pipelines that keep two frames in flight: frame i+1's gather (collective) may be
  * issued - on another stream - before frame i's exchange_merge (collective), so it travels under frame i's scan (no collective). */
 int apds_shard_slot_create(void* shard, int max_queries_per_rank, int kmax, void** slot);

@@ -100,6 +100,9 @@ int shardhost_counts(void* h, int nq, int* counts) {
 int shardhost_knn(void* h, const void* q, int nq, const int* counts, int k, void* out_keys) {
     return guarded([&] { static_cast<Handle*>(h)->m->knn(q, nq, counts, k, out_keys, nullptr); });
 }
+int shardhost_knn_replicated(void* h, const void* q, int nq, int root, int k, void* out_keys) {
+    return guarded([&] { static_cast<Handle*>(h)->m->knn_replicated(q, nq, root, k, out_keys, nullptr); });
+}
 int shardhost_slot_create(void* h, int max_queries, int kmax, void** slot) {
     return guarded([&] { *slot = static_cast<Handle*>(h)->m->slot_create(max_queries, kmax); });
 }

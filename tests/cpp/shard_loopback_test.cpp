@@ -159,7 +159,24 @@ void rank_main(int rank, int world, int transport, const apds_comm_id* id, const
     OK(apds_shard_slot_destroy(shard, slotA));
     OK(apds_shard_slot_destroy(shard, slotB));
     OK(apds_stream_destroy(side));
-    // an oversize frame must be refused by every rank alike, not hang
+    // (4) the strong-scaling form: ONE frame (rank 0's queries) known to every rank, or brought by rank `world - 1` alone and broadcast;
+    // every rank must end with the whole frame's single-device keys
+    {
+        const std::vector<uint8_t>& q0 = (*queries)[0];
+        const int n0 = (int)(q0.size() / 64);
+        const std::vector<uint64_t>& expect0 = (*want)[0];
+        DevBuf dq0(q0.size() + 64), dr((size_t)n0 * k * 8 + 64);
+        OK(apds_dev_upload(dq0.p, q0.data(), q0.size(), nullptr));
+        std::vector<uint64_t> rep((size_t)n0 * k);
+        OK(apds_shard_knn_replicated(shard, dq0.p, n0, -1, k, dr.p, nullptr));
+        OK(apds_dev_download(rep.data(), dr.p, rep.size() * 8, nullptr));
+        CHECK(rep == expect0, "rank %d/%d: replicated-form keys differ from the single-device keys", rank, world);
+        std::fill(rep.begin(), rep.end(), 0);
+        const int root = world - 1;
+        OK(apds_shard_knn_replicated(shard, rank == root ? dq0.p : nullptr, n0, root, k, dr.p, nullptr));
+        OK(apds_dev_download(rep.data(), dr.p, rep.size() * 8, nullptr));
+        CHECK(rep == expect0, "rank %d/%d: broadcast-form keys differ from the single-device keys", rank, world);
+    }
     OK(apds_shard_destroy(shard));
     OK(apds_thread_release());
 }
@@ -235,6 +252,71 @@ void table_shard_case() {
     printf("table shard (apds_db_shard): world 2 ... %s\n", failures.load() ? "FAILED" : "ok");
 }
 
+// `shard_loopback_test lag`: the event-lifetime race of round 3, deterministically. Started with APDS_TEST_LOOPBACK_LAG="0:300" rank 0
+// sleeps 300 ms between the closing barrier of every collective and its closing hipStreamWaitEvent on the peers' `done` events; rank 1
+// leaves its last collective at once, destroys its shard and releases its thread context while rank 0 is still asleep. With the events
+// owned by the rank's transport (the round-3 bug) rank 0 then waits on destroyed events ("invalid resource handle"); they belong to the
+// hub, which lives until the last rank detaches.
+int lag_case() {
+    const int world = 2, nt = 4000, k = 2, nq = 300;
+    std::vector<uint8_t> db = random_rows(nt, 0x1A6);
+    std::vector<std::vector<uint8_t>> queries((size_t)world);
+    std::vector<std::vector<uint64_t>> want((size_t)world);
+    for (int r = 0; r < world; r++) {
+        queries[(size_t)r] = make_queries(db, nt, nq, 0x1A60 + (uint64_t)r);
+        want[(size_t)r] = single_device_keys(queries[(size_t)r], nq, db, nt, k);
+    }
+    apds_comm_id id;
+    OK(apds_comm_id_create(APDS_TRANSPORT_LOOPBACK, &id));
+    auto body = [&](int rank) {
+        OK(apds_set_device(0));
+        const int lo = rank * nt / world, hi = (rank + 1) * nt / world;
+        DevBuf rows((size_t)(hi - lo) * 64), dq((size_t)nq * 64), dk((size_t)nq * k * 8);
+        OK(apds_dev_upload(rows.p, db.data() + (size_t)lo * 64, (size_t)(hi - lo) * 64, nullptr));
+        OK(apds_dev_upload(dq.p, queries[(size_t)rank].data(), (size_t)nq * 64, nullptr));
+        OK(apds_stream_synchronize(nullptr));
+        void* shard = nullptr;
+        OK(apds_shard_create(&shard, rank, world, APDS_TRANSPORT_LOOPBACK, &id, nullptr, rows.p, hi - lo, (uint32_t)lo));
+        std::vector<int> counts = {nq, nq};
+        for (int rep = 0; rep < 3; rep++) OK(apds_shard_knn(shard, dq.p, nq, counts.data(), k, dk.p, nullptr));
+        std::vector<uint64_t> got((size_t)nq * k);
+        OK(apds_dev_download(got.data(), dk.p, got.size() * 8, nullptr));
+        CHECK(got == want[(size_t)rank], "lag case: rank %d keys differ", rank);
+        OK(apds_shard_destroy(shard));   // rank 1 gets here while rank 0 still sleeps in front of its closing waits
+        OK(apds_thread_release());
+    };
+    std::thread a(body, 0), b(body, 1);
+    a.join();
+    b.join();
+    // a second attachment of a live rank is refused and must leave the first attachment usable
+    {
+        apds_comm_id id2;
+        OK(apds_comm_id_create(APDS_TRANSPORT_LOOPBACK, &id2));
+        OK(apds_set_device(0));
+        void *first = nullptr, *second = nullptr;
+        std::thread peer([&] {
+            OK(apds_set_device(0));
+            void* sh = nullptr;
+            OK(apds_shard_create(&sh, 1, 2, APDS_TRANSPORT_LOOPBACK, &id2, nullptr, nullptr, 0, 0));
+            int c[2] = {-1, -1};
+            OK(apds_shard_counts(sh, 5, c, nullptr));
+            CHECK(c[0] == 3 && c[1] == 5, "double-attach case: peer counts %d %d", c[0], c[1]);
+            OK(apds_shard_destroy(sh));
+            OK(apds_thread_release());
+        });
+        OK(apds_shard_create(&first, 0, 2, APDS_TRANSPORT_LOOPBACK, &id2, nullptr, nullptr, 0, 0));
+        const int rc = apds_shard_create(&second, 0, 2, APDS_TRANSPORT_LOOPBACK, &id2, nullptr, nullptr, 0, 0);
+        CHECK(rc == -5 && !second, "a second attachment of rank 0 returned %d", rc);
+        int c[2] = {-1, -1};
+        OK(apds_shard_counts(first, 3, c, nullptr));   // the first attachment's post and events are intact
+        CHECK(c[0] == 3 && c[1] == 5, "double-attach case: counts %d %d", c[0], c[1]);
+        peer.join();
+        OK(apds_shard_destroy(first));
+    }
+    printf("lag + double attach ... %s\n%d failed\n", failures.load() ? "FAILED" : "ok", failures.load());
+    return failures.load() ? 1 : 0;
+}
+
 }  // namespace
 
 // `shard_loopback_test fuzz <cases> <seed>`: random worlds (1 .. 6 ranks), row counts from one row up (shards without rows included), query
@@ -262,10 +344,13 @@ int main(int argc, char** argv) {
         fprintf(stderr, "no HIP device\n");
         return 2;
     }
+    if (argc >= 2 && std::string(argv[1]) == "lag") return lag_case();
     if (argc >= 3 && std::string(argv[1]) == "fuzz") return fuzz(atoi(argv[2]), argc >= 4 ? strtoull(argv[3], nullptr, 10) : 1);
     run_world(2, APDS_TRANSPORT_LOOPBACK, 6001, {700, 1300}, 2, "loopback");
     run_world(4, APDS_TRANSPORT_LOOPBACK, 40003, {1500, 0, 2300, 37}, 2, "loopback");
     run_world(3, APDS_TRANSPORT_LOOPBACK, 5000, {64, 65, 1}, 1, "loopback");
+    run_world(3, APDS_TRANSPORT_LOOPBACK, 20011, {300, 0, 77}, 24, "loopback, k above 16 (paged scan, any-k merge)");
+    run_world(2, APDS_TRANSPORT_LOOPBACK, 9001, {130, 200}, 3, "loopback, k = 3");
     run_world(1, APDS_TRANSPORT_RCCL, 9000, {1100}, 2, "rccl (world 1: communicator, all-gather, send/recv group)");
     table_shard_case();
     int ver = 0;

@@ -31,7 +31,7 @@ def test_threads_as_ranks_equal_the_single_device_keys(gpu_pkg, tmp_path):
     out = subprocess.run([_build(tmp_path)], capture_output=True, text=True, timeout=600)
     print(out.stdout, out.stderr)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert out.stdout.count("... ok") == 5 and "0 failed" in out.stdout
+    assert out.stdout.count("... ok") == 7 and "0 failed" in out.stdout
     assert "rccl version code" in out.stdout and "rccl version code 0" not in out.stdout
 
 
@@ -40,9 +40,21 @@ def test_random_worlds_over_the_loopback_transport(gpu_pkg, tmp_path):
     # `fuzz <cases> <seed>`: 1 .. 6 ranks, one row and up (shards without rows), query counts around the message rounding, k = 1 / 2,
     # every form (one call, counts ahead, split with two frames in flight) against the single-device keys. 3000 worlds of this seed found
     # the one bug of the kind so far (a rank destroying its events while a slower peer still waited on them, case 898).
-    out = subprocess.run([_build(tmp_path), "fuzz", "1000", "11"], capture_output=True, text=True, timeout=900)
+    # (150 worlds here as a smoke run; the race itself is pinned deterministically below. profiles/r03/shard_loopback_fuzz.txt: 6000 worlds.)
+    out = subprocess.run([_build(tmp_path), "fuzz", "150", "11"], capture_output=True, text=True, timeout=900)
     print(out.stdout[-3000:], out.stderr[-3000:])
-    assert out.returncode == 0 and out.stdout.count("... ok") == 1000 and "0 failed" in out.stdout
+    assert out.returncode == 0 and out.stdout.count("... ok") == 150 and "0 failed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_a_lagging_rank_outlives_its_peers_shard(gpu_pkg, tmp_path):
+    # the event-lifetime race of round 3 made deterministic: rank 0 is held for 300 ms in front of the closing event waits of every
+    # collective (test hook APDS_TEST_LOOPBACK_LAG) while rank 1 destroys its shard; then: a second attachment of a live rank is refused
+    # without harming the first
+    env = dict(os.environ, APDS_TEST_LOOPBACK_LAG="0:300")
+    out = subprocess.run([_build(tmp_path), "lag"], capture_output=True, text=True, timeout=300, env=env)
+    print(out.stdout[-3000:], out.stderr[-3000:])
+    assert out.returncode == 0 and "lag + double attach ... ok" in out.stdout and "0 failed" in out.stdout
 
 
 @pytest.mark.gpu

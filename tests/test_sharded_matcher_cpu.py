@@ -86,6 +86,11 @@ class HostShard:
         self.check(self.L.shardhost_knn(self.h, q64.ctypes.data_as(C.c_void_p), len(q64), ca, k, out.ctypes.data_as(C.c_void_p)))
         return out
 
+    def knn_replicated(self, q64, nq, root, k):
+        out = np.zeros((nq, k), np.uint64)
+        self.check(self.L.shardhost_knn_replicated(self.h, q64.ctypes.data_as(C.c_void_p) if q64 is not None else None, nq, root, k, out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def slot(self, max_queries, kmax):
         s = C.c_void_p()
         self.check(self.L.shardhost_slot_create(self.h, max_queries, kmax, C.byref(s)))
@@ -142,6 +147,18 @@ def _worker(rank, world, port, nt, nqs, result_dir, so):
     # a frame larger than the slot is refused on every rank alike (the size rule depends on the counts only), before any collective
     big = [c + 5000 for c in counts]
     ok = ok and m.gather(slots[0], np.zeros((big[rank], 64), np.uint8), big) == -215
+    # the strong-scaling form (SURVEY 8e's literal shape): ONE frame's queries (a seed every rank knows), replicated on every rank or brought
+    # by the last rank alone and broadcast; per-shard top-k, ALL-GATHER of the key lists, merge: every rank ends with the whole answer.
+    # k = 3 also goes through a merge width that is not a power of two.
+    fq, _ = pkg.synth.make_queries(db, 41, seed=77)
+    fq[0] = db[7]
+    fq64 = np.zeros((len(fq), 64), np.uint8)
+    fq64[:, :61] = fq
+    for kk in (2, 3):
+        f_idx, f_d = oracle.knn_hamming(fq, db, kk)
+        f_want = (f_d.astype(np.uint64) << np.uint64(32)) | f_idx.astype(np.uint64)
+        ok = ok and np.array_equal(m.knn_replicated(fq64, len(fq64), -1, kk), f_want)
+        ok = ok and np.array_equal(m.knn_replicated(fq64 if rank == world - 1 else None, len(fq64), world - 1, kk), f_want)
     want_idx, want_d = oracle.knn_hamming(q, db, 2)
     got_idx = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
     got_d = (keys >> np.uint64(32)).astype(np.int64)
