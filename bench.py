@@ -365,24 +365,50 @@ def main():
         check(L.apds_dev_timing_enable(0))
         timers = {n: pkg._lib.kernel_ms(n) for n in ("hamming_topk", "hamming_topk_sample", "akaze_extract", "ransac_score")}
     else:
-        if args.warmup:
-            pipe.run(frames, args.warmup, filter_strength=args.filter_strength)
-        fence()
-        t0 = time.perf_counter()
-        stats, timers = pipe.run(frames, args.steps, filter_strength=args.filter_strength, timing=True)
-        fence()
-        elapsed = time.perf_counter() - t0
+        # The library's own pipeline (apds_pipeline_*, csrc/pipeline.cpp): the timed loop below makes C calls only - submit K frames, poll K
+        # results - no torch op, no python thread; the stage threads, streams, events and slots live inside libapds_hip.so.
+        FR = pkg._lib.FrameResult
+
+        def stream_frames(handle, fargs, count):
+            res, out = FR(), []
+            for i in range(count):
+                ptr, stride, on_dev = fargs[i % len(fargs)]
+                check(L.apds_pipeline_submit(handle, ptr, stride, on_dev, None))
+            for i in range(count):
+                check(L.apds_pipeline_poll(handle, C.byref(res), 1))
+                if res.status != 0:
+                    raise RuntimeError(f"frame {res.frame} failed in the pipeline: status {res.status}")
+                out.append(dict(n_keypoints=res.n_keypoints, n_matches=res.n_matches, n_inliers=res.n_inliers, H=True if res.homography_found else None))
+            return out
+
+        def timed_stream(frame_list, warm):
+            handle = pipe.prepare(frame_list[0].shape, filter_strength=args.filter_strength, timing=True)
+            fargs = [pipe.frame_args(f) for f in frame_list]
+            if warm:
+                stream_frames(handle, fargs, warm)
+            if os.environ.get("APDS_BENCH_FRESH_PIPE") == "1":      # A/B: fresh stage threads for the timed region (what the python pipeline of rounds 1-3 had)
+                pipe._destroy_native()
+                handle = pipe.prepare(frame_list[0].shape, filter_strength=args.filter_strength, timing=True)
+            pipe.stats(reset=True)
+            fence()
+            t_start = time.perf_counter()
+            got = stream_frames(handle, fargs, args.steps)
+            fence()
+            return time.perf_counter() - t_start, got, pipe.stats(reset=True)
+
+        elapsed, stats, st = timed_stream(frames, args.warmup)
+        timers = {"hamming_topk": (st.hamming_topk_ms, st.hamming_topk_launches), "hamming_topk_sample": (st.hamming_topk_sample_ms, st.hamming_topk_sample_launches),
+                  "akaze_extract": (st.akaze_extract_ms, st.akaze_extract_calls), "ransac_score": (st.ransac_score_ms, st.ransac_score_launches)}
+        pipe.gap_log = [float(st.match_gaps_first_ms[i]) for i in range(min(16, st.match_gaps))]
+        pipe.gap_mean = float(st.match_gap_mean_ms) if st.match_gaps else None
+        if st.match_lds_cap_set_at_frame >= 0:
+            pipe.cap_events = [dict(frame=int(st.match_lds_cap_set_at_frame), gaps_ms=[round(float(g), 2) for g in st.match_lds_cap_gaps_ms])]
     elapsed_host = None
     if args.host_frames and not args.serial:
-        # the same K steps with every frame coming from pinned host memory: the extraction worker uploads it (hipMemcpyAsync on its own
+        # the same K steps with every frame coming from pinned host memory: an extraction worker uploads it (hipMemcpyAsync on its own
         # stream, into a per-slot device buffer) in front of the extraction, so frame i+1's PCIe copy travels under frame i's match
         host_frames = [torch.from_numpy(f).pin_memory() for f in frames_np]
-        pipe.run(host_frames, max(args.warmup, 2), filter_strength=args.filter_strength)
-        fence()
-        t0 = time.perf_counter()
-        stats_host, _ = pipe.run(host_frames, args.steps, filter_strength=args.filter_strength)
-        fence()
-        elapsed_host = time.perf_counter() - t0
+        elapsed_host, stats_host, _ = timed_stream(host_frames, max(args.warmup, 2))
         assert [s["n_keypoints"] for s in stats_host] == [s["n_keypoints"] for s in stats], "host-frame run differs from the resident run"
 
     def max_over_ranks(v):
@@ -457,10 +483,10 @@ def main():
                        "tile": T, "db_rows": NDB, "db_rows_per_gpu": rows_local,
                        "db_composition": ("all rows are AKAZE descriptors of images (shifted frames + %d blended variants), shuffled" % real_variants) if args.db == "real"
                                          else f"{P} AKAZE descriptors of the frames' shifted copies + {NDB - P} i.i.d. random rows", "frames_per_step": world, "parallelism": f"frame-dp{world}+db-shard{world}",
-                       "stage_overlap": "none (serial)" if args.serial else "extract (2 workers, alternate frames) | match (threshold pre-pass, main scan and record merge of consecutive frames on three streams) | homography, software-pipelined over frames",
+                       "stage_overlap": "none (serial)" if args.serial else "extract (2 workers, alternate frames) | match (threshold pre-pass, main scan and record merge of consecutive frames on three streams) | homography, software-pipelined over frames by the library's own host threads (apds_pipeline_*: the timed loop is K submits + K polls)",
                        "match_occupancy_cap": ({"lds_bytes": 55000, "set_at": pipe.cap_events[0]} if getattr(pipe, "cap_events", None) else
                                                {"lds_bytes": int(os.environ.get("APDS_MATCH_LDS_CAP", "0") or 0)}),
-                       "match_stream_gap_ms": (round(float(np.mean(pipe.gap_log)), 3) if getattr(pipe, "gap_log", None) else None),
+                       "match_stream_gap_ms": (round(pipe.gap_mean, 3) if getattr(pipe, "gap_mean", None) is not None else None),
                        "match_stream_gaps_ms_first16": ([round(float(g), 2) for g in pipe.gap_log[:16]] if getattr(pipe, "gap_log", None) else None),
                        "keypoints_per_frame": K, "matches_per_frame": float(np.mean([s["n_matches"] for s in stats])),
                        "inliers_per_frame": float(np.mean([s["n_inliers"] for s in stats])), "homography_found": all(s["H"] is not None for s in stats)},

@@ -31,6 +31,7 @@ SYMBOLS = [
     "apds_comm_id_create", "apds_shard_create", "apds_shard_destroy", "apds_shard_info", "apds_shard_counts", "apds_shard_knn", "apds_shard_knn_replicated", "apds_shard_slot_create",
     "apds_shard_slot_destroy", "apds_shard_gather", "apds_shard_scan", "apds_shard_exchange_merge", "apds_db_shard",
     "apds_dev_alloc", "apds_dev_release", "apds_dev_upload", "apds_dev_download", "apds_stream_synchronize",
+    "apds_pipeline_create", "apds_pipeline_submit", "apds_pipeline_poll", "apds_pipeline_stats", "apds_pipeline_destroy",
     "apds_dev_topk_state_create", "apds_dev_topk_state_destroy", "apds_dev_topk_prepass", "apds_dev_topk_scan", "apds_dev_topk_merge",
 ]
 
@@ -50,6 +51,32 @@ HOST_ALL_TO_ALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_siz
 
 class HostTransport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("all_gather", HOST_ALL_GATHER), ("all_to_all", HOST_ALL_TO_ALL)]
+
+
+class PipelineParams(C.Structure):
+    """apds_pipeline_params (include/apds.h)"""
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("channels", C.c_int), ("max_points", C.c_int), ("n_slots", C.c_int), ("extract_workers", C.c_int),
+                ("filter_strength", C.c_float), ("homography_method", C.c_int), ("reproj_threshold", C.c_double), ("max_iters", C.c_int),
+                ("confidence", C.c_double), ("timing", C.c_int), ("match_lds_cap", C.c_int), ("match_stream", C.c_void_p), ("debug_extract_delay_ms", C.c_double)]
+
+
+class FrameResult(C.Structure):
+    """apds_frame_result"""
+    _fields_ = [("frame", C.c_int64), ("status", C.c_int), ("n_keypoints", C.c_int), ("n_matches", C.c_int), ("n_inliers", C.c_int), ("homography_found", C.c_int),
+                ("H", C.c_double * 9)]
+
+
+class PipelineCounters(C.Structure):
+    """apds_pipeline_counters"""
+    _fields_ = [("frames_submitted", C.c_int64), ("frames_done", C.c_int64),
+                ("hamming_topk_ms", C.c_double), ("hamming_topk_sample_ms", C.c_double), ("akaze_extract_ms", C.c_double), ("ransac_score_ms", C.c_double),
+                ("hamming_topk_launches", C.c_int), ("hamming_topk_sample_launches", C.c_int), ("akaze_extract_calls", C.c_int), ("ransac_score_launches", C.c_int),
+                ("match_gap_mean_ms", C.c_double), ("match_gaps", C.c_int), ("match_gaps_first_ms", C.c_float * 16),
+                ("match_lds_cap_bytes", C.c_int), ("match_lds_cap_set_at_frame", C.c_int), ("match_lds_cap_gaps_ms", C.c_float * 6),
+                ("extract_workers", C.c_int), ("slots", C.c_int), ("split_scan", C.c_int), ("world", C.c_int)]
+
+
+PIPELINE_NOT_READY = 1
 
 
 class ApdsError(RuntimeError):
@@ -159,6 +186,11 @@ def lib():
             "apds_dev_upload": (i, [vp, vp, sz, vp]),
             "apds_dev_download": (i, [vp, vp, sz, vp]),
             "apds_stream_synchronize": (i, [vp]),
+            "apds_pipeline_create": (i, [pp, vp, i64, u32, vp, vp, i64, C.POINTER(PipelineParams)]),
+            "apds_pipeline_submit": (i, [vp, vp, sz, i, C.POINTER(i64)]),
+            "apds_pipeline_poll": (i, [vp, C.POINTER(FrameResult), i]),
+            "apds_pipeline_stats": (i, [vp, C.POINTER(PipelineCounters), i]),
+            "apds_pipeline_destroy": (i, [vp]),
             "apds_dev_topk_state_create": (i, [pp]),
             "apds_dev_topk_state_destroy": (i, [vp]),
             "apds_dev_topk_prepass": (i, [vp, vp, i, vp, i64, u32, i, vp]),

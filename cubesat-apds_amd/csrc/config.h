@@ -31,6 +31,11 @@ struct Config {
     int ransac_batch;     // APDS_RANSAC_BATCH first speculated batch of RANSAC hypotheses (512)
     int pnp_batch;        // APDS_PNP_BATCH    hypotheses per PnP batch (2048)
     int l2_sample_div;    // APDS_L2_SAMPLE_DIV  the bf16 screen's threshold sample = rows / this (12)
+    // ---- streamed frame pipeline (apds_pipeline_*)
+    int pipe_extract_workers;   // APDS_EXTRACT_WORKERS  extraction threads when the caller's params say 0 (2)
+    int pipe_match_split;       // APDS_MATCH_SPLIT      1: pre-pass / main scan / merge of consecutive frames on three streams (one GPU)
+    int pipe_adaptive_cap;      // APDS_ADAPTIVE_CAP     1: the starvation watch may cap the main scan's occupancy
+    int pipe_prio;              // APDS_PIPE_PRIO        stream priority of the short-kernel stages (-1 = high)
     // ---- test hooks
     int loopback_lag_rank, loopback_lag_ms;   // APDS_TEST_LOOPBACK_LAG="rank:ms"  that rank sleeps before the closing waits of every loopback collective
 };

@@ -35,6 +35,8 @@ void rgba_to_bgra_device(const uint8_t* rgba, size_t n_pixels, uint8_t* bgra, hi
 // ingest.hip
 std::atomic<int>& match_lds_cap();   // match_hamming.hip: occupancy cap of the main Hamming scan
 std::atomic<int>& last_scan_launch_lds();
+void set_thread_scan_cap(int bytes);   // occupancy cap of the scans THIS thread launches (-1: the process-wide one)
+int count_nonzero_device(const uint8_t* bytes, int n, int* count_dev, hipStream_t s);   // misc.hip: synchronises s
 void band_merger_device(const float* r, const float* g, const float* b, size_t n, const double* mm, int bgra, uint8_t* out, hipStream_t s);
 void warp_perspective_device(const uint8_t* src, int rows, int cols, const double* M, int dst_rows, int dst_cols, uint8_t* dst, hipStream_t s);
 

@@ -809,6 +809,10 @@ std::atomic<int>& match_lds_cap() {
     static std::atomic<int> cap{config().match_lds_cap};
     return cap;
 }
+// The same cap for the scans launched by ONE host thread (the streamed pipeline's match worker, when its starvation watch decides to
+// cap): -1 = the process-wide value applies.
+static thread_local int tl_scan_cap = -1;
+void set_thread_scan_cap(int bytes) { tl_scan_cap = bytes; }
 
 // Work items are (64*T queries) x (rows_per_chunk train rows) per wave. Items are kept small enough that the
 // grid is many dispatch rounds deep (the block scheduler then balances the tail), but not so small that the
@@ -849,7 +853,7 @@ static void launch_topk(const void* q, int nq, const void* t, long long nt, cons
     // workgroups resident per CU (160 KB / cap). Two waves per SIMD already issue at full VALU rate; capping there leaves
     // registers, wave slots and the rest of the LDS free, so the short kernels of the other pipeline stages are dispatched
     // at once instead of waiting for a match wave to retire. Applies to every variant of the scan (all T, all K).
-    const size_t cap = (size_t)std::max(0, match_lds_cap().load(std::memory_order_relaxed));
+    const size_t cap = (size_t)std::max(0, tl_scan_cap >= 0 ? tl_scan_cap : match_lds_cap().load(std::memory_order_relaxed));
     last_scan_launch_lds().store((int)cap, std::memory_order_relaxed);
     if constexpr (K == 16) {
         if (floor_keys) {   // one page of a paged scan

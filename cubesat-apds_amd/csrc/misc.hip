@@ -35,6 +35,26 @@ __global__ void rgba_to_bgra_kernel(const uint32_t* __restrict__ in, size_t n, u
     }
 }
 
+// set bytes of a mask (the inlier count of a homography's mask: the pipeline's per-frame figure)
+__global__ void count_nonzero_kernel(const uint8_t* __restrict__ b, int n, int* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
+    int c = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c += b[i] != 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+
+int count_nonzero_device(const uint8_t* bytes, int n, int* count_dev, hipStream_t s) {
+    if (n <= 0) return 0;
+    HIP_CHECK(hipMemsetAsync(count_dev, 0, sizeof(int), s));
+    hipLaunchKernelGGL(count_nonzero_kernel, dim3(std::min(64, ceil_div(n, 256))), dim3(256), 0, s, bytes, n, count_dev);
+    HIP_CHECK(hipGetLastError());
+    int* host = ctx().pinned_ints(1);
+    HIP_CHECK(hipMemcpyAsync(host, count_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    return host[0];
+}
+
 void points_from_matches_device(const apds_keypoint* kp1, int n1, const apds_keypoint* kp2, int n2, const apds_dmatch* m, int nm,
                                 int bug_compatible, float* pts1, float* pts2, int* err_flag, hipStream_t s) {
     if (nm <= 0) return;

@@ -40,6 +40,10 @@ const Config& config() {
         k.ransac_batch = env("APDS_RANSAC_BATCH", 512);
         k.pnp_batch = env("APDS_PNP_BATCH", 2048);
         k.l2_sample_div = std::max(1, env("APDS_L2_SAMPLE_DIV", 12));
+        k.pipe_extract_workers = std::max(1, env("APDS_EXTRACT_WORKERS", 2));
+        k.pipe_match_split = env("APDS_MATCH_SPLIT", 1);
+        k.pipe_adaptive_cap = env("APDS_ADAPTIVE_CAP", 1);
+        k.pipe_prio = env("APDS_PIPE_PRIO", -1);
         k.loopback_lag_rank = -1;
         k.loopback_lag_ms = 0;
         if (const char* lag = getenv("APDS_TEST_LOOPBACK_LAG")) {

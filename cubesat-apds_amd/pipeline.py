@@ -1,4 +1,4 @@
-"""Device-resident composition of the hot path and its multi-GPU form.
+"""Device-resident composition of the hot path and its multi-GPU form (python fronts of the C ABI's apds_shard_* and apds_pipeline_*).
 
 frame (u8, HBM) -> AKAZE -> descriptors -> Hamming top-2 against a resident descriptor DB -> ratio test ->
 matched points -> RANSAC homography.  The reference only chains these steps inside unit tests
@@ -16,7 +16,6 @@ torch is used for device buffers and streams only; every compute step is a libap
 (RCCL; or the host-callback transport over a gloo group when several ranks share one GPU).
 """
 import ctypes as C
-import time
 
 import numpy as np
 import torch
@@ -304,387 +303,135 @@ class FramePipeline:
 
 
 class StreamedFramePipeline:
-    """The same path as FramePipeline, software-pipelined over a stream of frames: three host threads, each with its own
-    HIP stream and device workspace (the C ABI is re-entrant per thread): extract | match | ratio filter + point gather +
-    homography. Frame i+1 is extracted (HBM-bound stencils, raised wave priority) while frame i is matched
-    (integer-VALU-bound), and frame i-1's filter/RANSAC host round trips hide behind both. The match stage never
-    synchronises with the host (single GPU), so match kernels of consecutive frames queue back to back. Stages hand
-    over through HIP events; results come back in frame order."""
+    """The same path as FramePipeline, software-pipelined over a stream of frames - a FRONT of the library's own pipeline
+    (apds_pipeline_create / _submit / _poll / _stats / _destroy, csrc/pipeline.cpp): the stage threads (two extraction workers, the match
+    worker with its three streams, the homography worker), their HIP streams, events, slots and the starvation watch live inside
+    libapds_hip.so, so a Rust or C++ host gets the same frames/s from four calls. What this class adds: the torch tensors behind the
+    pointers (train rows, their keypoints, frames), the transport choice for a sharded DB (ShardedMatcher), and results as dicts."""
 
     def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=6, reserve_cus=0,
                  n_cus=256, meta_group=None, extract_workers=None):
         import os
-        import queue
-        self.queue = queue
-        # Extraction is ~100 short launches and ~8 count read-backs per frame: 3 ms of GPU work whose WALL time, once the
-        # match kernel owns every CU, is set by dispatch and host round-trip latency (measured 8-33 ms depending on the
-        # box). Two workers extract alternate frames on two streams, so a frame may take up to two match periods of wall
-        # time before extraction paces the pipeline. Each worker owns its share of the slots (a shared pool would let one
-        # worker run ahead with every slot while the ordering thread waits for the other's frame).
-        self.extract_workers = max(1, int(extract_workers if extract_workers is not None else os.environ.get("APDS_EXTRACT_WORKERS", "2")))
-        slots = max(slots, 2 * self.extract_workers)
         self.dev = torch.device(device)
         self.matcher = ShardedMatcher(db_rows64, index_base, group, meta_group=meta_group)
-        self._masked_stream_handle = None
-        self.cap_bytes = 0                # occupancy cap this pipeline runs its scans with (set by the starvation watch)
         self.n_db = db_xy.shape[0]
-        kp = torch.zeros((self.n_db, 7), dtype=torch.float32, device=self.dev)
+        kp = torch.zeros((self.n_db, 7), dtype=torch.float32, device=self.dev)     # 28-byte cv::KeyPoint rows of ALL train rows (x, y used)
         kp[:, 0:2] = db_xy
         self.db_kp = kp
         self.cap = max_points
-        self.slots = []
-        for _ in range(slots):
-            s = dict(kps=torch.empty((self.cap, 7), dtype=torch.float32, device=self.dev),
-                     desc=torch.empty((self.cap, 64), dtype=torch.uint8, device=self.dev),
-                     matches=torch.empty((self.cap, 4), dtype=torch.int32, device=self.dev),
-                     p1=torch.empty((self.cap, 2), dtype=torch.float32, device=self.dev),
-                     p2=torch.empty((self.cap, 2), dtype=torch.float32, device=self.dev),
-                     mask=torch.empty(self.cap, dtype=torch.uint8, device=self.dev),
-                     keys=torch.empty((self.cap, 2), dtype=torch.int64, device=self.dev), keys_view=None,
-                     ev_extract=torch.cuda.Event(), ev_match=torch.cuda.Event(), K=0, M=0, index=0,
-                     ev_mstart=torch.cuda.Event(enable_timing=True), ev_mend=torch.cuda.Event(enable_timing=True),
-                     ev_pre=torch.cuda.Event(), ev_scan=torch.cuda.Event(), topk_state=None,
-                     owner=len(self.slots) % self.extract_workers,
-                     gq=self.matcher.make_buffers(self.cap) if self.matcher.world > 1 else None)
-            self.slots.append(s)
-        # the match kernel alone fills every CU for ~30 ms; the short extraction / homography kernels get the high-priority
-        # queues so that their blocks are dispatched as soon as match workgroups retire
-        hp = int(os.environ.get("APDS_PIPE_PRIO", "-1"))      # priority of the short-kernel streams (extraction, homography, query gather)
-        self.streams = [torch.cuda.Stream(self.dev, priority=hp), torch.cuda.Stream(self.dev, priority=0), torch.cuda.Stream(self.dev, priority=hp)]
-        # Optional (APDS_MATCH_WORKERS=2, single GPU only): two match workers alternate frames on two streams, so the short,
-        # poorly filled phases of one frame's match (threshold pre-pass, merges, grid tail) run under the other frame's
-        # main kernel: +1 % frames/s, but per-launch kernel times then overlap and no longer read as kernel efficiency,
-        # so the default is one worker. With a sharded DB the collectives must be issued in frame order by one thread.
-        self.extract_streams = [self.streams[0]] + [torch.cuda.Stream(self.dev, priority=hp) for _ in range(self.extract_workers - 1)]
-        # 1: cap the match kernel's occupancy when the match stream is seen starving (see match_worker); APDS_ADAPTIVE_CAP=0 turns it off
-        self.adaptive_cap = os.environ.get("APDS_ADAPTIVE_CAP", "1") != "0"
+        self.n_slots = slots
+        self.extract_workers = int(extract_workers if extract_workers is not None else os.environ.get("APDS_EXTRACT_WORKERS", "0") or 0)
+        self.debug_extract_delay = float(os.environ.get("APDS_DEBUG_EXTRACT_DELAY_MS", "0")) * 1e-3    # test hook (seconds)
+        self.cap_bytes = 0              # occupancy cap this pipeline's scans run with (set by the starvation watch; kept across re-creations)
         self.cap_events = []
-        self.gap_log = []                 # idle time of the match stream before each frame's match (ms), for diagnosis
-        self.debug_extract_delay = float(os.environ.get("APDS_DEBUG_EXTRACT_DELAY_MS", "0")) * 1e-3
-        self.match_workers = 2 if (group is None and os.environ.get("APDS_MATCH_WORKERS", "1") == "2") else 1
-        self.gather_stream = torch.cuda.Stream(self.dev, priority=hp) if self.matcher.world > 1 else None
-        # One GPU: the scan of a frame is issued as three launches groups on three streams (apds_dev_topk_prepass / _scan / _merge on a
-        # per-slot state object): frame i + 1's threshold pre-pass and frame i - 1's record merge run beside frame i's main scan, so the
-        # main scans follow each other on their stream without the ~0.8 ms of pre-pass, merge and dependent-launch gaps between them.
-        # Per-launch event timing stays on the main kernel only (its stream carries nothing else). APDS_MATCH_SPLIT=0: one call per frame.
-        self.split_match = self.matcher.world == 1 and os.environ.get("APDS_MATCH_SPLIT", "1") != "0" and self.match_workers == 1
-        if self.split_match:
-            self.pre_stream = torch.cuda.Stream(self.dev, priority=0)
-            self.merge_stream = torch.cuda.Stream(self.dev, priority=hp)
-            for s in self.slots:
-                h = C.c_void_p()
-                check(lib().apds_dev_topk_state_create(C.byref(h)))
-                s["topk_state"] = h
+        self.gap_log = []               # idle time of the match stream before each frame's main scan (ms; the first 16 of a run)
+        self.gap_mean = None
+        self._masked_stream_handle = None
+        self._pipe, self._key = None, None
         if reserve_cus > 0:
             # keep `reserve_cus` CUs (spread evenly over the CU index space) out of the MATCH stream only
             words = (n_cus + 31) // 32
             mask = np.full(words, 0xFFFFFFFF, np.uint32)
-            import os
-            layout = os.environ.get("APDS_CU_MASK_LAYOUT", "spread")
-            if layout == "tail":
-                cus = range(n_cus - reserve_cus, n_cus)
-            elif layout == "head":
-                cus = range(reserve_cus)
-            elif layout == "wordtop":      # the top bits of every 32-bit word
-                per = max(1, reserve_cus // words)
-                cus = [wd * 32 + 31 - b for wd in range(words) for b in range(per)]
-            else:
-                stride = n_cus // reserve_cus
-                cus = [r * stride for r in range(reserve_cus)]
-            for cu in cus:
+            stride = n_cus // reserve_cus
+            for cu in (r * stride for r in range(reserve_cus)):
                 mask[cu // 32] &= ~np.uint32(1 << (cu % 32))
             h = C.c_void_p()
             check(lib().apds_stream_create(0, _lib.ptr(mask), words, C.byref(h)))
             self._masked_stream_handle = h
-            self.streams[1] = torch.cuda.ExternalStream(h.value, device=self.dev)
-        # built AFTER the CU-mask block: the match workers launch on these, so the masked stream must already be in place
-        self.match_streams = [self.streams[1]] + [torch.cuda.Stream(self.dev, priority=0) for _ in range(self.match_workers - 1)]
         torch.cuda.synchronize()
 
+    # ---- the native handle ------------------------------------------------------------------------------------------------------------
+    def _ensure(self, shape, filter_strength, reproj_thr, max_iters, confidence, timing):
+        rows, cols = int(shape[0]), int(shape[1])
+        ch = 1 if len(shape) == 2 else int(shape[2])
+        key = (rows, cols, ch, float(filter_strength), float(reproj_thr), int(max_iters), float(confidence), bool(timing), float(self.debug_extract_delay),
+               int(self.cap_bytes))
+        if self._pipe is not None and key == self._key:
+            return
+        self._destroy_native()
+        p = _lib.PipelineParams(rows=rows, cols=cols, channels=ch, max_points=int(self.cap), n_slots=int(self.n_slots), extract_workers=int(self.extract_workers),
+                                filter_strength=float(filter_strength), homography_method=8, reproj_threshold=float(reproj_thr), max_iters=int(max_iters),
+                                confidence=float(confidence), timing=1 if timing else 0, match_lds_cap=int(self.cap_bytes),
+                                match_stream=self._masked_stream_handle, debug_extract_delay_ms=float(self.debug_extract_delay) * 1e3)
+        h = C.c_void_p()
+        m = self.matcher
+        check(lib().apds_set_device(self.dev.index or 0))
+        check(lib().apds_pipeline_create(C.byref(h), m.rows.data_ptr(), int(m.rows.shape[0]), m.index_base, m.handle, self.db_kp.data_ptr(), self.n_db, C.byref(p)))
+        self._pipe, self._key = h, key
+
+    def _destroy_native(self):
+        h, self._pipe = self._pipe, None
+        if h is not None:
+            check(lib().apds_pipeline_destroy(h))
+
     def close(self):
-        """Destroy the CU-masked match stream (if any). The pipeline must be idle."""
+        """Destroy the native pipeline and the CU-masked match stream (if any)."""
+        self._destroy_native()
         h, self._masked_stream_handle = self._masked_stream_handle, None
         if h is not None:
-            torch.cuda.synchronize()
             lib().apds_stream_destroy(h)
-        for s in getattr(self, "slots", []):
-            st, s["topk_state"] = s.get("topk_state"), None
-            if st:
-                lib().apds_dev_topk_state_destroy(st)
 
     def __del__(self):
         try:
             self.close()
-        except Exception:
+        except Exception:   # noqa: BLE001
             pass
 
+    # ---- submit / poll (what bench.py's timed loop calls, through the bound C functions directly) -----------------------------------------
+    def prepare(self, frame_shape, filter_strength=0.8, reproj_thr=3.0, max_iters=2000, confidence=0.995, timing=False):
+        """Create (or keep) the native pipeline for frames of this shape and these parameters; returns its handle (void*)."""
+        self._ensure(frame_shape, filter_strength, reproj_thr, max_iters, confidence, timing)
+        return self._pipe
+
+    @staticmethod
+    def frame_args(f):
+        """(pointer, row stride in bytes, on_device) of a [H, W(, C)] u8 tensor: a device tensor, or a host tensor (pinned: overlapped upload)."""
+        return C.c_void_p(f.data_ptr()), int(f.stride(0)), 1 if f.is_cuda else 0
+
+    @staticmethod
+    def result_dict(r):
+        return dict(n_keypoints=r.n_keypoints, n_matches=r.n_matches, n_inliers=r.n_inliers, status=r.status,
+                    H=np.array(r.H, np.float64).reshape(3, 3) if r.homography_found else None)
+
+    def stats(self, reset=False):
+        st = _lib.PipelineCounters()
+        check(lib().apds_pipeline_stats(self._pipe, C.byref(st), 1 if reset else 0))
+        return st
+
     def run(self, frames, count, filter_strength=0.8, reproj_thr=3.0, max_iters=2000, confidence=0.995, timing=False):
-        """Push `count` frames (cycled from `frames`) through the three stages. Returns (results in frame order, timers)."""
-        import threading
+        """Push `count` frames (cycled from `frames`) through the pipeline. Returns (results in frame order, timers)."""
         L = lib()
-        q1, q2 = self.queue.Queue(), self.queue.Queue()
-        E = self.extract_workers
-        q_free = [self.queue.Queue() for _ in range(E)]      # per extraction worker: its own slots
-        q_ext = [self.queue.Queue() for _ in range(E)]       # per extraction worker: its finished frames, in its order
-        q_any = self.queue.Queue()                           # tokens: which worker finished a frame (arrival order)
-        for s in self.slots:
-            q_free[s["owner"]].put(s)
-        results = [None] * count
-        timers, errors = {}, []
-        dev_index = self.dev.index or 0
-        # The occupancy cap of the scan is process-wide in the library; a pipeline that decided to cap (starvation watch) applies
-        # its cap for the duration of its own runs only and puts the previous value back when the run ends.
-        cap_restore = [None]
-        if self.cap_bytes:
-            old = C.c_int(0)
-            check(L.apds_dev_match_lds_cap(self.cap_bytes, C.byref(old)))
-            cap_restore[0] = old.value
-
-        def guarded(fn):
-            def wrap():
-                try:
-                    torch.cuda.set_device(dev_index)
-                    check(L.apds_set_device(dev_index))
-                    check(L.apds_dev_timing_enable(1 if timing else 0))
-                    fn()
-                except BaseException as e:   # surface worker failures instead of dead-locking the queues
-                    errors.append(e)
-                    q1.put(None)
-                    q2.put(None)
-                    for q in q_ext + q_free + [q_any]:
-                        q.put(None)
-                finally:
-                    try:
-                        L.apds_dev_timing_enable(0)
-                        torch.cuda.synchronize()
-                        # this worker's stream + device workspace (threads are per run(); long-lived stage threads that keep their
-                        # workspaces across runs measured 0.5 ms/frame SLOWER, reproducibly, so each run starts from fresh ones)
-                        L.apds_thread_release()
-                    except Exception:
-                        pass
-            return wrap
-
-        def collect(names):
-            if timing:
-                for n in names:
-                    ms, k = _lib.kernel_ms(n)
-                    timers[n] = (ms, k)
-
-        timer_lock = threading.Lock()
-
-        def make_extract_worker(e):
-            def extract_worker():
-                stream = self.extract_streams[e]
-                with torch.cuda.stream(stream):
-                    for i in range(e, count, E):
-                        s = q_free[e].get()
-                        if s is None:
-                            return
-                        f = frames[i % len(frames)]
-                        if not f.is_cuda:
-                            # a host frame (pinned memory): upload it on THIS worker's stream in front of the extraction, into the slot's own
-                            # device buffer; the other extraction worker and the match run meanwhile, so the PCIe copy is overlapped
-                            if s.get("frame") is None or s["frame"].shape != f.shape:
-                                s["frame"] = torch.empty(f.shape, dtype=f.dtype, device=self.dev)
-                            s["frame"].copy_(f, non_blocking=True)
-                            f = s["frame"]
-                        ch = 1 if f.dim() == 2 else f.shape[2]
-                        n = C.c_int(0)
-                        check(L.apds_dev_akaze_extract(f.data_ptr(), f.shape[0], f.shape[1], ch, f.stride(0), self.cap, s["kps"].data_ptr(),
-                                                       s["desc"].data_ptr(), self.cap, C.byref(n), torch_stream()))
-                        s["K"], s["index"] = n.value, i
-                        s["ev_extract"].record(stream)
-                        if self.debug_extract_delay > 0:       # test hook: emulate a box on which extraction cannot keep up
-                            time.sleep(self.debug_extract_delay)
-                        q_ext[e].put(s)
-                        q_any.put(e)
-                    if timing:
-                        ms, k = _lib.kernel_ms("akaze_extract")
-                        with timer_lock:
-                            old = timers.get("akaze_extract", (0.0, 0))
-                            timers["akaze_extract"] = (old[0] + ms, old[1] + k)
-            return extract_worker
-
-        def order_worker():
-            # Sharded DB: frames back into order; the host-side count exchange (one gloo collective per frame, which every rank
-            # must issue in the same order) happens here, so the match thread stays free of host synchronisation.
-            # One GPU: no collective, so nothing requires frame order on the match stream (results are stored by frame index):
-            # frames go to the match first come, first served. One of the two extraction workers tends to finish just after
-            # a match ends (its last kernels only run freely once the match kernel is gone); in frame order the match stream then
-            # waited ~1.2 ms for every second frame, now it takes the other worker's next frame, which is already there.
-            if self.matcher.world > 1:
-                for i in range(count):
-                    s = q_ext[i % E].get()
-                    if s is None:
-                        return
-                    s["counts"] = self.matcher.exchange_counts(s["K"])
-                    q1.put(s)
-                q1.put(None)
-                return
-            for _ in range(count):
-                e = q_any.get()            # a worker's token: its next finished frame is in q_ext[e]
-                if e is None:
-                    return
-                s = q_ext[e].get()
-                if s is None:
-                    return
-                s["counts"] = [int(s["K"])]
-                q1.put(s)
-            q1.put(None)
-
-        done_lock = threading.Lock()
-        alive = [self.match_workers]
-
-        def sharded_match_worker():
-            # Sharded DB: this thread issues ALL collectives of the run, in the same order on every rank: gather(i+1) [its own
-            # stream, waits only for frame i+1's extraction] BEFORE exchange(i) [match stream, after scan(i)], so the query
-            # all-gather of the next frame travels under the current frame's scan. Frame i's scan is launched before the thread
-            # blocks on frame i+1, so the GPU never waits for the host here.
-            stream, m, prev = self.match_streams[0], self.matcher, None
-            with torch.cuda.stream(stream):
-                while True:
-                    s = q1.get()
-                    if s is not None and s["counts"] is not None:
-                        with torch.cuda.stream(self.gather_stream):
-                            self.gather_stream.wait_event(s["ev_extract"])
-                            m.gather_queries(s["desc"][:s["K"]], s["counts"], s["gq"])
-                    if prev is not None:
-                        prev["keys_view"] = m.exchange_merge(prev["gq"], 2, out=prev["keys"])
-                        prev["ev_match"].record(stream)
-                        q2.put(prev)
-                        prev = None
-                    if s is None:
-                        break
-                    if s["counts"] is None:      # no host-side count exchange available: one-call form (synchronises the stream)
-                        stream.wait_event(s["ev_extract"])
-                        s["keys_view"] = m.knn(s["desc"][:s["K"]], 2, out=s["keys"])
-                        s["ev_match"].record(stream)
-                        q2.put(s)
-                        continue
-                    m.scan_gathered(s["gq"], 2)
-                    prev = s
-                if timing:
-                    for n in ("hamming_topk", "hamming_topk_sample"):
-                        timers[n] = _lib.kernel_ms(n)
-                q2.put(None)
-
-        def make_match_worker(stream):
-            def match_worker():
-                # Starvation watch (single match worker): the match stream should never wait for a frame. On some boxes the short
-                # extraction kernels are dispatched so late under the match kernel, which owns every wave slot, that extraction
-                # paces the pipeline (36 ms per frame instead of 30, seen on about one box in eight). The gap on the match stream
-                # between one frame's last match kernel and the next frame's first is measured with events; if at least three of
-                # six consecutive gaps exceed 4 ms (the healthy pattern is 0.01 / 1.2 ms alternating) the match kernel's occupancy is capped at two workgroups per CU (apds_dev_match_lds_cap), which leaves
-                # wave slots free for the other stages at ~1.5 % of match throughput.
-                watch = self.adaptive_cap and self.match_workers == 1 and self.cap_bytes == 0
-                pending, gaps, prev = [], [], None
-                with torch.cuda.stream(stream):
-                    while True:
-                        s = q1.get()
-                        if s is None:
-                            q1.put(None)            # let the other match worker see the end marker too
-                            break
-                        if self.split_match and s["K"] > 0:
-                            m, K = self.matcher, s["K"]
-                            with torch.cuda.stream(self.pre_stream):        # threshold pre-pass: beside the previous frame's main scan
-                                self.pre_stream.wait_event(s["ev_extract"])
-                                check(L.apds_dev_topk_prepass(s["topk_state"], s["desc"].data_ptr(), K, m.rows.data_ptr(), int(m.rows.shape[0]), m.index_base, 2,
-                                                              torch_stream()))
-                                s["ev_pre"].record(self.pre_stream)
-                            stream.wait_event(s["ev_pre"])
-                            if watch:
-                                s["ev_mstart"].record(stream)
-                            check(L.apds_dev_topk_scan(s["topk_state"], s["desc"].data_ptr(), m.rows.data_ptr(), torch_stream()))
-                            s["ev_scan"].record(stream)
-                            if watch:
-                                s["ev_mend"].record(stream)
-                            with torch.cuda.stream(self.merge_stream):      # record merge: beside the next frame's main scan
-                                self.merge_stream.wait_event(s["ev_scan"])
-                                check(L.apds_dev_topk_merge(s["topk_state"], m.index_base, s["keys"].data_ptr(), torch_stream()))
-                                s["ev_match"].record(self.merge_stream)
-                            s["keys_view"] = s["keys"][:K]
-                        else:
-                            stream.wait_event(s["ev_extract"])
-                            if watch:
-                                s["ev_mstart"].record(stream)
-                            s["keys_view"] = self.matcher.knn(s["desc"][:s["K"]], 2, out=s["keys"], counts=s["counts"])
-                            s["ev_match"].record(stream)
-                            if watch:
-                                s["ev_mend"].record(stream)
-                        if watch:
-                            if prev is not None and s["index"] >= 4:           # the first frames are the pipeline filling up
-                                pending.append((prev["ev_mend"], s["ev_mstart"]))
-                            prev = s
-                            while pending and pending[0][1].query():       # both recorded before it, both complete
-                                a, b = pending.pop(0)
-                                try:
-                                    g = a.elapsed_time(b)
-                                except RuntimeError:                        # an event was re-recorded in the meantime: skip the sample
-                                    continue
-                                if 0.0 <= g < 1000.0:
-                                    gaps.append(g)
-                                    self.gap_log.append(g)
-                            # with two extraction workers late frames arrive in pairs (gaps alternate long / short), and one long
-                            # stall (an allocation, a page fault storm) is not starvation: at least three of the last six gaps
-                            if len(gaps) >= 6 and sum(1 for g in gaps[-6:] if g > 4.0) >= 3:
-                                old = C.c_int(0)
-                                check(L.apds_dev_match_lds_cap(55000, C.byref(old)))
-                                self.cap_bytes = 55000                 # this pipeline's later runs start capped; run() restores the
-                                cap_restore[0] = old.value if cap_restore[0] is None else cap_restore[0]   # process-wide value when it ends
-                                self.cap_events.append(dict(frame=s["index"], gaps_ms=[round(g, 2) for g in gaps[-6:]], previous=old.value))
-                                watch = False
-                        q2.put(s)
-                    with done_lock:
-                        alive[0] -= 1
-                        last = alive[0] == 0
-                    if timing:
-                        for n in ("hamming_topk", "hamming_topk_sample"):
-                            ms, k = _lib.kernel_ms(n)
-                            with done_lock:
-                                old = timers.get(n, (0.0, 0))
-                                timers[n] = (old[0] + ms, old[1] + k)
-                    if last:
-                        q2.put(None)
-            return match_worker
-
-        def homography_worker():
-            with torch.cuda.stream(self.streams[2]):
-                while True:
-                    s = q2.get()
-                    if s is None:
-                        break
-                    self.streams[2].wait_event(s["ev_match"])
-                    K, M = s["K"], 0
-                    if K > 0:
-                        nm = C.c_int(0)
-                        check(L.apds_dev_ratio_filter(s["keys_view"].data_ptr(), K, 2, float(filter_strength), s["matches"].data_ptr(), C.byref(nm),
-                                                      torch_stream()))
-                        M = nm.value
-                    out = dict(n_keypoints=K, n_matches=M, H=None, n_inliers=0)
-                    if M >= 4:
-                        check(L.apds_dev_points_from_matches(s["kps"].data_ptr(), K, self.db_kp.data_ptr(), self.n_db, s["matches"].data_ptr(), M, 0,
-                                                             s["p1"].data_ptr(), s["p2"].data_ptr(), torch_stream()))
-                        H = np.zeros(9, np.float64)
-                        rc = L.apds_dev_find_homography(s["p1"].data_ptr(), s["p2"].data_ptr(), M, 8, float(reproj_thr), int(max_iters),
-                                                        float(confidence), _lib.ptr(H), s["mask"].data_ptr(), torch_stream())
-                        if rc == 0:
-                            out["H"] = H.reshape(3, 3)
-                            out["n_inliers"] = int(s["mask"][:M].sum().item())
-                        elif rc != _lib.ERR_EMPTY:
-                            check(rc)
-                    results[s["index"]] = out
-                    q_free[s["owner"]].put(s)
-                collect(["ransac_score"])
-
-        match_stage = [sharded_match_worker] if self.matcher.world > 1 else [make_match_worker(st) for st in self.match_streams]
-        workers = [make_extract_worker(e) for e in range(E)] + [order_worker] + match_stage + [homography_worker]
-        threads = [threading.Thread(target=guarded(f), daemon=True) for f in workers]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
-        if cap_restore[0] is not None:
-            check(L.apds_dev_match_lds_cap(cap_restore[0], None))
-        if errors:
-            raise errors[0]
+        self._ensure(frames[0].shape, filter_strength, reproj_thr, max_iters, confidence, timing)
+        if timing:
+            self.stats(reset=True)
+        args = [self.frame_args(f) for f in frames]
+        res = _lib.FrameResult()
+        results = []
+        for i in range(count):
+            ptr, stride, on_dev = args[i % len(args)]
+            check(L.apds_pipeline_submit(self._pipe, ptr, stride, on_dev, None))
+            while True:       # take what is finished, so the result queue stays short on long runs
+                rc = L.apds_pipeline_poll(self._pipe, C.byref(res), 0)
+                if rc != 0:
+                    if rc < 0:
+                        check(rc)
+                    break
+                results.append(self.result_dict(res))
+        while len(results) < count:
+            check(L.apds_pipeline_poll(self._pipe, C.byref(res), 1))
+            results.append(self.result_dict(res))
+        for i, r in enumerate(results):
+            if r["status"] != 0:
+                raise _lib.ApdsError(r["status"], f"frame {i} failed in the pipeline")
+        st = self.stats(reset=timing)
+        timers = {}
+        if timing:
+            timers = {"hamming_topk": (st.hamming_topk_ms, st.hamming_topk_launches), "hamming_topk_sample": (st.hamming_topk_sample_ms, st.hamming_topk_sample_launches),
+                      "akaze_extract": (st.akaze_extract_ms, st.akaze_extract_calls), "ransac_score": (st.ransac_score_ms, st.ransac_score_launches)}
+        self.gap_log = [float(st.match_gaps_first_ms[i]) for i in range(min(16, st.match_gaps))]
+        self.gap_mean = float(st.match_gap_mean_ms) if st.match_gaps else None
+        if st.match_lds_cap_set_at_frame >= 0 and not self.cap_events:
+            self.cap_events.append(dict(frame=int(st.match_lds_cap_set_at_frame), gaps_ms=[round(float(g), 2) for g in st.match_lds_cap_gaps_ms], previous=0))
+            self.cap_bytes = int(st.match_lds_cap_bytes)
+            self._key = self._key[:-1] + (int(self.cap_bytes),)     # the live native pipeline IS capped: no re-creation for that
         return results, timers

@@ -262,6 +262,70 @@ int apds_shard_exchange_merge(void* shard, void* slot, int k, void* out_keys_dev
  * positions in the view, i.e. what apds_db_knn_match returns. */
 int apds_db_shard(void* db, int rank, int world, int transport, const apds_comm_id* id, const apds_host_transport* host, void** shard);
 
+/* ---- the streamed frame pipeline ------------------------------------------------------------------------------------------------------
+ * frame -> apds_dev_akaze_extract -> Hamming top-2 against the resident train rows -> ratio test (lib.rs:107-111) -> matched points
+ * (lib.rs:161-180, the intended gather) -> find_homography_mat (mod.rs:231-259), software-pipelined over a stream of frames by host
+ * threads INSIDE the library: two extraction workers on alternate frames | the match (threshold pre-pass, main scan and record merge of
+ * consecutive frames on three streams; with a shard handle: the query gather of frame i+1 issued before the key exchange of frame i) |
+ * ratio filter + points + homography, each with its own HIP stream and device workspace. This is the composed path the north-star metric
+ * (frames/s) is measured on; a host needs four calls. The reference chains the steps only inside unit tests (lib.rs:197-249); its
+ * production caller runs extraction from a rayon pool without a lock (preprocessor/src/main.rs:227-245), which is what the workers mirror.
+ * Results leave in frame order and equal, frame by frame, what the one-call entry points give (tests/cpp/pipeline_test.cpp). */
+typedef struct apds_pipeline_params {
+    int rows, cols, channels;   /* frame geometry: every frame of one pipeline has it (channels 1, 3 or 4) */
+    int max_points;             /* <= 0: APDS_MAX_POINTS (lib.rs:12-13) */
+    int n_slots;                /* frames in flight; 0 = 6 (never fewer than two per extraction worker) */
+    int extract_workers;        /* host threads extracting alternate frames; 0 = 2 */
+    float filter_strength;      /* Lowe ratio of get_knn_matches (lib.rs:107-111; the reference's test uses 0.3, lib.rs:222) */
+    int homography_method;      /* APDS_HOMOGRAPHY_* (mod.rs:25-31) */
+    double reproj_threshold;    /* <= 0: 3.0 (mod.rs:248) */
+    int max_iters;              /* <= 0: 2000 (OpenCV's default) */
+    double confidence;          /* outside (0, 1): 0.995 (OpenCV's default) */
+    int timing;                 /* 1: HIP-event timing of the stage kernels on their launch streams (apds_pipeline_stats) */
+    int match_lds_cap;          /* > 0: occupancy cap of this pipeline's scans from the first frame on (see apds_dev_match_lds_cap); 0: the starvation watch decides */
+    void* match_stream;         /* optional stream for the main scan (e.g. apds_stream_create with a CU mask); NULL = the pipeline's own */
+    double debug_extract_delay_ms; /* test hook: every extraction is handed on this much late (exercises the starvation watch) */
+} apds_pipeline_params;
+typedef struct apds_frame_result {
+    int64_t frame;              /* the number apds_pipeline_submit gave the frame */
+    int status;                 /* APDS_OK, or the status of the stage that failed for THIS frame (the pipeline goes on; text: apds_last_error after the poll) */
+    int n_keypoints, n_matches, n_inliers;
+    int homography_found;       /* 0: fewer than four matches, or no model (MatError::Empty, mod.rs:258) */
+    double H[9];                /* row major, H[8] == 1 */
+} apds_frame_result;
+typedef struct apds_pipeline_counters {
+    int64_t frames_submitted, frames_done;
+    /* summed HIP-event times and launch counts since the last reset (params.timing = 1): the main scan, the threshold pre-pass, whole
+     * extractions (wall span on their stream), RANSAC scoring */
+    double hamming_topk_ms, hamming_topk_sample_ms, akaze_extract_ms, ransac_score_ms;
+    int hamming_topk_launches, hamming_topk_sample_launches, akaze_extract_calls, ransac_score_launches;
+    /* idle time of the match stream in front of each frame's main scan (the starvation watch's measurement) */
+    double match_gap_mean_ms;
+    int match_gaps;
+    float match_gaps_first_ms[16];
+    int match_lds_cap_bytes, match_lds_cap_set_at_frame;   /* 0 / -1: the watch never capped */
+    float match_lds_cap_gaps_ms[6];                        /* the six gaps that made it cap */
+    int extract_workers, slots, split_scan, world;
+} apds_pipeline_counters;
+#define APDS_PIPELINE_NOT_READY 1   /* apds_pipeline_poll: the next frame (in submission order) is not finished, or nothing is in flight */
+/* The train set: db_rows64_dev = n_rows x 64-byte rows whose global indices start at index_base (one GPU), or `shard` = an apds_shard_*
+ * handle (the rows arguments are then ignored; every rank must submit the same number of frames, and all collective calls of that handle
+ * come from the pipeline from then on). db_kps_dev: the keypoints of ALL train rows (n_db_total x 28 bytes, indexed by global row: the
+ * matched points' coordinates). Everything is borrowed until apds_pipeline_destroy. The pipeline lives on the calling thread's device. */
+int apds_pipeline_create(void** pipe, const void* db_rows64_dev, int64_t n_rows, uint32_t index_base, void* shard, const void* db_kps_dev, int64_t n_db_total,
+                         const apds_pipeline_params* params);
+/* Hands one frame over (on_device 0: host memory, uploaded by an extraction worker on its own stream - pinned memory makes the copy
+ * overlap; 1: device memory) and returns at once unless every slot is in flight (then it blocks until one is free). The frame must stay
+ * valid until its result has been polled. *frame_id (may be NULL) = its number, counted from 0. One submitting thread at a time. */
+int apds_pipeline_submit(void* pipe, const void* frame, size_t stride_bytes, int on_device, int64_t* frame_id);
+/* The next result in submission order. wait 0: APDS_PIPELINE_NOT_READY if that frame is not finished; wait 1: blocks until it is (returns
+ * APDS_PIPELINE_NOT_READY only when no frame is in flight). A negative status = the pipeline itself has failed (every later call repeats it). */
+int apds_pipeline_poll(void* pipe, apds_frame_result* result, int wait);
+/* Counters and (params.timing) kernel times. Waits for the frames in flight to finish first. reset 1: the sums start again from zero. */
+int apds_pipeline_stats(void* pipe, apds_pipeline_counters* out, int reset);
+/* Drains the frames in flight, joins the workers, releases streams and buffers. */
+int apds_pipeline_destroy(void* pipe);
+
 /* ---- device-resident API ------------------------------------------------------------------- */
 /* All pointers below are HIP device pointers. stream: hipStream_t or NULL (the thread's own stream).
  * Calls are asynchronous on that stream unless they return a count to the host. */

@@ -14,6 +14,11 @@ def test_header_symbols_are_exported(pkg):
     L = pkg.lib()
     for name in declared:
         assert hasattr(L, name), name
+    # ... and nothing else: the dynamic symbol table's apds_* functions are exactly the header's (no undeclared entry points)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln and ln.split()[-1].startswith("apds_")}
+    assert exported == declared, exported ^ declared
 
 
 def test_struct_layouts(pkg):

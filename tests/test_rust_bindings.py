@@ -137,7 +137,7 @@ def test_shim_crates_and_integration_doc_only_use_existing_bindings():
             used.add(name)
     # the crate surface the reference exposes is forwarded: extraction, both matchers, the point gather, homography, raster_to_mat, warp, PnP
     for name in ("apds_akaze_extract", "apds_get_knn_matches", "apds_get_bruteforce_matches", "apds_get_points_from_matches", "apds_find_homography",
-                 "apds_raster_to_mat", "apds_warp_perspective", "apds_pnp_solver_ransac", "apds_tile_extract_batch", "apds_set_device", "apds_shard_knn"):
+                 "apds_raster_to_mat", "apds_warp_perspective", "apds_pnp_solver_ransac", "apds_tile_extract_batch", "apds_set_device", "apds_shard_knn", "apds_pipeline_create", "apds_pipeline_submit", "apds_pipeline_poll"):
         assert name in used, name
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name in set(re.findall(r"apds_sys::(apds_[a-z0-9_]+)", doc)):
@@ -156,3 +156,16 @@ def test_shared_struct_layouts():
     assert "pub bytes: [c_char; APDS_COMM_ID_BYTES]" in text and "pub const APDS_COMM_ID_BYTES: usize = 128;" in text
     ht = re.search(r"pub struct apds_host_transport \{(.*?)\n\}", text, flags=re.S).group(1)
     assert ht.index("user") < ht.index("all_gather") < ht.index("all_to_all")
+    # the pipeline's plain-data structs: the same field names in the same order as the header (this test's own parse of both texts)
+    hdr = re.sub(r"/\*.*?\*/", " ", open(HEADER).read(), flags=re.S)
+    for name in ("apds_pipeline_params", "apds_frame_result", "apds_pipeline_counters"):
+        cbody = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), hdr, flags=re.S).group(1)
+        cnames = []
+        for decl in cbody.split(";"):
+            decl = decl.strip()
+            if decl:
+                first, *rest = decl.split(",")
+                cnames.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1] if "[" not in first else re.findall(r"([A-Za-z_][A-Za-z0-9_]*)\s*\[", first)[-1])
+                cnames += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", r)[0] for r in rest]
+        rbody = re.search(r"pub struct %s \{(.*?)\n\}" % name, text, flags=re.S).group(1)
+        assert re.findall(r"pub (\w+):", rbody) == cnames, (name, cnames)

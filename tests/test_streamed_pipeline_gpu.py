@@ -1,6 +1,7 @@
-"""GPU: StreamedFramePipeline (bench.py's default path: extract | match | homography on their own threads and streams, two extraction
-workers, ordering thread) must give, frame by frame, what the one-frame-at-a-time FramePipeline gives; and its starvation watch must
-cap the match kernel's occupancy when extraction is made artificially late."""
+"""GPU: the library's streamed pipeline (apds_pipeline_*, csrc/pipeline.cpp; bench.py's default path: extract | match | homography on
+their own host threads and streams inside libapds_hip.so, two extraction workers) through its python front must give, frame by frame,
+what the one-frame-at-a-time FramePipeline gives; and its starvation watch must cap the occupancy of ITS scans when extraction is made
+artificially late. (tests/cpp/pipeline_test.cpp drives the same four calls from a g++-built host.)"""
 import ctypes as C
 
 import numpy as np
@@ -93,21 +94,36 @@ def test_starvation_watch_caps_the_match_kernel(gpu_pkg):
         # take the one-query-per-lane kernel variants, not only the T = 4 one)
         check(L.apds_dev_match_last_launch_lds(C.byref(lds)))
         assert lds.value == 55000 and streamed.cap_bytes == 55000
-        # the cap is scoped to the pipeline's runs: the process-wide value is back to what it was
+        # the cap is scoped to the pipeline's own match thread: the process-wide value was never touched
         check(L.apds_dev_match_lds_cap(0, C.byref(old)))
         assert old.value == 0
-        # a second run of the same pipeline starts capped and restores again
+        # a second run of the same pipeline - re-created, because the delay parameter changed - starts capped
         streamed.debug_extract_delay = 0.0
         streamed.run(frames, 3, filter_strength=0.3)
         check(L.apds_dev_match_last_launch_lds(C.byref(lds)))
-        check(L.apds_dev_match_lds_cap(0, C.byref(old)))
-        assert lds.value == 55000 and old.value == 0
+        assert lds.value == 55000 and streamed.stats().match_lds_cap_bytes == 55000
         # and another matcher in the same process is not capped
         pl.FramePipeline(db, db_xy).step(frames[0], filter_strength=0.3)
         check(L.apds_dev_match_last_launch_lds(C.byref(lds)))
         assert lds.value == 0
     finally:
+        streamed.close()
         check(L.apds_dev_match_lds_cap(0, None))
+
+
+def test_host_frames_and_resident_frames_give_the_same_results(gpu_pkg):
+    """apds_pipeline_submit(on_device = 0): the extraction worker uploads the frame on its own stream in front of the extraction."""
+    pl, frames, db, db_xy = _setup(gpu_pkg, T=512, ndb=40000, nframes=2)
+    streamed = pl.StreamedFramePipeline(db, db_xy)
+    want, _ = streamed.run(frames, 5, filter_strength=0.3)
+    host = [f.cpu().pin_memory() for f in frames]
+    got, timers = streamed.run(host, 5, filter_strength=0.3, timing=True)
+    for a, b in zip(want, got):
+        assert a["n_keypoints"] == b["n_keypoints"] > 100 and a["n_matches"] == b["n_matches"] and a["n_inliers"] == b["n_inliers"]
+        assert a["H"] is not None and np.array_equal(a["H"], b["H"])
+    # timing on: every frame's main scan and extraction were timed with HIP events on their launch streams
+    assert timers["hamming_topk"][1] == 5 and timers["hamming_topk"][0] > 0 and timers["akaze_extract"][1] == 5
+    streamed.close()
 
 
 def test_reserved_cus_reach_the_match_stream(gpu_pkg):
@@ -115,8 +131,7 @@ def test_reserved_cus_reach_the_match_stream(gpu_pkg):
     pl, frames, db, db_xy = _setup(gpu_pkg)
     streamed = pl.StreamedFramePipeline(db, db_xy, reserve_cus=16)
     try:
-        assert streamed._masked_stream_handle is not None
-        assert streamed.match_streams[0].cuda_stream == streamed._masked_stream_handle.value == streamed.streams[1].cuda_stream
+        assert streamed._masked_stream_handle is not None       # (handed to the native pipeline as apds_pipeline_params.match_stream)
         got, _ = streamed.run(frames, 4, filter_strength=0.3)
         assert all(r is not None and r["H"] is not None for r in got)
     finally:

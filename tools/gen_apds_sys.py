@@ -17,7 +17,9 @@ OUT = os.path.join(ROOT, "rust_shim", "apds_sys", "src", "lib.rs")
 
 BASE = {"void": "c_void", "char": "c_char", "int": "c_int", "float": "f32", "double": "f64", "size_t": "usize", "uint8_t": "u8", "int32_t": "i32",
         "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "apds_keypoint": "apds_keypoint", "apds_dmatch": "apds_dmatch",
-        "apds_comm_id": "apds_comm_id", "apds_host_transport": "apds_host_transport"}
+        "apds_comm_id": "apds_comm_id", "apds_host_transport": "apds_host_transport", "apds_pipeline_params": "apds_pipeline_params",
+        "apds_frame_result": "apds_frame_result", "apds_pipeline_counters": "apds_pipeline_counters"}
+POD_STRUCTS = ["apds_pipeline_params", "apds_frame_result", "apds_pipeline_counters"]     # plain-data structs translated field by field
 RESERVED = {"type", "match", "ref", "box", "move", "in", "fn", "loop", "mod", "use", "where", "impl", "self", "super", "crate", "dyn", "as"}
 
 
@@ -77,8 +79,30 @@ def parse_header(text):
     return funcs, defines, enums
 
 
+def pod_struct(text, name):
+    """`typedef struct name { scalar fields, fixed arrays, void* } name;` -> a #[repr(C)] Rust struct with the same fields in the same order."""
+    body = re.search(r"typedef\s+struct\s+%s\s*\{(.*?)\}\s*%s\s*;" % (name, name), strip_comments(text), flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"^(.*?)\s*([A-Za-z_][A-Za-z0-9_]*(?:\s*\[\s*\d+\s*\])?(?:\s*,\s*[A-Za-z_][A-Za-z0-9_]*(?:\s*\[\s*\d+\s*\])?)*)$", decl)
+        ctype, names = m.group(1).strip(), m.group(2)
+        for n in names.split(","):
+            n = n.strip()
+            arr = re.match(r"^([A-Za-z_][A-Za-z0-9_]*)\s*\[\s*(\d+)\s*\]$", n)
+            rt = rust_type(ctype)
+            fields.append((arr.group(1), f"[{rt}; {arr.group(2)}]") if arr else (n, rt))
+    lines = ["#[repr(C)]", "#[derive(Clone, Copy)]", f"pub struct {name} {{"]
+    lines += [f"    pub {n}: {t}," for n, t in fields]
+    lines.append("}")
+    return "\n".join(lines)
+
+
 def generate():
-    funcs, defines, enums = parse_header(open(HEADER).read())
+    header_text = open(HEADER).read()
+    funcs, defines, enums = parse_header(header_text)
     L = []
     L.append("//! Raw bindings of include/apds.h - GENERATED by tools/gen_apds_sys.py from the header (every function of the C ABI); do not edit by")
     L.append("//! hand. The build image has no Rust toolchain: tests/test_rust_bindings.py re-parses this file and the header independently and")
@@ -89,6 +113,9 @@ def generate():
     for k, v in defines:
         v = v.strip("()")
         if k in ("APDS_MAX_POINTS",):
+            continue
+        if k == "APDS_PIPELINE_NOT_READY":
+            L.append(f"pub const {k}: c_int = {v};")
             continue
         ty = "usize" if k in ("APDS_COMM_ID_BYTES", "APDS_DESC_BYTES", "APDS_DESC_STRIDE") else "c_int"
         L.append(f"pub const {k}: {ty} = {v};")
@@ -112,6 +139,10 @@ def generate():
              "    pub all_gather: Option<unsafe extern \"C\" fn(user: *mut c_void, send: *const c_void, recv: *mut c_void, bytes_per_rank: usize) -> c_int>,\n"
              "    pub all_to_all: Option<unsafe extern \"C\" fn(user: *mut c_void, send: *const c_void, send_off: *const usize, send_bytes: *const usize, recv: *mut c_void,\n"
              "                                                recv_off: *const usize, recv_bytes: *const usize) -> c_int>,\n}")
+    for name in POD_STRUCTS:
+        L.append("")
+        L.append(f"/// {name} (include/apds.h): the streamed frame pipeline's plain-data structs, field for field")
+        L.append(pod_struct(header_text, name))
     L.append("")
     L.append('extern "C" {')
     for ret, name, args in funcs:
