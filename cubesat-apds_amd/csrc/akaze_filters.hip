@@ -305,7 +305,7 @@ __global__ __launch_bounds__(FNT) void smooth_flow_kernel(const float* __restric
 }
 
 // The same pass on register strips, for the tiles that lie inside the image together with their halo (no clamping, no reflection):
-// a wave owns 64 columns x (RB + 6) rows, one column per lane; the 5-tap row pass takes its neighbours through DPP wave shifts, the
+// a wave owns 64 columns x (RB + 6) rows, one column per lane; the 5-tap row pass takes its neighbours through DP wave shifts, the
 // column pass and the Scharr rows come out of the lane's own registers. Every value is produced by the same operations in the same
 // order as in smooth_flow_kernel. Lanes [3, 61) and strip rows [3, 3 + RB) are final.
 __device__ __forceinline__ float dpp_next(float v) {   // lane i <- lane i + 1
@@ -390,7 +390,7 @@ void smooth_flow_strip_kernel(const float* __restrict__ src, float* __restrict__
 // ---- a1.1 + a1.2 + the gradient pass of a1.3 on register strips (large images) ---------------------------------------------------
 // image -> gray (registers) -> { 9-tap Gaussian -> Lt[0] } and { 5-tap Gaussian -> unnormalised Scharr -> |grad| + its maximum over
 // the interior }: one read of the image instead of gray_kernel, gauss_kernel<4>, gauss_kernel<2> and deriv_pair_kernel<2> with
-// their three f32 round trips. A wave owns 64 columns x (RB + 8) rows, one column per lane; x +- 1 .. 4 come through chained DPP
+// their three f32 round trips. A wave owns 64 columns x (RB + 8) rows, one column per lane; x +- 1 .. 4 come through chained DP
 // wave shifts (the same shifted values serve both Gaussians). Borders: both Gaussians replicate THE GRAY IMAGE, which clamped
 // loads give for free; the Scharr pass reflects (101) its input, the 5-tap result, so at the image edge the missing neighbour is
 // the opposite one (lane x + 1 for x - 1 at x = 0, row 1 for row -1, ...): selects in the BORDER waves only. Same operations in
@@ -532,11 +532,12 @@ void base_strip_kernel(const uint8_t* __restrict__ img, int w, int h, int stride
 // wave's 64 LDS atomics hit a handful of addresses and serialise; each thread reads four consecutive pixels of a row per step.
 template <int SUB>
 __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __restrict__ modg, int w, int h, const unsigned int* __restrict__ hmax_bits,
-                                                              int* __restrict__ hist, size_t bstride) {
+                                                              int* __restrict__ hist, float* __restrict__ k_oct, int n_oct, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     APDS_BOFS(modg);
     APDS_BOFS(hmax_bits);
     APDS_BOFS(hist);
+    APDS_BOFS(k_oct);
     constexpr int PITCH = 301;                          // odd pitch: the copies of a bin sit in different banks
     __shared__ int s_hist[SUB * PITCH];
     for (int i = threadIdx.x; i < SUB * PITCH; i += 256) s_hist[i] = 0;
@@ -567,29 +568,32 @@ __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __rest
         for (int sidx = 0; sidx < SUB; sidx++) sum += s_hist[sidx * PITCH + i];
         if (sum) atomicAdd(&hist[i], sum);
     }
-}
-
-// single thread: kcontrast and its per-octave values k, k*0.75, (k*0.75)*0.75, ...
-__global__ void kcontrast_finish_kernel(const int* __restrict__ hist, const unsigned int* __restrict__ hmax_bits, int w, int h,
-                                        float* __restrict__ k_oct, int n_oct, size_t bstride) {
-    APDS_RAISE_WAVE_PRIORITY();
-    if (threadIdx.x || blockIdx.x) return;
-    APDS_BOFS(hist);
-    APDS_BOFS(hmax_bits);
-    APDS_BOFS(k_oct);
-    const float hmax = __uint_as_float(*hmax_bits);
+    // The block that finishes LAST turns the histogram into kcontrast and its per-octave values k, k*0.75, (k*0.75)*0.75, ... (round 3 ran
+    // a one-thread kernel for that: a launch on the critical path whose 300 dependent loads took 5 us on an idle GPU and 37 us beside the
+    // first Hessian kernel). hist[300] is the ticket counter (zeroed with the histogram): a block draws its ticket after its own bins are
+    // in the device-wide histogram (fence), and the holder of the last ticket therefore sees every block's.
+    __shared__ int s_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(&hist[300], 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    for (int i = threadIdx.x; i < 300; i += 256) s_hist[i] = __hip_atomic_load(&hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x) return;
     float k = 0.03f;
     if (hmax != 0.0f && w > 2 && h > 2) {
         const int nbins = 300;
         const int total = (w - 2) * (h - 2);
-        const int nthreshold = (int)((total - hist[0]) * 0.7f);
+        const int nthreshold = (int)((total - s_hist[0]) * 0.7f);
         int nelements = 0;
         for (int b = 1; b < nbins; b++) {
             if (nelements >= nthreshold) {
                 k = hmax * b / nbins;
                 break;
             }
-            nelements += hist[b];
+            nelements += s_hist[b];
         }
     }
     for (int o = 0; o < n_oct; o++) {
@@ -788,10 +792,14 @@ __device__ __forceinline__ float pm_g2_point(const float* r0, const float* r1, c
 template <int PW, int NT>
 __device__ __forceinline__ void fed_patches(const float* __restrict__ s_t, const float* __restrict__ s_f, float* __restrict__ e0, float* __restrict__ e1,
                                             int P, int S, const LevelSteps& steps, int gx0, int gy0, int w, int h, bool inside,
-                                            float* __restrict__ Lnew) {
+                                            float* __restrict__ Lnew, bool shrink) {
     const int R = P - 6;                       // the region is local [3, P - 3)^2
     const int TG = (R + PW - 1) / PW;          // patches per row
     const int tid = threadIdx.x;
+    // (every wave an 8 x 8 block of patches instead of two rows of them - so that the shrinking zone idles waves in both directions - with
+    // the planes' pitch padded against bank conflicts was built and measured in round 4: 24.8 / 25.7 / 30.6 / 32.0 us for the four 512^2
+    // levels against 23.0 / 24.7 / 29.6 / 32.0: a step of the one-block-per-CU levels is bound by its barrier and LDS round trips, not by
+    // issue slots. Removed.)
     const int ty = div_small(tid, 1.0f / (float)TG), tx = tid - ty * TG;
     const bool active = ty < TG;
     const int x0 = 3 + PW * tx, y0 = 3 + PW * ty;   // (patches of the last row / column may reach up to PW - 1 positions past the region)
@@ -837,16 +845,25 @@ __device__ __forceinline__ void fed_patches(const float* __restrict__ s_t, const
         }
     }
     __syncthreads();   // every thread has read its start values: e0 / e1 (the smoothing planes) may be overwritten
+    // Shrinking (round 4): the tile is all that leaves the kernel, so after step k only the positions within m = S - 1 - k of it have to be
+    // right. A patch computes step k if it reaches into that zone, and stores its values before step k if it computed step k - 1 (its
+    // neighbours in the zone read them); the others sit out - whole waves of them skip the step's LDS traffic and arithmetic. What an idle
+    // or half-needed patch leaves in LDS is stale, and so is what gets computed from it at positions outside the zone, but a position inside
+    // the zone of step k only ever reads positions inside the zone of step k - 1: the tile's values are bit for bit those of the full sweep.
+    const int c_lo0 = S + 3, c_hi0 = S + 3 + LFT;
     for (int k = 0; k < S; k++) {
         float* __restrict__ e = (k & 1) ? e1 : e0;
-        if (active) {
+        const int m = shrink ? S - 1 - k : P;
+        const bool computes = active && x0 < c_hi0 + m && x0 + PW > c_lo0 - m && y0 < c_hi0 + m && y0 + PW > c_lo0 - m;
+        const bool stores = active && (k == 0 || (x0 < c_hi0 + m + 1 && x0 + PW > c_lo0 - m - 1 && y0 < c_hi0 + m + 1 && y0 + PW > c_lo0 - m - 1));
+        if (stores) {
 #pragma unroll
             for (int a = 0; a < PW; a++)
 #pragma unroll
                 for (int b = 0; b < PW; b++) e[(y0 + a) * P + x0 + b] = t[a][b];
         }
         __syncthreads();
-        if (active) {
+        if (computes) {
             float lf[PW], rt[PW], up[PW], dn[PW];
 #pragma unroll
             for (int a = 0; a < PW; a++) {
@@ -899,7 +916,7 @@ __device__ __forceinline__ void fed_patches(const float* __restrict__ s_t, const
 template <int NT>
 __global__ __launch_bounds__(NT) void level_fused_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow_out,
                                                           const float* __restrict__ flow_in, float* __restrict__ Lnew, int w, int h, GaussTaps taps,
-                                                          const float* __restrict__ kptr, LevelSteps steps, size_t bstride) {
+                                                          const float* __restrict__ kptr, LevelSteps steps, size_t bstride, int shrink) {
     APDS_RAISE_WAVE_PRIORITY();
     APDS_BOFS(src);
     APDS_BOFS(smooth);
@@ -1008,13 +1025,13 @@ __global__ __launch_bounds__(NT) void level_fused_kernel(const float* __restrict
         __syncthreads();
     }
     const int hr = (P - 5) >> 1;   // patches per row with 2 x 2 patches
-    if (hr * hr <= NT) fed_patches<2, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew);
-    else fed_patches<3, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew);
+    if (hr * hr <= NT) fed_patches<2, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew, shrink != 0);
+    else fed_patches<3, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew, shrink != 0);
 }
 
 // ---- FED steps on register strips (the large levels) -------------------------------------------------------------
 // One wave owns a strip of 64 columns x (RB + 2S) rows of Lt and of the conductivity, one column per lane, all rows in registers
-// (fully unrolled, static register indices): no LDS, no barriers. Horizontal neighbours come through DPP wave shifts. With
+// (fully unrolled, static register indices): no LDS, no barriers. Horizontal neighbours come through DP wave shifts. With
 //   P[x] = (f[x] + f[x+1]) * (t[x+1] - t[x])        Q[r] = (f[r] + f[r+1]) * (t[r+1] - t[r])
 // the four flux terms of nld_point are xp = P[x], xm = -P[x-1], yp = Q[r], ym = -Q[r-1] EXACTLY: float addition commutes,
 // a - b == -(b - a) and (-a) * b == -(a * b) in IEEE arithmetic, and x + (-y) is x - y. So a step costs one P and one Q per point
@@ -1373,8 +1390,7 @@ void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsign
     // the histogram's grid shrinks with the image: 1024 blocks for one large frame, a share of that for each image of a batch
     const int hist_blocks = std::max(8, std::min(1024, ceil_div((long long)w * h, 4096)));
     // 16 sub-histograms per block (8: 1.755, 16: 1.739, 32: 1.763 ms per 4096^2 extraction, profiles/r03/half_sample_ab.txt)
-    hipLaunchKernelGGL(kcontrast_hist_kernel<16>, dim3(hist_blocks, 1, b.n), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist, b.stride);
-    hipLaunchKernelGGL(kcontrast_finish_kernel, dim3(1, 1, b.n), dim3(64), 0, s, hist, hmax_bits, w, h, k_oct, n_oct, b.stride);
+    hipLaunchKernelGGL(kcontrast_hist_kernel<16>, dim3(hist_blocks, 1, b.n), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist, k_oct, n_oct, b.stride);
 }
 // image -> Lt[0] (and, if want_modg, |grad| of the sigma = 1 image + its interior maximum) in one pass on register strips. Returns
 // false when the image is too small to pay (the launch-bound small tiles keep the separate kernels) or does not fit 32-bit offsets.
@@ -1443,6 +1459,10 @@ void launch_level_fused(const float* src, float* smooth, float* flow_out, const 
     st.n = nsteps;
     for (int i = 0; i < nsteps; i++) st.v[i] = step_sizes[i];
     const int P = LFT + 2 * nsteps + 6;
+    const dim3 grid(ceil_div(w, LFT), ceil_div(h, LFT), b.n);
+    // several tiles per CU: 512-thread blocks, so that three or four of them share a CU; otherwise all the threads one tile can use
+    const bool small_blocks = nsteps <= LF_MAX_STEPS_512 && (size_t)grid.x * grid.y * grid.z >= 512;
+    const int shrink = config().fed_shrink ? 1 : 0;
     const size_t lds = (size_t)(3 * P * P) * sizeof(float);
     static bool opted = false;   // above the default dynamic-LDS limit: opt in once (idempotent, so a race is harmless)
     if (!opted) {
@@ -1451,13 +1471,10 @@ void launch_level_fused(const float* src, float* smooth, float* flow_out, const 
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&level_fused_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PM5 * PM5 * 4));
         opted = true;
     }
-    const dim3 grid(ceil_div(w, LFT), ceil_div(h, LFT), b.n);
-    // several tiles per CU: 512-thread blocks, so that three or four of them share a CU; otherwise all the threads one tile can use
-    const bool small_blocks = nsteps <= LF_MAX_STEPS_512 && (size_t)grid.x * grid.y * grid.z >= 512;
     if (small_blocks)
-        hipLaunchKernelGGL((level_fused_kernel<512>), grid, dim3(512), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride);
+        hipLaunchKernelGGL((level_fused_kernel<512>), grid, dim3(512), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride, shrink);
     else
-        hipLaunchKernelGGL((level_fused_kernel<1024>), grid, dim3(1024), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride);
+        hipLaunchKernelGGL((level_fused_kernel<1024>), grid, dim3(1024), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride, shrink);
 }
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s, const Batch& b) {
     hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 512), ceil_div(dh, HS_ROWS), b.n), dim3(256), 0, s, src, sw, dst, dw, dh, b.stride);

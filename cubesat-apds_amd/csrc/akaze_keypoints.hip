@@ -656,8 +656,19 @@ __device__ __forceinline__ void wave_lds_phase() {
 
 // Keypoints [range[0], min(range[1], n_cap)) of this image (range: two consecutive ints of the image's slab, written by the stage's
 // scan; nullptr: [0, n_cap)): the counts stay on the device, and the blocks stride over the range, so the grid need not match it.
+// Which groups of four keypoints a block takes. Plain: block b takes groups b, b + gridDim.x, ... XCD-aware (xcd_ranges): workgroups are
+// dealt round-robin over the 8 XCDs, so block b runs on XCD b % 8; that XCD gets ONE contiguous eighth of the groups and its blocks walk
+// it in order. Keypoints are in level-major, row-major order: neighbours in the list are neighbours in the image, their sample patches
+// overlap, and one XCD's L2 then serves both instead of two L2s fetching the same lines.
+#define KP_GROUP_LOOP(kb, begin, n, xcd_ranges)                                                                                          \
+    const int kp_groups_ = ((n) - (begin) + 3) >> 2, kp_nbx_ = ((int)gridDim.x + 7) >> 3;                                               \
+    const int kp_x_ = (int)blockIdx.x & 7, kp_lo_ = (int)((long long)kp_groups_ * kp_x_ >> 3), kp_hi_ = (int)((long long)kp_groups_ * (kp_x_ + 1) >> 3); \
+    const int kp_first_ = (xcd_ranges) ? kp_lo_ + ((int)blockIdx.x >> 3) : (int)blockIdx.x, kp_end_ = (xcd_ranges) ? kp_hi_ : kp_groups_; \
+    const int kp_stride_ = (xcd_ranges) ? kp_nbx_ : (int)gridDim.x;                                                                       \
+    for (int kg_ = kp_first_, kb = (begin) + 4 * kg_; kg_ < kp_end_; kg_ += kp_stride_, kb = (begin) + 4 * kg_)
+
 __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_keypoint* __restrict__ kps, const int* __restrict__ range, int n_cap, size_t kp_bstride,
-                                                          float ang_step, int nkeys) {
+                                                          float ang_step, int nkeys, int xcd_ranges) {
     APDS_RAISE_WAVE_PRIORITY();
     const int begin = range ? bofs(range, T.bstride)[0] : 0;
     const int n = range ? min(bofs(range, T.bstride)[1], n_cap) : n_cap;
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(256) void orientation_kernel(LevelTable T, apds_key
     __shared__ uint8_t s_bin[4][112];
     __shared__ int s_start[4][44];
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int kb = begin + (int)blockIdx.x * 4; kb < n; kb += (int)gridDim.x * 4) {   // block-uniform trip count
+    KP_GROUP_LOOP(kb, begin, n, xcd_ranges) {   // block-uniform trip count
     const int ki = kb + wv;
     const bool live = ki < n;
     const apds_keypoint kp = kps[live ? ki : kb];
@@ -863,7 +874,7 @@ __constant__ MldbLut c_mldb = make_mldb_lut();
 // HBM. Walking the lattice in the direction closest to the image's rows for the keypoint's angle (fewer lines per load) changed nothing,
 // and neither did dropping the block-wide barriers: the bytes have to come from HBM whatever the order.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void mldb_kernel(LevelTable T, const apds_keypoint* __restrict__ kps, const int* __restrict__ range, int n_cap, size_t kp_bstride,
-                                                   uint32_t* __restrict__ desc64, size_t desc_bstride) {
+                                                   uint32_t* __restrict__ desc64, size_t desc_bstride, int xcd_ranges) {
     APDS_RAISE_WAVE_PRIORITY();
     const int begin = range ? bofs(range, T.bstride)[0] : 0;
     const int n = range ? min(bofs(range, T.bstride)[1], n_cap) : n_cap;
@@ -896,7 +907,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     int step1, base1, step2, base2;
     chain_geometry(lane, step1, base1);
     chain_geometry(min(64 + lane, 86), step2, base2);
-    for (int kb = begin + (int)blockIdx.x * 4; kb < n; kb += (int)gridDim.x * 4) {   // block-uniform trip count
+    KP_GROUP_LOOP(kb, begin, n, xcd_ranges) {   // block-uniform trip count
     const int ki = kb + wv;
     const bool live = ki < n;
     const apds_keypoint kp = kps[live ? ki : kb];
@@ -1296,7 +1307,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     auto layout = [&](Arena& A) {
         list_count = A.take<int>(AKAZE_MAX_LEVELS);
         hmax_bits = A.take<unsigned int>(1);
-        hist = A.take<int>(300);
+        hist = A.take<int>(304);                  // 300 bins + the ticket counter of kcontrast_hist_kernel's last block
         pend_count = A.take<int>(3 * AKAZE_MAX_LEVELS * PEND_PITCH);
         kp_base = A.take<int>(8);                 // kp_base[k] = keypoints of the stages before stage k (kp_base[0] stays 0)
         fine_counts = A.take<int>(n_fine + 1024);      // ranked compaction: keypoints per 128-byte chunk of the masks (then their prefix)
@@ -1365,6 +1376,10 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // ---- a1.1 / a1.2 / a1.3
     const GaussTaps g16 = gauss_taps(9, (double)soffset), g10 = gauss_taps(5, 1.0);
     if (launch_base_strips(img, H, W, channels, stride, g16, g10, ev[0].Lt, tmpF, hmax_bits, L > 1, s, bt)) {   // large images: one fused pass
+        // (Round 4, measured and removed: forking level 0's Hessian kernel HERE, in front of the contrast-factor pass - it needs Lt[0] only.
+        // Its long-lived waves take the machine first and the histogram kernel, which the level chain waits for, then ran 139 us instead of
+        // 43: +65 us per frame. Whatever is launched first owns the wave slots until its waves retire: only work the chain does not wait
+        // for may go second. profiles/r04/exp_ab.txt)
         if (L > 1) launch_kcontrast(nullptr, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s, bt, /*gradient_done=*/true);
     } else {
         launch_gray(img, H, W, channels, stride, gray, s, bt);
@@ -1433,7 +1448,8 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     const float ang_step = (float)(2.0 * M_PI / 42);
     const int nkeys = (int)((float)(2.0 * M_PI) / ang_step);
     // per-keypoint kernels stride over the stage's keypoints: the grid only has to be of the right order (this thread's last image)
-    const int kp_blocks = std::min(16384, std::max(256, ceil_div((long long)(c.akaze_kp_estimate > 0 ? c.akaze_kp_estimate : 32768) * 5 / 4, 4)));
+    const int kp_blocks = (std::min(16384, std::max(256, ceil_div((long long)(c.akaze_kp_estimate > 0 ? c.akaze_kp_estimate : 32768) * 5 / 4, 4))) + 7) & ~7;
+    const int xcd_ranges = config().kp_xcd ? 1 : 0;
 
     // Stage: make levels (prev_m, m] final and emit them. Needs the Hessian kernels of levels <= D = min(m + 1, L - 1).
     //   phase 0 (a level's candidates delete weaker neighbours in the level below): passes i in (prev_D, D]
@@ -1492,9 +1508,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         }
         // ---- a1.8 / a1.9 over the stage's keypoints [kp_base[k], kp_base[k + 1]), capped at the output capacity
         hipLaunchKernelGGL(orientation_kernel, dim3(kp_blocks, 1, B), dim3(256), 0, s_kp, T, kps_out, (const int*)base_k, std::min(capacity, max_points),
-                           kp_bstride, ang_step, nkeys);
+                           kp_bstride, ang_step, nkeys, xcd_ranges);
         hipLaunchKernelGGL(mldb_kernel, dim3(kp_blocks, 1, B), dim3(256), 0, s_kp, T, (const apds_keypoint*)kps_out, (const int*)base_k,
-                           std::min(capacity, max_points), kp_bstride, reinterpret_cast<uint32_t*>(desc64_out), desc_bstride);
+                           std::min(capacity, max_points), kp_bstride, reinterpret_cast<uint32_t*>(desc64_out), desc_bstride, xcd_ranges);
         n_stage++;
     };
     auto run_stage = [&](int prev_m, int m) {
@@ -1697,9 +1713,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             hipLaunchKernelGGL(emit_keypoints_kernel, dim3(nb_all), dim3(SCAN_BLOCK), 0, s, Tb, (const uint8_t*)(mask_all + (size_t)bi * slab), 0ll, total_pix,
                                (const int*)bc, (const int*)nullptr, kps_all, K[bi], (size_t)0);
             hipLaunchKernelGGL(rank_select_kernel, dim3(ceil_div(K[bi], 256)), dim3(256), 0, s, (const apds_keypoint*)kps_all, K[bi], keep, kp_b);
-            hipLaunchKernelGGL(orientation_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, Tb, kp_b, (const int*)nullptr, keep, (size_t)0, ang_step, nkeys);
+            hipLaunchKernelGGL(orientation_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, Tb, kp_b, (const int*)nullptr, keep, (size_t)0, ang_step, nkeys, 0);
             hipLaunchKernelGGL(mldb_kernel, dim3(ceil_div(keep, 4)), dim3(256), 0, s, Tb, (const apds_keypoint*)kp_b, (const int*)nullptr, keep, (size_t)0,
-                               reinterpret_cast<uint32_t*>(desc64_out + (size_t)bi * desc_bstride), (size_t)0);
+                               reinterpret_cast<uint32_t*>(desc64_out + (size_t)bi * desc_bstride), (size_t)0, 0);
         }
         HIP_CHECK(hipGetLastError());
         // these kernels read the calling thread's workspace (kps_all, masks, planes): the same thread's NEXT call, possibly on another

@@ -19,6 +19,8 @@ struct Config {
     int doh_strip;        // APDS_DOH_STRIP    streaming Hessian / extrema kernel (levels >= 8 Mpx)
     int doh_strip_rows;   // APDS_DOH_STRIP_ROWS  band height of that kernel (0 = chosen by level size); test hook
     int kp_ranked;        // APDS_KP_RANKED    1: candidates place themselves (default); 0: two passes over the masks
+    int kp_xcd;           // APDS_KP_XCD       1: every XCD takes one contiguous eighth of the keypoints in the orientation / descriptor kernels (default); 0: blocks stride over all of them
+    int fed_shrink;       // APDS_FED_SHRINK   1: level_fused_kernel's FED steps skip the patches outside the zone the tile still depends on (default); 0: every step sweeps the whole region
     // ---- AKAZE extraction: scheduling
     int akaze_fork;       // APDS_AKAZE_FORK   Hessian kernels on a side stream: 1 when the caller is the only library thread, 0 never, 2 always
     int side_probe;       // APDS_SIDE_PROBE   1: pick the side stream by a one-time concurrency probe; 0: the first stream created

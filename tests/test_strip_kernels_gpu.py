@@ -45,7 +45,14 @@ def test_akaze_parity_with_lds_fused_levels_on_every_level(gpu_pkg):
 def test_akaze_parity_on_the_round_2_path(gpu_pkg):
     """separate smoothing / FED launches per level, keypoints placed by two passes over the masks, the LDS-tile Hessian kernel on every
     level with the masks cleared by the zeroing kernel, default events: none of round 3's streaming kernels"""
-    _rerun({"APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STRIP": "0", "APDS_KP_RANKED": "0", "APDS_EVENT_SCOPE": "1", "APDS_DOH_STRIP": "0", "APDS_LEVEL_STREAM": "0"})
+    _rerun({"APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STRIP": "0", "APDS_KP_RANKED": "0", "APDS_EVENT_SCOPE": "1", "APDS_DOH_STRIP": "0", "APDS_LEVEL_STREAM": "0",
+            "APDS_KP_XCD": "0"})
+
+
+def test_akaze_parity_with_full_fed_sweeps_in_the_fused_levels(gpu_pkg):
+    """level_fused_kernel on every level without round 4's shrinking zone (every FED step sweeps the whole halo'd region, as in round 3): the
+    default (shrinking) runs in the test above and in test_akaze_gpu.py itself."""
+    _rerun({"APDS_LEVEL_FUSE": "2", "APDS_LEVEL_STRIP": "0", "APDS_FED_SHRINK": "0"})
 
 
 def test_akaze_parity_with_the_streaming_kernels_on_every_level(gpu_pkg):
