@@ -51,30 +51,43 @@ def detect_algorithmic_bytes(w, h):
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same args>`
     as a child process (one rank per GPU, rendezvous on 127.0.0.1, a free port), pass rank 0's JSON line through and return the child's exit
-    code. The parent never imports torch or touches HIP."""
+    code. The parent never imports torch or touches HIP. If the ranks fail on the library's own RCCL communicator (the default transport) and
+    the caller did not pin a transport, a FRESH set of ranks is started with --transport torch (the same exchange through torch.distributed's
+    collectives): the first multi-GPU run a node ever gives this code should not be lost to a communicator set-up problem."""
     import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.abspath(__file__)] + sys.argv[1:]
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    lines = 0
-    for line in proc.stdout:
-        if line.lstrip().startswith("{"):          # the contract: ONE JSON line on stdout; anything else a rank printed goes to stderr
-            sys.stdout.write(line)
-            sys.stdout.flush()
-            lines += 1
-        else:
-            sys.stderr.write(line)
-    rc = proc.wait()
-    if rc == 0 and lines != 1:
-        print(f"bench.py: the ranks exited 0 but printed {lines} JSON lines", file=sys.stderr)
-        rc = 1
+
+    def run_once(extra):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+               os.path.abspath(__file__)] + sys.argv[1:] + extra
+        proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        json_lines = []
+        for line in proc.stdout:
+            if line.lstrip().startswith("{"):          # the contract: ONE JSON line on stdout; anything else a rank printed goes to stderr
+                json_lines.append(line)
+            else:
+                sys.stderr.write(line)
+        rc = proc.wait()
+        if rc == 0 and len(json_lines) != 1:
+            print(f"bench.py: the ranks exited 0 but printed {len(json_lines)} JSON lines", file=sys.stderr)
+            rc = 1
+        return rc, json_lines
+
+    pinned = any(a == "--transport" or a.startswith("--transport=") for a in sys.argv[1:])
+    rc, lines = run_once([])
+    if rc != 0 and not pinned:
+        print(f"bench.py: the ranks exited {rc} on the default transport (the library's own RCCL communicator); starting a fresh set with --transport torch",
+              file=sys.stderr, flush=True)
+        rc, lines = run_once(["--transport", "torch", "--transport-fallback-from", f"rccl (exit code {rc})"])
+    if rc == 0:
+        sys.stdout.write(lines[0])
+        sys.stdout.flush()
     return rc
 
 
@@ -103,6 +116,12 @@ def main():
                          "the extraction stream): reported as value_host_frames next to the resident `value` (the reference's bench times Mat "
                          "construction + extraction, benchmarks/benches/feature_extraction.rs:35-45)")
     ap.add_argument("--no-host-frames", dest="host_frames", action="store_false", help="skip the host-frames leg")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1: what carries the match step's exchange. rccl (default): the library's own RCCL communicator (ncclCommInitRank inside "
+                         "libapds_hip.so, id broadcast through the torch group). torch: the same all-gather / all-to-all through torch.distributed's "
+                         "device collectives on its nccl group (device-callback transport). Started bare, `--gpus N` tries rccl first and starts a "
+                         "fresh set of ranks on torch if that set exits non-zero")
+    ap.add_argument("--transport-fallback-from", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -137,15 +156,6 @@ def main():
             else:
                 dist.init_process_group(backend)
             group = dist.group.WORLD
-            # host-side exchange of the per-frame query counts (no device sync). Single node: loopback is always usable, the
-            # container hostname may not resolve. If gloo cannot be set up the pipeline falls back to a device-side count gather.
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            try:
-                meta_group = dist.new_group(backend="gloo")
-                dist.barrier(group=meta_group)        # connect now (and print now), not inside the timed region
-            except Exception as e:   # noqa: BLE001
-                print(f"[bench] gloo meta group unavailable ({e}); using device-side counts", file=sys.stderr, flush=True)
-                meta_group = None
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -334,10 +344,13 @@ def main():
         check(L.apds_thread_release())
         check(L.apds_release_cached_memory())
         check(L.apds_set_device(dev_index))
+    if world > 1 and os.environ.get("APDS_BENCH_FAIL_TRANSPORT") == args.transport:     # test hook: this transport "cannot be set up" (exercises the fallback)
+        raise SystemExit(f"bench.py: APDS_BENCH_FAIL_TRANSPORT={args.transport}: simulated communicator failure")
     if args.serial:
         pipe = pl.FramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev))
     else:
-        pipe = pl.StreamedFramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev), reserve_cus=args.reserve_cus, meta_group=meta_group)
+        pipe = pl.StreamedFramePipeline(db_local, db_xy, index_base=lo, group=group, device=str(dev), reserve_cus=args.reserve_cus, meta_group=meta_group,
+                                        transport=args.transport)
 
     def run_step(i):
         return pipe.step(frames[i % len(frames)], filter_strength=args.filter_strength)
@@ -490,7 +503,8 @@ def main():
                        "match_stream_gaps_ms_first16": ([round(float(g), 2) for g in pipe.gap_log[:16]] if getattr(pipe, "gap_log", None) else None),
                        "keypoints_per_frame": K, "matches_per_frame": float(np.mean([s["n_matches"] for s in stats])),
                        "inliers_per_frame": float(np.mean([s["n_inliers"] for s in stats])), "homography_found": all(s["H"] is not None for s in stats)},
-            "collectives": collectives_info(torch, dist, world, backend, meta_group),
+            "collectives": dict(collectives_info(torch, dist, world, backend, meta_group), transport=pipe.matcher.info()["transport"] if hasattr(pipe, "matcher") else None,
+                                transport_requested=args.transport, fell_back_from=args.transport_fallback_from),
             "value_host_frames": (world * args.steps / elapsed_host) if elapsed_host else None,
             "ms_per_step_host_frames": (elapsed_host / args.steps * 1e3) if elapsed_host else None,
             "mmatches_per_s": world * K * args.steps / elapsed / 1e6,
@@ -560,7 +574,7 @@ def collectives_info(torch, dist, world, backend, meta_group):
         rccl = None
     return {"world": world, "backend": ("rccl (torch.distributed 'nccl')" if backend == "nccl" else backend) if world > 1 else "none (one rank, no exchange step)",
             "rccl_version": rccl, "ranks_in_group": dist.get_world_size() if world > 1 else 1,
-            "count_exchange": "gloo host group" if meta_group is not None else ("device-side gather" if world > 1 else None),
+            "count_exchange": "apds_shard_counts: a 4-byte all-gather through the same transport, issued by the pipeline's match thread on its own stream" if world > 1 else None,
             "exchange": "all-gather of query rows + all-to-all of per-shard top-2 keys + u64-min merge" if world > 1 else None}
 
 

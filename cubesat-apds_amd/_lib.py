@@ -36,7 +36,7 @@ SYMBOLS = [
 ]
 
 # multi-GPU sharded matcher (include/apds.h: apds_comm_id, apds_host_transport)
-TRANSPORT_RCCL, TRANSPORT_LOOPBACK, TRANSPORT_HOST = 0, 1, 2
+TRANSPORT_RCCL, TRANSPORT_LOOPBACK, TRANSPORT_HOST, TRANSPORT_DEVICE = 0, 1, 2, 3
 COMM_ID_BYTES = 128
 
 
@@ -51,6 +51,16 @@ HOST_ALL_TO_ALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_siz
 
 class HostTransport(C.Structure):
     _fields_ = [("user", C.c_void_p), ("all_gather", HOST_ALL_GATHER), ("all_to_all", HOST_ALL_TO_ALL)]
+
+
+# apds_device_transport: the same two callbacks on DEVICE buffers, with the stream they are ordered on
+DEV_ALL_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+DEV_ALL_TO_ALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.c_void_p, C.POINTER(C.c_size_t),
+                             C.POINTER(C.c_size_t), C.c_void_p)
+
+
+class DeviceTransport(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("all_gather", DEV_ALL_GATHER), ("all_to_all", DEV_ALL_TO_ALL)]
 
 
 class PipelineParams(C.Structure):
@@ -169,7 +179,7 @@ def lib():
             "apds_db_view_download": (i, [vp, vp, vp, vp, vp]),
             "apds_db_knn_match": (i, [vp, vp, i, i, i, vp, vp]),
             "apds_comm_id_create": (i, [i, C.POINTER(CommId)]),
-            "apds_shard_create": (i, [pp, i, i, i, C.POINTER(CommId), C.POINTER(HostTransport), vp, i64, u32]),
+            "apds_shard_create": (i, [pp, i, i, i, C.POINTER(CommId), vp, vp, i64, u32]),
             "apds_shard_destroy": (i, [vp]),
             "apds_shard_info": (i, [vp, ip, ip, C.POINTER(i64), C.POINTER(u32), C.POINTER(C.c_char_p), ip]),
             "apds_shard_counts": (i, [vp, i, ip, vp]),

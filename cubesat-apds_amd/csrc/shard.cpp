@@ -168,6 +168,34 @@ struct RcclTransport final : Transport {
     }
 };
 
+// ---- the host program's communicator on device buffers (e.g. torch.distributed over its own RCCL communicator) ---------------------------------
+struct DeviceCallbackTransport final : Transport {
+    apds_device_transport cb;
+    int* counts_dev = nullptr;
+    DeviceCallbackTransport(const apds_device_transport& c, int rank_, int world_) : cb(c) {
+        rank = rank_;
+        world = world_;
+        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&counts_dev), (size_t)(world + 1) * sizeof(int)));
+    }
+    ~DeviceCallbackTransport() override {
+        if (counts_dev) (void)hipFree(counts_dev);
+    }
+    const char* name() const override { return "device-callbacks"; }
+    void counts(int mine, int* all, void* s) override {
+        hipStream_t st = pick_stream(s);
+        HIP_CHECK(hipMemcpyAsync(counts_dev + world, &mine, sizeof(int), hipMemcpyHostToDevice, st));
+        if (cb.all_gather(cb.user, counts_dev + world, counts_dev, sizeof(int), st)) throw ShardError(APDS_ERR_INTERNAL, "device all_gather callback failed");
+        HIP_CHECK(hipMemcpyAsync(all, counts_dev, (size_t)world * sizeof(int), hipMemcpyDeviceToHost, st));
+        HIP_CHECK(hipStreamSynchronize(st));
+    }
+    void all_gather(const void* send, void* recv, size_t bytes, void* s) override {
+        if (cb.all_gather(cb.user, send, recv, bytes, pick_stream(s))) throw ShardError(APDS_ERR_INTERNAL, "device all_gather callback failed");
+    }
+    void all_to_all(const void* send, const size_t* soff, const size_t* sbytes, void* recv, const size_t* roff, const size_t* rbytes, void* s) override {
+        if (cb.all_to_all(cb.user, send, soff, sbytes, recv, roff, rbytes, pick_stream(s))) throw ShardError(APDS_ERR_INTERNAL, "device all_to_all callback failed");
+    }
+};
+
 // ---- loopback: the ranks are threads of this process -------------------------------------------------------------------------------------
 struct Hub {
     const int world;
@@ -370,7 +398,7 @@ int apds_shard_create(void** shard, int rank, int world, int transport, const ap
         auto h = std::make_unique<ShardHandle>();
         h->device = c.device;
         h->transport = transport;
-        if (world == 1 && transport != APDS_TRANSPORT_RCCL) {
+        if (world == 1 && transport != APDS_TRANSPORT_RCCL && transport != APDS_TRANSPORT_DEVICE) {
             struct Solo final : Transport {
                 const char* name() const override { return "none (one rank)"; }
                 void counts(int mine, int* all, void*) override { all[0] = mine; }
@@ -387,12 +415,16 @@ int apds_shard_create(void** shard, int rank, int world, int transport, const ap
         } else if (transport == APDS_TRANSPORT_HOST) {
             APDS_REQUIRE(host && host->all_gather && host->all_to_all, APDS_ERR_BAD_ARG, "the host transport needs both callbacks");
             h->tr = std::make_unique<HostTransport>(h->dev, HostCallbacks{host->user, host->all_gather, host->all_to_all}, rank, world);
+        } else if (transport == APDS_TRANSPORT_DEVICE) {
+            const apds_device_transport* dt = reinterpret_cast<const apds_device_transport*>(host);
+            APDS_REQUIRE(dt && dt->all_gather && dt->all_to_all, APDS_ERR_BAD_ARG, "the device-callback transport needs both callbacks");
+            h->tr = std::make_unique<DeviceCallbackTransport>(*dt, rank, world);
         } else {
             fail(APDS_ERR_BAD_ARG, "unknown transport");
         }
         h->tr->rank = rank;
         h->tr->world = world;
-        h->m = std::make_unique<Matcher>(h->dev, *h->tr, rows64_dev, n_rows, index_base, /*force_exchange=*/transport == APDS_TRANSPORT_RCCL);
+        h->m = std::make_unique<Matcher>(h->dev, *h->tr, rows64_dev, n_rows, index_base, /*force_exchange=*/transport == APDS_TRANSPORT_RCCL || transport == APDS_TRANSPORT_DEVICE);
         *shard = h.release();
     });
 }

@@ -85,6 +85,52 @@ def host_transport_from_group(dist, group):
     return ht
 
 
+class _DevBytes:
+    """A library-owned device buffer as something torch.as_tensor can wrap without a copy (__cuda_array_interface__; ROCm builds read it too)."""
+
+    def __init__(self, addr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(addr), False), "version": 2, "strides": None}
+
+
+def device_transport_from_group(dist, group, device):
+    """apds_device_transport (include/apds.h) over a torch.distributed process group whose collectives take DEVICE tensors ("nccl" = RCCL):
+    the library's exchange buffers are wrapped as tensors in place and the collectives are issued on the stream the library names, so the
+    exchange travels over torch's own RCCL communicator. The second way onto xGMI: bench.py falls back to it (--transport torch) if the
+    library's own communicator (APDS_TRANSPORT_RCCL: ncclCommInitRank beside torch's) cannot be set up on a node."""
+    world = dist.get_world_size(group)
+
+    def view(addr, n):
+        if not n:
+            return torch.empty(0, dtype=torch.uint8, device=device)
+        return torch.as_tensor(_DevBytes(addr, n), device=device)
+
+    def all_gather(_user, send, recv, nbytes, stream):
+        try:
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=device)):
+                dist.all_gather_into_tensor(view(recv, nbytes * world), view(send, nbytes), group=group)
+            return 0
+        except Exception:   # noqa: BLE001 - an exception must not unwind through the C frames
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def all_to_all(_user, send, soff, sbytes, recv, roff, rbytes, stream):
+        try:
+            so, sb, ro, rb = ([int(a[p]) for p in range(world)] for a in (soff, sbytes, roff, rbytes))
+            assert all(so[p] == sum(sb[:p]) for p in range(world)) and all(ro[p] == sum(rb[:p]) for p in range(world)), "blocks are not contiguous"
+            with torch.cuda.stream(torch.cuda.ExternalStream(int(stream), device=device)):
+                dist.all_to_all_single(view(recv, sum(rb)), view(send, sum(sb)), output_split_sizes=rb, input_split_sizes=sb, group=group)
+            return 0
+        except Exception:   # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    dt = _lib.DeviceTransport(None, _lib.DEV_ALL_GATHER(all_gather), _lib.DEV_ALL_TO_ALL(all_to_all))
+    dt._keep = (all_gather, all_to_all)
+    return dt
+
+
 class GatheredQueries:
     """One frame's exchange slot of a shard handle (apds_shard_slot_create): the buffers live in the library; `merged` is where
     exchange_merge leaves the keys when the caller passes no output tensor."""
@@ -115,13 +161,14 @@ class ShardedMatcher:
     local shard with global row indices, all-to-all of the keys, u64-min merge (= the single-GPU result, lowest-index tie-break
     included). What this class adds is the choice of transport from the torch process group it is given:
       * no group / one rank: no exchange step, the scan is called directly;
-      * a "nccl" group: the library's RCCL transport (its own communicator; rank 0's id travels through the torch group once);
+      * a "nccl" group: the library's RCCL transport (its own communicator; rank 0's id travels through the torch group once), or -
+        transport="torch" - device callbacks that run the same two collectives through torch.distributed on that group;
       * a "gloo" group: the host-callback transport over that group (several ranks on one GPU: rehearsal).
     The three steps are separate calls (gather_queries / scan_gathered / exchange_merge) so that a pipeline can issue frame i+1's query
     gather on another stream BEFORE frame i's key exchange. All collective calls must come from ONE thread in the same order on every
     rank. No per-frame allocations."""
 
-    def __init__(self, local_rows64, index_base, group=None, pad_rows=32768, meta_group=None, kmax=2, always_exchange=False):
+    def __init__(self, local_rows64, index_base, group=None, pad_rows=32768, meta_group=None, kmax=2, always_exchange=False, transport="rccl"):
         self.rows = local_rows64            # borrowed by the shard handle for its whole life
         self.index_base = int(index_base)
         self.group = group
@@ -145,7 +192,13 @@ class ShardedMatcher:
         backend = dist.get_backend(group)
         h = C.c_void_p()
         n_rows = int(local_rows64.shape[0])
-        if backend == "nccl":
+        if backend == "nccl" and transport == "torch":
+            # the exchange over torch's own RCCL communicator: device callbacks on this group
+            self._dev_transport = device_transport_from_group(dist, group, local_rows64.device)
+            check(L.apds_shard_create(C.byref(h), self.rank, self.world, _lib.TRANSPORT_DEVICE, None, C.byref(self._dev_transport), local_rows64.data_ptr(), n_rows,
+                                      self.index_base))
+            self.transport = "device-callbacks (torch.distributed nccl)"
+        elif backend == "nccl":
             # rank 0 creates the RCCL id; 128 bytes through the torch group; every rank then joins the library's own communicator
             cid = _lib.CommId()
             if self.rank == 0:
@@ -310,10 +363,10 @@ class StreamedFramePipeline:
     pointers (train rows, their keypoints, frames), the transport choice for a sharded DB (ShardedMatcher), and results as dicts."""
 
     def __init__(self, db_rows64, db_xy, index_base=0, group=None, max_points=(1 << 18) - 1, device="cuda:0", slots=6, reserve_cus=0,
-                 n_cus=256, meta_group=None, extract_workers=None):
+                 n_cus=256, meta_group=None, extract_workers=None, transport="rccl"):
         import os
         self.dev = torch.device(device)
-        self.matcher = ShardedMatcher(db_rows64, index_base, group, meta_group=meta_group)
+        self.matcher = ShardedMatcher(db_rows64, index_base, group, meta_group=meta_group, transport=transport)
         self.n_db = db_xy.shape[0]
         kp = torch.zeros((self.n_db, 7), dtype=torch.float32, device=self.dev)     # 28-byte cv::KeyPoint rows of ALL train rows (x, y used)
         kp[:, 0:2] = db_xy

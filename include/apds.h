@@ -220,7 +220,7 @@ int apds_db_knn_match(void* db, const uint8_t* query_desc, int n_query, int desc
 typedef struct apds_comm_id {
     char bytes[APDS_COMM_ID_BYTES];
 } apds_comm_id;
-enum { APDS_TRANSPORT_RCCL = 0, APDS_TRANSPORT_LOOPBACK = 1, APDS_TRANSPORT_HOST = 2 };
+enum { APDS_TRANSPORT_RCCL = 0, APDS_TRANSPORT_LOOPBACK = 1, APDS_TRANSPORT_HOST = 2, APDS_TRANSPORT_DEVICE = 3 };
 typedef struct apds_host_transport {
     void* user;
     /* recv = every rank's bytes_per_rank bytes, rank-major; return 0 on success */
@@ -229,10 +229,20 @@ typedef struct apds_host_transport {
     int (*all_to_all)(void* user, const void* send, const size_t* send_off, const size_t* send_bytes, void* recv, const size_t* recv_off,
                       const size_t* recv_bytes);
 } apds_host_transport;
+/* APDS_TRANSPORT_DEVICE: the host program's communicator as two callbacks on DEVICE buffers, ordered on the hipStream_t they are given (e.g.
+ * torch.distributed's device collectives over its own RCCL communicator: the second way onto xGMI if the library's own communicator cannot be
+ * set up beside the host's). Passed to apds_shard_create through the `host` argument (same layout, one more argument per callback). */
+typedef struct apds_device_transport {
+    void* user;
+    int (*all_gather)(void* user, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+    int (*all_to_all)(void* user, const void* send_dev, const size_t* send_off, const size_t* send_bytes, void* recv_dev, const size_t* recv_off,
+                      const size_t* recv_bytes, void* stream);
+} apds_device_transport;
 /* A fresh communicator id for `transport` (RCCL: ncclGetUniqueId; loopback: a process-unique name; host: zeros). Called by ONE rank. */
 int apds_comm_id_create(int transport, apds_comm_id* id);
 /* Collective. The shard lives on the calling thread's device (apds_set_device first). rows64_dev: n_rows x 64-byte rows, borrowed for
- * the life of the handle. index_base = global index of the shard's first row. id: RCCL / loopback; host: the host transport's callbacks. */
+ * the life of the handle. index_base = global index of the shard's first row. id: RCCL / loopback; host: the host transport's callbacks
+ * (APDS_TRANSPORT_DEVICE: a pointer to an apds_device_transport, cast). */
 int apds_shard_create(void** shard, int rank, int world, int transport, const apds_comm_id* id, const apds_host_transport* host,
                       const void* rows64_dev, int64_t n_rows, uint32_t index_base);
 int apds_shard_destroy(void* shard);

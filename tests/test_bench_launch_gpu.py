@@ -40,6 +40,20 @@ def test_bare_two_rank_launch_prints_one_json_line(gpu_pkg):
     assert out["value"] > 0 and out["roofline"]["frac"] > 0
 
 
+def test_a_failing_first_transport_is_retried_on_the_second(gpu_pkg):
+    """The bare parent starts a fresh set of ranks with --transport torch when the first set (the library's own RCCL communicator) exits
+    non-zero; the JSON line says which transport ran and what it fell back from. (Over gloo both map onto host callbacks: what is under
+    test is the parent's retry, which never touches the GPU.)"""
+    rc, lines, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--tile", "1024", "--db-rows", "100000", "--no-cpu-baseline", "--no-host-frames"],
+                          {"APDS_BENCH_BACKEND": "gloo", "APDS_BENCH_FAIL_TRANSPORT": "rccl"})
+    assert rc == 0, err[-3000:]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["collectives"]["transport_requested"] == "torch" and "rccl" in out["collectives"]["fell_back_from"]
+    assert out["n_gpus"] == 2 and out["config"]["homography_found"] is True
+    assert "starting a fresh set with --transport torch" in err
+
+
 def test_single_gpu_line_carries_the_contract_fields(gpu_pkg):
     rc, lines, err = _run(["--steps", "3", "--warmup", "1", "--tile", "1024", "--db-rows", "100000", "--no-cpu-baseline", "--host-frames"])
     assert rc == 0, err[-3000:]

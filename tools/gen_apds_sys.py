@@ -18,7 +18,7 @@ OUT = os.path.join(ROOT, "rust_shim", "apds_sys", "src", "lib.rs")
 BASE = {"void": "c_void", "char": "c_char", "int": "c_int", "float": "f32", "double": "f64", "size_t": "usize", "uint8_t": "u8", "int32_t": "i32",
         "uint32_t": "u32", "int64_t": "i64", "uint64_t": "u64", "apds_keypoint": "apds_keypoint", "apds_dmatch": "apds_dmatch",
         "apds_comm_id": "apds_comm_id", "apds_host_transport": "apds_host_transport", "apds_pipeline_params": "apds_pipeline_params",
-        "apds_frame_result": "apds_frame_result", "apds_pipeline_counters": "apds_pipeline_counters"}
+        "apds_frame_result": "apds_frame_result", "apds_pipeline_counters": "apds_pipeline_counters", "apds_device_transport": "apds_device_transport"}
 POD_STRUCTS = ["apds_pipeline_params", "apds_frame_result", "apds_pipeline_counters"]     # plain-data structs translated field by field
 RESERVED = {"type", "match", "ref", "box", "move", "in", "fn", "loop", "mod", "use", "where", "impl", "self", "super", "crate", "dyn", "as"}
 
@@ -139,6 +139,12 @@ def generate():
              "    pub all_gather: Option<unsafe extern \"C\" fn(user: *mut c_void, send: *const c_void, recv: *mut c_void, bytes_per_rank: usize) -> c_int>,\n"
              "    pub all_to_all: Option<unsafe extern \"C\" fn(user: *mut c_void, send: *const c_void, send_off: *const usize, send_bytes: *const usize, recv: *mut c_void,\n"
              "                                                recv_off: *const usize, recv_bytes: *const usize) -> c_int>,\n}")
+    L.append("")
+    L.append("/// the host program's communicator as two callbacks on DEVICE buffers, ordered on the stream they are given (APDS_TRANSPORT_DEVICE)")
+    L.append("#[repr(C)]\n#[derive(Clone, Copy)]\npub struct apds_device_transport {\n    pub user: *mut c_void,\n"
+             "    pub all_gather: Option<unsafe extern \"C\" fn(user: *mut c_void, send_dev: *const c_void, recv_dev: *mut c_void, bytes_per_rank: usize, stream: *mut c_void) -> c_int>,\n"
+             "    pub all_to_all: Option<unsafe extern \"C\" fn(user: *mut c_void, send_dev: *const c_void, send_off: *const usize, send_bytes: *const usize, recv_dev: *mut c_void,\n"
+             "                                                recv_off: *const usize, recv_bytes: *const usize, stream: *mut c_void) -> c_int>,\n}")
     for name in POD_STRUCTS:
         L.append("")
         L.append(f"/// {name} (include/apds.h): the streamed frame pipeline's plain-data structs, field for field")

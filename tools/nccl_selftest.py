@@ -49,11 +49,24 @@ with torch.cuda.stream(torch.cuda.Stream(dev)):
     split_a = m.exchange_merge(bufs[0], 2).cpu().numpy().view(np.uint64).copy()
     m.scan_gathered(bufs[1], 2)
     split_b = m.exchange_merge(bufs[1], 2).cpu().numpy().view(np.uint64).copy()
+    # the same exchange through torch.distributed's own RCCL communicator (APDS_TRANSPORT_DEVICE: device callbacks on this group) - the
+    # fallback transport of bench.py (--transport torch) - and the strong-scaling form (one frame, all-gather of the per-shard keys)
+    mt = pl.ShardedMatcher(rows, 0, group=dist.group.WORLD, meta_group=meta, always_exchange=True, transport="torch")
+    info_t = mt.info()
+    assert info_t["transport"] == "device-callbacks" and info_t["world"] == 1, info_t
+    torch_call = mt.knn(qd, 2).cpu().numpy().view(np.uint64).copy()
+    rep = torch.empty((len(q), 2), dtype=torch.int64, device=dev)
+    pkg._lib.check(pkg.lib().apds_shard_knn_replicated(mt.handle, qd.data_ptr(), len(q), 0, 2, rep.data_ptr(), pl.torch_stream()))
+    rep_t = rep.cpu().numpy().view(np.uint64).copy()
+    pkg._lib.check(pkg.lib().apds_shard_knn_replicated(m.handle, qd.data_ptr(), len(q), -1, 2, rep.data_ptr(), pl.torch_stream()))
+    rep_r = rep.cpu().numpy().view(np.uint64).copy()
 torch.cuda.synchronize()
+assert np.array_equal(torch_call, direct) and np.array_equal(rep_t, direct) and np.array_equal(rep_r, direct)
 assert cnt == [len(q)] and np.array_equal(one_call, direct) and np.array_equal(split_a, direct) and np.array_equal(split_b[::-1], direct)
 planted = src >= 0
 assert np.array_equal((direct[planted, 0] & np.uint64(0xFFFFFFFF)).astype(np.int64), src[planted])
 dist.barrier()
 dist.destroy_process_group()
 print(f"nccl selftest OK: the library's RCCL transport (rccl {info['rccl_version']}) at world 1 - ncclAllGather of the queries + send/recv group of the keys between "
-      "library kernels, one-call and split forms - under a torch nccl group with a gloo meta group beside it, barrier")
+      "library kernels, one-call and split forms - under a torch nccl group with a gloo meta group beside it, barrier; the same exchange and the "
+      "replicated (all-gather of keys) form through torch.distributed device collectives (device-callback transport)")
