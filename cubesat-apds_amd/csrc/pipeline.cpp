@@ -328,34 +328,48 @@ struct Pipeline {
     }
 
     // ---- stage 2: match (row-sharded DB) -----------------------------------------------------------------------------------------------
-    // This thread issues ALL collectives of the pipeline, in frame order, the same order on every rank: counts(i+1) [a tiny all-gather on its
-    // own stream; the only host synchronisation, and frame i's scan is already queued behind it], gather(i+1) [its own stream, after that
-    // frame's extraction] BEFORE exchange(i) [match stream, after scan(i)]: the query all-gather of the next frame travels under the scan.
+    // This thread issues ALL collectives of the pipeline, in frame order, the same order on every rank: counts(i) [a tiny all-gather on its
+    // own stream; the only host synchronisation, and frame i-1's scan is already queued behind it], gather(i) [its own stream, after that
+    // frame's extraction] BEFORE exchange(i-1) [match stream, after scan(i-1)]: the query all-gather of a frame travels under the previous
+    // frame's scan. Deferring exchange(i-1) until frame i has arrived is only safe when frame i is certain to arrive on EVERY rank, and the
+    // choice must be the same everywhere (the collectives' order is at stake): each rank adds to its count a flag "frame i+1 is already
+    // submitted here", and frame i's exchange is deferred iff every rank set it. A host that streams (submits ahead of the results) gets
+    // the overlap on all frames but its last; a host that submits one frame and waits gets that frame's result without a successor.
     void sharded_match_worker() {
+        constexpr int NEXT_FLAG = 1 << 30;
         Slot* prev = nullptr;
         for (int64_t i = 0;; i++) {
             Slot* s = nullptr;
-            const bool have = q_ext[(size_t)(i % E)]->pop(s);
-            if (have && !s) {   // (the pipeline is idle: no frame is between gather and exchange)
+            if (!q_ext[(size_t)(i % E)]->pop(s)) break;
+            if (!s) {   // apds_pipeline_stats on the idle pipeline (no frame is between gather and exchange)
                 harvest({"hamming_topk", "hamming_topk_sample"});
                 i--;
                 continue;
             }
-            if (have) {
-                s->counts.assign((size_t)world, 0);
-                PIPE_OK(apds_shard_counts(shard, s->K, s->counts.data(), st_counts));
-                HIP_CHECK(hipStreamWaitEvent(st_gather, s->ev_extract, 0));
-                PIPE_OK(apds_shard_gather(shard, s->shard_slot, s->K ? s->desc : nullptr, s->K, s->counts.data(), st_gather));
+            bool next_here;
+            {
+                std::lock_guard<std::mutex> g(m);
+                next_here = next_submit > i + 1;
             }
-            if (prev) {
-                PIPE_OK(apds_shard_exchange_merge(shard, prev->shard_slot, 2, prev->keys, st_match));
-                HIP_CHECK(hipEventRecord(prev->ev_match, st_match));
-                q_homography.push(prev);
-                prev = nullptr;
+            s->counts.assign((size_t)world, 0);
+            PIPE_OK(apds_shard_counts(shard, s->K | (next_here ? NEXT_FLAG : 0), s->counts.data(), st_counts));
+            bool next_everywhere = true;
+            for (int& c : s->counts) {
+                next_everywhere = next_everywhere && (c & NEXT_FLAG);
+                c &= NEXT_FLAG - 1;
             }
-            if (!have) break;
+            HIP_CHECK(hipStreamWaitEvent(st_gather, s->ev_extract, 0));
+            PIPE_OK(apds_shard_gather(shard, s->shard_slot, s->K ? s->desc : nullptr, s->K, s->counts.data(), st_gather));
+            auto finish_exchange = [&](Slot* f) {
+                PIPE_OK(apds_shard_exchange_merge(shard, f->shard_slot, 2, f->keys, st_match));
+                HIP_CHECK(hipEventRecord(f->ev_match, st_match));
+                q_homography.push(f);
+            };
+            if (prev) finish_exchange(prev);
+            prev = nullptr;
             PIPE_OK(apds_shard_scan(shard, s->shard_slot, 2, st_match));
-            prev = s;
+            if (next_everywhere) prev = s;   // frame i+1 is on its way on every rank: its gather goes out first
+            else finish_exchange(s);
         }
         collect({"hamming_topk", "hamming_topk_sample"});
         q_homography.close();
