@@ -75,6 +75,62 @@ __global__ void warp_perspective_kernel(const uint32_t* __restrict__ src, int ro
     dst[(size_t)y * dst_cols + x] = out;
 }
 
+// The same map for the other element types warp_image_perspective<T: DataType> admits (mod.rs:271-300 is generic): CH interleaved channels
+// of u8 (OpenCV's fixed-point path: the 15-bit weight table above, (sum + 2^14) >> 15) or f32 (remapBilinear's float path: the four
+// weights (1-fy)(1-fx), (1-fy)fx, fy(1-fx), fy fx as float products of the 1/32-step fractions, ((v0 w0 + v1 w1) + v2 w2) + v3 w3 in
+// binary32, one operation each; a destination pixel whose 2x2 footprint lies wholly outside the source IS the border value).
+template <class T, int CH>
+__global__ void warp_perspective_generic_kernel(const T* __restrict__ src, int rows, int cols, double m0, double m1, double m2, double m3, double m4, double m5,
+                                                double m6, double m7, double m8, const short* __restrict__ tab, int dst_rows, int dst_cols, T* __restrict__ dst) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= dst_cols || y >= dst_rows) return;
+    const double X0 = m0 * x + m1 * y + m2, Y0 = m3 * x + m4 * y + m5;
+    double W = m6 * x + m7 * y + m8;
+    W = W ? 32. / W : 0;
+    const double fX = fmax((double)INT_MIN, fmin((double)INT_MAX, X0 * W));
+    const double fY = fmax((double)INT_MIN, fmin((double)INT_MAX, Y0 * W));
+    const int X = sat_int_rn(fX), Y = sat_int_rn(fY);
+    const int sx = X >> 5, sy = Y >> 5;
+    T* d = dst + ((size_t)y * dst_cols + x) * CH;
+    bool in[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int xx = sx + (k & 1), yy = sy + (k >> 1);
+        in[k] = xx >= 0 && xx < cols && yy >= 0 && yy < rows;
+    }
+    if constexpr (sizeof(T) == 1) {
+        const short* w = &tab[((Y & 31) * 32 + (X & 31)) * 4];
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            int v = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) v += (in[k] ? (int)src[((size_t)(sy + (k >> 1)) * cols + sx + (k & 1)) * CH + c] : 1) * w[k];   // border value 1
+            d[c] = (T)((v + (1 << 14)) >> 15);
+        }
+    } else {
+        if (!(in[0] || in[1] || in[2] || in[3])) {
+#pragma unroll
+            for (int c = 0; c < CH; c++) d[c] = (T)1;
+            return;
+        }
+        const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
+        const float w0 = (1.f - fy) * (1.f - fx), w1 = (1.f - fy) * fx, w2 = fy * (1.f - fx), w3 = fy * fx;
+#pragma unroll
+        for (int c = 0; c < CH; c++) {
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = in[k] ? (float)src[((size_t)(sy + (k >> 1)) * cols + sx + (k & 1)) * CH + c] : 1.0f;
+            float acc = v[0] * w0;
+            acc += v[1] * w1;
+            acc += v[2] * w2;
+            acc += v[3] * w3;
+            d[c] = (T)acc;
+        }
+    }
+}
+
 namespace {
 
 // 32x32 table of 2x2 fixed-point (15 bit) bilinear weights that sum to 2^15 (OpenCV's BilinearTab_i restated)
@@ -147,6 +203,33 @@ void warp_perspective_device(const uint8_t* src, int rows, int cols, const doubl
     hipLaunchKernelGGL(warp_perspective_kernel, dim3(ceil_div(dst_cols, 256), dst_rows), dim3(256), 0, s, reinterpret_cast<const uint32_t*>(src), rows, cols,
                        inv[0], inv[1], inv[2], inv[3], inv[4], inv[5], inv[6], inv[7], inv[8], (const short*)tab, dst_rows, dst_cols,
                        reinterpret_cast<uint32_t*>(dst));
+    HIP_CHECK(hipGetLastError());
+}
+
+// element = u8 (elem_bytes 1) or f32 (4), 1 / 3 / 4 interleaved channels; 8UC4 keeps its dword kernel
+void warp_perspective_any_device(const void* src, int rows, int cols, int channels, int elem_bytes, const double* M, int dst_rows, int dst_cols, void* dst,
+                                 hipStream_t s) {
+    if (elem_bytes == 1 && channels == 4) return warp_perspective_device(static_cast<const uint8_t*>(src), rows, cols, M, dst_rows, dst_cols, static_cast<uint8_t*>(dst), s);
+    double inv[9];
+    APDS_REQUIRE(invert3x3(M, inv), APDS_ERR_ASSERT, "perspective matrix is singular");
+    ThreadCtx& c = ctx();
+    short* tab = c.alloc_n<short>(32 * 32 * 4);
+    HIP_CHECK(hipMemcpyAsync(tab, bilinear_tab_host(), sizeof(short) * 32 * 32 * 4, hipMemcpyHostToDevice, s));
+    const dim3 grid(ceil_div(dst_cols, 256), dst_rows), block(256);
+    auto go = [&](auto kernel, auto* typed_src, auto* typed_dst) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, s, typed_src, rows, cols, inv[0], inv[1], inv[2], inv[3], inv[4], inv[5], inv[6], inv[7], inv[8], (const short*)tab,
+                           dst_rows, dst_cols, typed_dst);
+    };
+    const uint8_t* s8 = static_cast<const uint8_t*>(src);
+    uint8_t* d8 = static_cast<uint8_t*>(dst);
+    const float* sf = static_cast<const float*>(src);
+    float* df = static_cast<float*>(dst);
+    if (elem_bytes == 1 && channels == 1) go(warp_perspective_generic_kernel<uint8_t, 1>, s8, d8);
+    else if (elem_bytes == 1 && channels == 3) go(warp_perspective_generic_kernel<uint8_t, 3>, s8, d8);
+    else if (elem_bytes == 4 && channels == 1) go(warp_perspective_generic_kernel<float, 1>, sf, df);
+    else if (elem_bytes == 4 && channels == 3) go(warp_perspective_generic_kernel<float, 3>, sf, df);
+    else if (elem_bytes == 4 && channels == 4) go(warp_perspective_generic_kernel<float, 4>, sf, df);
+    else fail(APDS_ERR_ASSERT, "warp_perspective: element type must be u8 or f32 with 1, 3 or 4 channels");
     HIP_CHECK(hipGetLastError());
 }
 
@@ -263,21 +346,30 @@ int apds_dev_band_merger(const void* red, const void* green, const void* blue, s
     });
 }
 
-int apds_warp_perspective(const uint8_t* src, int rows, int cols, int channels, const double* M, int dst_rows, int dst_cols, uint8_t* dst) {
+static int warp_host(const void* src, int rows, int cols, int channels, int elem_bytes, const double* M, int dst_rows, int dst_cols, void* dst) {
     return guarded([&] {
         APDS_REQUIRE(src && M && dst, APDS_ERR_BAD_ARG, "null argument");
         APDS_REQUIRE(rows > 0 && cols > 0 && dst_rows > 0 && dst_cols > 0, APDS_ERR_ASSERT, "empty image");
-        APDS_REQUIRE(channels == 4, APDS_ERR_ASSERT, "warp_perspective is implemented for 4-channel u8 images (Vec4b, the type the reference warps)");
+        APDS_REQUIRE(channels == 1 || channels == 3 || channels == 4, APDS_ERR_ASSERT, "warp_perspective serves 1-, 3- and 4-channel images (u8 or f32 elements)");
         ThreadCtx& c = ctx();
         c.ws_reset();
         hipStream_t s = c.stream;
-        uint8_t* ds = c.alloc_n<uint8_t>((size_t)rows * cols * 4);
-        uint8_t* dd = c.alloc_n<uint8_t>((size_t)dst_rows * dst_cols * 4);
-        HIP_CHECK(hipMemcpyAsync(ds, src, (size_t)rows * cols * 4, hipMemcpyHostToDevice, s));
-        warp_perspective_device(ds, rows, cols, M, dst_rows, dst_cols, dd, s);
-        HIP_CHECK(hipMemcpyAsync(dst, dd, (size_t)dst_rows * dst_cols * 4, hipMemcpyDeviceToHost, s));
+        const size_t px = (size_t)channels * elem_bytes;
+        uint8_t* ds = c.alloc_n<uint8_t>((size_t)rows * cols * px);
+        uint8_t* dd = c.alloc_n<uint8_t>((size_t)dst_rows * dst_cols * px);
+        HIP_CHECK(hipMemcpyAsync(ds, src, (size_t)rows * cols * px, hipMemcpyHostToDevice, s));
+        warp_perspective_any_device(ds, rows, cols, channels, elem_bytes, M, dst_rows, dst_cols, dd, s);
+        HIP_CHECK(hipMemcpyAsync(dst, dd, (size_t)dst_rows * dst_cols * px, hipMemcpyDeviceToHost, s));
         HIP_CHECK(hipStreamSynchronize(s));
     });
+}
+
+int apds_warp_perspective(const uint8_t* src, int rows, int cols, int channels, const double* M, int dst_rows, int dst_cols, uint8_t* dst) {
+    return warp_host(src, rows, cols, channels, 1, M, dst_rows, dst_cols, dst);
+}
+
+int apds_warp_perspective_f32(const float* src, int rows, int cols, int channels, const double* M, int dst_rows, int dst_cols, float* dst) {
+    return warp_host(src, rows, cols, channels, 4, M, dst_rows, dst_cols, dst);
 }
 
 }  // extern "C"

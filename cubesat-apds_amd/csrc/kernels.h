@@ -39,6 +39,8 @@ void set_thread_scan_cap(int bytes);   // occupancy cap of the scans THIS thread
 int count_nonzero_device(const uint8_t* bytes, int n, int* count_dev, hipStream_t s);   // misc.hip: synchronises s
 void band_merger_device(const float* r, const float* g, const float* b, size_t n, const double* mm, int bgra, uint8_t* out, hipStream_t s);
 void warp_perspective_device(const uint8_t* src, int rows, int cols, const double* M, int dst_rows, int dst_cols, uint8_t* dst, hipStream_t s);
+void warp_perspective_any_device(const void* src, int rows, int cols, int channels, int elem_bytes, const double* M, int dst_rows, int dst_cols, void* dst,
+                                 hipStream_t s);
 
 int world_coordinates_device(const double* xy, int n, const double* dgt_host, const double* egt_host, const double* elev, int ew, int eh, double* xyz,
                              hipStream_t s);

@@ -100,22 +100,26 @@ def find_homography_mat(input_pts, reference_pts, method=None, reproj_threshold=
 
 
 def warp_image_perspective(src, m, size=None):
-    """mod.rs:271-300 — warpPerspective(INTER_LINEAR, BORDER_CONSTANT (1,1,1,1)). src: Cmat of HxWx4 u8, m: Cmat<f64> 3x3,
+    """mod.rs:271-300 — warpPerspective(INTER_LINEAR, BORDER_CONSTANT (1,1,1,1)), generic over the element type as the reference
+    (`warp_image_perspective<T: DataType>`): src is a Cmat of HxW or HxWxC (C = 1, 3, 4) u8 or f32 elements, m: Cmat<f64> 3x3,
     size: (width, height) or None (= source size). Returns a Cmat of the same element type."""
-    img = np.ascontiguousarray(src.mat, np.uint8)
-    if img.ndim != 3 or img.shape[2] != 4:
-        raise MatError("Opencv", ApdsError(_lib.ERR_ASSERT, "warp_image_perspective is implemented for Vec4b images"))
+    a = np.asarray(src.mat)
+    if a.dtype not in (np.uint8, np.float32) or a.ndim not in (2, 3) or (a.ndim == 3 and a.shape[2] not in (1, 3, 4)):
+        raise MatError("Opencv", ApdsError(_lib.ERR_ASSERT, "warp_image_perspective serves u8 and f32 images of 1, 3 or 4 channels"))
+    img = np.ascontiguousarray(a)
     M = np.ascontiguousarray(m.mat, np.float64)
     if M.shape != (3, 3):
         raise MatError("Opencv", ApdsError(_lib.ERR_ASSERT, "m must be 3x3"))
     h, w = img.shape[:2]
+    ch = 1 if img.ndim == 2 else img.shape[2]
     dw, dh = (w, h) if size is None else (int(size[0]), int(size[1]))
-    out = np.zeros((dh, dw, 4), np.uint8)
+    out = np.zeros((dh, dw) if img.ndim == 2 else (dh, dw, ch), img.dtype)
     try:
-        check(lib().apds_warp_perspective(ptr(img), h, w, 4, ptr(M), dh, dw, ptr(out)))
+        fn = lib().apds_warp_perspective if img.dtype == np.uint8 else lib().apds_warp_perspective_f32
+        check(fn(ptr(img), h, w, ch, ptr(M), dh, dw, ptr(out)))
     except ApdsError as e:
         raise MatError("Opencv", e)
-    return Cmat(out, np.uint8, 4)
+    return Cmat(out, img.dtype.type, ch if img.ndim == 3 else 1)
 
 
 class SolvePnPMethod(enum.IntEnum):

@@ -142,8 +142,11 @@ int apds_tile_extract_batch(const float* const* red, const float* const* green, 
                             const double* minmax6, int max_points, apds_keypoint** kps, uint8_t** desc, int* counts, int* desc_bytes);
 
 /* homographier/src/homographier/mod.rs:271-300 warp_image_perspective: warpPerspective(src, M, size, INTER_LINEAR, BORDER_CONSTANT,
- * Scalar(1,1,1,1)). M (9 doubles) maps source to destination coordinates. channels must be 4 (Vec4b). */
+ * Scalar(1,1,1,1)). M (9 doubles) maps source to destination coordinates. The reference function is generic over the element type
+ * (warp_image_perspective<T: DataType>): u8 elements with 1, 3 or 4 interleaved channels here (u8, Vec3b, Vec4b - the type the reference's
+ * own caller warps), f32 elements (f32, Vec3f, Vec4f) through the _f32 entry. */
 int apds_warp_perspective(const uint8_t* src, int rows, int cols, int channels, const double* M, int dst_rows, int dst_cols, uint8_t* dst);
+int apds_warp_perspective_f32(const float* src, int rows, int cols, int channels, const double* M, int dst_rows, int dst_cols, float* dst);
 
 /* homographier/src/homographier/mod.rs:320-369 pnp_solver_ransac(point_correspondences, camera_intrinsic, iter_count, reproj_thres,
  * confidence, dist_coeffs, method) -> Result<Option<PNPRANSACSolution>, MatError>: cv::solvePnPRansac with useExtrinsicGuess = false and

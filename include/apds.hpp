@@ -14,6 +14,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <type_traits>
 #include <vector>
 
 #include "apds.h"
@@ -180,16 +181,30 @@ inline Result<std::pair<Cmat<double>, std::optional<Cmat<uint8_t>>>, MatError> f
     return R::Ok(Out{std::move(h.unwrap()), std::move(out_mask)});
 }
 
-/// mod.rs:271-300 — warpPerspective(INTER_LINEAR, BORDER_CONSTANT (1,1,1,1)); size = (width, height), None = the source size
-inline Result<Cmat<Vec4b>, MatError> warp_image_perspective(const Cmat<Vec4b>& src, const Cmat<double>& m, std::optional<std::pair<int, int>> size) {
-    using R = Result<Cmat<Vec4b>, MatError>;
+/// mod.rs:271-300 — warpPerspective(INTER_LINEAR, BORDER_CONSTANT (1,1,1,1)); size = (width, height), None = the source size. Generic over
+/// the element type like the reference (`warp_image_perspective<T: DataType>`): T = uint8_t, Vec3b, Vec4b, float, Vec3f, Vec4f.
+using Vec3b = std::array<uint8_t, 3>;   // cv::Vec3b
+using Vec3f = std::array<float, 3>;     // cv::Vec3f
+using Vec4f = std::array<float, 4>;     // cv::Vec4f
+template <class T>
+inline Result<Cmat<T>, MatError> warp_image_perspective(const Cmat<T>& src, const Cmat<double>& m, std::optional<std::pair<int, int>> size) {
+    using R = Result<Cmat<T>, MatError>;
+    constexpr bool is_u8 = std::is_same_v<T, uint8_t> || std::is_same_v<T, Vec3b> || std::is_same_v<T, Vec4b>;
+    constexpr bool is_f32 = std::is_same_v<T, float> || std::is_same_v<T, Vec3f> || std::is_same_v<T, Vec4f>;
+    static_assert(is_u8 || is_f32, "warp_image_perspective: u8 or f32 elements with 1, 3 or 4 channels");
+    constexpr int channels = (int)(sizeof(T) / (is_u8 ? 1 : 4));
     if (m.mat.rows != 3 || m.mat.cols != 3) return R::Err(MatError::opencv(Error{APDS_ERR_ASSERT, "m must be 3x3"}));
     const int dw = size ? size->first : src.mat.cols, dh = size ? size->second : src.mat.rows;
-    Mat<Vec4b> out(dh, dw);
-    const int rc = apds_warp_perspective(reinterpret_cast<const uint8_t*>(src.mat.data.data()), src.mat.rows, src.mat.cols, 4, m.mat.data.data(), dh, dw,
-                                         reinterpret_cast<uint8_t*>(out.data.data()));
+    Mat<T> out(dh, dw);
+    int rc;
+    if constexpr (is_u8)
+        rc = apds_warp_perspective(reinterpret_cast<const uint8_t*>(src.mat.data.data()), src.mat.rows, src.mat.cols, channels, m.mat.data.data(), dh, dw,
+                                   reinterpret_cast<uint8_t*>(out.data.data()));
+    else
+        rc = apds_warp_perspective_f32(reinterpret_cast<const float*>(src.mat.data.data()), src.mat.rows, src.mat.cols, channels, m.mat.data.data(), dh, dw,
+                                       reinterpret_cast<float*>(out.data.data()));
     if (rc != 0) return R::Err(from_status(rc));
-    return Cmat<Vec4b>::new_(std::move(out));
+    return Cmat<T>::new_(std::move(out));
 }
 
 /// opencv::calib3d::SolvePnPMethod values the reference can pass (mod.rs:4,327)

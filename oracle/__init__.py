@@ -120,6 +120,8 @@ def lib():
         L.oracle_gamma_correction.argtypes = [C.c_float, C.POINTER(C.c_int)]
         L.oracle_f32_to_u8.restype = C.c_int
         L.oracle_f32_to_u8.argtypes = [C.c_float, C.c_float, C.c_float, C.POINTER(C.c_int)]
+        L.oracle_warp_perspective_any.restype = C.c_int
+        L.oracle_warp_perspective_any.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_warp_perspective_8uc4.restype = C.c_int
         L.oracle_warp_perspective_8uc4.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.oracle_set_threads.argtypes = [C.c_int]
@@ -334,13 +336,34 @@ def band_merger(red, green, blue, minmax):
 
 
 def warp_perspective(src, M, size=None):
-    """homographier mod.rs:271-300 on an HxWx4 u8 image; size = (width, height) or None (source size)."""
-    src = np.ascontiguousarray(src, np.uint8)
+    """homographier mod.rs:271-300 on an HxW[xC] image of u8 or f32 elements (C = 1, 3, 4); size = (width, height) or None (source size).
+    HxWx4 u8 goes through the dedicated 8UC4 restatement, everything else through the generic one (tests compare the two on 8UC4)."""
+    src = np.asarray(src)
+    dt = np.float32 if src.dtype == np.float32 else np.uint8
+    src = np.ascontiguousarray(src, dt)
     h, w = src.shape[:2]
+    ch = 1 if src.ndim == 2 else src.shape[2]
     dw, dh = (w, h) if size is None else size
     M = np.ascontiguousarray(M, np.float64).reshape(9)
-    out = np.zeros((dh, dw, 4), np.uint8)
-    if lib().oracle_warp_perspective_8uc4(_ptr(src), h, w, _ptr(M), dh, dw, _ptr(out)) != 0:
+    out = np.zeros((dh, dw) if src.ndim == 2 else (dh, dw, ch), dt)
+    if dt == np.uint8 and ch == 4:
+        rc = lib().oracle_warp_perspective_8uc4(_ptr(src), h, w, _ptr(M), dh, dw, _ptr(out))
+    else:
+        rc = lib().oracle_warp_perspective_any(_ptr(src), h, w, ch, np.dtype(dt).itemsize, _ptr(M), dh, dw, _ptr(out))
+    if rc != 0:
+        raise RuntimeError("singular matrix" if rc == -1 else "unsupported element type")
+    return out
+
+
+def warp_perspective_generic(src, M, size=None):
+    """the generic restatement on any supported type, 8UC4 included (cross-check of the two texts)"""
+    src = np.ascontiguousarray(src)
+    h, w = src.shape[:2]
+    ch = 1 if src.ndim == 2 else src.shape[2]
+    dw, dh = (w, h) if size is None else size
+    M = np.ascontiguousarray(M, np.float64).reshape(9)
+    out = np.zeros((dh, dw) if src.ndim == 2 else (dh, dw, ch), src.dtype)
+    if lib().oracle_warp_perspective_any(_ptr(src), h, w, ch, src.dtype.itemsize, _ptr(M), dh, dw, _ptr(out)) != 0:
         raise RuntimeError("singular matrix")
     return out
 

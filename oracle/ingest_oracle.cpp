@@ -240,3 +240,62 @@ int oracle_world_coordinates(const double* xy, int n, const double* dgt, const d
 }
 
 }  // extern "C"
+
+// The same map for the other element types the generic reference function admits (warp_image_perspective<T: DataType>): `channels`
+// interleaved u8 (the fixed-point path above) or f32 elements. f32: cv::remap's float bilinear path - the four weights are float products
+// of the 1/32-step fractions (initInterTab2D), the value ((v0 w0 + v1 w1) + v2 w2) + v3 w3 in binary32, a destination pixel whose 2x2
+// footprint lies wholly outside the source is the border value itself. Restated from memory (OpenCV's SIMD variants may fuse the
+// multiply-adds: PARITY UNPINNED beyond the identity warp, mod.rs:683-707).
+int oracle_warp_perspective_any(const void* src_, int rows, int cols, int channels, int elem_bytes, const double* Min, int dst_rows, int dst_cols, void* dst_) {
+    double M[9];
+    if (!invert3x3(Min, M)) return -1;
+    if ((elem_bytes != 1 && elem_bytes != 4) || channels < 1 || channels > 4) return -2;
+    const short* tab = bilinear_tab();
+    for (int y = 0; y < dst_rows; y++)
+        for (int x = 0; x < dst_cols; x++) {
+            const double X0 = M[0] * x + M[1] * y + M[2], Y0 = M[3] * x + M[4] * y + M[5];
+            double W = M[6] * x + M[7] * y + M[8];
+            W = W ? 32. / W : 0;
+            const double fX = std::max((double)INT_MIN, std::min((double)INT_MAX, X0 * W));
+            const double fY = std::max((double)INT_MIN, std::min((double)INT_MAX, Y0 * W));
+            const int X = sat_int(fX), Y = sat_int(fY);
+            const int sx = X >> 5, sy = Y >> 5;
+            bool in[4];
+            size_t at[4];
+            bool any = false;
+            for (int k = 0; k < 4; k++) {
+                const int xx = sx + (k & 1), yy = sy + (k >> 1);
+                in[k] = xx >= 0 && xx < cols && yy >= 0 && yy < rows;
+                at[k] = in[k] ? ((size_t)yy * cols + xx) * channels : 0;
+                any = any || in[k];
+            }
+            const size_t o = ((size_t)y * dst_cols + x) * channels;
+            if (elem_bytes == 1) {
+                const uint8_t* src = static_cast<const uint8_t*>(src_);
+                uint8_t* dst = static_cast<uint8_t*>(dst_);
+                const short* w = &tab[((Y & 31) * 32 + (X & 31)) * 4];
+                for (int c = 0; c < channels; c++) {
+                    int v = 0;
+                    for (int k = 0; k < 4; k++) v += (in[k] ? src[at[k] + c] : 1) * w[k];
+                    dst[o + c] = (uint8_t)((v + (1 << 14)) >> 15);
+                }
+            } else {
+                const float* src = static_cast<const float*>(src_);
+                float* dst = static_cast<float*>(dst_);
+                if (!any) {
+                    for (int c = 0; c < channels; c++) dst[o + c] = 1.0f;
+                    continue;
+                }
+                const float fx = (float)(X & 31) * (1.f / 32), fy = (float)(Y & 31) * (1.f / 32);
+                const float w[4] = {(1.f - fy) * (1.f - fx), (1.f - fy) * fx, fy * (1.f - fx), fy * fx};
+                for (int c = 0; c < channels; c++) {
+                    float acc = (in[0] ? src[at[0] + c] : 1.0f) * w[0];
+                    acc += (in[1] ? src[at[1] + c] : 1.0f) * w[1];
+                    acc += (in[2] ? src[at[2] + c] : 1.0f) * w[2];
+                    acc += (in[3] ? src[at[3] + c] : 1.0f) * w[3];
+                    dst[o + c] = acc;
+                }
+            }
+        }
+    return 0;
+}

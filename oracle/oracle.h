@@ -141,6 +141,8 @@ int oracle_f32_to_u8(float v, float mn, float mx, int* ok);
 /* homographier mod.rs:271-300 warp_image_perspective: cv::warpPerspective(INTER_LINEAR, BORDER_CONSTANT (1,1,1,1)) on a
  * 4-channel u8 image; M maps src -> dst (it is inverted inside, as OpenCV does without WARP_INVERSE_MAP). Returns 0 / -1. */
 int oracle_warp_perspective_8uc4(const uint8_t* src, int rows, int cols, const double* M, int dst_rows, int dst_cols, uint8_t* dst);
+/* the same for `channels` (1..4) interleaved elements of elem_bytes 1 (u8, fixed-point bilinear) or 4 (f32, float bilinear) */
+int oracle_warp_perspective_any(const void* src, int rows, int cols, int channels, int elem_bytes, const double* M, int dst_rows, int dst_cols, void* dst);
 
 #ifdef __cplusplus
 }

@@ -57,3 +57,27 @@ def test_warp_image_perspective(gpu_pkg, oracle_mod):
     assert got.shape == (64, 128, 4) and np.array_equal(got, big.mat[:64, :128])
     with pytest.raises(hg.MatError):
         hg.warp_image_perspective(big, hg.Cmat(np.zeros((3, 3)), np.float64), None)
+
+
+def test_warp_image_perspective_is_generic_over_the_element_type(gpu_pkg, oracle_mod):
+    """mod.rs:271-300 is `warp_image_perspective<T: DataType>`: u8 and f32 elements with 1, 3 or 4 channels. u8: byte-equal to the oracle's
+    fixed-point restatement; f32: bit-equal to its float restatement (the same four products and three sums, no contraction)."""
+    hg = gpu_pkg.homographier
+    rng = np.random.default_rng(7)
+    Ms = [np.array([[0.93, -0.21, 9.0], [0.18, 1.07, -6.5], [4e-4, -7e-4, 1.0]]), np.array([[1, 0, 3.25], [0, 1, -2.75], [0, 0, 1.0]]),
+          np.array([[1.6, 0.1, -40.0], [-0.2, 1.5, 25.0], [1e-3, 2e-3, 1.0]])]
+    for dt in (np.uint8, np.float32):
+        for ch in (1, 3, 4):
+            shape = (61, 83) if ch == 1 else (61, 83, ch)
+            img = rng.integers(0, 256, shape).astype(dt) if dt == np.uint8 else rng.normal(0, 50, shape).astype(np.float32)
+            c = hg.Cmat(img, dt, ch)
+            # the reference's own KAT shape, for every type: the identity warp changes nothing (mod.rs:683-707)
+            assert np.array_equal(hg.warp_image_perspective(c, hg.Cmat(np.eye(3), np.float64), None).mat, img), (dt, ch)
+            for M in Ms:
+                for size in (None, (97, 45)):
+                    got = hg.warp_image_perspective(c, hg.Cmat(M, np.float64), size).mat
+                    want = oracle_mod.warp_perspective(img, M, size)
+                    assert got.dtype == dt and got.shape == want.shape
+                    assert np.array_equal(got.view(np.uint8), want.view(np.uint8)), (dt, ch, size)
+    with pytest.raises(hg.MatError):
+        hg.warp_image_perspective(hg.Cmat(np.zeros((8, 8, 2), np.uint8), np.uint8, 2), hg.Cmat(np.eye(3), np.float64), None)

@@ -307,3 +307,23 @@ def test_rho_oracle_on_the_reference_kat_and_on_planted_data(pkg, oracle_mod):
     for method in (4, 8, 16):
         ok, H, mask = oracle_mod.find_homography(s4, d4, method, 5.0)
         assert ok == ok0 and np.array_equal(H, H0) and mask.all()
+
+
+def test_warp_generic_types_kat(oracle_mod):
+    # mod.rs:683-707 for every element type the generic function admits: the identity warp is idempotent; the generic restatement equals the
+    # dedicated 8UC4 one on 8UC4; a whole-pixel shift moves pixels and fills the uncovered part with the border value 1
+    rng = np.random.default_rng(4)
+    for dt in (np.uint8, np.float32):
+        for ch in (1, 3, 4):
+            shape = (23, 31) if ch == 1 else (23, 31, ch)
+            img = rng.integers(0, 256, shape).astype(dt)
+            assert np.array_equal(oracle_mod.warp_perspective(img, np.eye(3)), img), (dt, ch)
+            sh = oracle_mod.warp_perspective(img, np.array([[1, 0, 3.0], [0, 1, 2.0], [0, 0, 1]]))
+            assert np.array_equal(sh[2:, 3:], img[:-2, :-3]) and np.all(sh[:2] == 1) and np.all(sh[:, :3] == 1), (dt, ch)
+    img4 = rng.integers(0, 256, (40, 52, 4)).astype(np.uint8)
+    M = np.array([[0.9, -0.2, 6.0], [0.25, 1.1, -3.0], [1e-3, -2e-3, 1.0]])
+    assert np.array_equal(oracle_mod.warp_perspective(img4, M), oracle_mod.warp_perspective_generic(img4, M))
+    # f32: a half-pixel shift is the mean of two neighbours (weights 0.5 / 0.5 exactly)
+    f = rng.normal(0, 10, (9, 12)).astype(np.float32)
+    half = oracle_mod.warp_perspective(f, np.array([[1, 0, 0.5], [0, 1, 0.0], [0, 0, 1]]))
+    assert np.array_equal(half[:, 1:], (f[:, :-1] * np.float32(0.5) + f[:, 1:] * np.float32(0.5)).astype(np.float32))
