@@ -204,10 +204,127 @@ bool host_p3p(const T* obj, const T* img, const Camera& cam, double* rvec, doubl
     return true;
 }
 
-// ---- SOLVEPNP_ITERATIVE: the final refinement over the inliers (host; six parameters, a few thousand residuals at most) ---------------
-// solvePnPRansac(flags = SOLVEPNP_ITERATIVE) as recalled for OpenCV >= 4.6: EPnP stays the RANSAC kernel and the final solvePnP starts
-// from the best RANSAC model (useExtrinsicGuess), i.e. cvFindExtrinsicCameraParams2 reduces to its Levenberg-Marquardt refinement:
-// CvLevMarq(6, 2 n, 20 iterations, FLT_EPSILON) around cvProjectPoints2's analytic Jacobian, zero distortion (mod.rs:344).
+// ---- SOLVEPNP_ITERATIVE: the final solvePnP over the inliers (host; six parameters, a few thousand residuals at most) ---------------------
+// solvePnPRansac(flags = SOLVEPNP_ITERATIVE) as recalled for OpenCV 4.8: EPnP stays the RANSAC kernel, and the final solvePnP runs with the
+// CALLER's useExtrinsicGuess, which the reference sets to false (mod.rs:354). cvFindExtrinsicCameraParams2 therefore builds its own
+// starting pose first - a homography for planar object points, the DLT otherwise (iterative_start_pose) - and then refines it with
+// CvLevMarq(6, 2 n, 20 iterations, FLT_EPSILON) around cvProjectPoints2's analytic Jacobian, zero distortion (mod.rs:344). With five
+// non-planar inliers the DLT cannot start ("needs at least 6 points"): solvePnPRansac catches that and keeps the RANSAC model.
+// (Rounds 2 - 3 started the refinement from the best RANSAC model for every input: ADVICE r3.)
+// obj: n x 3, img: n x 2 doubles. Returns false in the five-point case above.
+static bool iterative_start_pose(const double* obj, const double* img, int n, const Camera& cam, double* pose, hipStream_t s) {
+    std::vector<double> mn(2 * (size_t)n);
+    const double ifx = 1. / cam.fu, ify = 1. / cam.fv;
+    for (int i = 0; i < n; i++) {   // cvUndistortPoints with zero distortion
+        mn[2 * (size_t)i] = (img[2 * i] - cam.uc) * ifx;
+        mn[2 * (size_t)i + 1] = (img[2 * i + 1] - cam.vc) * ify;
+    }
+    double Mc[3] = {0, 0, 0}, MM[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) Mc[k] += obj[3 * i + k];
+    for (int k = 0; k < 3; k++) Mc[k] /= n;
+    for (int i = 0; i < n; i++) {
+        const double d[3] = {obj[3 * i] - Mc[0], obj[3 * i + 1] - Mc[1], obj[3 * i + 2] - Mc[2]};
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) MM[a * 3 + b] += d[a] * d[b];
+    }
+    double W[3], Ut[9], V[9];   // V = V^T (CV_SVD_V_T): its rows are the right singular vectors
+    pnp::svd3(MM, W, Ut, V);
+    double R[9], t[3];
+    if (W[2] / W[1] < 1e-3) {   // all object points in one plane
+        if (V[2] * V[2] + V[5] * V[5] < 1e-10)
+            for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1. : 0.;
+        const double det = V[0] * (V[4] * V[8] - V[5] * V[7]) - V[1] * (V[3] * V[8] - V[5] * V[6]) + V[2] * (V[3] * V[7] - V[4] * V[6]);
+        if (det < 0)
+            for (int i = 0; i < 9; i++) V[i] = -V[i];
+        double T[3];
+        for (int a = 0; a < 3; a++) T[a] = -(V[a * 3] * Mc[0] + V[a * 3 + 1] * Mc[1] + V[a * 3 + 2] * Mc[2]);
+        // the points in their plane -> the normalised image points: cv::findHomography (method 0) on float copies; this library's own
+        // find_homography_device does it (the least-squares path: host refit up to 256 points, device reductions above)
+        std::vector<float> src(2 * (size_t)n), dst(2 * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            const double* M = obj + 3 * i;
+            src[2 * (size_t)i] = (float)(V[0] * M[0] + V[1] * M[1] + V[2] * M[2] + T[0]);
+            src[2 * (size_t)i + 1] = (float)(V[3] * M[0] + V[4] * M[1] + V[5] * M[2] + T[1]);
+            dst[2 * (size_t)i] = (float)mn[2 * (size_t)i];
+            dst[2 * (size_t)i + 1] = (float)mn[2 * (size_t)i + 1];
+        }
+        ThreadCtx& c = ctx();
+        float* src_dev = c.alloc_n<float>(src.size());
+        float* dst_dev = c.alloc_n<float>(dst.size());
+        HIP_CHECK(hipMemcpyAsync(src_dev, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(dst_dev, dst.data(), dst.size() * sizeof(float), hipMemcpyHostToDevice, s));
+        double h[9];
+        const int found = find_homography_device(src_dev, dst_dev, n, 0, 3.0, 2000, 0.995, h, nullptr, s);
+        bool finite = found == 1;
+        for (int i = 0; i < 9 && finite; i++) finite = std::isfinite(h[i]);
+        if (finite) {
+            const double h1n = std::sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]), h2n = std::sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+            const double s1 = 1. / std::max(h1n, DBL_EPSILON), s2 = 1. / std::max(h2n, DBL_EPSILON), s3 = 2. / std::max(h1n + h2n, DBL_EPSILON);
+            for (int r = 0; r < 3; r++) {
+                t[r] = h[r * 3 + 2] * s3;
+                h[r * 3] *= s1;
+                h[r * 3 + 1] *= s2;
+            }
+            h[2] = h[3] * h[7] - h[6] * h[4];   // h3 = h1 x h2
+            h[5] = h[6] * h[1] - h[0] * h[7];
+            h[8] = h[0] * h[4] - h[3] * h[1];
+            double rv[3], Rh[9];
+            pnp::rvec_from_rotation(h, rv);     // (orthonormalises: cvRodrigues2 takes U V^T of its input first)
+            pnp::rotation_from_rvec(rv, Rh);
+            for (int a = 0; a < 3; a++) t[a] = (Rh[a * 3] * T[0] + Rh[a * 3 + 1] * T[1] + Rh[a * 3 + 2] * T[2]) + t[a];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) R[a * 3 + b] = Rh[a * 3] * V[b] + Rh[a * 3 + 1] * V[3 + b] + Rh[a * 3 + 2] * V[6 + b];
+        } else {
+            for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
+            t[0] = t[1] = t[2] = 0;
+        }
+    } else {   // non-planar: DLT
+        if (n < 6) return false;
+        double LL[144];
+        for (int i = 0; i < 144; i++) LL[i] = 0;
+        for (int i = 0; i < n; i++) {
+            const double* M = obj + 3 * i;
+            const double x = -mn[2 * (size_t)i], y = -mn[2 * (size_t)i + 1];
+            const double r1[12] = {M[0], M[1], M[2], 1., 0., 0., 0., 0., x * M[0], x * M[1], x * M[2], x};
+            const double r2[12] = {0., 0., 0., 0., M[0], M[1], M[2], 1., y * M[0], y * M[1], y * M[2], y};
+            for (int a = 0; a < 12; a++)
+                for (int b = 0; b < 12; b++) LL[a * 12 + b] += r1[a] * r1[b] + r2[a] * r2[b];
+        }
+        double LW[12], LAt[144], LV[144];
+        for (int i = 0; i < 12; i++)
+            for (int k = 0; k < 12; k++) LAt[i * 12 + k] = LL[k * 12 + i];
+        pnp::svd_rows<true>(pnp::Plain<double>{LAt}, 12, 12, pnp::Plain<double>{LW}, pnp::Plain<double>{LV});
+        double P[12];
+        for (int i = 0; i < 12; i++) P[i] = LV[11 * 12 + i];   // the 3 x 4 projection, row major
+        const double det = P[0] * (P[5] * P[10] - P[6] * P[9]) - P[1] * (P[4] * P[10] - P[6] * P[8]) + P[2] * (P[4] * P[9] - P[5] * P[8]);
+        if (det < 0)
+            for (int i = 0; i < 12; i++) P[i] = -P[i];
+        const double RR[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+        double sc = 0;
+        for (int i = 0; i < 9; i++) sc += RR[i] * RR[i];
+        sc = std::sqrt(sc);
+        double w3[3], U3t[9], V3t[9];
+        pnp::svd3(RR, w3, U3t, V3t);
+        double rn = 0;
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                R[a * 3 + b] = U3t[a] * V3t[b] + U3t[3 + a] * V3t[3 + b] + U3t[6 + a] * V3t[6 + b];   // U V^T
+                rn += R[a * 3 + b] * R[a * 3 + b];
+            }
+        const double k = std::sqrt(rn) / sc;
+        t[0] = P[3] * k;
+        t[1] = P[7] * k;
+        t[2] = P[11] * k;
+    }
+    pnp::rvec_from_rotation(R, pose);
+    pose[3] = t[0];
+    pose[4] = t[1];
+    pose[5] = t[2];
+    return true;
+}
+
+
 struct PoseRefiner {
     const double* obj;   // n x 3
     const double* img;   // n x 2
@@ -442,10 +559,10 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
             inliers[cnt++] = i;
         }
     APDS_REQUIRE(cnt == maxGood, APDS_ERR_INTERNAL, "inlier mask disagrees with the scored count");
-    if (method == APDS_SOLVEPNP_ITERATIVE) {   // Levenberg-Marquardt from the best RANSAC model
+    if (method == APDS_SOLVEPNP_ITERATIVE) {   // no extrinsic guess (mod.rs:354): homography / DLT start, then Levenberg-Marquardt
         double pose[6];
-        std::memcpy(pose, best, sizeof(pose));
-        PoseRefiner{oi.data(), ii.data(), cnt, cam, {}, {}}.run(pose);
+        std::memcpy(pose, best, sizeof(pose));   // (what stays when five non-planar inliers cannot start the DLT)
+        if (iterative_start_pose(oi.data(), ii.data(), cnt, cam, pose, s)) PoseRefiner{oi.data(), ii.data(), cnt, cam, {}, {}}.run(pose);
         std::memcpy(rvec, pose, 3 * sizeof(double));
         std::memcpy(tvec, pose + 3, 3 * sizeof(double));
     } else {

@@ -154,8 +154,10 @@ int apds_warp_perspective_f32(const float* src, int rows, int cols, int channels
  * obj_xyz: n Point3d (ImgObjCorrespondence::obj_point, mod.rs:53-65), img_xy: n Point2d, camera_intrinsic: 3x3 f64 row major.
  * method: cv::SolvePnPMethod; the shim passes method.unwrap_or(SOLVEPNP_EPNP) (mod.rs:360). Built: APDS_SOLVEPNP_EPNP (RANSAC kernel
  * EPnP on 5 points), APDS_SOLVEPNP_P3P (Gao's P3P on 4 points; also the kernel OpenCV switches to when n == 4) - the final pose
- * over the inliers is EPnP in both cases, as in OpenCV - and APDS_SOLVEPNP_ITERATIVE (EPnP kernel; final pose = Levenberg-Marquardt
- * refinement of the reprojection error from the best RANSAC model, <= 20 iterations). AP3P / SQPNP / ... return APDS_ERR_NOT_IMPLEMENTED.
+ * over the inliers is EPnP in both cases, as in OpenCV - and APDS_SOLVEPNP_ITERATIVE (EPnP kernel; final pose = solvePnP(ITERATIVE) over
+ * the inliers WITHOUT an extrinsic guess, as the reference's use_extrinsic_guess = false makes it: a homography (planar object points) or
+ * DLT (>= 6 points) start, then <= 20 Levenberg-Marquardt iterations on the reprojection error; with five non-planar inliers the RANSAC
+ * model stays, as in solvePnPRansac). AP3P / SQPNP / ... return APDS_ERR_NOT_IMPLEMENTED.
  * n < 4 -> APDS_ERR_ASSERT (mod.rs:627-638).
  * *found = 1: rvec[3], tvec[3], inliers[0..*n_inliers) filled (inliers: caller allocated, n ints); *found = 0: Ok(None). */
 #define APDS_SOLVEPNP_ITERATIVE 0

@@ -728,9 +728,9 @@ void pnp_errors(const float* obj, const float* img, int n, const double* K, cons
 
 // ---- SOLVEPNP_ITERATIVE: the final refinement of solvePnPRansac(..., flags = SOLVEPNP_ITERATIVE) ------------------------------------
 // Reference call site: homographier/src/homographier/mod.rs:327,359-360 (`method: Option<SolvePnPMethod>` handed to solve_pnp_ransac).
-// calib3d/solvepnp.cpp as recalled (OpenCV >= 4.6): the RANSAC kernel stays EPnP on 5 points, and the final solvePnP over the inliers
-// runs with the best RANSAC model as its extrinsic guess (`rvec = _local_model.col(0); useExtrinsicGuess = true`), which in
-// cvFindExtrinsicCameraParams2 (calibration.cpp) skips the DLT / homography initialisation and goes straight to the refinement:
+// calib3d/solvepnp.cpp as recalled (OpenCV 4.8): the RANSAC kernel stays EPnP on 5 points, and the final solvePnP over the inliers runs
+// with the CALLER's useExtrinsicGuess - false in the reference (mod.rs:354) - so cvFindExtrinsicCameraParams2 (calibration.cpp) first
+// builds its own starting pose (initial_pose_no_guess below: homography for planar sets, DLT otherwise) and then refines it:
 // CvLevMarq(6 parameters, 2 n residuals, max 20 iterations, eps FLT_EPSILON, completeSymmFlag) around cvProjectPoints2 with its
 // analytic Jacobian (Rodrigues' dR/dr, then d(proj)/d(r, t)). Zero distortion (mod.rs:344). PARITY UNPINNED; what the tests hold it
 // to is first-order optimality and an independent numpy optimiser (tests/test_external_anchors.py).
@@ -795,6 +795,117 @@ double l2_norm(const double* v, int n) {
     double s = 0;
     for (int i = 0; i < n; i++) s += v[i] * v[i];
     return std::sqrt(s);
+}
+
+// cvFindExtrinsicCameraParams2's starting pose when there is NO extrinsic guess - which is how the reference reaches it: mod.rs:354 passes
+// use_extrinsic_guess = false and solvePnPRansac hands that flag on to its final solvePnP over the inliers (rounds 2 - 3 started
+// the refinement from the best RANSAC model instead). calibration.cpp as recalled: image points normalised by the intrinsics; the object
+// points' 3 x 3 scatter decides planar / non-planar (w[2] / w[1] < 1e-3); planar: rotate the points into their plane, homography plane ->
+// normalised image (cv::findHomography, method 0, on float copies), columns h1, h2 scaled to unit length, t = h3 * 2 / (|h1| + |h2|), R made
+// orthonormal by Rodrigues there and back; non-planar: the 12 x 12 normal matrix of the DLT rows, its last singular vector as the 3 x 4
+// projection, R = U V^T of its left block, t rescaled by |R| / |block|. Returns 0 where OpenCV throws "DLT algorithm needs at least 6
+// points" (solvePnPRansac catches exactly that, for five inliers, and keeps the RANSAC model).
+int initial_pose_no_guess(const double* obj, const double* img, int n, const Camera& cam, double* param) {
+    std::vector<double> mn(2 * (size_t)n);
+    const double ifx = 1. / cam.fu, ify = 1. / cam.fv;
+    for (int i = 0; i < n; i++) {   // cvUndistortPoints with zero distortion
+        mn[2 * (size_t)i] = (img[2 * i] - cam.uc) * ifx;
+        mn[2 * (size_t)i + 1] = (img[2 * i + 1] - cam.vc) * ify;
+    }
+    double Mc[3] = {0, 0, 0}, MM[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) Mc[k] += obj[3 * i + k];
+    for (int k = 0; k < 3; k++) Mc[k] /= n;
+    for (int i = 0; i < n; i++) {
+        const double d[3] = {obj[3 * i] - Mc[0], obj[3 * i + 1] - Mc[1], obj[3 * i + 2] - Mc[2]};
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) MM[a * 3 + b] += d[a] * d[b];
+    }
+    double W[3], Ut[9], V[9];   // V holds V^T (CV_SVD_V_T)
+    svd(MM, 3, 3, W, Ut, V);
+    double R[9], t[3];
+    if (W[2] / W[1] < 1e-3) {   // a planar structure: all M's lie in the same plane
+        if (V[2] * V[2] + V[5] * V[5] < 1e-10)
+            for (int i = 0; i < 9; i++) V[i] = (i % 4 == 0) ? 1. : 0.;
+        const double det = V[0] * (V[4] * V[8] - V[5] * V[7]) - V[1] * (V[3] * V[8] - V[5] * V[6]) + V[2] * (V[3] * V[7] - V[4] * V[6]);
+        if (det < 0)
+            for (int i = 0; i < 9; i++) V[i] = -V[i];
+        double T[3];
+        for (int a = 0; a < 3; a++) T[a] = -(V[a * 3] * Mc[0] + V[a * 3 + 1] * Mc[1] + V[a * 3 + 2] * Mc[2]);
+        std::vector<float> src(2 * (size_t)n), dst(2 * (size_t)n);   // findHomography converts its points to CV_32F
+        for (int i = 0; i < n; i++) {
+            const double* M = obj + 3 * i;
+            src[2 * (size_t)i] = (float)(V[0] * M[0] + V[1] * M[1] + V[2] * M[2] + T[0]);
+            src[2 * (size_t)i + 1] = (float)(V[3] * M[0] + V[4] * M[1] + V[5] * M[2] + T[1]);
+            dst[2 * (size_t)i] = (float)mn[2 * (size_t)i];
+            dst[2 * (size_t)i + 1] = (float)mn[2 * (size_t)i + 1];
+        }
+        double h[9];
+        const int found = oracle_find_homography(src.data(), dst.data(), n, 0, 3.0, 2000, 0.995, h, nullptr);
+        bool finite = found == 1;
+        for (int i = 0; i < 9 && finite; i++) finite = std::isfinite(h[i]);
+        if (finite) {
+            const double h1n = std::sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]), h2n = std::sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+            const double s1 = 1. / std::max(h1n, DBL_EPSILON), s2 = 1. / std::max(h2n, DBL_EPSILON), s3 = 2. / std::max(h1n + h2n, DBL_EPSILON);
+            for (int r = 0; r < 3; r++) {
+                t[r] = h[r * 3 + 2] * s3;
+                h[r * 3] *= s1;
+                h[r * 3 + 1] *= s2;
+            }
+            h[2] = h[3] * h[7] - h[6] * h[4];   // h3 = h1 x h2
+            h[5] = h[6] * h[1] - h[0] * h[7];
+            h[8] = h[0] * h[4] - h[3] * h[1];
+            double rv[3], Rh[9];
+            rodrigues_to_vector(h, rv);
+            rodrigues_to_matrix(rv, Rh);
+            for (int a = 0; a < 3; a++) t[a] = (Rh[a * 3] * T[0] + Rh[a * 3 + 1] * T[1] + Rh[a * 3 + 2] * T[2]) + t[a];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) R[a * 3 + b] = Rh[a * 3] * V[b] + Rh[a * 3 + 1] * V[3 + b] + Rh[a * 3 + 2] * V[6 + b];
+        } else {
+            for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1. : 0.;
+            t[0] = t[1] = t[2] = 0;
+        }
+    } else {   // non-planar structure: DLT
+        if (n < 6) return 0;
+        double LL[144];
+        for (int i = 0; i < 144; i++) LL[i] = 0;
+        for (int i = 0; i < n; i++) {
+            const double* M = obj + 3 * i;
+            const double x = -mn[2 * (size_t)i], y = -mn[2 * (size_t)i + 1];
+            const double r1[12] = {M[0], M[1], M[2], 1., 0., 0., 0., 0., x * M[0], x * M[1], x * M[2], x};
+            const double r2[12] = {0., 0., 0., 0., M[0], M[1], M[2], 1., y * M[0], y * M[1], y * M[2], y};
+            for (int a = 0; a < 12; a++)
+                for (int b = 0; b < 12; b++) LL[a * 12 + b] += r1[a] * r1[b] + r2[a] * r2[b];
+        }
+        double LW[12], LUt[144], LV[144];
+        svd(LL, 12, 12, LW, LUt, LV);
+        double P[12];
+        for (int i = 0; i < 12; i++) P[i] = LV[11 * 12 + i];   // the 3 x 4 projection, row major
+        const double det = P[0] * (P[5] * P[10] - P[6] * P[9]) - P[1] * (P[4] * P[10] - P[6] * P[8]) + P[2] * (P[4] * P[9] - P[5] * P[8]);
+        if (det < 0)
+            for (int i = 0; i < 12; i++) P[i] = -P[i];
+        const double RR[9] = {P[0], P[1], P[2], P[4], P[5], P[6], P[8], P[9], P[10]};
+        double sc = 0;
+        for (int i = 0; i < 9; i++) sc += RR[i] * RR[i];
+        sc = std::sqrt(sc);
+        double w3[3], U3t[9], V3t[9];
+        svd(RR, 3, 3, w3, U3t, V3t);
+        double rn = 0;
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                R[a * 3 + b] = U3t[a] * V3t[b] + U3t[3 + a] * V3t[3 + b] + U3t[6 + a] * V3t[6 + b];   // U V^T
+                rn += R[a * 3 + b] * R[a * 3 + b];
+            }
+        const double k = std::sqrt(rn) / sc;
+        t[0] = P[3] * k;
+        t[1] = P[7] * k;
+        t[2] = P[11] * k;
+    }
+    rodrigues_to_vector(R, param);
+    param[3] = t[0];
+    param[4] = t[1];
+    param[5] = t[2];
+    return 1;
 }
 
 // CvLevMarq::update()'s state machine, unrolled into straight code; param: in = the initial pose (rvec, tvec), out = the refined one
@@ -1362,9 +1473,12 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
             for (int c = 0; c < 2; c++) ii.push_back((double)ip[2 * (size_t)i + c]);
             inliers[cnt++] = i;
         }
-    if (method == 0) {   // SOLVEPNP_ITERATIVE: Levenberg-Marquardt from the best RANSAC model over the inliers
+    if (method == 0) {
+        // SOLVEPNP_ITERATIVE: solvePnP over the inliers WITHOUT an extrinsic guess (mod.rs:354): homography / DLT start, then the
+        // Levenberg-Marquardt refinement. Five non-planar inliers cannot start the DLT: solvePnPRansac keeps the RANSAC model then.
         double param[6] = {best_r[0], best_r[1], best_r[2], best_t[0], best_t[1], best_t[2]};
-        refine_pose_lm(oi.data(), ii.data(), cnt, Camera{K[0], K[4], K[2], K[5]}, param);
+        const Camera camK{K[0], K[4], K[2], K[5]};
+        if (initial_pose_no_guess(oi.data(), ii.data(), cnt, camK, param)) refine_pose_lm(oi.data(), ii.data(), cnt, camK, param);
         std::memcpy(rvec, param, 3 * sizeof(double));
         std::memcpy(tvec, param + 3, 3 * sizeof(double));
     } else {

@@ -201,6 +201,28 @@ def check_iterative_pnp_solver(solve, synth):
     obj, img, K, rvec, tvec, _ = synth.make_pnp_set(400, seed=33, inlier_frac=1.1, noise=0.0)
     ok, r, t, idx = solve(obj, img, K, 100, 2.0, 0.99, 0)
     assert ok and len(idx) == 400 and np.abs(project(obj, rodrigues(r), t, K) - img).max() < 1e-4
+    # PLANAR object points (terrain without relief): the reference passes use_extrinsic_guess = false (mod.rs:354), so the final solvePnP
+    # starts from a homography plane -> image instead of the DLT. Whatever the start, the result must sit at the minimum of the
+    # reprojection error over its inliers and at the pose the data was made with.
+    obj, img, K, rvec, tvec, flag = synth.make_pnp_set(1500, seed=35, inlier_frac=0.75, noise=0.3)
+    obj = obj.copy()
+    obj[:, 2] = 0.0
+    rng = np.random.default_rng(35)
+    img = img.copy()
+    img[flag] = project(obj[flag], rodrigues(rvec), tvec, K) + rng.normal(0, 0.3, (int(flag.sum()), 2))
+    ok, r, t, idx = solve(obj, img, K, 500, 3.0, 0.99, 0)
+    assert ok and len(idx) >= 0.95 * flag.sum()
+    o, i = obj[idx].astype(np.float32).astype(np.float64), img[idx].astype(np.float32).astype(np.float64)
+    res, J = pose_residual_jacobian(r, t, o, i, K)
+    g = J.T @ res
+    scale = np.sqrt(np.diag(J.T @ J)) * np.sqrt(res @ res)
+    assert np.all(np.abs(g) <= 1e-5 * scale), (np.abs(g) / scale)
+    assert np.allclose(rodrigues(r), rodrigues(rvec), atol=3e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.5)
+    # six noise-free points in general position: RANSAC's five-point kernel, every point an inlier, the DLT start from exactly six
+    # points (the fewest it accepts), and a pose that reprojects them exactly
+    obj, img, K, rvec, tvec, _ = synth.make_pnp_set(6, seed=37, inlier_frac=1.1, noise=0.0)
+    ok, r, t, idx = solve(obj, img, K, 100, 2.0, 0.99, 0)
+    assert ok and len(idx) == 6 and np.abs(project(obj, rodrigues(r), t, K) - img).max() < 1e-3
 
 
 # ---------------------------------------------------------------------------------------------------------------- oracle (CPU)
