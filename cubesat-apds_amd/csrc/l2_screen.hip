@@ -28,6 +28,10 @@
 // each A read feeds three MFMAs. The accumulator starts from |t|^2 of its four rows, so an accumulator IS the ranking value
 // |t|^2 - 2 q~.t~ and the epilogue is two min and one compare per 16 x 16 block; like in the other matchers a lane owns one query
 // column, so the running top-2 (or the threshold) lives in the lane and insertions / appends are rare.
+// (Round 4, built, verified and removed: the same two passes on v_mfma_f32_32x32x16_bf16 - 64 resident queries per wave, twice the math per
+// issued MFMA, a third more per LDS byte. 144 - 149 VGPRs = three waves per SIMD, so blocks of twelve waves: keys identical, 252 ms per
+// screen instead of 209 (0.43 against 0.51 of the bf16 peak; profiles/r04/l2_screen_mfma32_ab.txt). The sixteen-value minimum tree per
+// accumulator and one wave less per SIMD cost more than the wider instruction returns.)
 #include <cmath>
 
 #include "config.h"
