@@ -33,7 +33,6 @@ struct Config {
     int ransac_batch;     // APDS_RANSAC_BATCH first speculated batch of RANSAC hypotheses (512)
     int pnp_batch;        // APDS_PNP_BATCH    hypotheses per PnP batch (2048)
     int l2_sample_div;    // APDS_L2_SAMPLE_DIV  the bf16 screen's threshold sample = rows / this (12)
-    int l2_screen_mfma32; // APDS_L2_SCREEN_MFMA32  1: the screen passes on v_mfma_f32_32x32x16_bf16 (64 queries per wave); 0: 16x16x32 (48 per wave)
     // ---- streamed frame pipeline (apds_pipeline_*)
     int pipe_extract_workers;   // APDS_EXTRACT_WORKERS  extraction threads when the caller's params say 0 (2)
     int pipe_match_split;       // APDS_MATCH_SPLIT      1: pre-pass / main scan / merge of consecutive frames on three streams (one GPU)

@@ -28,10 +28,10 @@
 // each A read feeds three MFMAs. The accumulator starts from |t|^2 of its four rows, so an accumulator IS the ranking value
 // |t|^2 - 2 q~.t~ and the epilogue is two min and one compare per 16 x 16 block; like in the other matchers a lane owns one query
 // column, so the running top-2 (or the threshold) lives in the lane and insertions / appends are rare.
-// (Round 4, built, verified and removed: the same two passes on v_mfma_f32_32x32x16_bf16 - 64 resident queries per wave, twice the math per
-// issued MFMA, a third more per LDS byte. 144 - 149 VGPRs = three waves per SIMD, so blocks of twelve waves: keys identical, 252 ms per
-// screen instead of 209 (0.43 against 0.51 of the bf16 peak; profiles/r04/l2_screen_mfma32_ab.txt). The sixteen-value minimum tree per
-// accumulator and one wave less per SIMD cost more than the wider instruction returns.)
+// (Round 4, built, verified and removed - commit a7e97b9: the same two passes on v_mfma_f32_32x32x16_bf16 - 64 resident queries per wave,
+// twice the math per issued MFMA, a third more per LDS byte. 144 - 149 VGPRs = three waves per SIMD, so blocks of twelve waves: keys
+// identical, 252 ms per screen instead of 209 (0.43 against 0.51 of the bf16 peak; profiles/r04/l2_screen_mfma32_ab.txt). The
+// sixteen-value minimum tree per accumulator and one wave less per SIMD cost more than the wider instruction returns.)
 #include <cmath>
 
 #include "config.h"
@@ -263,174 +263,6 @@ __global__ __launch_bounds__(512) void l2_screen_kernel(const uint16_t* __restri
     }
 }
 
-// The same two passes on v_mfma_f32_32x32x16_bf16 (round 4): twice the math per issued MFMA and a third more per LDS byte (one 1 KB A read of
-// a wave feeds two 32 x 32 x 16 products = 65536 flops instead of three 16 x 16 x 32 = 49152). A wave keeps 64 queries (two 32-column
-// blocks) as B operands: lane = (column l % 32, k chunk l / 32), eight k steps of 16; an accumulator is 32 rows x 32 queries, register i of a
-// lane is row 8 (i / 4) + 4 (l / 32) + i % 4 of its column - a lane still owns one query column per block, so the running top-2 / the
-// threshold stay in the lane. Tiles, staging, candidate regions and results are those of l2_screen_kernel (same keys, bit for bit).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// Its 64 resident queries + two 16-register accumulators make ~145 VGPRs: three waves per SIMD. A block is therefore TWELVE waves (three per
-// SIMD, one block per CU, 768 queries against each staged tile; the first eight waves do the staging): eight-wave blocks would leave every
-// SIMD with two waves.
-static constexpr int SC32_NC = 2;                 // 32-query column blocks per wave
-static constexpr int SC32_WAVES = 12;
-static constexpr int SC32_Q = SC32_WAVES * 32 * SC32_NC;   // queries per block
-
-template <int PASS>
-__global__ __launch_bounds__(SC32_WAVES * 64) void l2_screen32_kernel(const uint16_t* __restrict__ train_bf, const float* __restrict__ tnorm, int n_train,
-                                                          const uint16_t* __restrict__ query_bf, const float* __restrict__ qnorm, int nq, int tiles_per_split,
-                                                          uint32_t index_base, uint64_t* __restrict__ out, const float* __restrict__ theta,
-                                                          unsigned long long* __restrict__ cand, unsigned long long cand_cap,
-                                                          unsigned long long* __restrict__ cand_count) {
-    APDS_RAISE_WAVE_PRIORITY();
-    extern __shared__ __attribute__((aligned(128))) unsigned char sc_lds[];
-    auto tile_lds = [&](int buf) { return sc_lds + buf * (SC_TM * SC_PITCH); };
-    auto norm_lds = [&](int buf) { return reinterpret_cast<float*>(sc_lds + 2 * SC_TM * SC_PITCH) + buf * SC_TM; };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * SC32_Q + wave * 32 * SC32_NC;
-    const int n_tiles = (n_train + SC_TM - 1) / SC_TM;
-    const int tile_begin = blockIdx.y * tiles_per_split, tile_end = min(n_tiles, tile_begin + tiles_per_split);
-    const int block_id = blockIdx.y * gridDim.x + blockIdx.x;
-    __shared__ unsigned int s_cand_n;
-    if (PASS == 1 && tid == 0) s_cand_n = 0;
-    if (tile_begin >= tile_end) {
-        if (PASS == 1 && tid == 0) cand_count[block_id] = 0;
-        return;
-    }
-    const int col = lane & 31, kc = lane >> 5;
-    bf16x8 B[SC32_NC][8];
-    float qq[SC32_NC], th[SC32_NC];
-#pragma unroll
-    for (int c = 0; c < SC32_NC; c++) {
-        const int qi = min(q0 + 32 * c + col, nq - 1);
-#pragma unroll
-        for (int s = 0; s < 8; s++) B[c][s] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(query_bf + (size_t)qi * SC_D + 16 * s + 8 * kc));
-        qq[c] = qnorm[qi];
-        th[c] = PASS == 1 ? theta[qi] : 0.f;
-    }
-    ScTop2 best[SC32_NC];
-#pragma unroll
-    for (int c = 0; c < SC32_NC; c++) {
-        best[c].d0 = best[c].d1 = INFINITY;
-        best[c].i0 = best[c].i1 = 0xFFFFFFFFu;
-    }
-    uint4 pre0, pre1, pre2, pre3;
-    float pre_norm = INFINITY;
-    const int pr = tid >> 4, pg = tid & 15;
-    const bool stager = tid < 512;   // the tile is 2048 pieces of 16 bytes: four for each thread of the first eight waves
-    auto load_tile = [&](int tile) {
-        if (!stager) return;
-        const int r0 = tile * SC_TM + pr;
-        pre0 = *reinterpret_cast<const uint4*>(train_bf + (size_t)min(r0, n_train - 1) * SC_D + 8 * pg);
-        pre1 = *reinterpret_cast<const uint4*>(train_bf + (size_t)min(r0 + 32, n_train - 1) * SC_D + 8 * pg);
-        pre2 = *reinterpret_cast<const uint4*>(train_bf + (size_t)min(r0 + 64, n_train - 1) * SC_D + 8 * pg);
-        pre3 = *reinterpret_cast<const uint4*>(train_bf + (size_t)min(r0 + 96, n_train - 1) * SC_D + 8 * pg);
-        if (tid < SC_TM) {
-            const int row = tile * SC_TM + tid;
-            pre_norm = row < n_train ? tnorm[row] : INFINITY;
-        }
-    };
-    auto commit = [&](int buf) {
-        if (!stager) return;
-        unsigned char* d = tile_lds(buf) + pr * SC_PITCH + 16 * pg;
-        *reinterpret_cast<uint4*>(d) = pre0;
-        *reinterpret_cast<uint4*>(d + 32 * SC_PITCH) = pre1;
-        *reinterpret_cast<uint4*>(d + 64 * SC_PITCH) = pre2;
-        *reinterpret_cast<uint4*>(d + 96 * SC_PITCH) = pre3;
-        if (tid < SC_TM) norm_lds(buf)[tid] = pre_norm;
-    };
-    load_tile(tile_begin);
-    commit(0);
-    __syncthreads();
-
-    for (int tile = tile_begin; tile < tile_end; tile++) {
-        const int buf = (tile - tile_begin) & 1;
-        const bool more = tile + 1 < tile_end;
-        if (more) load_tile(tile + 1);
-        const unsigned char* T = tile_lds(buf);
-        const float* Nn = norm_lds(buf);
-#pragma unroll 2
-        for (int rb = 0; rb < 4; rb++) {                           // 32-row blocks of the tile
-            f32x16 acc[SC32_NC];
-#pragma unroll
-            for (int g = 0; g < 4; g++) {                          // |t|^2 of this lane's sixteen rows
-                const f32x4 n4 = *reinterpret_cast<const f32x4*>(Nn + rb * 32 + 8 * g + 4 * kc);
-#pragma unroll
-                for (int c = 0; c < SC32_NC; c++)
-#pragma unroll
-                    for (int j = 0; j < 4; j++) acc[c][4 * g + j] = n4[j];
-            }
-            const unsigned char* arow = T + (rb * 32 + col) * SC_PITCH + 16 * kc;
-#pragma unroll
-            for (int s = 0; s < 8; s++) {
-                const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow + 32 * s));
-#pragma unroll
-                for (int c = 0; c < SC32_NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B[c][s], acc[c], 0, 0, 0);
-            }
-            float mn[SC32_NC];
-            bool any_hit = false;
-#pragma unroll
-            for (int c = 0; c < SC32_NC; c++) {
-                float m = acc[c][0];
-#pragma unroll
-                for (int i = 1; i < 16; i++) m = fminf(m, acc[c][i]);
-                mn[c] = m;
-                any_hit |= PASS == 0 ? m < best[c].d1 : m <= th[c];
-            }
-            const uint32_t row0 = (uint32_t)(tile * SC_TM + rb * 32 + 4 * kc);
-            if (__any(any_hit)) {
-#pragma unroll
-                for (int c = 0; c < SC32_NC; c++) {
-                    const int qi = q0 + 32 * c + col;
-#pragma unroll
-                    for (int i = 0; i < 16; i++) {
-                        const uint32_t row = row0 + 8 * (i >> 2) + (i & 3);   // ascending in i: equal values keep the lower row first
-                        if (PASS == 0) {
-                            sc_insert(best[c], acc[c][i], row + index_base);
-                        } else if (acc[c][i] <= th[c] && qi < nq && (int)row < n_train) {
-                            const unsigned int pos = atomicAdd(&s_cand_n, 1u);
-                            if (pos < cand_cap) cand[(size_t)block_id * cand_cap + pos] = ((unsigned long long)(uint32_t)qi << 32) | (row + index_base);
-                        }
-                    }
-                }
-            }
-        }
-        if (more) commit(buf ^ 1);
-        __syncthreads();
-    }
-    if (PASS == 1 && tid == 0) cand_count[block_id] = s_cand_n;
-    if (PASS == 0) {
-        // a query column lives in two lanes (kc = 0, 1: different rows): fold them, lanes 0..31 write
-#pragma unroll
-        for (int c = 0; c < SC32_NC; c++) {
-            ScTop2 b = best[c];
-            const float od0 = __shfl_xor(b.d0, 32), od1 = __shfl_xor(b.d1, 32);
-            const uint32_t oi0 = (uint32_t)__shfl_xor((int)b.i0, 32), oi1 = (uint32_t)__shfl_xor((int)b.i1, 32);
-            ScTop2 m = b;
-            auto ins = [&](float d, uint32_t i) {
-                if (i == 0xFFFFFFFFu) return;
-                if (d < m.d0 || (d == m.d0 && i < m.i0)) {
-                    m.d1 = m.d0;
-                    m.i1 = m.i0;
-                    m.d0 = d;
-                    m.i0 = i;
-                } else if ((d < m.d1 || (d == m.d1 && i < m.i1)) && i != m.i0) {
-                    m.d1 = d;
-                    m.i1 = i;
-                }
-            };
-            ins(od0, oi0);
-            ins(od1, oi1);
-            const int qi = q0 + 32 * c + col;
-            if (kc == 0 && qi < nq) {
-                uint64_t* o = out + ((size_t)blockIdx.y * nq + qi) * 2;
-                o[0] = sc_key(fmaxf(qq[c] + m.d0, 0.f), m.i0);
-                o[1] = sc_key(fmaxf(qq[c] + m.d1, 0.f), m.i1);
-            }
-        }
-    }
-}
-
 // theta[q] (in units of u = d^2 - |q|^2): second screen distance + 2 eps(q) - |q|^2
 __global__ void screen_theta_kernel(const uint64_t* __restrict__ top2, const float* __restrict__ qnorm, int nq, const unsigned int* __restrict__ tmax_sq_bits,
                                     float* __restrict__ theta) {
@@ -505,9 +337,7 @@ bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt,
     hipLaunchKernelGGL(to_bf16_rows_kernel, dim3(ceil_div((long long)nq * SC_D / 4, 256)), dim3(256), 0, s, q, (long long)nq, 1.0f, qb);
     hipLaunchKernelGGL(to_bf16_rows_kernel, dim3(ceil_div(nt * SC_D / 4, 256)), dim3(256), 0, s, t, nt, -2.0f, tb);
     hipLaunchKernelGGL(max_norm_kernel, dim3(256), dim3(256), 0, s, (const float*)tn, nt, tmax);
-    const bool mfma32 = config().l2_screen_mfma32 != 0;   // APDS_L2_SCREEN_MFMA32: the 32 x 32 x 16 form of the two screen passes
-    const int block_q = mfma32 ? SC32_Q : SC_Q;
-    const int q_tiles = ceil_div(nq, block_q), t_tiles = ceil_div(nt, SC_TM);
+    const int q_tiles = ceil_div(nq, SC_Q), t_tiles = ceil_div(nt, SC_TM);
     int splits = std::max(1, std::min(t_tiles, ceil_div(256 * 2, q_tiles)));
     const int tiles_per_split = ceil_div(t_tiles, splits);
     splits = ceil_div(t_tiles, tiles_per_split);
@@ -525,7 +355,7 @@ bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt,
     float* theta = c.alloc_n<float>(nq);
     // candidate regions: one per block of pass B, `region` entries each (256 queries x 256 candidates: 4x what config 3 needs)
     const int n_blocks = q_tiles * splits;
-    const unsigned long long region = (unsigned long long)block_q * 192;
+    const unsigned long long region = (unsigned long long)SC_Q * 192;
     if ((unsigned long long)n_blocks * region > (1ull << 29)) return false;
     unsigned long long* cand = c.alloc_n<unsigned long long>((size_t)n_blocks * region);
     unsigned long long* keys = c.alloc_n<unsigned long long>((size_t)n_blocks * region);
@@ -533,15 +363,8 @@ bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt,
     const size_t lds = (size_t)2 * SC_TM * SC_PITCH + 2 * SC_TM * sizeof(float);
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen32_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen32_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         KernelTimer timer("l2_screen", s);
-        if (mfma32)
-            hipLaunchKernelGGL((l2_screen32_kernel<0>), dim3(q_tiles, s_splits), dim3(SC32_WAVES * 64), lds, s, (const uint16_t*)tb, (const float*)tn, (int)n_sample,
-                               (const uint16_t*)qb, (const float*)qn, nq, s_tiles_per_split, index_base, parts, (const float*)nullptr, (unsigned long long*)nullptr,
-                               0ull, (unsigned long long*)nullptr);
-        else
         hipLaunchKernelGGL((l2_screen_kernel<0>), dim3(q_tiles, s_splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)n_sample,
                            (const uint16_t*)qb, (const float*)qn, nq, s_tiles_per_split, index_base, parts, (const float*)nullptr, (unsigned long long*)nullptr, 0ull,
                            (unsigned long long*)nullptr);
@@ -550,10 +373,6 @@ bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt,
     hipLaunchKernelGGL(screen_theta_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, (const uint64_t*)top2, (const float*)qn, nq, (const unsigned int*)tmax, theta);
     {
         KernelTimer timer("l2_screen", s);
-        if (mfma32)
-            hipLaunchKernelGGL((l2_screen32_kernel<1>), dim3(q_tiles, splits), dim3(SC32_WAVES * 64), lds, s, (const uint16_t*)tb, (const float*)tn, (int)nt, (const uint16_t*)qb,
-                               (const float*)qn, nq, tiles_per_split, index_base, (uint64_t*)nullptr, (const float*)theta, cand, region, counts);
-        else
         hipLaunchKernelGGL((l2_screen_kernel<1>), dim3(q_tiles, splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)nt, (const uint16_t*)qb,
                            (const float*)qn, nq, tiles_per_split, index_base, (uint64_t*)nullptr, (const float*)theta, cand, region, counts);
     }

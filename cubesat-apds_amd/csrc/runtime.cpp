@@ -42,7 +42,6 @@ const Config& config() {
         k.ransac_batch = env("APDS_RANSAC_BATCH", 512);
         k.pnp_batch = env("APDS_PNP_BATCH", 2048);
         k.l2_sample_div = std::max(1, env("APDS_L2_SAMPLE_DIV", 12));
-        k.l2_screen_mfma32 = env("APDS_L2_SCREEN_MFMA32", 0);
         k.pipe_extract_workers = std::max(1, env("APDS_EXTRACT_WORKERS", 2));
         k.pipe_match_split = env("APDS_MATCH_SPLIT", 1);
         k.pipe_adaptive_cap = env("APDS_ADAPTIVE_CAP", 1);
