@@ -62,6 +62,8 @@ __global__ __launch_bounds__(PNP_THREADS) void pnp_hypothesis_kernel(const float
 
 // P3P kernel of the RANSAC loop: one thread per 4-point sample, everything in registers (closed form). valid[h] = 0 when the
 // three-point system has no admissible solution (runKernel then returns no model and the iteration is skipped).
+// AP3P = true: the same sample through ap3p.cpp's algebraic solver (SOLVEPNP_AP3P).
+template <bool AP3P>
 __global__ __launch_bounds__(64) void p3p_hypothesis_kernel(const float* __restrict__ obj, const float* __restrict__ img, const int* __restrict__ idx4, int B,
                                                             Camera cam, double* __restrict__ models, uint8_t* __restrict__ valid) {
     APDS_RAISE_WAVE_PRIORITY();
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(64) void p3p_hypothesis_kernel(const float* __restr
         mv[j] = (float)(cam.fv * yn + cam.vc);
     }
     double R[9], t[3], rv[3] = {0, 0, 0};
-    const bool ok = pnp::p3p_best_pose(cam, mu, mv, P, R, t);
+    const bool ok = AP3P ? pnp::ap3p_best_pose(cam, mu, mv, P, R, t) : pnp::p3p_best_pose(cam, mu, mv, P, R, t);
     if (ok) pnp::rvec_from_rotation(R, rv);
     double* m = models + (size_t)h * 6;
     m[0] = rv[0];
@@ -189,7 +191,7 @@ void host_epnp(const T* obj, const T* img, int n, const Camera& cam, double* rve
 
 // solvePnP(4 points, SOLVEPNP_P3P) on host arrays
 template <typename T>
-bool host_p3p(const T* obj, const T* img, const Camera& cam, double* rvec, double* tvec) {
+bool host_p3p(const T* obj, const T* img, const Camera& cam, double* rvec, double* tvec, bool ap3p = false) {
     const double ifx = 1. / cam.fu, ify = 1. / cam.fv;
     double mu[4], mv[4], P[12];
     for (int i = 0; i < 4; i++) {
@@ -199,7 +201,7 @@ bool host_p3p(const T* obj, const T* img, const Camera& cam, double* rvec, doubl
         for (int c = 0; c < 3; c++) P[3 * i + c] = obj[3 * i + c];
     }
     double R[9];
-    if (!pnp::p3p_best_pose(cam, mu, mv, P, R, tvec)) return false;
+    if (!(ap3p ? pnp::ap3p_best_pose(cam, mu, mv, P, R, tvec) : pnp::p3p_best_pose(cam, mu, mv, P, R, tvec))) return false;
     pnp::rvec_from_rotation(R, rvec);
     return true;
 }
@@ -469,10 +471,11 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     *n_inliers = 0;
     APDS_REQUIRE(obj_xyz && img_xy && K && rvec && tvec && inliers, APDS_ERR_BAD_ARG, "null argument");
     APDS_REQUIRE(n >= 4, APDS_ERR_ASSERT, "solvePnPRansac needs at least 4 correspondences");
-    APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP || method == APDS_SOLVEPNP_P3P || method == APDS_SOLVEPNP_ITERATIVE, APDS_ERR_NOT_IMPLEMENTED,
-                 "SOLVEPNP_EPNP (the reference's default), SOLVEPNP_P3P and SOLVEPNP_ITERATIVE are implemented");
-    // kernel choice of solvePnPRansac: P3P on 4 points when asked for, or when there are only 4 points; EPnP on 5 otherwise
-    const bool p3p = method == APDS_SOLVEPNP_P3P || n == 4;
+    APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP || method == APDS_SOLVEPNP_P3P || method == APDS_SOLVEPNP_ITERATIVE || method == APDS_SOLVEPNP_AP3P,
+                 APDS_ERR_NOT_IMPLEMENTED, "SOLVEPNP_EPNP (the reference's default), SOLVEPNP_P3P, SOLVEPNP_AP3P and SOLVEPNP_ITERATIVE are implemented");
+    // kernel choice of solvePnPRansac: P3P / AP3P on 4 points when asked for, P3P when there are only 4 points; EPnP on 5 otherwise
+    const bool ap3p = method == APDS_SOLVEPNP_AP3P;
+    const bool p3p = method == APDS_SOLVEPNP_P3P || ap3p || n == 4;
     const int model_points = p3p ? 4 : 5;
     const Camera cam{K[0], K[4], K[2], K[5]};
     // solvePnPRansac converts CV_64F points to CV_32F before anything else
@@ -481,7 +484,7 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     for (size_t i = 0; i < ip.size(); i++) ip[i] = (float)img_xy[i];
     if (n == model_points) {   // model_points == npoints: one direct solve, every point an inlier
         if (p3p) {
-            if (!host_p3p<float>(op.data(), ip.data(), cam, rvec, tvec)) return 0;
+            if (!host_p3p<float>(op.data(), ip.data(), cam, rvec, tvec, ap3p)) return 0;
         } else {
             host_epnp<float>(op.data(), ip.data(), n, cam, rvec, tvec);
         }
@@ -515,9 +518,12 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
         for (int b = 0; b < B; b++) next_sample(n, &idx[(size_t)b * model_points], rng, model_points);
         HIP_CHECK(hipMemcpyAsync(idx_dev, idx.data(), (size_t)B * model_points * sizeof(int), hipMemcpyHostToDevice, s));
         HIP_CHECK(hipMemsetAsync(good_dev, 0, (size_t)B * sizeof(int), s));
-        if (p3p)
-            hipLaunchKernelGGL(p3p_hypothesis_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const float*)obj_dev, (const float*)img_dev, (const int*)idx_dev, B, cam,
-                               models_dev, valid_dev);
+        if (ap3p)
+            hipLaunchKernelGGL(p3p_hypothesis_kernel<true>, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const float*)obj_dev, (const float*)img_dev, (const int*)idx_dev, B,
+                               cam, models_dev, valid_dev);
+        else if (p3p)
+            hipLaunchKernelGGL(p3p_hypothesis_kernel<false>, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const float*)obj_dev, (const float*)img_dev, (const int*)idx_dev, B,
+                               cam, models_dev, valid_dev);
         else
             hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(ceil_div(B, PNP_THREADS)), dim3(PNP_THREADS), PNP_LDS_BYTES, s, (const float*)obj_dev,
                                (const float*)img_dev, (const int*)idx_dev, B, cam, models_dev);
@@ -576,6 +582,8 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
 // comes back as NaNs)
 void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, const double* K, const int32_t* idx5, int B, int model_points,
                            double* models_host, hipStream_t s) {
+    const bool ap3p = model_points == 40;   // 40: four points through the AP3P solver
+    if (ap3p) model_points = 4;
     APDS_REQUIRE(obj_xyz && img_xy && K && idx5 && models_host && (model_points == 4 || model_points == 5) && n >= model_points && B >= 1, APDS_ERR_BAD_ARG,
                  "bad argument");
     for (int i = 0; i < B * model_points; i++) APDS_REQUIRE(idx5[i] >= 0 && idx5[i] < n, APDS_ERR_OUT_OF_RANGE, "sample index out of range");
@@ -592,8 +600,11 @@ void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, c
     HIP_CHECK(hipMemcpyAsync(obj_dev, op.data(), op.size() * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(img_dev, ip.data(), ip.size() * sizeof(float), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipMemcpyAsync(idx_dev, idx5, (size_t)B * model_points * sizeof(int), hipMemcpyHostToDevice, s));
-    if (model_points == 4)
-        hipLaunchKernelGGL(p3p_hypothesis_kernel, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const float*)obj_dev, (const float*)img_dev, (const int*)idx_dev, B, cam,
+    if (model_points == 4 && ap3p)
+        hipLaunchKernelGGL(p3p_hypothesis_kernel<true>, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const float*)obj_dev, (const float*)img_dev, (const int*)idx_dev, B, cam,
+                           models_dev, valid_dev);
+    else if (model_points == 4)
+        hipLaunchKernelGGL(p3p_hypothesis_kernel<false>, dim3(ceil_div(B, 64)), dim3(64), 0, s, (const float*)obj_dev, (const float*)img_dev, (const int*)idx_dev, B, cam,
                            models_dev, valid_dev);
     else
         hipLaunchKernelGGL(pnp_hypothesis_kernel, dim3(ceil_div(B, PNP_THREADS)), dim3(PNP_THREADS), PNP_LDS_BYTES, s, (const float*)obj_dev,

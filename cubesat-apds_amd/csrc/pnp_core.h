@@ -978,5 +978,202 @@ PNP_HD bool p3p_best_pose(const Camera& cam, const double* mu_in, const double* 
     return true;
 }
 
+// ---- AP3P (ap3p.cpp: Ke, Roumeliotis 2017) --------------------------------------------------------------------------------------------
+// The kernel solvePnPRansac uses for SOLVEPNP_AP3P (mod.rs:327,359 hands `Option<SolvePnPMethod>` straight through): a quartic in
+// cos(theta1') from the seven g coefficients, its four roots by Ferrari's closed form in complex arithmetic (the real parts of all four are
+// kept, as upstream does), two Newton polishing steps, rotation and translation per root with |cos| <= 1, poses ranked by the fourth
+// point. Written once for host and device; elementary functions in fixed order, so the oracle's separate restatement agrees bit for bit.
+struct Cx {
+    double re, im;
+};
+PNP_HD Cx cx_sqrt(Cx z) {   // principal square root
+    if (z.re == 0.0) {
+        const double t = sqrt(fabs(z.im) / 2);
+        return Cx{t, z.im < 0.0 ? -t : t};
+    }
+    const double m = sqrt(z.re * z.re + z.im * z.im);
+    const double t = sqrt(2 * (m + fabs(z.re)));
+    const double u = t / 2;
+    return z.re > 0.0 ? Cx{u, z.im / t} : Cx{fabs(z.im) / t, z.im < 0.0 ? -u : u};
+}
+PNP_HD double atan2_fixed(double y, double x) {   // y != 0 or x != 0
+    const double ax = fabs(x), ay = fabs(y);
+    double a = ax >= ay ? atan_fixed(ay / ax) : 1.5707963267948966 - atan_fixed(ax / ay);
+    if (x < 0) a = 3.141592653589793 - a;
+    return y < 0 ? -a : a;
+}
+PNP_HD Cx cx_cbrt(Cx z) {   // principal value of pow(z, 1/3)
+    const double m = sqrt(z.re * z.re + z.im * z.im);
+    const double r = cbrt_fixed(m), th = atan2_fixed(z.im, z.re) / 3.0;
+    double sn, cs;
+    sincos_fixed(fabs(th), sn, cs);
+    return Cx{r * cs, th < 0 ? -(r * sn) : r * sn};
+}
+PNP_HD void ap3p_quartic(const double* f, double* roots) {
+    const double a4 = f[0], a3 = f[1], a2 = f[2], a1 = f[3], a0 = f[4];
+    const double a4_2 = a4 * a4, a3_2 = a3 * a3, a4_3 = a4_2 * a4, a2a4 = a2 * a4;
+    const double p4 = (8 * a2a4 - 3 * a3_2) / (8 * a4_2);
+    const double q4 = (a3_2 * a3 - 4 * a2a4 * a3 + 8 * a1 * a4_2) / (8 * a4_3);
+    const double r4 = (256 * a0 * a4_3 - 3 * (a3_2 * a3_2) - 64 * a1 * a3 * a4_2 + 16 * a2a4 * a3_2) / (256 * (a4_3 * a4));
+    const double p3 = ((p4 * p4) / 12 + r4) / 3;
+    const double q3 = (72 * r4 * p4 - 2 * p4 * p4 * p4 - 27 * q4 * q4) / 432;
+    double t;
+    Cx w = cx_sqrt(Cx{q3 * q3 - p3 * p3 * p3, 0.0});
+    if (q3 >= 0) w = Cx{-w.re - q3, -w.im};
+    else w = Cx{w.re - q3, w.im};
+    if (w.im == 0.0) {
+        const double c = w.re < 0 ? -cbrt_fixed(-w.re) : (w.re > 0 ? cbrt_fixed(w.re) : 0.0);
+        t = 2.0 * (c + p3 / c);
+    } else {
+        t = 4.0 * cx_cbrt(w).re;
+    }
+    const Cx sqrt_2m = cx_sqrt(Cx{-2 * p4 / 3 + t, 0.0});
+    const double B_4A = -a3 / (4 * a4);
+    const double complex1 = 4 * p4 / 3 + t;
+    const double den = sqrt_2m.re * sqrt_2m.re + sqrt_2m.im * sqrt_2m.im;   // 2 q4 / sqrt_2m
+    const Cx complex2{2 * q4 * sqrt_2m.re / den, -(2 * q4 * sqrt_2m.im) / den};
+    const double sqrt_2m_rh = sqrt_2m.re / 2;
+    const double sqrt1 = cx_sqrt(Cx{-(complex1 + complex2.re), -complex2.im}).re / 2;
+    roots[0] = B_4A + sqrt_2m_rh + sqrt1;
+    roots[1] = B_4A + sqrt_2m_rh - sqrt1;
+    const double sqrt_2m_lh = -sqrt_2m_rh;
+    const double sqrt2 = cx_sqrt(Cx{-(complex1 - complex2.re), complex2.im}).re / 2;
+    roots[2] = B_4A + sqrt_2m_lh + sqrt2;
+    roots[3] = B_4A + sqrt_2m_lh - sqrt2;
+    for (int it = 0; it < 2; it++)   // polishQuarticRoots
+        for (int j = 0; j < 4; j++) {
+            const double x = roots[j];
+            const double error = (((f[0] * x + f[1]) * x + f[2]) * x + f[3]) * x + f[4];
+            const double derivative = ((4 * f[0] * x + 3 * f[1]) * x + 2 * f[2]) * x + f[3];
+            roots[j] -= error / derivative;
+        }
+}
+PNP_HD void cross3(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+PNP_HD void mult3(const double* a, const double* b, double* r) {   // 3 x 3 row major
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+// solvePnP(SOLVEPNP_AP3P) on four correspondences (as p3p_best_pose): the first pose of the list sorted by the fourth point's error
+PNP_HD bool ap3p_best_pose(const Camera& cam, const double* mu_in, const double* mv_in, const double* P /*4x3*/, double* Rbest /*9*/, double* tbest /*3*/) {
+    const double inv_fx = 1. / cam.fu, inv_fy = 1. / cam.fv, cx_fx = cam.uc / cam.fu, cy_fy = cam.vc / cam.fv;
+    double b0[3], b1[3], b2[3];
+    {
+        double* bs[3] = {b0, b1, b2};
+        for (int i = 0; i < 3; i++) {
+            const double mu = inv_fx * mu_in[i] - cx_fx, mv = inv_fy * mv_in[i] - cy_fy;
+            const double mk = 1. / sqrt(mu * mu + mv * mv + 1);
+            bs[i][0] = mu * mk;
+            bs[i][1] = mv * mk;
+            bs[i][2] = mk;
+        }
+    }
+    const double mu3 = inv_fx * mu_in[3] - cx_fx, mv3 = inv_fy * mv_in[3] - cy_fy;
+    const double *w1 = P, *w2 = P + 3, *w3 = P + 6, *w4 = P + 9;
+    const double u0[3] = {w1[0] - w2[0], w1[1] - w2[1], w1[2] - w2[2]};
+    const double nu0 = sqrt(u0[0] * u0[0] + u0[1] * u0[1] + u0[2] * u0[2]);
+    const double k1[3] = {u0[0] / nu0, u0[1] / nu0, u0[2] / nu0};
+    double k3[3], tz[3], v1[3], v2[3];
+    cross3(b0, b1, k3);
+    const double nk3 = sqrt(k3[0] * k3[0] + k3[1] * k3[1] + k3[2] * k3[2]);
+    for (int i = 0; i < 3; i++) k3[i] /= nk3;
+    cross3(b0, k3, tz);
+    cross3(b0, b2, v1);
+    cross3(b1, b2, v2);
+    const double u1[3] = {w1[0] - w3[0], w1[1] - w3[1], w1[2] - w3[2]};
+    const double u1k1 = u1[0] * k1[0] + u1[1] * k1[1] + u1[2] * k1[2];
+    const double k3b3 = k3[0] * b2[0] + k3[1] * b2[1] + k3[2] * b2[2];
+    double f11 = k3b3;
+    double f13 = k3[0] * v1[0] + k3[1] * v1[1] + k3[2] * v1[2];
+    const double f15 = -u1k1 * f11;
+    double nl[3];
+    cross3(u1, k1, nl);
+    const double delta = sqrt(nl[0] * nl[0] + nl[1] * nl[1] + nl[2] * nl[2]);
+    for (int i = 0; i < 3; i++) nl[i] /= delta;
+    f11 *= delta;
+    f13 *= delta;
+    const double u2k1 = u1k1 - nu0;
+    double f21 = tz[0] * v2[0] + tz[1] * v2[1] + tz[2] * v2[2];
+    double f22 = nk3 * k3b3;
+    double f23 = k3[0] * v2[0] + k3[1] * v2[1] + k3[2] * v2[2];
+    const double f24 = u2k1 * f22;
+    const double f25 = -u2k1 * f21;
+    f21 *= delta;
+    f22 *= delta;
+    f23 *= delta;
+    const double g1 = f13 * f22, g2 = f13 * f25 - f15 * f23, g3 = f11 * f23 - f13 * f21, g4 = -f13 * f24, g5 = f11 * f22, g6 = f11 * f25 - f15 * f21,
+                 g7 = -f15 * f24;
+    const double coeffs[5] = {g5 * g5 + g1 * g1 + g3 * g3, 2 * (g5 * g6 + g1 * g2 + g3 * g4), g6 * g6 + 2 * g5 * g7 + g2 * g2 + g4 * g4 - g1 * g1 - g3 * g3,
+                              2 * (g6 * g7 - g1 * g2 - g3 * g4), g7 * g7 - g2 * g2 - g4 * g4};
+    double s[4];
+    ap3p_quartic(coeffs, s);
+    double temp[3];
+    cross3(k1, nl, temp);
+    const double Ck1nl[9] = {k1[0], nl[0], temp[0], k1[1], nl[1], temp[1], k1[2], nl[2], temp[2]};
+    const double Cb1k3tzT[9] = {b0[0], b0[1], b0[2], k3[0], k3[1], k3[2], tz[0], tz[1], tz[2]};
+    const double sc = delta / k3b3;
+    const double b3p[3] = {sc * b2[0], sc * b2[1], sc * b2[2]};
+    // the head of OpenCV's insertion sort by the fourth point's error: the first pose whose error no later pose undercuts STRICTLY...
+    // a stable insertion sort puts the earliest of the smallest errors first (a NaN neither moves nor lets anything pass it): replayed below
+    double Rs[4][9], ts[4][3], errs[4];
+    int nb = 0;
+    for (int i = 0; i < 4; i++) {
+        const double ctheta1p = s[i];
+        if (!(fabs(ctheta1p) <= 1)) continue;
+        double stheta1p = sqrt(1 - ctheta1p * ctheta1p);
+        stheta1p = (k3b3 > 0) ? stheta1p : -stheta1p;
+        double ctheta3 = g1 * ctheta1p + g2;
+        double stheta3 = g3 * ctheta1p + g4;
+        const double ntheta3 = stheta1p / ((g5 * ctheta1p + g6) * ctheta1p + g7);
+        ctheta3 *= ntheta3;
+        stheta3 *= ntheta3;
+        const double C13[9] = {ctheta3, 0, -stheta3, stheta1p * stheta3, ctheta1p, stheta1p * ctheta3, ctheta1p * stheta3, -stheta1p, ctheta1p * ctheta3};
+        double tmp[9], Rm[9];
+        mult3(Ck1nl, C13, tmp);
+        mult3(tmp, Cb1k3tzT, Rm);
+        const double rp3[3] = {w3[0] * Rm[0] + w3[1] * Rm[3] + w3[2] * Rm[6], w3[0] * Rm[1] + w3[1] * Rm[4] + w3[2] * Rm[7], w3[0] * Rm[2] + w3[1] * Rm[5] + w3[2] * Rm[8]};
+        double Rt[9], tt[3];
+        for (int k = 0; k < 3; k++) tt[k] = stheta1p * b3p[k] - rp3[k];
+        for (int a = 0; a < 3; a++)
+            for (int c = 0; c < 3; c++) Rt[3 * a + c] = Rm[3 * c + a];   // the pose is the transpose
+        const double X3p = Rt[0] * w4[0] + Rt[1] * w4[1] + Rt[2] * w4[2] + tt[0];
+        const double Y3p = Rt[3] * w4[0] + Rt[4] * w4[1] + Rt[5] * w4[2] + tt[1];
+        const double Z3p = Rt[6] * w4[0] + Rt[7] * w4[1] + Rt[8] * w4[2] + tt[2];
+        const double mu3p = X3p / Z3p, mv3p = Y3p / Z3p;
+        const double e = (mu3p - mu3) * (mu3p - mu3) + (mv3p - mv3) * (mv3p - mv3);
+        // static slots (no dynamically indexed register arrays on the device)
+#define APDS_AP3P_PUT(K)                                   \
+    if (nb == K) {                                         \
+        for (int q = 0; q < 9; q++) Rs[K][q] = Rt[q];      \
+        for (int q = 0; q < 3; q++) ts[K][q] = tt[q];      \
+        errs[K] = e;                                       \
+    }
+        APDS_AP3P_PUT(0)
+        APDS_AP3P_PUT(1)
+        APDS_AP3P_PUT(2)
+        APDS_AP3P_PUT(3)
+#undef APDS_AP3P_PUT
+        nb++;
+    }
+    if (nb <= 0) return false;
+    int order[4] = {0, 1, 2, 3};
+    for (int i = 1; i < nb; i++)
+        for (int j = i; j > 0 && errs[j - 1] > errs[j]; j--) {
+            const double e = errs[j];
+            errs[j] = errs[j - 1];
+            errs[j - 1] = e;
+            const int o = order[j];
+            order[j] = order[j - 1];
+            order[j - 1] = o;
+        }
+    const int h = order[0];
+    for (int k = 0; k < 9; k++) Rbest[k] = h == 0 ? Rs[0][k] : (h == 1 ? Rs[1][k] : (h == 2 ? Rs[2][k] : Rs[3][k]));
+    for (int k = 0; k < 3; k++) tbest[k] = h == 0 ? ts[0][k] : (h == 1 ? ts[1][k] : (h == 2 ? ts[2][k] : ts[3][k]));
+    return true;
+}
+
 }  // namespace pnp
 }  // namespace apds

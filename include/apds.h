@@ -153,11 +153,11 @@ int apds_warp_perspective_f32(const float* src, int rows, int cols, int channels
  * distCoeffs = zeros(4,1) (mod.rs:344 shadows the dist_coeffs argument with zeros, so it never reaches OpenCV and is not part of this ABI).
  * obj_xyz: n Point3d (ImgObjCorrespondence::obj_point, mod.rs:53-65), img_xy: n Point2d, camera_intrinsic: 3x3 f64 row major.
  * method: cv::SolvePnPMethod; the shim passes method.unwrap_or(SOLVEPNP_EPNP) (mod.rs:360). Built: APDS_SOLVEPNP_EPNP (RANSAC kernel
- * EPnP on 5 points), APDS_SOLVEPNP_P3P (Gao's P3P on 4 points; also the kernel OpenCV switches to when n == 4) - the final pose
- * over the inliers is EPnP in both cases, as in OpenCV - and APDS_SOLVEPNP_ITERATIVE (EPnP kernel; final pose = solvePnP(ITERATIVE) over
+ * EPnP on 5 points), APDS_SOLVEPNP_P3P (Gao's P3P on 4 points; also the kernel OpenCV switches to when n == 4), APDS_SOLVEPNP_AP3P (Ke and
+ * Roumeliotis' algebraic P3P on 4 points) - the final pose over the inliers is EPnP in these cases, as in OpenCV - and APDS_SOLVEPNP_ITERATIVE (EPnP kernel; final pose = solvePnP(ITERATIVE) over
  * the inliers WITHOUT an extrinsic guess, as the reference's use_extrinsic_guess = false makes it: a homography (planar object points) or
  * DLT (>= 6 points) start, then <= 20 Levenberg-Marquardt iterations on the reprojection error; with five non-planar inliers the RANSAC
- * model stays, as in solvePnPRansac). AP3P / SQPNP / ... return APDS_ERR_NOT_IMPLEMENTED.
+ * model stays, as in solvePnPRansac). SQPNP / IPPE / ... return APDS_ERR_NOT_IMPLEMENTED.
  * n < 4 -> APDS_ERR_ASSERT (mod.rs:627-638).
  * *found = 1: rvec[3], tvec[3], inliers[0..*n_inliers) filled (inliers: caller allocated, n ints); *found = 0: Ok(None). */
 #define APDS_SOLVEPNP_ITERATIVE 0
@@ -427,7 +427,7 @@ int apds_release_cached_memory(void);
 int apds_akaze_debug_plane(const uint8_t* img, int rows, int cols, int channels, size_t stride_bytes, int level, int which, void* out_plane);
 
 /* Test hook: the pose (rvec, tvec: 6 doubles per sample) of n_samples explicit samples as the RANSAC kernels compute them:
- * model_points 5 = EPnP on 5 correspondences, 4 = P3P on 4 (three solve, the fourth ranks; NaNs when there is no pose). */
+ * model_points 5 = EPnP on 5 correspondences, 4 = P3P on 4 (three solve, the fourth ranks; NaNs when there is no pose), 40 = AP3P on 4. */
 int apds_pnp_hypotheses(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, const int32_t* samples, int n_samples,
                         int model_points, double* models);
 

@@ -98,6 +98,8 @@ def lib():
         L.oracle_pnp_hypothesis.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_pnp_ransac_samples4.restype = C.c_int
         L.oracle_pnp_ransac_samples4.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        L.oracle_pnp_ap3p_hypothesis.restype = C.c_int
+        L.oracle_pnp_ap3p_hypothesis.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_pnp_p3p_hypothesis.restype = C.c_int
         L.oracle_pnp_p3p_hypothesis.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_rodrigues.restype = None
@@ -463,3 +465,14 @@ def pnp_p3p_hypothesis(obj, img, idx4, K):
     rvec, tvec = np.zeros(3), np.zeros(3)
     ok = lib().oracle_pnp_p3p_hypothesis(_ptr(obj), _ptr(img), _ptr(idx4), _ptr(K), _ptr(rvec), _ptr(tvec))
     return ok == 1, rvec, tvec
+
+
+def pnp_ap3p_hypothesis(obj, img, idx4, K):
+    """SOLVEPNP_AP3P's kernel on one 4-point sample: the first three points solve, the fourth ranks. Returns (ok, rvec, tvec)."""
+    obj = np.ascontiguousarray(obj, np.float64)
+    img = np.ascontiguousarray(img, np.float64)
+    idx4 = np.ascontiguousarray(idx4, np.int32)
+    K = np.ascontiguousarray(K, np.float64)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    ok = lib().oracle_pnp_ap3p_hypothesis(_ptr(obj), _ptr(img), _ptr(idx4), _ptr(K), _ptr(rvec), _ptr(tvec))
+    return bool(ok), rvec, tvec

@@ -115,6 +115,7 @@ int  oracle_pnp_ransac_samples(int n, int iters, int32_t* idx5 /* iters*5 */);
 int  oracle_pnp_hypothesis(const double* obj_xyz, const double* img_xy, const int32_t* idx5, const double* K, double* rvec, double* tvec);
 int  oracle_pnp_ransac_samples4(int n, int iters, int32_t* idx4 /* iters*4 */);
 int  oracle_pnp_p3p_hypothesis(const double* obj_xyz, const double* img_xy, const int32_t* idx4, const double* K, double* rvec, double* tvec);
+int oracle_pnp_ap3p_hypothesis(const double* obj_xyz, const double* img_xy, const int32_t* idx4, const double* K, double* rvec, double* tvec);   /* SOLVEPNP_AP3P kernel */
 void oracle_rodrigues(const double* in, int in_is_matrix, double* out);
 void oracle_det_acos(const double* c, int n, double* out);
 

@@ -1324,6 +1324,199 @@ bool solve_pnp_p3p(const T* obj, const T* img, const double* K, double* rvec, do
     return true;
 }
 
+// ---- ap3p.cpp (Ke, Roumeliotis 2017: "An efficient algebraic solution to the perspective-three-point problem") ---------------------------
+// SOLVEPNP_AP3P: the kernel solvePnPRansac switches to for flags == SOLVEPNP_AP3P (4 points per sample, the fourth ranks the poses; the
+// final pose over the inliers is EPnP, as for P3P). Restated from memory of calib3d/src/ap3p.cpp: a quartic in cos(theta1') from the
+// seven g coefficients, its four roots by Ferrari's closed form in COMPLEX arithmetic (the real parts of all four are kept, as upstream
+// does), two Newton polishing steps, then rotation and translation per root with |cos| <= 1. Elementary functions are the fixed-order
+// ones of this file, so the HIP path (csrc/pnp_core.h) agrees bit for bit. PARITY UNPINNED (oracle.h); the anchors of
+// tests/test_external_anchors.py hold it to the construction of the data.
+struct Cx {
+    double re, im;
+};
+Cx cx_sqrt(Cx z) {   // principal square root (libstdc++'s formula)
+    if (z.re == 0.0) {
+        const double t = std::sqrt(std::fabs(z.im) / 2);
+        return Cx{t, z.im < 0.0 ? -t : t};
+    }
+    const double m = std::sqrt(z.re * z.re + z.im * z.im);
+    const double t = std::sqrt(2 * (m + std::fabs(z.re)));
+    const double u = t / 2;
+    return z.re > 0.0 ? Cx{u, z.im / t} : Cx{std::fabs(z.im) / t, z.im < 0.0 ? -u : u};
+}
+double det_atan2(double y, double x) {   // for y != 0 or x != 0
+    const double ax = std::fabs(x), ay = std::fabs(y);
+    double a = ax >= ay ? det_atan(ay / ax) : 1.5707963267948966 - det_atan(ax / ay);
+    if (x < 0) a = 3.141592653589793 - a;
+    return y < 0 ? -a : a;
+}
+Cx cx_cbrt(Cx z) {   // principal value of pow(z, 1/3)
+    const double m = std::sqrt(z.re * z.re + z.im * z.im);
+    const double r = det_cbrt(m), th = det_atan2(z.im, z.re) / 3.0;
+    double sn, cs;
+    det_sincos(std::fabs(th), sn, cs);
+    return Cx{r * cs, th < 0 ? -(r * sn) : r * sn};
+}
+void ap3p_solve_quartic(const double* f, double* roots) {
+    const double a4 = f[0], a3 = f[1], a2 = f[2], a1 = f[3], a0 = f[4];
+    const double a4_2 = a4 * a4, a3_2 = a3 * a3, a4_3 = a4_2 * a4, a2a4 = a2 * a4;
+    const double p4 = (8 * a2a4 - 3 * a3_2) / (8 * a4_2);
+    const double q4 = (a3_2 * a3 - 4 * a2a4 * a3 + 8 * a1 * a4_2) / (8 * a4_3);
+    const double r4 = (256 * a0 * a4_3 - 3 * (a3_2 * a3_2) - 64 * a1 * a3 * a4_2 + 16 * a2a4 * a3_2) / (256 * (a4_3 * a4));
+    const double p3 = ((p4 * p4) / 12 + r4) / 3;
+    const double q3 = (72 * r4 * p4 - 2 * p4 * p4 * p4 - 27 * q4 * q4) / 432;
+    double t;
+    Cx w = cx_sqrt(Cx{q3 * q3 - p3 * p3 * p3, 0.0});
+    if (q3 >= 0) w = Cx{-w.re - q3, -w.im};
+    else w = Cx{w.re - q3, w.im};
+    if (w.im == 0.0) {
+        const double c = w.re < 0 ? -det_cbrt(-w.re) : (w.re > 0 ? det_cbrt(w.re) : 0.0);
+        t = 2.0 * (c + p3 / c);
+    } else {
+        t = 4.0 * cx_cbrt(w).re;
+    }
+    const Cx sqrt_2m = cx_sqrt(Cx{-2 * p4 / 3 + t, 0.0});
+    const double B_4A = -a3 / (4 * a4);
+    const double complex1 = 4 * p4 / 3 + t;
+    const double den = sqrt_2m.re * sqrt_2m.re + sqrt_2m.im * sqrt_2m.im;   // 2 q4 / sqrt_2m
+    const Cx complex2{2 * q4 * sqrt_2m.re / den, -(2 * q4 * sqrt_2m.im) / den};
+    const double sqrt_2m_rh = sqrt_2m.re / 2;
+    const double sqrt1 = cx_sqrt(Cx{-(complex1 + complex2.re), -complex2.im}).re / 2;
+    roots[0] = B_4A + sqrt_2m_rh + sqrt1;
+    roots[1] = B_4A + sqrt_2m_rh - sqrt1;
+    const double sqrt_2m_lh = -sqrt_2m_rh;
+    const double sqrt2 = cx_sqrt(Cx{-(complex1 - complex2.re), complex2.im}).re / 2;
+    roots[2] = B_4A + sqrt_2m_lh + sqrt2;
+    roots[3] = B_4A + sqrt_2m_lh - sqrt2;
+    for (int it = 0; it < 2; it++)   // polishQuarticRoots
+        for (int j = 0; j < 4; j++) {
+            const double x = roots[j];
+            const double error = (((f[0] * x + f[1]) * x + f[2]) * x + f[3]) * x + f[4];
+            const double derivative = ((4 * f[0] * x + 3 * f[1]) * x + 2 * f[2]) * x + f[3];
+            roots[j] -= error / derivative;
+        }
+}
+inline void v3_cross(const double* a, const double* b, double* c) {
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline double v3_norm(const double* a) { return std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]); }
+inline void m3_mult(const double a[3][3], const double b[3][3], double r[3][3]) {
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) r[i][j] = a[i][0] * b[0][j] + a[i][1] * b[1][j] + a[i][2] * b[2][j];
+}
+// ap3p::solve + computePoses for four correspondences: up to four poses from the first three, sorted by the fourth's error
+int ap3p_solve(const Camera& cam, const double* mu_in, const double* mv_in, const double P[4][3], double R[4][3][3], double t[4][3]) {
+    const double inv_fx = 1. / cam.fu, inv_fy = 1. / cam.fv, cx_fx = cam.uc / cam.fu, cy_fy = cam.vc / cam.fv;
+    double b[3][3];   // unit bearing vectors of the first three points
+    for (int i = 0; i < 3; i++) {
+        const double mu = inv_fx * mu_in[i] - cx_fx, mv = inv_fy * mv_in[i] - cy_fy;
+        const double mk = 1. / std::sqrt(mu * mu + mv * mv + 1);
+        b[i][0] = mu * mk;
+        b[i][1] = mv * mk;
+        b[i][2] = mk;
+    }
+    const double mu3 = inv_fx * mu_in[3] - cx_fx, mv3 = inv_fy * mv_in[3] - cy_fy;
+    const double *w1 = P[0], *w2 = P[1], *w3 = P[2];
+    double u0[3] = {w1[0] - w2[0], w1[1] - w2[1], w1[2] - w2[2]};
+    const double nu0 = v3_norm(u0);
+    const double k1[3] = {u0[0] / nu0, u0[1] / nu0, u0[2] / nu0};
+    double k3[3], tz[3], v1[3], v2[3];
+    v3_cross(b[0], b[1], k3);
+    const double nk3 = v3_norm(k3);
+    for (int i = 0; i < 3; i++) k3[i] /= nk3;
+    v3_cross(b[0], k3, tz);
+    v3_cross(b[0], b[2], v1);
+    v3_cross(b[1], b[2], v2);
+    const double u1[3] = {w1[0] - w3[0], w1[1] - w3[1], w1[2] - w3[2]};
+    const double u1k1 = u1[0] * k1[0] + u1[1] * k1[1] + u1[2] * k1[2];
+    const double k3b3 = k3[0] * b[2][0] + k3[1] * b[2][1] + k3[2] * b[2][2];
+    double f11 = k3b3;
+    double f13 = k3[0] * v1[0] + k3[1] * v1[1] + k3[2] * v1[2];
+    const double f15 = -u1k1 * f11;
+    double nl[3];
+    v3_cross(u1, k1, nl);
+    const double delta = v3_norm(nl);
+    for (int i = 0; i < 3; i++) nl[i] /= delta;
+    f11 *= delta;
+    f13 *= delta;
+    const double u2k1 = u1k1 - nu0;
+    double f21 = tz[0] * v2[0] + tz[1] * v2[1] + tz[2] * v2[2];
+    double f22 = nk3 * k3b3;
+    double f23 = k3[0] * v2[0] + k3[1] * v2[1] + k3[2] * v2[2];
+    const double f24 = u2k1 * f22;
+    const double f25 = -u2k1 * f21;
+    f21 *= delta;
+    f22 *= delta;
+    f23 *= delta;
+    const double g1 = f13 * f22, g2 = f13 * f25 - f15 * f23, g3 = f11 * f23 - f13 * f21, g4 = -f13 * f24, g5 = f11 * f22, g6 = f11 * f25 - f15 * f21,
+                 g7 = -f15 * f24;
+    const double coeffs[5] = {g5 * g5 + g1 * g1 + g3 * g3, 2 * (g5 * g6 + g1 * g2 + g3 * g4), g6 * g6 + 2 * g5 * g7 + g2 * g2 + g4 * g4 - g1 * g1 - g3 * g3,
+                              2 * (g6 * g7 - g1 * g2 - g3 * g4), g7 * g7 - g2 * g2 - g4 * g4};
+    double s[4];
+    ap3p_solve_quartic(coeffs, s);
+    double temp[3];
+    v3_cross(k1, nl, temp);
+    const double Ck1nl[3][3] = {{k1[0], nl[0], temp[0]}, {k1[1], nl[1], temp[1]}, {k1[2], nl[2], temp[2]}};
+    const double Cb1k3tzT[3][3] = {{b[0][0], b[0][1], b[0][2]}, {k3[0], k3[1], k3[2]}, {tz[0], tz[1], tz[2]}};
+    const double sc = delta / k3b3;
+    const double b3p[3] = {sc * b[2][0], sc * b[2][1], sc * b[2][2]};
+    double reproj_errors[4];
+    int nb = 0;
+    for (int i = 0; i < 4; i++) {
+        const double ctheta1p = s[i];
+        if (!(std::fabs(ctheta1p) <= 1)) continue;   // (upstream: abs(c) > 1 -> skip; a NaN root is skipped here)
+        double stheta1p = std::sqrt(1 - ctheta1p * ctheta1p);
+        stheta1p = (k3b3 > 0) ? stheta1p : -stheta1p;
+        double ctheta3 = g1 * ctheta1p + g2;
+        double stheta3 = g3 * ctheta1p + g4;
+        const double ntheta3 = stheta1p / ((g5 * ctheta1p + g6) * ctheta1p + g7);
+        ctheta3 *= ntheta3;
+        stheta3 *= ntheta3;
+        const double C13[3][3] = {{ctheta3, 0, -stheta3}, {stheta1p * stheta3, ctheta1p, stheta1p * ctheta3}, {ctheta1p * stheta3, -stheta1p, ctheta1p * ctheta3}};
+        double tmp[3][3], Rm[3][3];
+        m3_mult(Ck1nl, C13, tmp);
+        m3_mult(tmp, Cb1k3tzT, Rm);
+        const double rp3[3] = {w3[0] * Rm[0][0] + w3[1] * Rm[1][0] + w3[2] * Rm[2][0], w3[0] * Rm[0][1] + w3[1] * Rm[1][1] + w3[2] * Rm[2][1],
+                               w3[0] * Rm[0][2] + w3[1] * Rm[1][2] + w3[2] * Rm[2][2]};
+        for (int k = 0; k < 3; k++) t[nb][k] = stheta1p * b3p[k] - rp3[k];
+        for (int a = 0; a < 3; a++)
+            for (int c = 0; c < 3; c++) R[nb][a][c] = Rm[c][a];   // the pose is the transpose
+        const double X3p = R[nb][0][0] * P[3][0] + R[nb][0][1] * P[3][1] + R[nb][0][2] * P[3][2] + t[nb][0];
+        const double Y3p = R[nb][1][0] * P[3][0] + R[nb][1][1] * P[3][1] + R[nb][1][2] * P[3][2] + t[nb][1];
+        const double Z3p = R[nb][2][0] * P[3][0] + R[nb][2][1] * P[3][1] + R[nb][2][2] * P[3][2] + t[nb][2];
+        const double mu3p = X3p / Z3p, mv3p = Y3p / Z3p;
+        reproj_errors[nb] = (mu3p - mu3) * (mu3p - mu3) + (mv3p - mv3) * (mv3p - mv3);
+        nb++;
+    }
+    for (int i = 1; i < nb; i++)
+        for (int j = i; j > 0 && reproj_errors[j - 1] > reproj_errors[j]; j--) {
+            std::swap(reproj_errors[j], reproj_errors[j - 1]);
+            for (int k = 0; k < 9; k++) std::swap((&R[j][0][0])[k], (&R[j - 1][0][0])[k]);
+            for (int k = 0; k < 3; k++) std::swap(t[j][k], t[j - 1][k]);
+        }
+    return nb;
+}
+
+template <typename T>
+bool solve_pnp_ap3p(const T* obj, const T* img, const double* K, double* rvec, double* tvec) {
+    const Camera cam{K[0], K[4], K[2], K[5]};
+    const double ifx = 1. / K[0], ify = 1. / K[4];
+    double mu[4], mv[4], P[4][3];
+    for (int i = 0; i < 4; i++) {
+        const double xn = ((double)img[2 * i] - K[2]) * ifx, yn = ((double)img[2 * i + 1] - K[5]) * ify;
+        mu[i] = (T)(K[0] * xn + K[2]);
+        mv[i] = (T)(K[4] * yn + K[5]);
+        for (int c = 0; c < 3; c++) P[i][c] = obj[3 * i + c];
+    }
+    double R[4][3][3], t[4][3];
+    if (ap3p_solve(cam, mu, mv, P, R, t) <= 0) return false;
+    rodrigues_to_vector(&R[0][0][0], rvec);
+    for (int i = 0; i < 3; i++) tvec[i] = t[0][i];
+    return true;
+}
+
 int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     p = std::max(p, 0.);
     p = std::min(p, 1.);
@@ -1395,6 +1588,15 @@ int oracle_pnp_p3p_hypothesis(const double* obj_xyz, const double* img_xy, const
     return solve_pnp_p3p<float>(o, m, K, rvec, tvec) ? 1 : 0;
 }
 
+int oracle_pnp_ap3p_hypothesis(const double* obj_xyz, const double* img_xy, const int32_t* idx4, const double* K, double* rvec, double* tvec) {
+    float o[12], m[8];
+    for (int j = 0; j < 4; j++) {
+        for (int c = 0; c < 3; c++) o[3 * j + c] = (float)obj_xyz[3 * idx4[j] + c];
+        for (int c = 0; c < 2; c++) m[2 * j + c] = (float)img_xy[2 * idx4[j] + c];
+    }
+    return solve_pnp_ap3p<float>(o, m, K, rvec, tvec) ? 1 : 0;
+}
+
 int oracle_pnp_ransac_samples4(int n, int iters, int32_t* idx4) {
     RNG rng((uint64_t)-1);
     for (int it = 0; it < iters; it++) {
@@ -1409,9 +1611,11 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
                             double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers) {
     *n_inliers = 0;
     if (n < 4 || !obj_xyz || !img_xy || !K) return -215;          // CV_Assert(npoints >= 4 && ...)
-    if (method != 0 /* SOLVEPNP_ITERATIVE */ && method != 1 /* SOLVEPNP_EPNP */ && method != 2 /* SOLVEPNP_P3P */) return -213;   // AP3P, SQPNP, ...: not restated
-    // kernel choice of solvePnPRansac: P3P on 4 points when asked for, or when there are only 4 points; EPnP on 5 otherwise
-    const bool p3p = method == 2 || n == 4;
+    if (method != 0 /* SOLVEPNP_ITERATIVE */ && method != 1 /* SOLVEPNP_EPNP */ && method != 2 /* SOLVEPNP_P3P */ && method != 5 /* SOLVEPNP_AP3P */)
+        return -213;   // SQPNP, IPPE, ...: not restated
+    // kernel choice of solvePnPRansac: P3P / AP3P on 4 points when asked for, P3P when there are only 4 points; EPnP on 5 otherwise
+    const bool ap3p = method == 5;
+    const bool p3p = method == 2 || method == 5 || n == 4;
     const int modelPoints = p3p ? 4 : 5;
     // Point3d / Point2d -> CV_32F (solvePnPRansac converts CV_64F inputs to float)
     std::vector<float> op(3 * (size_t)n), ip(2 * (size_t)n);
@@ -1423,7 +1627,7 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
     int maxGoodCount = 0;
     if (n == modelPoints) {   // one direct solve, every point an inlier
         if (p3p) {
-            if (!solve_pnp_p3p<float>(op.data(), ip.data(), K, rvec, tvec)) return 0;
+            if (!(ap3p ? solve_pnp_ap3p<float>(op.data(), ip.data(), K, rvec, tvec) : solve_pnp_p3p<float>(op.data(), ip.data(), K, rvec, tvec))) return 0;
         } else {
             solve_pnp_epnp<float>(op.data(), ip.data(), n, K, rvec, tvec);
         }
@@ -1444,7 +1648,7 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
         }
         double r[3], tv[3];
         if (p3p) {
-            if (!solve_pnp_p3p<float>(o, m, K, r, tv)) continue;   // runKernel returned 0 models
+            if (!(ap3p ? solve_pnp_ap3p<float>(o, m, K, r, tv) : solve_pnp_p3p<float>(o, m, K, r, tv))) continue;   // runKernel returned 0 models
         } else {
             solve_pnp_epnp<float>(o, m, 5, K, r, tv);
         }

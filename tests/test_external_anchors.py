@@ -225,7 +225,33 @@ def check_iterative_pnp_solver(solve, synth):
     assert ok and len(idx) == 6 and np.abs(project(obj, rodrigues(r), t, K) - img).max() < 1e-3
 
 
+def check_ap3p_solver(solve, synth):
+    """SOLVEPNP_AP3P (4-point algebraic kernel in the RANSAC loop, EPnP over the inliers at the end): what the construction of the data says -
+    noise-free correspondences give back the pose they were projected with, every point an inlier; with pixel noise and 40 % outliers the
+    consensus set is the planted one and the pose is the planted pose to the noise level."""
+    obj, img, K, rvec, tvec, _ = synth.make_pnp_set(400, seed=43, inlier_frac=1.1, noise=0.0)
+    ok, r, t, idx = solve(obj, img, K, 100, 2.0, 0.99, 5)          # 5 = SOLVEPNP_AP3P
+    assert ok and len(idx) == 400 and np.abs(project(obj, rodrigues(r), t, K) - img).max() < 2e-2
+    obj, img, K, rvec, tvec, flag = synth.make_pnp_set(3000, seed=45, inlier_frac=0.6, noise=0.4)
+    ok, r, t, idx = solve(obj, img, K, 500, 3.0, 0.99, 5)
+    assert ok
+    planted = np.flatnonzero(flag)
+    assert len(np.intersect1d(idx, planted)) >= 0.97 * len(planted) and len(np.setdiff1d(idx, planted)) <= 0.01 * len(planted)
+    assert np.allclose(rodrigues(r), rodrigues(rvec), atol=2e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.0)
+    # exactly four correspondences with the AP3P flag: one direct solve that reprojects all four
+    o4, i4 = obj[planted[:4]], project(obj[planted[:4]], rodrigues(rvec), tvec, K)
+    ok, r, t, idx = solve(o4, i4, K, 50, 2.0, 0.99, 5)
+    assert ok and len(idx) == 4 and np.abs(project(o4, rodrigues(r), t, K) - i4).max() < 2e-2
+
+
 # ---------------------------------------------------------------------------------------------------------------- oracle (CPU)
+def test_oracle_ap3p_against_external_anchors(pkg, oracle_mod):
+    def solve(obj, img, K, iters, thr, conf, method):
+        rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, iters, thr, conf, method=method)
+        return rc == 1, r, t, idx
+    check_ap3p_solver(solve, pkg.synth)
+
+
 def test_oracle_iterative_pnp_against_external_anchors(pkg, oracle_mod):
     def solve(obj, img, K, iters, thr, conf, method):
         rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, iters, thr, conf, method=method)
@@ -272,6 +298,19 @@ def test_gpu_pnp_against_external_anchors(gpu_pkg):
             return False, None, None, None
         return True, sol.rvec.mat.ravel(), sol.tvec.mat.ravel(), sol.inliers.mat.ravel()
     check_pnp_solver(solve, gpu_pkg.synth)
+
+
+@pytest.mark.gpu
+def test_gpu_ap3p_against_external_anchors(gpu_pkg):
+    hg = gpu_pkg.homographier
+
+    def solve(obj, img, K, iters, thr, conf, method):
+        corr = [hg.ImgObjCorrespondence(o, i) for o, i in zip(obj, img)]
+        sol = hg.pnp_solver_ransac(corr, hg.Cmat(np.ascontiguousarray(K, np.float64), np.float64), iters, thr, conf, None, hg.SolvePnPMethod(method))
+        if sol is None:
+            return False, None, None, None
+        return True, sol.rvec.mat.ravel(), sol.tvec.mat.ravel(), sol.inliers.mat.ravel()
+    check_ap3p_solver(solve, gpu_pkg.synth)
 
 
 @pytest.mark.gpu

@@ -8,12 +8,12 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def _hyp(pkg, obj, img, K, idx):
+def _hyp(pkg, obj, img, K, idx, model_points=None):
     idx = np.ascontiguousarray(idx, np.int32)
     out = np.zeros((len(idx), 6))
     K = np.ascontiguousarray(K, np.float64)
-    rc = pkg.lib().apds_pnp_hypotheses(pkg._lib.ptr(obj), pkg._lib.ptr(img), len(obj), pkg._lib.ptr(K), pkg._lib.ptr(idx), len(idx), idx.shape[1],
-                                       pkg._lib.ptr(out))
+    rc = pkg.lib().apds_pnp_hypotheses(pkg._lib.ptr(obj), pkg._lib.ptr(img), len(obj), pkg._lib.ptr(K), pkg._lib.ptr(idx), len(idx),
+                                       model_points or idx.shape[1], pkg._lib.ptr(out))
     assert rc == 0, pkg.lib().apds_last_error()
     return out
 
@@ -85,10 +85,40 @@ def test_p3p_ransac_matches_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, t
     assert np.allclose(r, rvec, atol=3e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.0)
 
 
+def test_ap3p_hypotheses_bit_identical_to_oracle(gpu_pkg, oracle_mod):
+    """SOLVEPNP_AP3P's kernel (ap3p.cpp restated: csrc/pnp_core.h ap3p_best_pose / oracle/pnp_oracle.cpp ap3p_solve): one thread per 4-point
+    sample, the pose of every sample equal to the oracle's bit for bit (apds_pnp_hypotheses with model_points = 40)."""
+    obj, img, K, _, _, _ = gpu_pkg.synth.make_pnp_set(2000, inlier_frac=0.6, noise=0.5)
+    idx = oracle_mod.pnp_ransac_samples4(len(obj), 400)
+    got = _hyp(gpu_pkg, obj, img, K, idx, model_points=40)
+    n_found = 0
+    for b in range(len(idx)):
+        found, r, t = oracle_mod.pnp_ap3p_hypothesis(obj, img, idx[b], K)
+        if found:
+            n_found += 1
+            assert np.array_equal(got[b], np.concatenate([r, t]), equal_nan=True), (b, got[b], r, t)
+        else:
+            assert np.isnan(got[b]).all()
+    assert n_found > 300
+
+
+@pytest.mark.parametrize("n,frac,noise,iters,thr,conf", [(2000, 0.6, 0.5, 1000, 3.0, 0.99), (50000, 0.4, 0.5, 2000, 2.0, 0.995),
+                                                        (300, 0.9, 0.2, 100, 8.0, 0.99), (5, 1.1, 0.0, 50, 2.0, 0.99), (4, 1.1, 0.0, 50, 2.0, 0.99)])
+def test_ap3p_ransac_matches_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, thr, conf):
+    hg = gpu_pkg.homographier
+    obj, img, K, rvec, tvec, inl = gpu_pkg.synth.make_pnp_set(n, seed=27 + n, inlier_frac=frac, noise=noise)
+    sol = _solve(gpu_pkg, obj, img, K, iters, thr, conf, hg.SolvePnPMethod.SOLVEPNP_AP3P)
+    rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, iters, thr, conf, method=5)
+    assert (sol is not None) == (rc == 1) and rc == 1
+    assert np.array_equal(sol.inliers.mat.ravel(), idx)
+    assert np.array_equal(sol.rvec.mat.ravel(), r) and np.array_equal(sol.tvec.mat.ravel(), t)
+    assert np.allclose(r, rvec, atol=3e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.0)
+
+
 def test_four_points_and_unbuilt_methods(gpu_pkg, oracle_mod):
     hg = gpu_pkg.homographier
     obj, img, K, _, _, inl = gpu_pkg.synth.make_pnp_set(400, inlier_frac=0.5, noise=0.5)
-    for method in (hg.SolvePnPMethod.SOLVEPNP_AP3P,):
+    for method in (8, 6):        # SOLVEPNP_SQPNP, SOLVEPNP_IPPE: handed through like every Option<SolvePnPMethod> (mod.rs:359), not built
         with pytest.raises(hg.MatError) as e:
             _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, method)
         assert e.value.inner.code == -213
