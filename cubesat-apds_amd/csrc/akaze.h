@@ -64,14 +64,15 @@ void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsign
                       const Batch& b, bool gradient_done = false);
 bool launch_base_strips(const void* img, int rows, int cols, int channels, size_t stride, const GaussTaps& g16, const GaussTaps& g10, float* Lt0, float* modg,
                         unsigned int* hmax_bits, bool want_modg, hipStream_t s, const Batch& b);
-void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b);
+bool launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b,
+                      float* half_out = nullptr);
 bool launch_level_strips(const float* src, float* smooth, float* flow_out, float* Lnew, int w, int h, const GaussTaps& taps, const float* kptr,
                          const float* step_sizes, int nsteps, hipStream_t s, const Batch& b);
 bool launch_level_stream(const float* src, float* smooth, float* flow_out, float* Lnew, int w, int h, const GaussTaps& taps, const float* kptr,
-                         const float* step_sizes, int nsteps, hipStream_t s, const Batch& b);
+                         const float* step_sizes, int nsteps, hipStream_t s, const Batch& b, float* half_out = nullptr);
 int level_fused_max_steps();
 void launch_level_fused(const float* src, float* smooth, float* flow_out, const float* flow_in, float* Lnew, int w, int h, const GaussTaps& taps,
-                        const float* kptr, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b);
+                        const float* kptr, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b, float* half_out = nullptr);
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s, const Batch& b);
 void launch_area_resize(const float* src, int sw, float* dst, int dw, int dh, const int* xofs, const float* xw, const int* xcnt, const int* yofs,
                         const float* yw, const int* ycnt, hipStream_t s, const Batch& b);

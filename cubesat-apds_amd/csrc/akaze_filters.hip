@@ -792,7 +792,7 @@ __device__ __forceinline__ float pm_g2_point(const float* r0, const float* r1, c
 template <int PW, int NT>
 __device__ __forceinline__ void fed_patches(const float* __restrict__ s_t, const float* __restrict__ s_f, float* __restrict__ e0, float* __restrict__ e1,
                                             int P, int S, const LevelSteps& steps, int gx0, int gy0, int w, int h, bool inside,
-                                            float* __restrict__ Lnew, bool shrink) {
+                                            float* __restrict__ Lnew, bool shrink, float* __restrict__ half) {
     const int R = P - 6;                       // the region is local [3, P - 3)^2
     const int TG = (R + PW - 1) / PW;          // patches per row
     const int tid = threadIdx.x;
@@ -901,6 +901,7 @@ __device__ __forceinline__ void fed_patches(const float* __restrict__ s_t, const
                 }
         }
     }
+    if (half) __syncthreads();   // the last step's neighbour reads of e0 / e1 are done: e0 takes the tile once more
     if (active) {
         const int c_lo = S + 3, c_hi = S + 3 + LFT;
 #pragma unroll
@@ -908,19 +909,37 @@ __device__ __forceinline__ void fed_patches(const float* __restrict__ s_t, const
 #pragma unroll
             for (int b = 0; b < PW; b++) {
                 const int lx = x0 + b, ly = y0 + a, gx = gx0 + lx, gy = gy0 + ly;
-                if (lx >= c_lo && lx < c_hi && ly >= c_lo && ly < c_hi && gx < w && gy < h) Lnew[(size_t)gy * w + gx] = t[a][b];
+                if (lx >= c_lo && lx < c_hi && ly >= c_lo && ly < c_hi && gx < w && gy < h) {
+                    Lnew[(size_t)gy * w + gx] = t[a][b];
+                    if (half) e0[ly * P + lx] = t[a][b];
+                }
             }
+    }
+    if (half) {
+        // the last level of an octave: the next octave's start image from the tile, ((a + b) + (c + d)) * 0.25 as half_sample_kernel forms
+        // it (tiles start on multiples of 32: the 2 x 2 blocks never straddle tiles); block-uniform branch
+        __syncthreads();
+        const int c_lo = S + 3, hw = w >> 1, hh = h >> 1;
+        for (int i = tid; i < (LFT / 2) * (LFT / 2); i += NT) {
+            const int oy = i / (LFT / 2), ox = i - oy * (LFT / 2);
+            const int gx = (gx0 + c_lo) / 2 + ox, gy = (gy0 + c_lo) / 2 + oy;
+            if (gx < hw && gy < hh) {
+                const float* q = &e0[(c_lo + 2 * oy) * P + c_lo + 2 * ox];
+                half[(size_t)gy * hw + gx] = ((q[0] + q[1]) + (q[P] + q[P + 1])) * 0.25f;
+            }
+        }
     }
 }
 
 template <int NT>
 __global__ __launch_bounds__(NT) void level_fused_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow_out,
                                                           const float* __restrict__ flow_in, float* __restrict__ Lnew, int w, int h, GaussTaps taps,
-                                                          const float* __restrict__ kptr, LevelSteps steps, size_t bstride, int shrink) {
+                                                          const float* __restrict__ kptr, LevelSteps steps, size_t bstride, int shrink, float* __restrict__ half) {
     APDS_RAISE_WAVE_PRIORITY();
     APDS_BOFS(src);
     APDS_BOFS(smooth);
     APDS_BOFS(Lnew);
+    if (half) APDS_BOFS(half);
     APDS_BOFS(kptr);
     if (flow_out) APDS_BOFS(flow_out);
     if (flow_in) APDS_BOFS(flow_in);
@@ -1025,8 +1044,8 @@ __global__ __launch_bounds__(NT) void level_fused_kernel(const float* __restrict
         __syncthreads();
     }
     const int hr = (P - 5) >> 1;   // patches per row with 2 x 2 patches
-    if (hr * hr <= NT) fed_patches<2, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew, shrink != 0);
-    else fed_patches<3, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew, shrink != 0);
+    if (hr * hr <= NT) fed_patches<2, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew, shrink != 0, half);
+    else fed_patches<3, NT>(s_a, s_f, s_sm, s_a, P, S, steps, gx0, gy0, w, h, inside, Lnew, shrink != 0, half);
 }
 
 // ---- FED steps on register strips (the large levels) -------------------------------------------------------------
@@ -1048,7 +1067,7 @@ __device__ __forceinline__ float dpp_from_prev_lane(float v) {   // lane i <- la
 
 template <int S, int RB, bool BORDER>
 __device__ __forceinline__ void nld_strip(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
-                                          const NldSteps& steps, int gx0, int y0) {
+                                          const NldSteps& steps, int gx0, int y0, float* __restrict__ half) {
     constexpr int R = RB + 2 * S;
     const int lane = threadIdx.x & 63;
     const int gx = gx0 + lane;
@@ -1098,6 +1117,21 @@ __device__ __forceinline__ void nld_strip(const float* __restrict__ Lt, const fl
         for (int r = S; r < S + RB; r++)
             if (!BORDER || ys + r < h) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t[r]), rn, 4 * gx, (ys + r) * w * 4, 0);
     }
+    if (half) {
+        // the last level of an octave: the next octave's start image, ((a + b) + (c + d)) * 0.25 as half_sample_kernel forms it, from the
+        // rows in registers (bands start on even rows, strips on even columns: pairs never straddle waves). wave-uniform branch.
+        static_assert((RB & 1) == 0, "row pairs must stay inside a band");
+        const int hw = w >> 1;
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(half, 0, hw * (h >> 1) * 4, 0x00020000);
+        const bool col_ok = lane >= S && lane < 64 - S && !(gx & 1) && gx + 1 < w;
+#pragma unroll
+        for (int r = S; r < S + RB; r += 2) {
+            const float top = t[r] + dpp_from_next_lane(t[r]);
+            const float bot = t[r + 1] + dpp_from_next_lane(t[r + 1]);
+            if (col_ok && (!BORDER || ys + r + 1 < h))
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (top + bot) * 0.25f), rh, 2 * gx, ((ys + r) >> 1) * hw * 4, 0);
+        }
+    }
 }
 
 template <int S, int RB>
@@ -1108,11 +1142,12 @@ template <int S, int RB>
 #define APDS_STRIP_RB 16
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_WAVES, 8))) void nld_strip_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
-                                                         NldSteps steps, int strips, int nwaves, size_t bstride) {
+                                                         NldSteps steps, int strips, int nwaves, size_t bstride, float* __restrict__ half) {
     APDS_RAISE_WAVE_PRIORITY();
     APDS_BOFS(Lt);
     APDS_BOFS(Lf);
     APDS_BOFS(Lnew);
+    if (half) APDS_BOFS(half);
     constexpr int VW = 64 - 2 * S;              // columns a wave finishes
     // wave-uniform by construction; readfirstlane tells the compiler, so that row bases and row conditions live in scalar registers
     const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1121,8 +1156,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_
     const int strip = id - band * strips;
     const int gx0 = strip * VW - S, y0 = band * RB;
     const bool border = gx0 < 0 || gx0 + 64 > w || y0 - S < 0 || y0 + RB + S > h;
-    if (border) nld_strip<S, RB, true>(Lt, Lf, Lnew, w, h, steps, gx0, y0);
-    else nld_strip<S, RB, false>(Lt, Lf, Lnew, w, h, steps, gx0, y0);
+    if (border) nld_strip<S, RB, true>(Lt, Lf, Lnew, w, h, steps, gx0, y0, half);
+    else nld_strip<S, RB, false>(Lt, Lf, Lnew, w, h, steps, gx0, y0, half);
 }
 
 // ---- resize(INTER_AREA) by exactly 2: mean of 2x2 ---------------------------------------------------------
@@ -1417,12 +1452,15 @@ static void nld_multi_launch(const float* Lt, const float* Lf, float* Lnew, int 
     hipLaunchKernelGGL((nld_multi_kernel<S, 1024>), grid, dim3(1024), 0, s, Lt, Lf, Lnew, w, h, st, b.stride);
 }
 template <int S>
-static void nld_strip_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s, const Batch& b) {
+static void nld_strip_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s, const Batch& b, float* half) {
     constexpr int RB = APDS_STRIP_RB;
     const int strips = ceil_div(w, 64 - 2 * S), nwaves = strips * ceil_div(h, RB);
-    hipLaunchKernelGGL((nld_strip_kernel<S, RB>), dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves, b.stride);
+    hipLaunchKernelGGL((nld_strip_kernel<S, RB>), dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves, b.stride, half);
 }
-void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b) {
+// half_out (optional): ask the launch to write the 2 x 2 area means of Lnew as well (the next octave's start image). Returns whether it did
+// (the register-strip form can; the LDS-tile form of the small launches cannot: the caller then runs half_sample_kernel).
+bool launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int h, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b,
+                      float* half_out) {
     NldSteps st{};
     for (int i = 0; i < nsteps; i++) st.v[i] = step_sizes[i];
     // register strips for the throughput-bound launches (up to 4 steps on launches of at least 1 Mpx, a batch counted as a whole);
@@ -1431,10 +1469,10 @@ void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int 
     const int strip_mode = config().nld_strip;
     if (strip_mode && nsteps <= 4 && ((size_t)w * h * b.n >= ((size_t)1 << 20) || strip_mode == 2) && (size_t)w * h < ((size_t)1 << 29)) {   // 32-bit byte offsets
         switch (nsteps) {
-            case 1: nld_strip_launch<1>(Lt, Lf, Lnew, w, h, st, s, b); return;
-            case 2: nld_strip_launch<2>(Lt, Lf, Lnew, w, h, st, s, b); return;
-            case 3: nld_strip_launch<3>(Lt, Lf, Lnew, w, h, st, s, b); return;
-            default: nld_strip_launch<4>(Lt, Lf, Lnew, w, h, st, s, b); return;
+            case 1: nld_strip_launch<1>(Lt, Lf, Lnew, w, h, st, s, b, half_out); return half_out != nullptr;
+            case 2: nld_strip_launch<2>(Lt, Lf, Lnew, w, h, st, s, b, half_out); return half_out != nullptr;
+            case 3: nld_strip_launch<3>(Lt, Lf, Lnew, w, h, st, s, b, half_out); return half_out != nullptr;
+            default: nld_strip_launch<4>(Lt, Lf, Lnew, w, h, st, s, b, half_out); return half_out != nullptr;
         }
     }
     switch (nsteps) {
@@ -1448,12 +1486,13 @@ void launch_nld_multi(const float* Lt, const float* Lf, float* Lnew, int w, int 
         case 8: nld_multi_launch<8>(Lt, Lf, Lnew, w, h, st, s, b); break;
         default: fail(APDS_ERR_INTERNAL, "nld_multi: 1..8 steps per launch");
     }
+    return false;
 }
 // one launch for a level: Lsmooth, conductivity (kept in LDS; written to flow_out only if the caller continues with more steps)
 // and `nsteps` <= level_fused_max_steps() FED steps from `src` into `Lnew` (src, smooth, Lnew distinct planes)
 int level_fused_max_steps() { return LF_MAX_STEPS; }
 void launch_level_fused(const float* src, float* smooth, float* flow_out, const float* flow_in, float* Lnew, int w, int h, const GaussTaps& taps,
-                        const float* kptr, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b) {
+                        const float* kptr, const float* step_sizes, int nsteps, hipStream_t s, const Batch& b, float* half_out) {
     APDS_REQUIRE(nsteps >= 1 && nsteps <= LF_MAX_STEPS, APDS_ERR_INTERNAL, "level_fused: 1..29 steps");
     LevelSteps st{};
     st.n = nsteps;
@@ -1472,9 +1511,10 @@ void launch_level_fused(const float* src, float* smooth, float* flow_out, const 
         opted = true;
     }
     if (small_blocks)
-        hipLaunchKernelGGL((level_fused_kernel<512>), grid, dim3(512), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride, shrink);
+        hipLaunchKernelGGL((level_fused_kernel<512>), grid, dim3(512), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride, shrink, half_out);
     else
-        hipLaunchKernelGGL((level_fused_kernel<1024>), grid, dim3(1024), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride, shrink);
+        hipLaunchKernelGGL((level_fused_kernel<1024>), grid, dim3(1024), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride, shrink,
+                           half_out);
 }
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s, const Batch& b) {
     hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 512), ceil_div(dh, HS_ROWS), b.n), dim3(256), 0, s, src, sw, dst, dw, dh, b.stride);

@@ -1299,7 +1299,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // zero-initialised head of the slab (one 2-D memset clears it for the whole batch): counters, then keypoint masks and statuses
     int *list_count, *hist, *pend_count, *block_counts, *kp_base, *fine_counts, *coarse_counts;
     unsigned int* hmax_bits;
-    float *k_oct, *gray, *tmpS, *tmpF, *tmpP;
+    float *k_oct, *gray, *tmpS, *tmpF, *tmpP, *tmpH;
     uint8_t *mask_all, *status_all;
     std::vector<uint32_t*> lists(L), pend(L);
     std::vector<float*> lsm(L);
@@ -1323,6 +1323,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         tmpS = A.take<float>(n0);
         tmpF = A.take<float>(n0);
         tmpP = A.take<float>(n0);
+        tmpH = A.take<float>(n0 / 4 + 64);        // the next octave's start image when the last level of an octave writes it itself
         for (int i = 0; i < L; i++) {
             LevelDesc& e = ev[i];
             const size_t n = (size_t)e.w * e.h;
@@ -1520,9 +1521,18 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // (Running only the suppression passes of the large octaves' levels early, on a third stream under the small-octave chain, was built
     // and measured as well: bit-identical, 1.844 against 1.825 ms — the passes' scattered loads slow the chain by more than they hide.)
     // ---- a1.4 / a1.5 per level: Lsmooth -> (Lx, Ly, Ldet) and flow; FED steps ping-pong into Lt[i]
+    // Round 4: the launch that finishes the last level of an octave also writes the next octave's start image (the 2 x 2 area means of its
+    // Lt, into tmpH) when its kernel family can (level_stream, nld_strip, level_fused): half_sample_kernel - 40 + 14 + 5 us of passes over
+    // finished planes on the critical path of a 4096^2 frame - then does not run. APDS_HALF_FUSE=0: always the separate kernel.
+    const float* fused_start = nullptr;   // set by level i - 1 when it wrote level i's start image
     for (int i = 0; i < L; i++) {
         LevelDesc& e = ev[i];
         const float* smooth;
+        // does the NEXT level start an octave from exactly half this level's size (the 2 x 2 mean; odd sizes take the general area resize)?
+        const bool want_half = config().half_fuse && i > 0 && i + 1 < L && ev[i + 1].octave > e.octave && e.w == 2 * ev[i + 1].w && e.h == 2 * ev[i + 1].h;
+        bool did_half = false;
+        const float* my_start = fused_start;
+        fused_start = nullptr;
         if (i == 0) {
             smooth = e.Lt;
         } else {
@@ -1536,7 +1546,9 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             const bool fused_level = e.nsteps > 0 && level_fuse && ((size_t)e.w * e.h * B <= (size_t)1 << 20 || level_fuse == 2);
             const int head = fused_level ? std::min(e.nsteps, level_fused_max_steps()) : 0;
             const int launches = (e.nsteps - head + fuse - 1) / fuse + (fused_level ? 1 : 0);
-            if (e.octave > p.octave) {
+            if (e.octave > p.octave && my_start) {
+                P = my_start;   // written by the previous level's last launch
+            } else if (e.octave > p.octave) {
                 float* dstP = (launches % 2 == 0) ? e.Lt : tmpP;   // so that the last pass lands in e.Lt
                 if (p.w == 2 * e.w && p.h == 2 * e.h) {
                     launch_half_sample(p.Lt, p.w, dstP, e.w, e.h, s, bt);
@@ -1575,8 +1587,17 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
                 const int g = (e.nsteps + launches - 1) / launches;
                 float* out = ((launches - 1) % 2 == 0) ? e.Lt : tmpP;
                 for (int j = 0; j < g; j++) st[j] = e.tau[j] * 0.5f;
-                if (g <= 4 && (launch_level_stream(P, lsm[i], launches > 1 ? tmpF : nullptr, out, e.w, e.h, g10, k_oct + e.octave, st, g, s, bt) ||
-                               launch_level_strips(P, lsm[i], launches > 1 ? tmpF : nullptr, out, e.w, e.h, g10, k_oct + e.octave, st, g, s, bt))) {
+                const bool last_here = want_half && g == e.nsteps;   // this launch finishes the level
+                bool ran = false;
+                if (g <= 4) {
+                    if (launch_level_stream(P, lsm[i], launches > 1 ? tmpF : nullptr, out, e.w, e.h, g10, k_oct + e.octave, st, g, s, bt, last_here ? tmpH : nullptr)) {
+                        ran = true;
+                        did_half = last_here;
+                    } else {
+                        ran = launch_level_strips(P, lsm[i], launches > 1 ? tmpF : nullptr, out, e.w, e.h, g10, k_oct + e.octave, st, g, s, bt);
+                    }
+                }
+                if (ran) {
                     strip_done = true;
                     k = g;
                     in = out;
@@ -1590,8 +1611,10 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             if (fused_level) {
                 float* out = ((launches - 1) % 2 == 0) ? e.Lt : tmpP;
                 for (int j = 0; j < head; j++) st[j] = e.tau[j] * 0.5f;
+                const bool last_here = want_half && head == e.nsteps;
                 launch_level_fused(P, lsm[i], !smooth_first && head < e.nsteps ? tmpF : nullptr, smooth_first ? tmpF : nullptr, out, e.w, e.h, g10,
-                                   k_oct + e.octave, st, head, s, bt);
+                                   k_oct + e.octave, st, head, s, bt, last_here ? tmpH : nullptr);
+                did_half = did_half || last_here;
                 k = head;
                 in = out;
                 pass = 1;
@@ -1602,10 +1625,12 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
                 // spread the steps evenly over the launches (e.g. 11 steps, fuse 8 -> 6 + 5)
                 const int g = (e.nsteps - k + (launches - pass) - 1) / (launches - pass);
                 for (int j = 0; j < g; j++) st[j] = e.tau[k + j] * 0.5f;
-                launch_nld_multi(in, tmpF, out, e.w, e.h, st, g, s, bt);
+                const bool last_here = want_half && k + g == e.nsteps;
+                if (launch_nld_multi(in, tmpF, out, e.w, e.h, st, g, s, bt, last_here ? tmpH : nullptr)) did_half = true;
                 k += g;
                 in = out;
             }
+            if (did_half) fused_start = tmpH;
             if (e.nsteps == 0 && P != e.Lt)   // (never with AKAZE's parameters: every level but the first has FED steps)
                 for (int bi = 0; bi < B; bi++)
                     HIP_CHECK(hipMemcpyAsync(reinterpret_cast<char*>(e.Lt) + (size_t)bi * slab, reinterpret_cast<const char*>(P) + (size_t)bi * slab,

@@ -42,6 +42,7 @@ struct LevelStreamArgs {
     float* smooth;
     float* flow_out;
     float* Lnew;
+    float* half;     // the next octave's start image (2 x 2 means of Lnew, (w / 2) x (h / 2)) or null: see store_half below
     const float* kptr;
     int w, h, strips, bands, rb;
     GaussTaps taps;
@@ -79,6 +80,25 @@ __device__ __forceinline__ void level_stream_rows(const LevelStreamArgs& a, int 
         const bool ok = row >= y0 && row < y1;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(plane, 0, ok ? plane_bytes : 0, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), rs, xo4, __builtin_amdgcn_readfirstlane(ok ? row * w * 4 : 0), 0);
+    };
+    // Round 4: when this level is the last of its octave the kernel also writes the next octave's start image - the 2 x 2 area mean
+    // ((a + b) + (c + d)) * 0.25 of half_sample_kernel, same operands in the same order - from the rows it has in hand: the separate pass
+    // over the plane (40 us on the level chain's critical path at 4096^2) is gone. A lane with an even column pairs with its right
+    // neighbour (DPP), an odd row with the row before it (kept in `hprev`); columns pair inside a strip (VW and the strip origins are
+    // even), rows inside a band (the launcher makes the band height even).
+    const bool do_half = a.half != nullptr;
+    const int hw = w >> 1;
+    const int half_bytes = hw * (h >> 1) * 4;
+    const int hx4 = (mine && !(gx & 1) && gx + 1 < w) ? 2 * gx : DROP;   // 4 * (gx / 2)
+    float hprev = 0.0f;
+    auto store_half = [&](float out, int row) {
+        // rows row - 1 (hprev) and row; stored when row is odd and both lie in [y0, y1) (y0 is even, so row - 1 >= y0 whenever row > y0)
+        const float top = hprev + lane_next(hprev);
+        const float bot = out + lane_next(out);
+        const bool ok = (row & 1) && row > y0 && row < y1;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(a.half, 0, ok ? half_bytes : 0, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, (top + bot) * 0.25f), rs, hx4, __builtin_amdgcn_readfirstlane(ok ? (row >> 1) * hw * 4 : 0), 0);
+        hprev = out;
     };
     float P[8], G[8], F[8], FX[8], FY[8], rd[4], rs[4], TT[S][2], qprev[S];
 #pragma unroll
@@ -166,7 +186,10 @@ __device__ __forceinline__ void level_stream_rows(const LevelStreamArgs& a, int 
                 if (XEDGE && YEDGE && edge_col && (rho == 0 || rho == h - 1)) out = tc;
                 qprev[s - 1] = q;
                 if (s < S) TT[s - 1][(j - lag) & 1] = out;
-                else store_row(a.Lnew, out, rho);
+                else {
+                    store_row(a.Lnew, out, rho);
+                    if (do_half) store_half(out, rho);
+                }
             }
         }
 #pragma unroll
@@ -184,6 +207,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     a.Lnew = bofs(a.Lnew, bstride);
     a.kptr = bofs(a.kptr, bstride);
     if (FLOW_OUT) a.flow_out = bofs(a.flow_out, bstride);
+    if (a.half) a.half = bofs(a.half, bstride);
     constexpr int H = S + 3, VW = 64 - 2 * H;
     const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (id >= a.strips * a.bands) return;   // no barriers in this kernel
@@ -201,17 +225,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 // Lsmooth, conductivity and the level's first `nsteps` (1 .. 4) FED steps, streaming form. False: not a level for it (the caller takes
 // level_strip_kernel).
 bool launch_level_stream(const float* src, float* smooth, float* flow_out, float* Lnew, int w, int h, const GaussTaps& taps, const float* kptr,
-                         const float* step_sizes, int nsteps, hipStream_t s, const Batch& b) {
+                         const float* step_sizes, int nsteps, hipStream_t s, const Batch& b, float* half_out) {
     const int mode = config().level_stream;
     if (mode == 0 || nsteps < 1 || nsteps > 4 || (size_t)w * h >= ((size_t)1 << 29) || w < 64 || h < 32) return false;
     if (mode != 2 && (size_t)w * h * b.n < ((size_t)1 << 23)) return false;
     const int H = nsteps + 3, vw = 64 - 2 * H;
     const int strips = ceil_div(w, vw);
-    LevelStreamArgs a{src, smooth, flow_out, Lnew, kptr, w, h, strips, 0, 0, taps, {}};
+    LevelStreamArgs a{src, smooth, flow_out, Lnew, half_out, kptr, w, h, strips, 0, 0, taps, {}};
     for (int i = 0; i < nsteps; i++) a.steps.v[i] = step_sizes[i];
     auto rows_for = [&](auto kernel) { return config().level_stream_rows > 0 ? config().level_stream_rows : stream_band_rows(kernel, strips, h, b.n, 64, 16); };
     auto go = [&](auto kernel) {
         a.rb = rows_for(kernel);
+        if (half_out) a.rb = (a.rb + 1) & ~1;   // row pairs of the fused half-sample stay inside a band
         a.bands = ceil_div(h, a.rb);
         hipLaunchKernelGGL(kernel, dim3(ceil_div((long long)a.strips * a.bands, 4), 1, b.n), dim3(256), 0, s, a, b.stride);
     };

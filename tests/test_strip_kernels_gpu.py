@@ -46,7 +46,7 @@ def test_akaze_parity_on_the_round_2_path(gpu_pkg):
     """separate smoothing / FED launches per level, keypoints placed by two passes over the masks, the LDS-tile Hessian kernel on every
     level with the masks cleared by the zeroing kernel, default events: none of round 3's streaming kernels"""
     _rerun({"APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STRIP": "0", "APDS_KP_RANKED": "0", "APDS_EVENT_SCOPE": "1", "APDS_DOH_STRIP": "0", "APDS_LEVEL_STREAM": "0",
-            "APDS_KP_XCD": "0"})
+            "APDS_KP_XCD": "0", "APDS_HALF_FUSE": "0"})
 
 
 def test_akaze_parity_with_full_fed_sweeps_in_the_fused_levels(gpu_pkg):
