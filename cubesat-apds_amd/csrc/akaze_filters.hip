@@ -532,12 +532,11 @@ void base_strip_kernel(const uint8_t* __restrict__ img, int w, int h, int stride
 // wave's 64 LDS atomics hit a handful of addresses and serialise; each thread reads four consecutive pixels of a row per step.
 template <int SUB>
 __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __restrict__ modg, int w, int h, const unsigned int* __restrict__ hmax_bits,
-                                                              int* __restrict__ hist, float* __restrict__ k_oct, int n_oct, size_t bstride) {
+                                                              int* __restrict__ hist, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     APDS_BOFS(modg);
     APDS_BOFS(hmax_bits);
     APDS_BOFS(hist);
-    APDS_BOFS(k_oct);
     constexpr int PITCH = 301;                          // odd pitch: the copies of a bin sit in different banks
     __shared__ int s_hist[SUB * PITCH];
     for (int i = threadIdx.x; i < SUB * PITCH; i += 256) s_hist[i] = 0;
@@ -568,38 +567,58 @@ __global__ __launch_bounds__(256) void kcontrast_hist_kernel(const float* __rest
         for (int sidx = 0; sidx < SUB; sidx++) sum += s_hist[sidx * PITCH + i];
         if (sum) atomicAdd(&hist[i], sum);
     }
-    // The block that finishes LAST turns the histogram into kcontrast and its per-octave values k, k*0.75, (k*0.75)*0.75, ... (round 3 ran
-    // a one-thread kernel for that: a launch on the critical path whose 300 dependent loads took 5 us on an idle GPU and 37 us beside the
-    // first Hessian kernel). hist[300] is the ticket counter (zeroed with the histogram): a block draws its ticket after its own bins are
-    // in the device-wide histogram (fence), and the holder of the last ticket therefore sees every block's.
-    __shared__ int s_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&hist[300], 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (int i = threadIdx.x; i < 300; i += 256) s_hist[i] = __hip_atomic_load(&hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (threadIdx.x) return;
+}
+// histogram -> kcontrast and its per-octave values k, k*0.75, (k*0.75)*0.75, ... One wave: lane l owns bins [5l, 5l + 5), a wave scan gives
+// every bin the count of the bins in front of it, and the first bin b >= 1 with (bins 1 .. b-1) >= the 70 % threshold names k - the value the
+// sequential loop of the reference (nldiffusion_functions.cpp compute_k_percentile) stops at. (Round 4 measured this inside the histogram
+// kernel, done by the block that draws the last of gridDim.x tickets: 1024 same-address device-scope atomics behind 1024 fences took the
+// histogram kernel from 43 to 81 us - 139 beside a Hessian kernel. A launch of its own, 300 loads wide instead of 300 loads deep, is cheaper.)
+__global__ __launch_bounds__(64) void kcontrast_finish_kernel(const int* __restrict__ hist, const unsigned int* __restrict__ hmax_bits, int w, int h,
+                                                               float* __restrict__ k_oct, int n_oct, size_t bstride) {
+    APDS_RAISE_WAVE_PRIORITY();
+    APDS_BOFS(hist);
+    APDS_BOFS(hmax_bits);
+    APDS_BOFS(k_oct);
+    const int lane = threadIdx.x;
+    const float hmax = __uint_as_float(*hmax_bits);
+    constexpr int nbins = 300;
+    int v[5], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int bin = lane * 5 + j;
+        v[j] = bin < nbins ? hist[bin] : 0;
+        if (bin >= 1) mine += v[j];
+    }
+    const int h0 = __shfl(v[0], 0);
+    int incl = mine;    // inclusive scan over lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
     float k = 0.03f;
     if (hmax != 0.0f && w > 2 && h > 2) {
-        const int nbins = 300;
         const int total = (w - 2) * (h - 2);
-        const int nthreshold = (int)((total - s_hist[0]) * 0.7f);
-        int nelements = 0;
-        for (int b = 1; b < nbins; b++) {
-            if (nelements >= nthreshold) {
-                k = hmax * b / nbins;
-                break;
-            }
-            nelements += s_hist[b];
+        const int nthreshold = (int)((total - h0) * 0.7f);
+        int before = incl - mine;   // bins 1 .. 5 * lane - 1
+        int hit = nbins;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+            const int bin = lane * 5 + j;
+            if (bin >= 1 && bin < nbins && before >= nthreshold && hit == nbins) hit = bin;
+            if (bin >= 1) before += v[j];
+        }
+        const unsigned long long any = __ballot(hit < nbins);
+        if (any) {
+            const int b = __shfl(hit, __ffsll((long long)any) - 1);
+            k = hmax * b / nbins;
         }
     }
-    for (int o = 0; o < n_oct; o++) {
-        k_oct[o] = k;
-        k *= 0.75f;
-    }
+    if (lane == 0)
+        for (int o = 0; o < n_oct; o++) {
+            k_oct[o] = k;
+            k *= 0.75f;
+        }
 }
 
 // ---- explicit FED diffusion steps: Lnew = Lt + step_size * div(c grad Lt), several steps per pass (temporal blocking) ----
@@ -1065,7 +1084,7 @@ __device__ __forceinline__ float dpp_from_prev_lane(float v) {   // lane i <- la
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));   // wave_shr:1
 }
 
-template <int S, int RB, bool BORDER>
+template <int S, int RB, bool BORDER, bool HALF>
 __device__ __forceinline__ void nld_strip(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
                                           const NldSteps& steps, int gx0, int y0, float* __restrict__ half) {
     constexpr int R = RB + 2 * S;
@@ -1117,9 +1136,10 @@ __device__ __forceinline__ void nld_strip(const float* __restrict__ Lt, const fl
         for (int r = S; r < S + RB; r++)
             if (!BORDER || ys + r < h) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, t[r]), rn, 4 * gx, (ys + r) * w * 4, 0);
     }
-    if (half) {
+    if (HALF) {
         // the last level of an octave: the next octave's start image, ((a + b) + (c + d)) * 0.25 as half_sample_kernel forms it, from the
-        // rows in registers (bands start on even rows, strips on even columns: pairs never straddle waves). wave-uniform branch.
+        // rows in registers (bands start on even rows, strips on even columns: pairs never straddle waves). A template parameter, so that the
+        // plain instantiations keep their register allocation.
         static_assert((RB & 1) == 0, "row pairs must stay inside a band");
         const int hw = w >> 1;
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(half, 0, hw * (h >> 1) * 4, 0x00020000);
@@ -1134,7 +1154,7 @@ __device__ __forceinline__ void nld_strip(const float* __restrict__ Lt, const fl
     }
 }
 
-template <int S, int RB>
+template <int S, int RB, bool HALF = false>
 #ifndef APDS_STRIP_WAVES
 #define APDS_STRIP_WAVES 4
 #endif
@@ -1147,7 +1167,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_
     APDS_BOFS(Lt);
     APDS_BOFS(Lf);
     APDS_BOFS(Lnew);
-    if (half) APDS_BOFS(half);
+    if (HALF) APDS_BOFS(half);
     constexpr int VW = 64 - 2 * S;              // columns a wave finishes
     // wave-uniform by construction; readfirstlane tells the compiler, so that row bases and row conditions live in scalar registers
     const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -1156,8 +1176,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_
     const int strip = id - band * strips;
     const int gx0 = strip * VW - S, y0 = band * RB;
     const bool border = gx0 < 0 || gx0 + 64 > w || y0 - S < 0 || y0 + RB + S > h;
-    if (border) nld_strip<S, RB, true>(Lt, Lf, Lnew, w, h, steps, gx0, y0, half);
-    else nld_strip<S, RB, false>(Lt, Lf, Lnew, w, h, steps, gx0, y0, half);
+    if (border) nld_strip<S, RB, true, HALF>(Lt, Lf, Lnew, w, h, steps, gx0, y0, half);
+    else nld_strip<S, RB, false, HALF>(Lt, Lf, Lnew, w, h, steps, gx0, y0, half);
 }
 
 // ---- resize(INTER_AREA) by exactly 2: mean of 2x2 ---------------------------------------------------------
@@ -1425,7 +1445,8 @@ void launch_kcontrast(const float* smooth, float* modg_tmp, int w, int h, unsign
     // the histogram's grid shrinks with the image: 1024 blocks for one large frame, a share of that for each image of a batch
     const int hist_blocks = std::max(8, std::min(1024, ceil_div((long long)w * h, 4096)));
     // 16 sub-histograms per block (8: 1.755, 16: 1.739, 32: 1.763 ms per 4096^2 extraction, profiles/r03/half_sample_ab.txt)
-    hipLaunchKernelGGL(kcontrast_hist_kernel<16>, dim3(hist_blocks, 1, b.n), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist, k_oct, n_oct, b.stride);
+    hipLaunchKernelGGL(kcontrast_hist_kernel<16>, dim3(hist_blocks, 1, b.n), dim3(256), 0, s, modg_tmp, w, h, hmax_bits, hist, b.stride);
+    hipLaunchKernelGGL(kcontrast_finish_kernel, dim3(1, 1, b.n), dim3(64), 0, s, hist, hmax_bits, w, h, k_oct, n_oct, b.stride);
 }
 // image -> Lt[0] (and, if want_modg, |grad| of the sigma = 1 image + its interior maximum) in one pass on register strips. Returns
 // false when the image is too small to pay (the launch-bound small tiles keep the separate kernels) or does not fit 32-bit offsets.
@@ -1455,7 +1476,11 @@ template <int S>
 static void nld_strip_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s, const Batch& b, float* half) {
     constexpr int RB = APDS_STRIP_RB;
     const int strips = ceil_div(w, 64 - 2 * S), nwaves = strips * ceil_div(h, RB);
-    hipLaunchKernelGGL((nld_strip_kernel<S, RB>), dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves, b.stride, half);
+    if (half)
+        hipLaunchKernelGGL((nld_strip_kernel<S, RB, true>), dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves, b.stride, half);
+    else
+        hipLaunchKernelGGL((nld_strip_kernel<S, RB, false>), dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves, b.stride,
+                           (float*)nullptr);
 }
 // half_out (optional): ask the launch to write the 2 x 2 area means of Lnew as well (the next octave's start image). Returns whether it did
 // (the register-strip form can; the LDS-tile form of the small launches cannot: the caller then runs half_sample_kernel).

@@ -1376,11 +1376,16 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
 
     // ---- a1.1 / a1.2 / a1.3
     const GaussTaps g16 = gauss_taps(9, (double)soffset), g10 = gauss_taps(5, 1.0);
+    bool early_forked = false;
     if (launch_base_strips(img, H, W, channels, stride, g16, g10, ev[0].Lt, tmpF, hmax_bits, L > 1, s, bt)) {   // large images: one fused pass
-        // (Round 4, measured and removed: forking level 0's Hessian kernel HERE, in front of the contrast-factor pass - it needs Lt[0] only.
-        // Its long-lived waves take the machine first and the histogram kernel, which the level chain waits for, then ran 139 us instead of
-        // 43: +65 us per frame. Whatever is launched first owns the wave slots until its waves retire: only work the chain does not wait
-        // for may go second. profiles/r04/exp_ab.txt)
+        // APDS_EARLY_FORK=1: level 0's Hessian kernel needs Lt[0] only and may start here, beside the contrast-factor pass. Measured three
+        // times in round 4 (profiles/r04/ab_env_half_fuse.txt: 1.649 / 1.656 / 1.642 against 1.649 / 1.636 / 1.636 ms): the histogram kernel
+        // the level chain waits for shares the machine with a kernel nothing waits for, and what the Hessian stream gains at the front it
+        // has no use for at the back (its kernels follow the level chain from the second octave on). Off by default.
+        if (fork_doh && L > 1 && config().early_fork) {
+            HIP_CHECK(hipEventRecord(c.fork_event(0), s));
+            early_forked = true;
+        }
         if (L > 1) launch_kcontrast(nullptr, tmpF, W, H, hmax_bits, hist, k_oct, n_oct, s, bt, /*gradient_done=*/true);
     } else {
         launch_gray(img, H, W, channels, stride, gray, s, bt);
@@ -1641,7 +1646,7 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         // a1.5 + a1.6: first / second derivatives, determinant, and the level's 3x3 extrema (mask + candidate list)
         if (fork_doh && i == 0) {   // level 0: Lsmooth is Lt[0], ready after the base stage
             c.fork_open = true;
-            HIP_CHECK(hipEventRecord(c.fork_event(0), s));
+            if (!early_forked) HIP_CHECK(hipEventRecord(c.fork_event(0), s));
             HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
         }
         // the determinant plane of a level is stored whole only when somebody asked to see it (apds_akaze_debug_plane)

@@ -49,7 +49,7 @@ struct LevelStreamArgs {
     StreamSteps steps;
 };
 
-template <int S, bool XEDGE, bool YEDGE, bool FLOW_OUT>
+template <int S, bool XEDGE, bool YEDGE, bool FLOW_OUT, bool HALF>
 __device__ __forceinline__ void level_stream_rows(const LevelStreamArgs& a, int strip, int band) {
     constexpr int H = S + 3;              // halo: S (FED) + 1 (Scharr ring) + 2 (Gaussian)
     constexpr int VW = 64 - 2 * H;
@@ -85,8 +85,9 @@ __device__ __forceinline__ void level_stream_rows(const LevelStreamArgs& a, int 
     // ((a + b) + (c + d)) * 0.25 of half_sample_kernel, same operands in the same order - from the rows it has in hand: the separate pass
     // over the plane (40 us on the level chain's critical path at 4096^2) is gone. A lane with an even column pairs with its right
     // neighbour (DPP), an odd row with the row before it (kept in `hprev`); columns pair inside a strip (VW and the strip origins are
-    // even), rows inside a band (the launcher makes the band height even).
-    const bool do_half = a.half != nullptr;
+    // even), rows inside a band (the launcher makes the band height even). HALF is a template parameter: the plain instantiations keep
+    // the register allocation they were tuned with (as a run-time flag it changed the schedule of ALL of them: 70 instead of 103 VGPRs, 90
+    // / 97 us instead of 71 / 74 for the 16-Mpx levels).
     const int hw = w >> 1;
     const int half_bytes = hw * (h >> 1) * 4;
     const int hx4 = (mine && !(gx & 1) && gx + 1 < w) ? 2 * gx : DROP;   // 4 * (gx / 2)
@@ -188,7 +189,7 @@ __device__ __forceinline__ void level_stream_rows(const LevelStreamArgs& a, int 
                 if (s < S) TT[s - 1][(j - lag) & 1] = out;
                 else {
                     store_row(a.Lnew, out, rho);
-                    if (do_half) store_half(out, rho);
+                    if (HALF) store_half(out, rho);
                 }
             }
         }
@@ -199,7 +200,7 @@ __device__ __forceinline__ void level_stream_rows(const LevelStreamArgs& a, int 
 
 }  // namespace
 
-template <int S, bool FLOW_OUT>
+template <int S, bool FLOW_OUT, bool HALF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void level_stream_kernel(LevelStreamArgs a, size_t bstride) {
     APDS_RAISE_WAVE_PRIORITY();
     a.src = bofs(a.src, bstride);
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     a.Lnew = bofs(a.Lnew, bstride);
     a.kptr = bofs(a.kptr, bstride);
     if (FLOW_OUT) a.flow_out = bofs(a.flow_out, bstride);
-    if (a.half) a.half = bofs(a.half, bstride);
+    if (HALF) a.half = bofs(a.half, bstride);
     constexpr int H = S + 3, VW = 64 - 2 * H;
     const int id = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (id >= a.strips * a.bands) return;   // no barriers in this kernel
@@ -216,10 +217,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int gx0 = strip * VW - H, y0 = band * a.rb;
     const bool xedge = gx0 < 0 || gx0 + 64 > a.w;
     const bool yedge = y0 - H < 0 || y0 + a.rb + H + 16 > a.h;   // (+ 16: the unrolled loop's padding and the prefetch stay inside the image)
-    if (xedge && yedge) level_stream_rows<S, true, true, FLOW_OUT>(a, strip, band);
-    else if (xedge) level_stream_rows<S, true, false, FLOW_OUT>(a, strip, band);
-    else if (yedge) level_stream_rows<S, false, true, FLOW_OUT>(a, strip, band);
-    else level_stream_rows<S, false, false, FLOW_OUT>(a, strip, band);
+    if (xedge && yedge) level_stream_rows<S, true, true, FLOW_OUT, HALF>(a, strip, band);
+    else if (xedge) level_stream_rows<S, true, false, FLOW_OUT, HALF>(a, strip, band);
+    else if (yedge) level_stream_rows<S, false, true, FLOW_OUT, HALF>(a, strip, band);
+    else level_stream_rows<S, false, false, FLOW_OUT, HALF>(a, strip, band);
 }
 
 // Lsmooth, conductivity and the level's first `nsteps` (1 .. 4) FED steps, streaming form. False: not a level for it (the caller takes
@@ -240,7 +241,16 @@ bool launch_level_stream(const float* src, float* smooth, float* flow_out, float
         a.bands = ceil_div(h, a.rb);
         hipLaunchKernelGGL(kernel, dim3(ceil_div((long long)a.strips * a.bands, 4), 1, b.n), dim3(256), 0, s, a, b.stride);
     };
-    if (flow_out) {
+    APDS_REQUIRE(!(half_out && flow_out), APDS_ERR_INTERNAL, "level_stream: a launch that finishes its level writes no conductivity plane");
+    if (half_out) {
+        switch (nsteps) {
+            case 1: go(&level_stream_kernel<1, false, true>); break;
+            case 2: go(&level_stream_kernel<2, false, true>); break;
+            case 3: go(&level_stream_kernel<3, false, true>); break;
+            default: go(&level_stream_kernel<4, false, true>); break;
+        }
+    } else if (flow_out) {
+        a.half = nullptr;
         switch (nsteps) {
             case 1: go(&level_stream_kernel<1, true>); break;
             case 2: go(&level_stream_kernel<2, true>); break;

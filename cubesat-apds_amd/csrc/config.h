@@ -20,6 +20,7 @@ struct Config {
     int doh_strip_rows;   // APDS_DOH_STRIP_ROWS  band height of that kernel (0 = chosen by level size); test hook
     int kp_ranked;        // APDS_KP_RANKED    1: candidates place themselves (default); 0: two passes over the masks
     int kp_xcd;           // APDS_KP_XCD       1: every XCD takes one contiguous eighth of the keypoints in the orientation / descriptor kernels (default); 0: blocks stride over all of them
+    int early_fork;       // APDS_EARLY_FORK   1: level 0's Hessian kernel may start as soon as the base pass is done, beside the contrast-factor pass; 0 (default): after it
     int half_fuse;        // APDS_HALF_FUSE    1: the launch that finishes an octave's last level also writes the next octave's start image (default); 0: half_sample_kernel
     int fed_shrink;       // APDS_FED_SHRINK   1: level_fused_kernel's FED steps skip the patches outside the zone the tile still depends on (default); 0: every step sweeps the whole region
     // ---- AKAZE extraction: scheduling

@@ -34,6 +34,7 @@ const Config& config() {
         k.kp_xcd = env("APDS_KP_XCD", 1);
         k.fed_shrink = env("APDS_FED_SHRINK", 1);
         k.half_fuse = env("APDS_HALF_FUSE", 1);
+        k.early_fork = env("APDS_EARLY_FORK", 0);
         k.akaze_fork = env("APDS_AKAZE_FORK", 1);
         k.side_probe = env("APDS_SIDE_PROBE", 1);
         k.event_scope = env("APDS_EVENT_SCOPE", 2);

@@ -104,8 +104,8 @@ int  oracle_ransac_samples(const float* src_xy, const float* dst_xy, int n, int 
 /* mod.rs:320-369 pnp_solver_ransac -> cv::solvePnPRansac(obj Point3d[n], img Point2d[n], K 3x3 f64, distCoeffs = zeros(4,1)
  * (mod.rs:344), useExtrinsicGuess false, iterations, reproj_thr, confidence, inliers, method). method: cv::SolvePnPMethod value
  * (1 = SOLVEPNP_EPNP, the reference's default). Returns 1 if a pose was found (rvec, tvec, inliers[0..*n_inliers) filled),
- * 0 if none, -215 for n < 4 / null arguments (mod.rs:627-638), -213 for methods other than EPNP (1) and P3P (2). n == 4 runs
- * through the P3P kernel, as in OpenCV.
+ * 0 if none, -215 for n < 4 / null arguments (mod.rs:627-638), -213 for methods other than ITERATIVE (0), EPNP (1), P3P (2) and
+ * AP3P (5). n == 4 runs through the P3P kernel, as in OpenCV.
  * PARITY UNPINNED, see pnp_oracle.cpp. */
 int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, const double* K, int iterations, float reproj_thr,
                             double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers);

@@ -248,10 +248,16 @@ def test_pnp_ransac_recovers_planted_pose(oracle_mod, pkg):
     got3[idx3] = True
     assert rc3 == 1 and (got3 & inl).sum() > 0.97 * inl.sum() and (got3 & ~inl).sum() <= 0.002 * len(obj) + 2
     assert np.allclose(r3, rvec, atol=2e-3) and np.allclose(t3, tvec, rtol=2e-3, atol=0.5)
-    # n == 4 goes through P3P directly (all four are inliers); AP3P is not restated
+    # n == 4 goes through P3P directly (all four are inliers)
     rc4, r4, t4, idx4 = oracle_mod.solve_pnp_ransac(obj[inl][:4], img[inl][:4], K)
     assert rc4 == 1 and list(idx4) == [0, 1, 2, 3] and np.isfinite(r4).all()
-    assert oracle_mod.solve_pnp_ransac(obj, img, K, method=5)[0] == -213
+    # SOLVEPNP_AP3P: Ke and Roumeliotis' P3P as the RANSAC kernel
+    rc5, r5, t5, idx5 = oracle_mod.solve_pnp_ransac(obj, img, K, 1000, 3.0, 0.99, method=5)
+    got5 = np.zeros(len(obj), bool)
+    got5[idx5] = True
+    assert rc5 == 1 and (got5 & inl).sum() > 0.97 * inl.sum() and (got5 & ~inl).sum() <= 0.002 * len(obj) + 2
+    assert np.allclose(r5, rvec, atol=2e-3) and np.allclose(t5, tvec, rtol=2e-3, atol=0.5)
+    assert oracle_mod.solve_pnp_ransac(obj, img, K, method=8)[0] == -213   # SQPNP is not restated
     # SOLVEPNP_ITERATIVE: EPnP's RANSAC (hence the same inliers as the default method), then the Levenberg-Marquardt refinement
     rc0, r0, t0, idx0 = oracle_mod.solve_pnp_ransac(obj, img, K, 1000, 3.0, 0.99, method=0)
     assert rc0 == 1 and np.array_equal(idx0, idx)
