@@ -953,8 +953,10 @@ __device__ __forceinline__ void fed_patches(const float* __restrict__ s_t, const
 template <int NT>
 __global__ __launch_bounds__(NT) void level_fused_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow_out,
                                                           const float* __restrict__ flow_in, float* __restrict__ Lnew, int w, int h, GaussTaps taps,
-                                                          const float* __restrict__ kptr, LevelSteps steps, size_t bstride, int shrink, float* __restrict__ half) {
+                                                          const float* __restrict__ kptr, LevelSteps steps, size_t bstride, int shrink, float* __restrict__ half,
+                                                          ForkSignal sig) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_FORK_SIGNAL(sig);
     APDS_BOFS(src);
     APDS_BOFS(smooth);
     APDS_BOFS(Lnew);
@@ -1162,8 +1164,9 @@ template <int S, int RB, bool HALF = false>
 #define APDS_STRIP_RB 16
 #endif
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(APDS_STRIP_WAVES, 8))) void nld_strip_kernel(const float* __restrict__ Lt, const float* __restrict__ Lf, float* __restrict__ Lnew, int w, int h,
-                                                         NldSteps steps, int strips, int nwaves, size_t bstride, float* __restrict__ half) {
+                                                         NldSteps steps, int strips, int nwaves, size_t bstride, float* __restrict__ half, ForkSignal sig) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_FORK_SIGNAL(sig);
     APDS_BOFS(Lt);
     APDS_BOFS(Lf);
     APDS_BOFS(Lnew);
@@ -1476,11 +1479,13 @@ template <int S>
 static void nld_strip_launch(const float* Lt, const float* Lf, float* Lnew, int w, int h, const NldSteps& st, hipStream_t s, const Batch& b, float* half) {
     constexpr int RB = APDS_STRIP_RB;
     const int strips = ceil_div(w, 64 - 2 * S), nwaves = strips * ceil_div(h, RB);
+    const ForkSignal sig = ctx().take_fork_signal();
     if (half)
-        hipLaunchKernelGGL((nld_strip_kernel<S, RB, true>), dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves, b.stride, half);
+        hipLaunchKernelGGL((nld_strip_kernel<S, RB, true>), dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves, b.stride, half,
+                           sig);
     else
         hipLaunchKernelGGL((nld_strip_kernel<S, RB, false>), dim3(ceil_div(nwaves, 4), 1, b.n), dim3(256), 0, s, Lt, Lf, Lnew, w, h, st, strips, nwaves, b.stride,
-                           (float*)nullptr);
+                           (float*)nullptr, sig);
 }
 // half_out (optional): ask the launch to write the 2 x 2 area means of Lnew as well (the next octave's start image). Returns whether it did
 // (the register-strip form can; the LDS-tile form of the small launches cannot: the caller then runs half_sample_kernel).
@@ -1535,11 +1540,13 @@ void launch_level_fused(const float* src, float* smooth, float* flow_out, const 
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&level_fused_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PM5 * PM5 * 4));
         opted = true;
     }
+    const ForkSignal sig = ctx().take_fork_signal();
     if (small_blocks)
-        hipLaunchKernelGGL((level_fused_kernel<512>), grid, dim3(512), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride, shrink, half_out);
+        hipLaunchKernelGGL((level_fused_kernel<512>), grid, dim3(512), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride, shrink, half_out,
+                           sig);
     else
         hipLaunchKernelGGL((level_fused_kernel<1024>), grid, dim3(1024), lds, s, src, smooth, flow_out, flow_in, Lnew, w, h, taps, kptr, st, b.stride, shrink,
-                           half_out);
+                           half_out, sig);
 }
 void launch_half_sample(const float* src, int sw, float* dst, int dw, int dh, hipStream_t s, const Batch& b) {
     hipLaunchKernelGGL(half_sample_kernel, dim3(ceil_div(dw, 512), ceil_div(dh, HS_ROWS), b.n), dim3(256), 0, s, src, sw, dst, dw, dh, b.stride);

@@ -1530,6 +1530,49 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
     // Lt, into tmpH) when its kernel family can (level_stream, nld_strip, level_fused): half_sample_kernel - 40 + 14 + 5 us of passes over
     // finished planes on the critical path of a 4096^2 frame - then does not run. APDS_HALF_FUSE=0: always the separate kernel.
     const float* fused_start = nullptr;   // set by level i - 1 when it wrote level i's start image
+    // The fork to the Hessian stream. In a chain of short kernels an event recorded on the main stream costs 3.4 us each time (the marker
+    // packet sits between two dependent kernels: tools/probes/fork_probe.hip, profiles/r04/fork_probe.txt - 16 forks: 236 us against 174 for
+    // the same kernels without any dependency), and under rocprofv3 the timeline shows 5 us gaps behind every fork. APDS_FLAG_FORK=1 (round
+    // 4): the NEXT kernel of the chain stores a sequence number as its first act (APDS_FORK_SIGNAL; it starts when its predecessor is done),
+    // and the Hessian stream waits for that value (hipStreamWaitValue32 on 8 bytes of signal memory - a one-thread polling kernel of the
+    // runtime): nothing sits between the chain's kernels (189 us in the probe). The wait is queued only AFTER the kernel that carries the
+    // value - every wait depends on something submitted earlier, as with events, so no cycle of blocked hardware queues can form - which is
+    // why a level whose fork comes after its last kernel hands its Hessian launch to the next level (deferred). A launcher that cannot carry
+    // a signal leaves it armed: a one-thread kernel stores it then. MEASURED on the real frame: 1.635 against 1.641 ms over nine same-box
+    // rounds (profiles/r04/ab_env_flag_fork.txt) - the chain's kernels are long and the marker is processed under the tail of the one before
+    // it; the 42 us the profiled timeline promises (profiles/r04/timeline_flag_fork.txt) are the profiler's. Bit-identical, covered by
+    // tests/test_strip_kernels_gpu.py; off by default: 6 us do not pay for a polling kernel per fork.
+    const bool flag_fork = fork_doh && config().flag_fork && c.fork_flag_ready();
+    c.fork_pending = ForkSignal{};
+    if (flag_fork && c.fork_seq > 0x7FFF0000u) {   // (every earlier wait was joined: start the sequence again)
+        launch_fork_signal(ForkSignal{c.fork_flag, 0}, s);
+        c.fork_seq = 0;
+    }
+    struct DeferredHessian {
+        int level;
+        const float* smooth;
+        float kside, kmid;
+        unsigned value;
+    };
+    DeferredHessian deferred{-1, nullptr, 0, 0, 0};
+    unsigned fork_value = 0;
+    // the determinant plane of a level is stored whole only when somebody asked to see it (apds_akaze_debug_plane)
+    const bool dense_det = akaze_debug_request().armed;
+    auto launch_hessian = [&](const DeferredHessian& d, hipStream_t st) {
+        const LevelDesc& le = ev[d.level];
+        if (!(d.level < n_strip_levels &&
+              launch_doh_strips(d.smooth, le.Lxy, le.Ldet, le.w, le.h, le.sigma_size, d.kside, d.kmid, le.border, dthreshold, mask_all + le.pix_offset,
+                                status_all + le.pix_offset, lists[d.level], list_count + d.level, st, bt, dense_det)))
+            launch_doh_fused(d.smooth, le.Lxy, le.Ldet, le.w, le.h, le.sigma_size, d.kside, d.kmid, le.border, dthreshold, mask_all + le.pix_offset,
+                             lists[d.level], list_count + d.level, st, bt);
+    };
+    auto flush_deferred = [&]() {
+        if (deferred.level < 0) return;
+        launch_fork_signal(c.take_fork_signal(), s);   // (nothing if a chain kernel has taken it)
+        HIP_CHECK(hipStreamWaitValue32(s_doh, c.fork_flag, deferred.value, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        launch_hessian(deferred, s_doh);
+        deferred.level = -1;
+    };
     for (int i = 0; i < L; i++) {
         LevelDesc& e = ev[i];
         const float* smooth;
@@ -1578,6 +1621,11 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
             smooth = lsm[i];
             auto fork_here = [&]() {   // Lsmooth of this level exists from here on
                 if (!fork_doh) return;
+                if (flag_fork) {
+                    flush_deferred();   // the kernel just launched carried the previous level's signal
+                    fork_value = c.arm_fork_signal().value;
+                    return;
+                }
                 HIP_CHECK(hipEventRecord(c.fork_event(i), s));
                 HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(i), 0));
             };
@@ -1646,20 +1694,26 @@ int akaze_extract_batch_device(const void* img, int n_img, size_t img_bstride, i
         // a1.5 + a1.6: first / second derivatives, determinant, and the level's 3x3 extrema (mask + candidate list)
         if (fork_doh && i == 0) {   // level 0: Lsmooth is Lt[0], ready after the base stage
             c.fork_open = true;
-            if (!early_forked) HIP_CHECK(hipEventRecord(c.fork_event(0), s));
-            HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
+            if (flag_fork) {
+                fork_value = c.arm_fork_signal().value;
+            } else {
+                if (!early_forked) HIP_CHECK(hipEventRecord(c.fork_event(0), s));
+                HIP_CHECK(hipStreamWaitEvent(s_doh, c.fork_event(0), 0));
+            }
         }
-        // the determinant plane of a level is stored whole only when somebody asked to see it (apds_akaze_debug_plane)
-        const bool dense_det = akaze_debug_request().armed;
-        auto launch_hessian = [&](hipStream_t st) {
-            const LevelDesc& le = ev[i];
-            if (!(i < n_strip_levels && launch_doh_strips(smooth, le.Lxy, le.Ldet, le.w, le.h, le.sigma_size, kside, kmid, le.border, dthreshold,
-                                                           mask_all + le.pix_offset, status_all + le.pix_offset, lists[i], list_count + i, st, bt, dense_det)))
-                launch_doh_fused(smooth, le.Lxy, le.Ldet, le.w, le.h, le.sigma_size, kside, kmid, le.border, dthreshold, mask_all + le.pix_offset, lists[i],
-                                 list_count + i, st, bt);
-        };
-        launch_hessian(s_doh);
+        if (flag_fork) {
+            const DeferredHessian mine{i, smooth, kside, kmid, fork_value};
+            if (!c.fork_pending.flag) {   // a later kernel of this level has taken the signal: the Hessian kernel can be queued now
+                HIP_CHECK(hipStreamWaitValue32(s_doh, c.fork_flag, mine.value, hipStreamWaitValueGte, 0xFFFFFFFFu));
+                launch_hessian(mine, s_doh);
+            } else {
+                deferred = mine;          // the next level's first kernel will carry it
+            }
+        } else {
+            launch_hessian(DeferredHessian{i, smooth, kside, kmid, 0}, s_doh);
+        }
     }
+    if (flag_fork) flush_deferred();
     if (fork_doh) {   // join: everything after this point reads what the Hessian kernels wrote
         if (!c.join_event) HIP_CHECK(hipEventCreateWithFlags(&c.join_event, stream_event_flags()));
         HIP_CHECK(hipEventRecord(c.join_event, s_doh));

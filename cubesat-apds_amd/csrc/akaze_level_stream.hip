@@ -201,8 +201,9 @@ __device__ __forceinline__ void level_stream_rows(const LevelStreamArgs& a, int 
 }  // namespace
 
 template <int S, bool FLOW_OUT, bool HALF = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void level_stream_kernel(LevelStreamArgs a, size_t bstride) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) void level_stream_kernel(LevelStreamArgs a, size_t bstride, ForkSignal sig) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_FORK_SIGNAL(sig);
     a.src = bofs(a.src, bstride);
     a.smooth = bofs(a.smooth, bstride);
     a.Lnew = bofs(a.Lnew, bstride);
@@ -239,7 +240,7 @@ bool launch_level_stream(const float* src, float* smooth, float* flow_out, float
         a.rb = rows_for(kernel);
         if (half_out) a.rb = (a.rb + 1) & ~1;   // row pairs of the fused half-sample stay inside a band
         a.bands = ceil_div(h, a.rb);
-        hipLaunchKernelGGL(kernel, dim3(ceil_div((long long)a.strips * a.bands, 4), 1, b.n), dim3(256), 0, s, a, b.stride);
+        hipLaunchKernelGGL(kernel, dim3(ceil_div((long long)a.strips * a.bands, 4), 1, b.n), dim3(256), 0, s, a, b.stride, ctx().take_fork_signal());
     };
     APDS_REQUIRE(!(half_out && flow_out), APDS_ERR_INTERNAL, "level_stream: a launch that finishes its level writes no conductivity plane");
     if (half_out) {

@@ -169,8 +169,9 @@ __device__ __forceinline__ void level_strip(const float* __restrict__ src, float
 template <int S, int RB, bool FLOW_OUT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(S >= APDS_STRIP_WIDE_FROM ? 3 : APDS_STRIP_WAVES, 8)))
 void level_strip_kernel(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow_out, float* __restrict__ Lnew, int w, int h,
-                        GaussTaps taps, const float* __restrict__ kptr, NldSteps steps, int strips, int nwaves, size_t bstride) {
+                        GaussTaps taps, const float* __restrict__ kptr, NldSteps steps, int strips, int nwaves, size_t bstride, ForkSignal sig) {
     APDS_RAISE_WAVE_PRIORITY();
+    APDS_FORK_SIGNAL(sig);
     APDS_BOFS(src);
     APDS_BOFS(smooth);
     APDS_BOFS(Lnew);
@@ -197,10 +198,11 @@ static void level_strip_launch(const float* src, float* smooth, float* flow_out,
     constexpr int RB = APDS_STRIP_RB;
     const int strips = ceil_div(w, 64 - 2 * (S + 3)), nwaves = strips * ceil_div(h, RB);
     const dim3 grid(ceil_div(nwaves, 4), 1, b.n);
+    const ForkSignal sig = ctx().take_fork_signal();
     if (flow_out)
-        hipLaunchKernelGGL((level_strip_kernel<S, RB, true>), grid, dim3(256), 0, s, src, smooth, flow_out, Lnew, w, h, taps, kptr, st, strips, nwaves, b.stride);
+        hipLaunchKernelGGL((level_strip_kernel<S, RB, true>), grid, dim3(256), 0, s, src, smooth, flow_out, Lnew, w, h, taps, kptr, st, strips, nwaves, b.stride, sig);
     else
-        hipLaunchKernelGGL((level_strip_kernel<S, RB, false>), grid, dim3(256), 0, s, src, smooth, flow_out, Lnew, w, h, taps, kptr, st, strips, nwaves, b.stride);
+        hipLaunchKernelGGL((level_strip_kernel<S, RB, false>), grid, dim3(256), 0, s, src, smooth, flow_out, Lnew, w, h, taps, kptr, st, strips, nwaves, b.stride, sig);
 }
 bool launch_level_strips(const float* src, float* smooth, float* flow_out, float* Lnew, int w, int h, const GaussTaps& taps, const float* kptr,
                          const float* step_sizes, int nsteps, hipStream_t s, const Batch& b) {

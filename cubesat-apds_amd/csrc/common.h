@@ -17,6 +17,13 @@
 // on other streams) would starve. They raise their own wave priority; they need few issue slots, so the match loses
 // almost nothing and the stages overlap.
 #define APDS_RAISE_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
+// First act of a main-chain kernel when a fork is armed (ForkSignal below): its first block reports that the kernel has STARTED, i.e. that
+// everything in front of it on its stream is done and written back. The side stream's hipStreamWaitValue32 waits for that value.
+#define APDS_FORK_SIGNAL(sig)                                                                                              \
+    do {                                                                                                                   \
+        if ((sig).flag && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0)                                       \
+            __hip_atomic_store((sig).flag, (sig).value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);                      \
+    } while (0)
 
 namespace apds {
 
@@ -47,6 +54,11 @@ inline void hip_check(hipError_t e, const char* what, const char* file, int line
         if (!(cond)) ::apds::fail((code), (msg)); \
     } while (0)
 
+// "my predecessor on this stream is done": what a kernel of the main chain stores as its first act when a fork is armed
+struct ForkSignal {
+    unsigned* flag = nullptr;
+    unsigned value = 0;
+};
 // Per host thread: device ordinal, a private stream, a bump-allocated workspace that only grows.
 struct ThreadCtx {
     int device = 0;
@@ -67,6 +79,19 @@ struct ThreadCtx {
     hipEvent_t join_event = nullptr;
     int akaze_first_batch[2] = {8, 8};          // suppression rounds to launch before the first host check, per phase (adaptive)
     int akaze_batch_streak[2] = {0, 0};
+    // fork without an event (round 4): the first block of the NEXT kernel on the main stream stores a sequence number to `fork_flag`
+    // (signal memory), the side stream waits for that value (hipStreamWaitValue32). A launcher that supports it takes the armed signal.
+    unsigned* fork_flag = nullptr;              // 8 bytes of signal memory, allocated on first use; null if the runtime refused
+    bool fork_flag_tried = false;
+    unsigned fork_seq = 0;
+    ForkSignal fork_pending{};                  // armed and not yet given to a kernel
+    bool fork_flag_ready();                     // allocate on first use; false -> use events
+    ForkSignal arm_fork_signal() { return fork_pending = ForkSignal{fork_flag, ++fork_seq}; }
+    ForkSignal take_fork_signal() {
+        const ForkSignal r = fork_pending;
+        fork_pending = ForkSignal{};
+        return r;
+    }
     bool fork_open = false;                     // side-stream work was issued and not yet joined (only after an error in between)
     int akaze_kp_estimate = 0;                  // keypoints of this thread's previous image (grid size of the per-keypoint kernels)
     int* host_ints = nullptr;                   // pinned host memory for count read-backs (a pageable target makes the copy a staged, blocking one)
@@ -93,6 +118,8 @@ std::atomic<int>& live_contexts();   // host threads that currently own a stream
 // asked. So: four candidates (consecutive creations: different queues), each timed once with a spinning one-wave kernel on it and one
 // on `caller`; the candidate whose pair finishes first does not share the caller's queue. ~0.3 ms, once per (thread, caller stream).
 hipStream_t side_stream_beside(hipStream_t caller);
+// a one-thread kernel that stores an armed fork signal no chain kernel has taken (the launchers that cannot carry one)
+void launch_fork_signal(ForkSignal sig, hipStream_t s);
 // the candidate streams of released threads, per device (creating and destroying four streams per short-lived thread costs milliseconds)
 bool take_cached_side_stream(int device, hipStream_t& out);
 void cache_side_stream(int device, hipStream_t st);

@@ -112,4 +112,9 @@ hipStream_t side_stream_beside(hipStream_t caller) {
     return c.side_probe_choice;
 }
 
+__global__ void fork_signal_kernel(ForkSignal sig) { APDS_FORK_SIGNAL(sig); }
+void launch_fork_signal(ForkSignal sig, hipStream_t s) {
+    if (sig.flag) hipLaunchKernelGGL(fork_signal_kernel, dim3(1), dim3(64), 0, s, sig);
+}
+
 }  // namespace apds

@@ -38,6 +38,7 @@ const Config& config() {
         k.akaze_fork = env("APDS_AKAZE_FORK", 1);
         k.side_probe = env("APDS_SIDE_PROBE", 1);
         k.event_scope = env("APDS_EVENT_SCOPE", 2);
+        k.flag_fork = env("APDS_FLAG_FORK", 0);
         k.debug_host_time = env("APDS_DEBUG_HOST_TIME", 0);
         k.match_lds_cap = env("APDS_MATCH_LDS_CAP", 0);
         k.match_sample = env("APDS_MATCH_SAMPLE", 16384);
@@ -179,6 +180,26 @@ void ThreadCtx::drop_side() {
     if (join_event) (void)hipEventDestroy(join_event);
     join_event = nullptr;
     fork_open = false;
+    if (fork_flag) (void)hipFree(fork_flag);
+    fork_flag = nullptr;
+    fork_flag_tried = false;
+    fork_seq = 0;
+    fork_pending = ForkSignal{};
+}
+
+bool ThreadCtx::fork_flag_ready() {
+    if (!fork_flag_tried) {
+        fork_flag_tried = true;
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, 8, hipMallocSignalMemory) == hipSuccess && p) {
+            fork_flag = static_cast<unsigned*>(p);
+            *reinterpret_cast<volatile unsigned long long*>(p) = 0;   // signal memory is host-visible
+            fork_seq = 0;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    return fork_flag != nullptr;
 }
 
 // Events that order one GPU stream after another of the same device: no timing and no system-scope fence when the event completes.

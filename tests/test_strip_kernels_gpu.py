@@ -63,3 +63,12 @@ def test_akaze_parity_with_the_streaming_kernels_on_every_level(gpu_pkg):
     clamped columns, partial last bands; once with 16-row bands and once with tall ones."""
     _rerun({"APDS_DOH_STRIP": "2", "APDS_DOH_STRIP_ROWS": "16", "APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "16", "APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0"})
     _rerun({"APDS_DOH_STRIP": "2", "APDS_DOH_STRIP_ROWS": "112", "APDS_LEVEL_STREAM": "2", "APDS_LEVEL_STREAM_ROWS": "100", "APDS_LEVEL_STRIP": "2", "APDS_LEVEL_FUSE": "0"})
+
+
+def test_akaze_parity_with_the_value_fork(gpu_pkg):
+    """APDS_FLAG_FORK=1: the Hessian stream waits for a sequence number that the next kernel of the level chain stores as its first act
+    (hipStreamWaitValue32) instead of for an event recorded between the chain's kernels; levels whose fork follows their last kernel defer
+    their Hessian launch to the next level. Every kernel family's launcher carries the signal here (streaming, strips, LDS-fused; the small
+    separate kernels take the one-thread fallback)."""
+    _rerun({"APDS_FLAG_FORK": "1"})
+    _rerun({"APDS_FLAG_FORK": "1", "APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STRIP": "0", "APDS_LEVEL_STREAM": "0"})
