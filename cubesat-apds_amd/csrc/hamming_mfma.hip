@@ -1,0 +1,249 @@
+// csrc/hamming_mfma.hip — Hamming top-1 / top-2 of 512-bit rows on the FP4 matrix pipe (get_knn_matches, lib.rs:94-114, k <= 2).
+//
+// Brute-force Hamming matching is all pairs x all bits: Q x N x 512 one-bit products. match_hamming.hip forms them on the vector ALU
+// (xor + popcount per dword: 32 lane-operations per pair, bound by the half-rate v_bcnt at 52 T lane-op/s = 1.6e12 pairs/s). CDNA4's
+// matrix cores multiply 4-bit operands at ~10 PFLOP/s dense, and a bit IS a 4-bit float: with
+//     train bit  -> e2m1  1.0 (0x2)        query bit -> e2m1 -2.0 (0xC)        accumulator preset to popcount(train row)
+// one v_mfma_scale_f32_16x16x128_f8f6f4 (unit scales) adds -2 * (t AND q) over 128 bit positions for 16 x 16 pairs, and after four of
+// them the accumulator holds popcount(t) - 2 popcount(t AND q) = hamming(t, q) - popcount(q): the ranking value of the pair, EXACT (every
+// product is 0 or -2, every partial sum an integer of magnitude <= 1024: nothing rounds in binary32). The distances, the ties (lower train
+// row first) and therefore the keys are those of hamming_topk_kernel bit for bit (tests/test_match_gpu.py runs both).
+// 2 * 512 flop per pair on the 10 PF pipe is a ceiling of 9.8e12 pairs/s, six times the vector formulation's.
+//
+// Two steps per call:
+//   hm_expand_rows_kernel   64-byte rows -> 256-byte rows of fp4 nibbles (one dword -> 16 bytes; bit k of dword d is element 32 d + k;
+//                           any order would do as long as both operands use the same one) + popcount per row as a float
+//   hamming_mfma_kernel     the structure of l2_screen_kernel (same tile shapes: there K = 128 bf16 elements are 256 bytes, here K = 512
+//                           fp4 elements are): block = 8 waves x 48 queries held as B operands in registers for the whole kernel,
+//                           128-row train tiles double-buffered in LDS (pitch 272 B: conflict-free ds_read_b128), each A read feeds three
+//                           MFMAs, running top-2 per query column in the lanes, insertion code only when some lane has a hit.
+#include "config.h"
+#include "kernels.h"
+
+namespace apds {
+
+typedef int hm_v8i __attribute__((ext_vector_type(8)));
+typedef float hm_f32x4 __attribute__((ext_vector_type(4)));
+
+static constexpr int HM_TM = 128;             // train rows per tile
+static constexpr int HM_NC = 3;               // 16-query column blocks per wave
+static constexpr int HM_Q = 8 * 16 * HM_NC;   // queries per block (8 waves)
+static constexpr int HM_PITCH = 272;          // bytes per staged train row (256 + 16)
+static constexpr int HM_UNIT_SCALE = 0x7F7F7F7F;   // E8M0 127 = 2^0 in every byte
+static constexpr uint64_t HM_EMPTY = ~0ull;
+
+// 8 bits -> 8 nibbles holding `nib` where the bit is set
+__device__ __forceinline__ uint32_t hm_spread8(uint32_t b, uint32_t nib) {
+    uint32_t t = b & 0xFFu;
+    t = (t | (t << 12)) & 0x000F000Fu;
+    t = (t | (t << 6)) & 0x03030303u;
+    t = (t | (t << 3)) & 0x11111111u;
+    return t * nib;
+}
+
+// rows: n x 16 dwords. out: n x 16 uint4 (dword d of a row -> uint4 d). pc: popcount of each row. One thread per dword.
+__global__ __launch_bounds__(256) void hm_expand_rows_kernel(const uint32_t* __restrict__ rows, long long n, uint32_t nib, uint4* __restrict__ out,
+                                                             float* __restrict__ pc) {
+    APDS_RAISE_WAVE_PRIORITY();
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t d = i < n * 16 ? rows[i] : 0u;
+    int v = __popc(d);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);   // the 16 lanes of a row are aligned: 256 threads = 16 rows
+    if (i >= n * 16) return;
+    out[i] = make_uint4(hm_spread8(d, nib), hm_spread8(d >> 8, nib), hm_spread8(d >> 16, nib), hm_spread8(d >> 24, nib));
+    if ((threadIdx.x & 15) == 0) pc[i >> 4] = (float)v;
+}
+
+struct HmTop2 {
+    float d0, d1;
+    uint32_t i0, i1;
+};
+__device__ __forceinline__ void hm_insert(HmTop2& b, float d, uint32_t idx) {   // rows arrive in ascending order: strict '<' keeps the lower row of a tie
+    if (d < b.d1) {
+        if (d < b.d0) {
+            b.d1 = b.d0;
+            b.i1 = b.i0;
+            b.d0 = d;
+            b.i0 = idx;
+        } else {
+            b.d1 = d;
+            b.i1 = idx;
+        }
+    }
+}
+
+// out[split][nq][2]: keys (distance << 32 | row + index_base), EMPTY where the split holds fewer than two rows
+__global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
+                                                           const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
+                                                           uint32_t index_base, uint64_t* __restrict__ out) {
+    APDS_RAISE_WAVE_PRIORITY();
+    extern __shared__ __attribute__((aligned(128))) unsigned char hm_lds[];
+    auto tile_lds = [&](int buf) { return hm_lds + buf * (HM_TM * HM_PITCH); };
+    auto norm_lds = [&](int buf) { return reinterpret_cast<float*>(hm_lds + 2 * HM_TM * HM_PITCH) + buf * HM_TM; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.x * HM_Q + wave * 16 * HM_NC;         // this wave's queries
+    const int n_tiles = (n_train + HM_TM - 1) / HM_TM;
+    const int tile_begin = blockIdx.y * tiles_per_split, tile_end = min(n_tiles, tile_begin + tiles_per_split);
+    const int col = lane & 15, kq = lane >> 4;                     // accumulator column / k chunk (operands) / row group (accumulators)
+
+    // B operands: query (q0 + 16 c + col), elements 128 s + 32 kq .. + 31 (dword 4 s + kq of the row), for the four k steps s
+    uint4 B[HM_NC][4];
+    float qq[HM_NC];
+#pragma unroll
+    for (int c = 0; c < HM_NC; c++) {
+        const int qi = min(q0 + 16 * c + col, nq - 1);
+#pragma unroll
+        for (int s = 0; s < 4; s++) B[c][s] = query_fp4[(size_t)qi * 16 + 4 * s + kq];
+        qq[c] = qpc[qi];
+    }
+    HmTop2 best[HM_NC];
+#pragma unroll
+    for (int c = 0; c < HM_NC; c++) {
+        best[c].d0 = best[c].d1 = INFINITY;
+        best[c].i0 = best[c].i1 = 0xFFFFFFFFu;
+    }
+
+    if (tile_begin < tile_end) {
+        // staging: the tile is 128 rows x 256 B = 2048 pieces of 16 B, four per thread; rows past the end re-read the last row and get a
+        // popcount of +inf, so they never rank
+        uint4 pre0, pre1, pre2, pre3;
+        float pre_norm = INFINITY;
+        const int pr = tid >> 4, pg = tid & 15;   // piece p of this thread: row 32 p + pr, 16-byte group pg
+        auto load_tile = [&](int tile) {
+            const int r0 = tile * HM_TM + pr;
+            pre0 = train_fp4[(size_t)min(r0, n_train - 1) * 16 + pg];
+            pre1 = train_fp4[(size_t)min(r0 + 32, n_train - 1) * 16 + pg];
+            pre2 = train_fp4[(size_t)min(r0 + 64, n_train - 1) * 16 + pg];
+            pre3 = train_fp4[(size_t)min(r0 + 96, n_train - 1) * 16 + pg];
+            if (tid < HM_TM) {
+                const int row = tile * HM_TM + tid;
+                pre_norm = row < n_train ? tpc[row] : INFINITY;
+            }
+        };
+        auto commit = [&](int buf) {
+            unsigned char* d = tile_lds(buf) + pr * HM_PITCH + 16 * pg;
+            *reinterpret_cast<uint4*>(d) = pre0;
+            *reinterpret_cast<uint4*>(d + 32 * HM_PITCH) = pre1;
+            *reinterpret_cast<uint4*>(d + 64 * HM_PITCH) = pre2;
+            *reinterpret_cast<uint4*>(d + 96 * HM_PITCH) = pre3;
+            if (tid < HM_TM) norm_lds(buf)[tid] = pre_norm;
+        };
+        load_tile(tile_begin);
+        commit(0);
+        __syncthreads();
+
+        for (int tile = tile_begin; tile < tile_end; tile++) {
+            const int buf = (tile - tile_begin) & 1;
+            const bool more = tile + 1 < tile_end;
+            if (more) load_tile(tile + 1);
+            const unsigned char* T = tile_lds(buf);
+            const float* Nn = norm_lds(buf);
+#pragma unroll 2
+            for (int rb = 0; rb < 8; rb++) {                           // 16-row blocks of the tile
+                const hm_f32x4 init = *reinterpret_cast<const hm_f32x4*>(Nn + rb * 16 + 4 * kq);   // popcount of this lane's four rows
+                hm_f32x4 acc[HM_NC];
+#pragma unroll
+                for (int c = 0; c < HM_NC; c++) acc[c] = init;
+                const unsigned char* arow = T + (rb * 16 + col) * HM_PITCH + 16 * kq;
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(arow + 64 * s);
+                    const hm_v8i A = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+#pragma unroll
+                    for (int c = 0; c < HM_NC; c++) {
+                        const hm_v8i Bv = {(int)B[c][s].x, (int)B[c][s].y, (int)B[c][s].z, (int)B[c][s].w, 0, 0, 0, 0};
+                        acc[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, Bv, acc[c], 4, 4, 0, HM_UNIT_SCALE, 0, HM_UNIT_SCALE);
+                    }
+                }
+                // acc = hamming - popcount(query) for rows 4 kq + j of the block, query column `col` of each of the wave's query blocks
+                bool any_hit = false;
+#pragma unroll
+                for (int c = 0; c < HM_NC; c++) {
+                    const float mn = fminf(fminf(acc[c][0], acc[c][1]), fminf(acc[c][2], acc[c][3]));
+                    any_hit |= mn < best[c].d1;
+                }
+                if (__any(any_hit)) {
+                    const uint32_t row0 = (uint32_t)(tile * HM_TM + rb * 16 + 4 * kq) + index_base;
+#pragma unroll
+                    for (int c = 0; c < HM_NC; c++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) hm_insert(best[c], acc[c][j], row0 + j);
+                }
+            }
+            if (more) commit(buf ^ 1);
+            __syncthreads();   // the next tile is staged; everybody is done with this one
+        }
+    }
+    // a query column lives in four lanes (kq = 0..3, different rows): fold them with shuffles, lanes 0..15 write
+#pragma unroll
+    for (int c = 0; c < HM_NC; c++) {
+        HmTop2 b = best[c];
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) {
+            const float od0 = __shfl_xor(b.d0, off), od1 = __shfl_xor(b.d1, off);
+            const uint32_t oi0 = (uint32_t)__shfl_xor((int)b.i0, off), oi1 = (uint32_t)__shfl_xor((int)b.i1, off);
+            HmTop2 m = b;   // merge two sorted pairs; equal values: lower row first
+            auto ins = [&](float d, uint32_t i) {
+                if (i == 0xFFFFFFFFu) return;
+                if (d < m.d0 || (d == m.d0 && i < m.i0)) {
+                    m.d1 = m.d0;
+                    m.i1 = m.i0;
+                    m.d0 = d;
+                    m.i0 = i;
+                } else if ((d < m.d1 || (d == m.d1 && i < m.i1)) && i != m.i0) {
+                    m.d1 = d;
+                    m.i1 = i;
+                }
+            };
+            ins(od0, oi0);
+            ins(od1, oi1);
+            b = m;
+        }
+        const int qi = q0 + 16 * c + col;
+        if (kq == 0 && qi < nq) {
+            uint64_t* o = out + ((size_t)blockIdx.y * nq + qi) * 2;
+            o[0] = b.i0 == 0xFFFFFFFFu ? HM_EMPTY : ((uint64_t)(uint32_t)(int)(qq[c] + b.d0) << 32) | b.i0;
+            o[1] = b.i1 == 0xFFFFFFFFu ? HM_EMPTY : ((uint64_t)(uint32_t)(int)(qq[c] + b.d1) << 32) | b.i1;
+        }
+    }
+}
+
+// Top-k (k = 1 or 2) of nq queries over nt train rows, both 64-byte rows on the device. out: nq * k keys (distance << 32 | row + index_base).
+void hamming_mfma_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s) {
+    APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "the matrix-core matcher serves k = 1 and k = 2");
+    APDS_REQUIRE(nq > 0 && nt > 0 && nt < (1ll << 31), APDS_ERR_ASSERT, "the matrix-core matcher needs queries and train rows");
+    ThreadCtx& c = ctx();
+    uint4* q4 = c.alloc_n<uint4>((size_t)nq * 16);
+    float* qp = c.alloc_n<float>(nq);
+    uint4* t4 = c.alloc_n<uint4>((size_t)nt * 16);
+    float* tp = c.alloc_n<float>(nt);
+    hipLaunchKernelGGL(hm_expand_rows_kernel, dim3((unsigned)ceil_div((long long)nq * 16, 256)), dim3(256), 0, s, static_cast<const uint32_t*>(q), (long long)nq, 0xCu, q4,
+                       qp);
+    {
+        KernelTimer timer("hamming_expand", s);
+        hipLaunchKernelGGL(hm_expand_rows_kernel, dim3((unsigned)ceil_div(nt * 16, 256)), dim3(256), 0, s, static_cast<const uint32_t*>(t), nt, 0x2u, t4, tp);
+    }
+    const int q_tiles = ceil_div(nq, HM_Q), t_tiles = (int)ceil_div(nt, (long long)HM_TM);
+    // two blocks fit a CU (LDS): splits of the train rows fill the 512 slots when the queries alone do not
+    int splits = std::max(1, std::min(t_tiles, (256 * 2) / q_tiles));
+    const int tiles_per_split = ceil_div(t_tiles, splits);
+    splits = ceil_div(t_tiles, tiles_per_split);
+    uint64_t* parts = (splits == 1 && k == 2) ? out : c.alloc_n<uint64_t>((size_t)splits * nq * 2);
+    const size_t lds = (size_t)2 * HM_TM * HM_PITCH + 2 * HM_TM * sizeof(float);
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        KernelTimer timer("hamming_mfma", s);
+        hipLaunchKernelGGL(hamming_mfma_kernel, dim3(q_tiles, splits), dim3(512), lds, s, (const uint4*)t4, (const float*)tp, (int)nt, (const uint4*)q4,
+                           (const float*)qp, nq, tiles_per_split, index_base, parts);
+    }
+    if (parts != out) {
+        uint64_t* top2 = k == 2 ? out : c.alloc_n<uint64_t>((size_t)nq * 2);
+        if (splits > 1) merge_topk_device(parts, splits, nq, 2, top2, s);
+        else top2 = parts;
+        if (k == 1) take_first_columns_device(top2, nq, 2, 1, out, s);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace apds

@@ -8,6 +8,9 @@ namespace apds {
 // match_hamming.hip
 void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s);
 void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_t* out, hipStream_t s);
+void take_first_columns_device(const uint64_t* in, int nq, int kin, int kout, uint64_t* out, hipStream_t s);
+// hamming_mfma.hip: the same keys for k = 1, 2 from the FP4 matrix pipe (bit -> e2m1 operand, exact)
+void hamming_mfma_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s);
 // the scan of hamming_topk_device in three separately launched steps on a per-frame state object (k = 1, 2)
 void* topk_split_create();
 void topk_split_destroy(void* state);

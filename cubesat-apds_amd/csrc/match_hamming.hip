@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "config.h"
+#include "kernels.h"
 
 namespace apds {
 
@@ -1110,6 +1111,10 @@ void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uin
         topk_paged_device(q, nq, t, nt, index_base, k, out, s);
         return;
     }
+    if (k <= 2 && config().match_mfma) {   // the two nearest (all the crate surface consumes) come from the matrix cores
+        hamming_mfma_topk_device(q, nq, t, nt, index_base, k, out, s);
+        return;
+    }
     const int K = k <= 2 ? k : (k <= 4 ? 4 : (k <= 8 ? 8 : 16));
     uint64_t* dst = K == k ? out : ctx().alloc_n<uint64_t>((size_t)nq * K);
     switch (K) {
@@ -1123,6 +1128,11 @@ void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uin
         hipLaunchKernelGGL(take_first_columns_kernel, dim3(ceil_div((long long)nq * k, 256)), dim3(256), 0, s, (const uint64_t*)dst, nq, K, k, out);
         HIP_CHECK(hipGetLastError());
     }
+}
+
+void take_first_columns_device(const uint64_t* in, int nq, int kin, int kout, uint64_t* out, hipStream_t s) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(take_first_columns_kernel, dim3(ceil_div((long long)nq * kout, 256)), dim3(256), 0, s, in, nq, kin, kout, out);
 }
 
 void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_t* out, hipStream_t s) {
