@@ -27,6 +27,7 @@ import __graft_entry__ as graft  # noqa: E402
 
 METRIC = "frames/sec (detect+match+homography) 4k×4k tile vs 1M-desc DB; Mmatches/sec"
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP4_DENSE_PEAK_TFLOPS = 10000.0              # MI355X_MICROARCH.md: FP6/FP4 MFMA ~10 PF dense (the 20 PF spec figure is 2:1 sparse)
 VALU_FP32_LANE_RATE_SPEC = 256 * 128 * 2.4e9   # MI355X_MICROARCH.md: SIMD-32 x 4, a wave64 VALU op per 2 cycles = 128 lanes/clk/CU
 
 
@@ -477,7 +478,10 @@ def main():
             try:
                 tj = json.load(open(tpath))
                 # the PMC profile was taken on the default workload on one GPU: it says nothing about other DB / tile sizes
-                if (tj.get("db_rows_per_gpu", 1_000_000), tj.get("tile", 4096)) == (rows_local, args.tile) and args.db == "mixed":
+                backend_now = C.c_int(0)
+                check(L.apds_dev_match_backend(C.byref(backend_now)))
+                same_kernel = (tj.get("kernel", "hamming_topk_kernel<4, 2>") == "hamming_mfma_kernel") == bool(backend_now.value)
+                if (tj.get("db_rows_per_gpu", 1_000_000), tj.get("tile", 4096)) == (rows_local, args.tile) and args.db == "mixed" and same_kernel:
                     traffic = tj.get("hamming_topk_hbm_bytes_per_launch")
                     # not measured in this run: rocprofv3 --pmc passes (tools/profile_bench.sh) wrote the file; say which commit's
                     traffic_source = f"profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/profile_bench.sh; collected at {tj.get('commit', 'an earlier commit')})"
@@ -488,27 +492,38 @@ def main():
         achieved_gbps = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if topk_n else 0.0
         achieved_tops = match_ops / max(launches_per_step, 1e-9) / (avg_launch_ms * 1e-3) / 1e12 if topk_n else 0.0
         ms_per_step = elapsed / args.steps * 1e3
-        out = {
-            "metric": METRIC, "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8/u32 popcount (match), f32 (AKAZE), f64 (homography solve)", "data": "synthetic",
-            "config": {"workload": f"frame{T}x{T}_bgra_detect+describe -> hamming_top2 vs db{NDB} (sharded/{world}) -> ratio{args.filter_strength} -> ransac_homography",
-                       "tile": T, "db_rows": NDB, "db_rows_per_gpu": rows_local,
-                       "db_composition": ("all rows are AKAZE descriptors of images (shifted frames + %d blended variants), shuffled" % real_variants) if args.db == "real"
-                                         else f"{P} AKAZE descriptors of the frames' shifted copies + {NDB - P} i.i.d. random rows", "frames_per_step": world, "parallelism": f"frame-dp{world}+db-shard{world}",
-                       "stage_overlap": "none (serial)" if args.serial else "extract (2 workers, alternate frames) | match (threshold pre-pass, main scan and record merge of consecutive frames on three streams) | homography, software-pipelined over frames by the library's own host threads (apds_pipeline_*: the timed loop is K submits + K polls)",
-                       "match_occupancy_cap": ({"lds_bytes": 55000, "set_at": pipe.cap_events[0]} if getattr(pipe, "cap_events", None) else
-                                               {"lds_bytes": int(os.environ.get("APDS_MATCH_LDS_CAP", "0") or 0)}),
-                       "match_stream_gap_ms": (round(pipe.gap_mean, 3) if getattr(pipe, "gap_mean", None) is not None else None),
-                       "match_stream_gaps_ms_first16": ([round(float(g), 2) for g in pipe.gap_log[:16]] if getattr(pipe, "gap_log", None) else None),
-                       "keypoints_per_frame": K, "matches_per_frame": float(np.mean([s["n_matches"] for s in stats])),
-                       "inliers_per_frame": float(np.mean([s["n_inliers"] for s in stats])), "homography_found": all(s["H"] is not None for s in stats)},
-            "collectives": dict(collectives_info(torch, dist, world, backend, meta_group), transport=pipe.matcher.info()["transport"] if hasattr(pipe, "matcher") else None,
-                                transport_requested=args.transport, fell_back_from=args.transport_fallback_from),
-            "value_host_frames": (world * args.steps / elapsed_host) if elapsed_host else None,
-            "ms_per_step_host_frames": (elapsed_host / args.steps * 1e3) if elapsed_host else None,
-            "mmatches_per_s": world * K * args.steps / elapsed / 1e6,
-            "gpairs_per_s": world * Q_step * rows_local * args.steps / elapsed / 1e9,
+        mfma_backend = C.c_int(0)
+        check(L.apds_dev_match_backend(C.byref(mfma_backend)))
+        if mfma_backend.value:
+            # The matrix-core matcher (csrc/hamming_mfma.hip): ONE main launch per step over all rows (no threshold pre-pass; "hamming_topk_sample"
+            # times the expansion of the frame's queries into FP4 operands - the DB's expanded copy is made once at apds_pipeline_create).
+            # Algorithmic work per pair: 512 one-bit products + 512 adds on the padded 64-byte rows (SURVEY 8d counts the same 16 dwords) =
+            # 1024 flop; peak = the guide's dense FP4 figure (MI355X_MICROARCH.md: ~10 PF, f8f6f4 with e2m1 operands = 4x the BF16 rate).
+            rows_main = rows_local
+            match_ops = 32.0 * Q_step * rows_main
+            match_bytes = 64.0 * rows_main + 64.0 * Q_step + 8.0 * Q_step * 2
+            bytes_per_launch = match_bytes / max(launches_per_step, 1e-9)
+            achieved_gbps = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if topk_n else 0.0
+            flop_per_launch = 1024.0 * Q_step * rows_main / max(launches_per_step, 1e-9)
+            achieved_tflops = flop_per_launch / (avg_launch_ms * 1e-3) / 1e12 if topk_n else 0.0
+            solo_tflops = (1024.0 * stats[0]["n_keypoints"] * rows_main / (solo_launch_ms * 1e-3) / 1e12) if solo_launch_ms else None
+            lane_equiv = match_ops / max(launches_per_step, 1e-9) / (avg_launch_ms * 1e-3) / 1e12 if topk_n else 0.0
+            roofline = {"kernel": "hamming_mfma_kernel (v_mfma_scale_f32_16x16x128_f8f6f4, e2m1 operands: train bit -> 1.0, query bit -> -2.0, accumulator preset to popcount(train))",
+                        "bound": "mfma", "achieved": achieved_tflops, "peak": FP4_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tflops / FP4_DENSE_PEAK_TFLOPS,
+                        "traffic": traffic, "traffic_source": traffic_source, "launches_per_step": launches_per_step, "avg_launch_ms": avg_launch_ms,
+                        "solo": ({"avg_launch_ms": solo_launch_ms, "queries": int(stats[0]["n_keypoints"]), "achieved": solo_tflops, "frac": solo_tflops / FP4_DENSE_PEAK_TFLOPS,
+                                  "note": "the same kernel alone on the GPU after the timed region (frame 0's query count); `achieved` / `frac` above are the LIVE "
+                                          "launches of the timed region, which share the GPU with the extraction of the following frames"} if solo_launch_ms else None),
+                        "algorithmic_flop_per_launch": flop_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
+                        "tpairs_per_s": Q_step * rows_main / (topk_ms_step * 1e-3) / 1e12 if topk_ms_step else 0.0,
+                        "vector_alu_equivalent": {"achieved": lane_equiv, "unit": "T lane-op/s", "vs_valu_peak": lane_equiv / (VALU_FP32_LANE_RATE_SPEC / 1e12),
+                                                  "note": "SURVEY 8d's figure for this path (32 xor + popcount lane-operations per pair) divided by the launch time: what the "
+                                                          "vector-ALU formulation (APDS_MATCH_MFMA=0, hamming_topk_kernel: 0.63 of the 78.6 T peak, 0.97 of its xor + half-rate-bcnt ceiling) "
+                                                          "would have to issue to keep up"},
+                        "hbm": {"achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS},
+                        "note": "1024 algorithmic flop per pair (512 bit products + 512 adds, exact in binary32: every partial sum is an integer below 2^11); the kernel "
+                                "reads the train rows as 256-byte FP4 rows from the pipeline's expanded copy of the DB (4x the 64-byte rows `hbm` and `algorithmic_bytes_per_launch` count)"}
+        else:
             # The binding bound of the dominant kernel is integer-VALU issue, so that is what `roofline` carries:
             # achieved = ALGORITHMIC lane-ops (32 per pair: 16 dword xor + 16 popcount-accumulate) / launch time;
             # peak = the guide's VALU rate (MI355X_MICROARCH.md: 4 SIMD-32 per CU, a wave64 op every 2 cycles = 128 lanes/clk/CU x 256 CU x
@@ -516,7 +531,7 @@ def main():
             # rate measured on this GPU by the register-only microbenchmark in its best issue order (apds_dev_valu_popcount_peak; v_xor_b32
             # issues at the full rate, v_bcnt_u32_b32 at half of it: 2 + 4 cycles per dword pair, 52.4 T in theory; calibration
             # profiles/r02/valu_calib_*.log). north_star's "% of HBM" is the sub-object `hbm`.
-            "roofline": {"kernel": f"hamming_topk_kernel<{4 if Q_step >= 16384 else (2 if Q_step >= 8192 else 1)},2>", "bound": "int32-valu",
+            roofline = {"kernel": f"hamming_topk_kernel<{4 if Q_step >= 16384 else (2 if Q_step >= 8192 else 1)},2>", "bound": "int32-valu",
                          "achieved": achieved_tops, "peak": VALU_FP32_LANE_RATE_SPEC / 1e12, "unit": "T lane-op/s", "frac": achieved_tops / (VALU_FP32_LANE_RATE_SPEC / 1e12),
                          "mix_ceiling": peak.value / 1e12, "frac_of_mix_ceiling": achieved_tops / (peak.value / 1e12) if peak.value else None,
                          "mix_ceiling_source": "apds_dev_valu_popcount_peak in this run (xor at the full VALU rate + half-rate bcnt = 6 issue cycles per dword pair); calibration of every instruction kind: profiles/r02/valu_calib_patterns.log, valu_calib_modes.log",
@@ -531,7 +546,31 @@ def main():
                          "tpairs_per_s": Q_step * rows_main / (topk_ms_step * 1e-3) / 1e12 if topk_ms_step else 0.0,
                          "hbm": {"achieved": achieved_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved_gbps / HBM_PEAK_GBPS},
                          "note": "32 algorithmic lane-ops per pair; peak = 128 lanes/clk/CU x 256 CU x 2.4 GHz (the guide's full-rate VALU figure, which no popcount loop reaches: "
-                                 "v_bcnt_u32_b32 is a half-rate instruction); the kernel screens on 15 of the 16 dwords (30.6 issued ops per pair), so frac_of_mix_ceiling can pass 1.0 slightly"},
+                                 "v_bcnt_u32_b32 is a half-rate instruction); the kernel screens on 15 of the 16 dwords (30.6 issued ops per pair), so frac_of_mix_ceiling can pass 1.0 slightly"}
+        out = {
+            "metric": METRIC, "value": world * args.steps / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": ("fp4 e2m1 operands / f32 accumulate = exact integer Hamming (match), f32 (AKAZE), f64 (homography solve)" if mfma_backend.value
+                      else "u8/u32 popcount (match), f32 (AKAZE), f64 (homography solve)"), "data": "synthetic",
+            "config": {"workload": f"frame{T}x{T}_bgra_detect+describe -> hamming_top2 vs db{NDB} (sharded/{world}) -> ratio{args.filter_strength} -> ransac_homography",
+                       "tile": T, "db_rows": NDB, "db_rows_per_gpu": rows_local,
+                       "db_composition": ("all rows are AKAZE descriptors of images (shifted frames + %d blended variants), shuffled" % real_variants) if args.db == "real"
+                                         else f"{P} AKAZE descriptors of the frames' shifted copies + {NDB - P} i.i.d. random rows", "frames_per_step": world, "parallelism": f"frame-dp{world}+db-shard{world}",
+                       "match_backend": "matrix cores (hamming_mfma_kernel)" if mfma_backend.value else "vector ALU (hamming_topk_kernel)",
+                       "stage_overlap": "none (serial)" if args.serial else "extract (2 workers, alternate frames) | match (pre-pass, main scan and merge of consecutive frames on three streams) | homography, software-pipelined over frames by the library's own host threads (apds_pipeline_*: the timed loop is K submits + K polls)",
+                       "match_occupancy_cap": ({"lds_bytes": 55000, "set_at": pipe.cap_events[0]} if getattr(pipe, "cap_events", None) else
+                                               {"lds_bytes": int(os.environ.get("APDS_MATCH_LDS_CAP", "0") or 0)}),
+                       "match_stream_gap_ms": (round(pipe.gap_mean, 3) if getattr(pipe, "gap_mean", None) is not None else None),
+                       "match_stream_gaps_ms_first16": ([round(float(g), 2) for g in pipe.gap_log[:16]] if getattr(pipe, "gap_log", None) else None),
+                       "keypoints_per_frame": K, "matches_per_frame": float(np.mean([s["n_matches"] for s in stats])),
+                       "inliers_per_frame": float(np.mean([s["n_inliers"] for s in stats])), "homography_found": all(s["H"] is not None for s in stats)},
+            "collectives": dict(collectives_info(torch, dist, world, backend, meta_group), transport=pipe.matcher.info()["transport"] if hasattr(pipe, "matcher") else None,
+                                transport_requested=args.transport, fell_back_from=args.transport_fallback_from),
+            "value_host_frames": (world * args.steps / elapsed_host) if elapsed_host else None,
+            "ms_per_step_host_frames": (elapsed_host / args.steps * 1e3) if elapsed_host else None,
+            "mmatches_per_s": world * K * args.steps / elapsed / 1e6,
+            "gpairs_per_s": world * Q_step * rows_local * args.steps / elapsed / 1e9,
+            "roofline": roofline,
             "stages_ms_per_step": {"akaze_extract": akaze_ms / max(args.steps, 1), "hamming_topk": topk_ms_step,
                                    "hamming_topk_sample": sample_ms / max(args.steps, 1), "ransac_score": score_ms / max(args.steps, 1)},
             "detect_roofline": {"bound": "hbm", "algorithmic_bytes_per_frame": detect_algorithmic_bytes(T, T),

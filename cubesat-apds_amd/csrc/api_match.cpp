@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include "config.h"
 #include "kernels.h"
 
 using namespace apds;
@@ -226,6 +227,13 @@ int apds_dev_match_last_launch_lds(int* bytes) {
     return guarded([&] {
         APDS_REQUIRE(bytes, APDS_ERR_BAD_ARG, "null output");
         *bytes = last_scan_launch_lds().load();
+    });
+}
+
+int apds_dev_match_backend(int* matrix_cores) {
+    return guarded([&] {
+        APDS_REQUIRE(matrix_cores, APDS_ERR_BAD_ARG, "null output");
+        *matrix_cores = config().match_mfma ? 1 : 0;
     });
 }
 

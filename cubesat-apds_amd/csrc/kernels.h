@@ -11,6 +11,23 @@ void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_
 void take_first_columns_device(const uint64_t* in, int nq, int kin, int kout, uint64_t* out, hipStream_t s);
 // hamming_mfma.hip: the same keys for k = 1, 2 from the FP4 matrix pipe (bit -> e2m1 operand, exact)
 void hamming_mfma_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s);
+struct HmPlan {
+    int q_tiles, splits, tiles_per_split;
+};
+struct HmTrain {   // a train set expanded once (256 bytes of fp4 operands per row + popcounts), in device memory of its own
+    int device = 0;
+    const void* src = nullptr;
+    long long n = 0;
+    void* rows = nullptr;
+    float* pc = nullptr;
+};
+HmPlan hm_plan(int nq, long long nt);
+void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4, float* pc, hipStream_t s);
+void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_fp4, const float* tpc, long long nt, const HmPlan& p, uint32_t index_base,
+                    uint64_t* parts, hipStream_t s);
+void* hm_train_create(const void* rows64, long long n, hipStream_t s);
+void hm_train_destroy(void* train);
+void topk_split_use_train(void* state, const void* hm_train);   // a pre-expanded train set for the state's matrix-core scans (or null)
 // the scan of hamming_topk_device in three separately launched steps on a per-frame state object (k = 1, 2)
 void* topk_split_create();
 void topk_split_destroy(void* state);

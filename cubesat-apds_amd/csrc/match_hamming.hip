@@ -998,7 +998,76 @@ struct TopkSplitState {
     int nq = 0, k = 0;
     long long nt = 0, sample = 0;
     ChunkPlan sp{}, p{};
+    // the matrix-core form (hamming_mfma.hip): expanded queries, the split lists, and the expanded train rows - the caller's resident copy
+    // (topk_split_use_train) when it is one of exactly these rows, this state's own otherwise (expanded by every pre-pass)
+    bool mfma = false;
+    HmPlan hp{};
+    const HmTrain* shared_train = nullptr;
+    uint32_t index_base_mfma = 0;
+    size_t off_q4 = 0, off_qp = 0, off_t4 = 0, off_tp = 0, off_top2 = 0;
+    const void* t4 = nullptr;
+    const float* tp = nullptr;
 };
+
+static void split_reserve(TopkSplitState& st, size_t need) {
+    if (need <= st.cap) return;
+    // grow-only; a frame still using the old buffer is finished first (rare: the first frames of a run)
+    HIP_CHECK(hipDeviceSynchronize());
+    if (st.buf) (void)hipFree(st.buf);
+    st.buf = nullptr;
+    st.cap = 0;
+    const size_t want = need + need / 4;
+    HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.buf), want));
+    st.cap = want;
+}
+
+static void split_prepass_mfma(TopkSplitState& st, const void* q, int nq, const void* t, long long nt, int k, hipStream_t s) {
+    st.mfma = true;
+    st.nq = nq;
+    st.k = k;
+    st.nt = nt;
+    st.hp = hm_plan(nq, nt);
+    const bool shared = st.shared_train && st.shared_train->src == t && st.shared_train->n == nt;
+    size_t need = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = need;
+        need += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    st.off_q4 = take((size_t)nq * 256);
+    st.off_qp = take((size_t)nq * 4);
+    st.off_parts = take((size_t)st.hp.splits * nq * 16);
+    st.off_top2 = take((size_t)nq * 16);
+    if (!shared) {
+        st.off_t4 = take((size_t)nt * 256);
+        st.off_tp = take((size_t)nt * 4);
+    }
+    split_reserve(st, need);
+    KernelTimer timer("hamming_topk_sample", s);
+    hm_expand_device(q, nq, true, st.buf + st.off_q4, reinterpret_cast<float*>(st.buf + st.off_qp), s);
+    if (shared) {
+        st.t4 = st.shared_train->rows;
+        st.tp = st.shared_train->pc;
+    } else {
+        hm_expand_device(t, nt, false, st.buf + st.off_t4, reinterpret_cast<float*>(st.buf + st.off_tp), s);
+        st.t4 = st.buf + st.off_t4;
+        st.tp = reinterpret_cast<const float*>(st.buf + st.off_tp);
+    }
+    HIP_CHECK(hipGetLastError());
+}
+static void split_scan_mfma(TopkSplitState& st, hipStream_t s) {
+    hm_scan_device(st.buf + st.off_q4, reinterpret_cast<const float*>(st.buf + st.off_qp), st.nq, st.t4, st.tp, st.nt, st.hp, st.index_base_mfma,
+                   reinterpret_cast<uint64_t*>(st.buf + st.off_parts), s);
+}
+static void split_merge_mfma(TopkSplitState& st, uint64_t* out, hipStream_t s) {
+    const uint64_t* parts = reinterpret_cast<const uint64_t*>(st.buf + st.off_parts);
+    uint64_t* top2 = st.k == 2 ? out : reinterpret_cast<uint64_t*>(st.buf + st.off_top2);
+    if (st.hp.splits > 1) merge_topk_device(parts, st.hp.splits, st.nq, 2, top2, s);
+    else if (st.k == 2) HIP_CHECK(hipMemcpyAsync(out, parts, (size_t)st.nq * 16, hipMemcpyDeviceToDevice, s));
+    else top2 = const_cast<uint64_t*>(parts);
+    if (st.k == 1) take_first_columns_device(top2, st.nq, 2, 1, out, s);
+    HIP_CHECK(hipGetLastError());
+}
 
 static long long split_sample_rows(long long nt) {
     const int sample_rows = config().match_sample;
@@ -1025,15 +1094,7 @@ static void split_prepass_k(TopkSplitState& st, const void* q, int nq, const voi
         st.off_thr = take((size_t)nq * 4);
     }
     st.off_parts = take(record_words<K>(nq, st.p) * 4);
-    if (need > st.cap) {   // grow-only; a frame still using the old buffer is finished first (rare: the first frames of a run)
-        HIP_CHECK(hipDeviceSynchronize());
-        if (st.buf) (void)hipFree(st.buf);
-        st.buf = nullptr;
-        st.cap = 0;
-        const size_t want = need + need / 4;
-        HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.buf), want));
-        st.cap = want;
-    }
+    split_reserve(st, need);
     if (!st.sample) return;
     uint32_t* sparts = reinterpret_cast<uint32_t*>(st.buf + st.off_sparts);
     uint64_t* sample_keys = reinterpret_cast<uint64_t*>(st.buf + st.off_sample_keys);
@@ -1078,13 +1139,27 @@ void topk_split_prepass(void* h, const void* q, int nq, const void* t, long long
     APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "the split scan serves k = 1 and k = 2 (what the crate surface consumes, lib.rs:107-111)");
     APDS_REQUIRE(nq > 0 && nt > 0 && nt < (1ll << 31), APDS_ERR_ASSERT, "the split scan needs queries and train rows");
     TopkSplitState& st = *static_cast<TopkSplitState*>(h);
+    if (config().match_mfma) {
+        st.index_base_mfma = index_base;
+        split_prepass_mfma(st, q, nq, t, nt, k, s);
+        return;
+    }
+    st.mfma = false;
     if (k == 1) split_prepass_k<1>(st, q, nq, t, nt, index_base, s);
     else split_prepass_k<2>(st, q, nq, t, nt, index_base, s);
+}
+void topk_split_use_train(void* h, const void* hm_train) {
+    APDS_REQUIRE(h, APDS_ERR_BAD_ARG, "null scan state");
+    static_cast<TopkSplitState*>(h)->shared_train = static_cast<const HmTrain*>(hm_train);
 }
 void topk_split_scan(void* h, const void* q, const void* t, hipStream_t s) {
     APDS_REQUIRE(h, APDS_ERR_BAD_ARG, "null scan state");
     TopkSplitState& st = *static_cast<TopkSplitState*>(h);
     APDS_REQUIRE(st.nq > 0, APDS_ERR_ASSERT, "scan before pre-pass");
+    if (st.mfma) {
+        split_scan_mfma(st, s);
+        return;
+    }
     if (st.k == 1) split_scan_k<1>(st, q, t, s);
     else split_scan_k<2>(st, q, t, s);
 }
@@ -1092,6 +1167,11 @@ void topk_split_merge(void* h, uint32_t index_base, uint64_t* out, hipStream_t s
     APDS_REQUIRE(h && out, APDS_ERR_BAD_ARG, "null scan state / output");
     TopkSplitState& st = *static_cast<TopkSplitState*>(h);
     APDS_REQUIRE(st.nq > 0, APDS_ERR_ASSERT, "merge before pre-pass");
+    if (st.mfma) {
+        APDS_REQUIRE(index_base == st.index_base_mfma, APDS_ERR_ASSERT, "the merge's index base differs from the pre-pass's");
+        split_merge_mfma(st, out, s);
+        return;
+    }
     if (st.k == 1) split_merge_k<1>(st, index_base, out, s);
     else split_merge_k<2>(st, index_base, out, s);
 }

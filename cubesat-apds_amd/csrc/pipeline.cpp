@@ -103,6 +103,7 @@ struct Pipeline {
     apds_pipeline_params p{};
     int device = 0;
     const void* db_rows = nullptr;
+    void* db_expanded = nullptr;   // the train rows as matrix-core operands (hm_train_create), made once: the DB is resident for the pipeline's life
     int64_t n_rows = 0;
     uint32_t index_base = 0;
     void* shard = nullptr;
@@ -445,6 +446,8 @@ void destroy_pipeline(Pipeline* P) {
         if (s->topk_state) topk_split_destroy(s->topk_state);
         if (s->shard_slot && P->shard) (void)apds_shard_slot_destroy(P->shard, s->shard_slot);
     }
+    if (P->db_expanded) hm_train_destroy(P->db_expanded);
+    P->db_expanded = nullptr;
     if (!P->own_match_stream) P->st_match = nullptr;
     for (hipStream_t st : {P->st_match, P->st_pre, P->st_merge, P->st_homography, P->st_gather, P->st_counts})
         if (st) (void)hipStreamDestroy(st);
@@ -497,7 +500,8 @@ int apds_pipeline_create(void** pipe, const void* db_rows64_dev, int64_t n_rows,
         P->E = std::max(1, std::min(8, in.extract_workers > 0 ? in.extract_workers : cfg.pipe_extract_workers));
         const int n_slots = std::max(in.n_slots > 0 ? in.n_slots : 6, 2 * P->E);
         P->split = P->world == 1 && !shard && cfg.pipe_match_split != 0;
-        P->adaptive_cap = cfg.pipe_adaptive_cap != 0 && P->split && in.match_lds_cap == 0;
+        // (the starvation watch caps hamming_topk_kernel's occupancy: the matrix-core matcher has no such knob and is not watched)
+        P->adaptive_cap = cfg.pipe_adaptive_cap != 0 && P->split && in.match_lds_cap == 0 && !cfg.match_mfma;
         P->extract_delay_s = in.debug_extract_delay_ms > 0 ? in.debug_extract_delay_ms * 1e-3 : 0.0;
         if (P->p.reproj_threshold <= 0) P->p.reproj_threshold = 3.0;
         if (P->p.max_iters <= 0) P->p.max_iters = 2000;
@@ -517,6 +521,7 @@ int apds_pipeline_create(void** pipe, const void* db_rows64_dev, int64_t n_rows,
             HIP_CHECK(hipStreamCreateWithPriority(&P->st_gather, hipStreamNonBlocking, hp));
             HIP_CHECK(hipStreamCreateWithPriority(&P->st_counts, hipStreamNonBlocking, hp));
         }
+        if (P->split && cfg.match_mfma) P->db_expanded = hm_train_create(P->db_rows, P->n_rows, P->st_match);
         const size_t cap = (size_t)P->cap;
         for (int i = 0; i < n_slots; i++) {
             auto s = std::make_unique<Slot>();
@@ -531,7 +536,10 @@ int apds_pipeline_create(void** pipe, const void* db_rows64_dev, int64_t n_rows,
             for (hipEvent_t* ev : {&s->ev_extract, &s->ev_pre, &s->ev_scan, &s->ev_match}) HIP_CHECK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
             HIP_CHECK(hipEventCreate(&s->ev_mstart));
             HIP_CHECK(hipEventCreate(&s->ev_mend));
-            if (P->split) s->topk_state = topk_split_create();
+            if (P->split) {
+                s->topk_state = topk_split_create();
+                if (P->db_expanded) topk_split_use_train(s->topk_state, P->db_expanded);
+            }
             if (shard) {
                 const int rc = apds_shard_slot_create(shard, P->cap, 2, &s->shard_slot);
                 if (rc != APDS_OK) fail(rc, apds_last_error());

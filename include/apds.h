@@ -374,6 +374,10 @@ int apds_dev_match_lds_cap(int bytes, int* previous);
 /* Test hook: the dynamic-LDS request of the most recent scan launch of the process (-1 before the first); equals the cap in force for
  * every kernel variant (all tile widths, all k, persistent grid). */
 int apds_dev_match_last_launch_lds(int* bytes);
+/* Which kernel serves k <= 2 (everything lib.rs:94-126 consumes): *matrix_cores = 1: hamming_mfma_kernel - bits as FP4 (e2m1) operands of
+ * v_mfma_scale_f32_16x16x128_f8f6f4, exact integer distances (default); 0: hamming_topk_kernel, xor + popcount on the vector ALU
+ * (APDS_MATCH_MFMA=0; also what serves every k > 2). The keys are the same bit for bit. */
+int apds_dev_match_backend(int* matrix_cores);
 /* Lowe ratio filter on merged keys (k >= 2): writes compacted matches in query order, count to *n_matches (host). */
 int apds_dev_ratio_filter(const void* keys, int n_query, int k, float filter_strength, void* out_matches, int* n_matches, void* stream);
 /* Cross-check: given for every train row its best query key (from apds_dev_hamming_topk with roles swapped, k=1),

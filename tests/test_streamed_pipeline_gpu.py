@@ -4,6 +4,10 @@ what the one-frame-at-a-time FramePipeline gives; and its starvation watch must 
 artificially late. (tests/cpp/pipeline_test.cpp drives the same four calls from a g++-built host.)"""
 import ctypes as C
 
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 
@@ -81,6 +85,16 @@ def test_streamed_pipeline_with_frames_that_find_nothing(gpu_pkg):
 
 
 def test_starvation_watch_caps_the_match_kernel(gpu_pkg):
+    """The watch belongs to the vector-ALU matcher (its occupancy cap is an LDS request of hamming_topk_kernel); the matrix-core matcher
+    (the default, APDS_MATCH_MFMA=1) has no such knob and the pipeline does not watch it. The switch is read once per process, so under the
+    default this test runs itself again in a child process with APDS_MATCH_MFMA=0."""
+    if os.environ.get("APDS_MATCH_MFMA", "1") != "0":
+        env = dict(os.environ, APDS_MATCH_MFMA="0")
+        r = subprocess.run([sys.executable, "-m", "pytest", __file__ + "::test_starvation_watch_caps_the_match_kernel", "-q", "-m", "gpu", "-x", "-p",
+                            "no:cacheprovider"], env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-3000:], r.stderr[-1000:])
+        return
     pl, frames, db, db_xy = _setup(gpu_pkg)
     L, check = gpu_pkg.lib(), gpu_pkg._lib.check
     streamed = pl.StreamedFramePipeline(db, db_xy)

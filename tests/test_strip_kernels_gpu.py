@@ -72,3 +72,15 @@ def test_akaze_parity_with_the_value_fork(gpu_pkg):
     separate kernels take the one-thread fallback)."""
     _rerun({"APDS_FLAG_FORK": "1"})
     _rerun({"APDS_FLAG_FORK": "1", "APDS_LEVEL_FUSE": "0", "APDS_LEVEL_STRIP": "0", "APDS_LEVEL_STREAM": "0"})
+
+
+def test_match_parity_on_the_vector_alu_matcher(gpu_pkg):
+    """APDS_MATCH_MFMA=0: hamming_topk_kernel (xor + popcount on the vector ALU) serves k <= 2 as well - the default sends those to the FP4
+    matrix pipe (hamming_mfma.hip). Both must reproduce the oracle's keys: the match tests, the matcher fuzz, the sharded matcher and the
+    keypoint table's match run again in a child process on the vector kernel."""
+    env = dict(os.environ, APDS_MATCH_MFMA="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join("tests", "test_match_gpu.py"), os.path.join("tests", "test_fuzz_gpu.py") + "::test_match_random_shapes",
+                        os.path.join("tests", "test_shard_native.py"), os.path.join("tests", "test_keypoint_table_gpu.py"), "-q", "-m", "gpu", "-x", "-p",
+                        "no:cacheprovider"], env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-1000:])
+    assert " passed" in r.stdout and "failed" not in r.stdout
