@@ -33,6 +33,11 @@ static constexpr int HM_Q = 8 * 16 * HM_NC;   // queries per block (8 waves)
 static constexpr int HM_PITCH = 272;          // bytes per staged train row (256 + 16)
 static constexpr int HM_UNIT_SCALE = 0x7F7F7F7F;   // E8M0 127 = 2^0 in every byte
 static constexpr uint64_t HM_EMPTY = ~0ull;
+// Train popcounts are stored with this bias: the ranking value popcount(t) + 1024 - 2 (t AND q) is then a POSITIVE float (>= 512), and
+// positive floats order like their bit patterns - the epilogue compares them as unsigned integers (v_min3_u32 / v_min_u32 / v_cmp_lt_u32:
+// no NaN canonicalisation in front of every float minimum, six v_max_f32 less per 16 x 48 block of pairs). +inf (rows past the end) is
+// 0x7F800000: above every finite value, below the empty marker 0xFFFFFFFF.
+static constexpr int HM_BIAS = 1024;
 
 // 8 bits -> 8 nibbles holding `nib` where the bit is set
 __device__ __forceinline__ uint32_t hm_spread8(uint32_t b, uint32_t nib) {
@@ -43,8 +48,8 @@ __device__ __forceinline__ uint32_t hm_spread8(uint32_t b, uint32_t nib) {
     return t * nib;
 }
 
-// rows: n x 16 dwords. out: n x 16 uint4 (dword d of a row -> uint4 d). pc: popcount of each row. One thread per dword.
-__global__ __launch_bounds__(256) void hm_expand_rows_kernel(const uint32_t* __restrict__ rows, long long n, uint32_t nib, uint4* __restrict__ out,
+// rows: n x 16 dwords. out: n x 16 uint4 (dword d of a row -> uint4 d). pc: popcount of each row + bias. One thread per dword.
+__global__ __launch_bounds__(256) void hm_expand_rows_kernel(const uint32_t* __restrict__ rows, long long n, uint32_t nib, int bias, uint4* __restrict__ out,
                                                              float* __restrict__ pc) {
     APDS_RAISE_WAVE_PRIORITY();
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -54,14 +59,14 @@ __global__ __launch_bounds__(256) void hm_expand_rows_kernel(const uint32_t* __r
     for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);   // the 16 lanes of a row are aligned: 256 threads = 16 rows
     if (i >= n * 16) return;
     out[i] = make_uint4(hm_spread8(d, nib), hm_spread8(d >> 8, nib), hm_spread8(d >> 16, nib), hm_spread8(d >> 24, nib));
-    if ((threadIdx.x & 15) == 0) pc[i >> 4] = (float)v;
+    if ((threadIdx.x & 15) == 0) pc[i >> 4] = (float)(v + bias);
 }
 
 struct HmTop2 {
-    float d0, d1;
+    uint32_t d0, d1;   // bit patterns of the (positive) ranking values
     uint32_t i0, i1;
 };
-__device__ __forceinline__ void hm_insert(HmTop2& b, float d, uint32_t idx) {   // rows arrive in ascending order: strict '<' keeps the lower row of a tie
+__device__ __forceinline__ void hm_insert(HmTop2& b, uint32_t d, uint32_t idx) {   // rows arrive in ascending order: strict '<' keeps the lower row of a tie
     if (d < b.d1) {
         if (d < b.d0) {
             b.d1 = b.d0;
@@ -78,15 +83,16 @@ __device__ __forceinline__ void hm_insert(HmTop2& b, float d, uint32_t idx) {   
 // out[split][nq][2]: keys (distance << 32 | row + index_base), EMPTY where the split holds fewer than two rows
 __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
                                                            const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
-                                                           uint32_t index_base, uint64_t* __restrict__ out) {
+                                                           int q_tiles, int splits, uint32_t index_base, uint64_t* __restrict__ out) {
     APDS_RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(128))) unsigned char hm_lds[];
     auto tile_lds = [&](int buf) { return hm_lds + buf * (HM_TM * HM_PITCH); };
     auto norm_lds = [&](int buf) { return reinterpret_cast<float*>(hm_lds + 2 * HM_TM * HM_PITCH) + buf * HM_TM; };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * HM_Q + wave * 16 * HM_NC;         // this wave's queries
+    const int split = blockIdx.x / q_tiles, qtile = blockIdx.x % q_tiles;   // (consecutive workgroups: the query tiles of one split)
+    const int q0 = qtile * HM_Q + wave * 16 * HM_NC;              // this wave's queries
     const int n_tiles = (n_train + HM_TM - 1) / HM_TM;
-    const int tile_begin = blockIdx.y * tiles_per_split, tile_end = min(n_tiles, tile_begin + tiles_per_split);
+    const int tile_begin = split * tiles_per_split, tile_end = min(n_tiles, tile_begin + tiles_per_split);
     const int col = lane & 15, kq = lane >> 4;                     // accumulator column / k chunk (operands) / row group (accumulators)
 
     // B operands: query (q0 + 16 c + col), elements 128 s + 32 kq .. + 31 (dword 4 s + kq of the row), for the four k steps s
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restri
     HmTop2 best[HM_NC];
 #pragma unroll
     for (int c = 0; c < HM_NC; c++) {
-        best[c].d0 = best[c].d1 = INFINITY;
+        best[c].d0 = best[c].d1 = 0x7F800000u;   // +inf
         best[c].i0 = best[c].i1 = 0xFFFFFFFFu;
     }
 
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restri
                 bool any_hit = false;
 #pragma unroll
                 for (int c = 0; c < HM_NC; c++) {
-                    const float mn = fminf(fminf(acc[c][0], acc[c][1]), fminf(acc[c][2], acc[c][3]));
+                    const uint32_t mn = min(min(__float_as_uint(acc[c][0]), __float_as_uint(acc[c][1])), min(__float_as_uint(acc[c][2]), __float_as_uint(acc[c][3])));
                     any_hit |= mn < best[c].d1;
                 }
                 if (__any(any_hit)) {
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restri
 #pragma unroll
                     for (int c = 0; c < HM_NC; c++)
 #pragma unroll
-                        for (int j = 0; j < 4; j++) hm_insert(best[c], acc[c][j], row0 + j);
+                        for (int j = 0; j < 4; j++) hm_insert(best[c], __float_as_uint(acc[c][j]), row0 + j);
                 }
             }
             if (more) commit(buf ^ 1);
@@ -183,10 +189,10 @@ __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restri
         HmTop2 b = best[c];
 #pragma unroll
         for (int off = 16; off < 64; off <<= 1) {
-            const float od0 = __shfl_xor(b.d0, off), od1 = __shfl_xor(b.d1, off);
+            const uint32_t od0 = (uint32_t)__shfl_xor((int)b.d0, off), od1 = (uint32_t)__shfl_xor((int)b.d1, off);
             const uint32_t oi0 = (uint32_t)__shfl_xor((int)b.i0, off), oi1 = (uint32_t)__shfl_xor((int)b.i1, off);
             HmTop2 m = b;   // merge two sorted pairs; equal values: lower row first
-            auto ins = [&](float d, uint32_t i) {
+            auto ins = [&](uint32_t d, uint32_t i) {
                 if (i == 0xFFFFFFFFu) return;
                 if (d < m.d0 || (d == m.d0 && i < m.i0)) {
                     m.d1 = m.d0;
@@ -204,9 +210,9 @@ __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restri
         }
         const int qi = q0 + 16 * c + col;
         if (kq == 0 && qi < nq) {
-            uint64_t* o = out + ((size_t)blockIdx.y * nq + qi) * 2;
-            o[0] = b.i0 == 0xFFFFFFFFu ? HM_EMPTY : ((uint64_t)(uint32_t)(int)(qq[c] + b.d0) << 32) | b.i0;
-            o[1] = b.i1 == 0xFFFFFFFFu ? HM_EMPTY : ((uint64_t)(uint32_t)(int)(qq[c] + b.d1) << 32) | b.i1;
+            uint64_t* o = out + ((size_t)split * nq + qi) * 2;
+            o[0] = b.i0 == 0xFFFFFFFFu ? HM_EMPTY : ((uint64_t)(uint32_t)((int)(qq[c] + __uint_as_float(b.d0)) - HM_BIAS) << 32) | b.i0;
+            o[1] = b.i1 == 0xFFFFFFFFu ? HM_EMPTY : ((uint64_t)(uint32_t)((int)(qq[c] + __uint_as_float(b.d1)) - HM_BIAS) << 32) | b.i1;
         }
     }
 }
@@ -215,8 +221,22 @@ HmPlan hm_plan(int nq, long long nt) {
     HmPlan p;
     p.q_tiles = ceil_div(nq, HM_Q);
     const int t_tiles = (int)ceil_div(nt, (long long)HM_TM);
-    // two blocks fit a CU (LDS): splits of the train rows fill the 512 slots when the queries alone do not
-    p.splits = std::max(1, std::min(t_tiles, (256 * 2) / p.q_tiles));
+    constexpr int SLOTS = 256 * 2;   // two workgroups fit a CU (LDS, registers)
+    constexpr int OVERHEAD = 4;      // a workgroup's prologue and epilogue (operand loads, pipeline fill, key output) in tile times
+    // Splits of the train rows: they fill the slots when the query tiles alone do not, and they set the granularity of the last round of
+    // workgroups (92 query tiles x 5 splits = 460 workgroups leave a tenth of the chip idle for the whole launch; x 11 = 1012 fill two
+    // rounds to 99 %). The count that minimises rounds x (tiles per split + overhead); the split lists (16 bytes per query and split) stay
+    // below 256 MB. Measured and dropped: splits in multiples of eight pinned to the XCDs (the workgroups of an XCD then share every train
+    // tile through their L2) - no faster on any shape, slower where the fill got worse (profiles/r04/match_mfma_probe.txt): the kernel
+    // does not wait for its tile loads.
+    const int max_splits = (int)std::max<long long>(1, std::min<long long>(std::min(t_tiles, 128), (16ll << 20) / std::max(nq, 1)));
+    long long best_cost = -1;
+    p.splits = 1;
+    for (int sp = 1; sp <= max_splits; sp++) {
+        const long long rounds = ceil_div((long long)p.q_tiles * sp, (long long)SLOTS);
+        const long long cost = rounds * (ceil_div(t_tiles, sp) + OVERHEAD);
+        if (best_cost < 0 || cost < best_cost) best_cost = cost, p.splits = sp;
+    }
     p.tiles_per_split = ceil_div(t_tiles, p.splits);
     p.splits = ceil_div(t_tiles, p.tiles_per_split);
     return p;
@@ -225,7 +245,7 @@ HmPlan hm_plan(int nq, long long nt) {
 void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4, float* pc, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(hm_expand_rows_kernel, dim3((unsigned)ceil_div(n * 16, 256)), dim3(256), 0, s, static_cast<const uint32_t*>(rows64), n, query ? 0xCu : 0x2u,
-                       static_cast<uint4*>(out_fp4), pc);
+                       query ? 0 : HM_BIAS, static_cast<uint4*>(out_fp4), pc);
 }
 
 // parts: [p.splits][nq][2] keys
@@ -238,8 +258,8 @@ void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_f
         opted.store(true);
     }
     KernelTimer timer("hamming_topk", s);   // (the name the pipeline's counters and bench.py know the main match kernel by)
-    hipLaunchKernelGGL(hamming_mfma_kernel, dim3(p.q_tiles, p.splits), dim3(512), lds, s, static_cast<const uint4*>(t_fp4), tpc, (int)nt,
-                       static_cast<const uint4*>(q_fp4), qpc, nq, p.tiles_per_split, index_base, parts);
+    hipLaunchKernelGGL(hamming_mfma_kernel, dim3((unsigned)p.q_tiles * p.splits), dim3(512), lds, s, static_cast<const uint4*>(t_fp4), tpc, (int)nt,
+                       static_cast<const uint4*>(q_fp4), qpc, nq, p.tiles_per_split, p.q_tiles, p.splits, index_base, parts);
 }
 
 // A train set expanded once (resident databases: the pipeline's, a shard's): rows + popcounts in memory of their own.
