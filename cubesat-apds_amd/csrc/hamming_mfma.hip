@@ -15,8 +15,10 @@
 //                           any order would do as long as both operands use the same one) + popcount per row as a float
 //   hamming_mfma_kernel     the structure of l2_screen_kernel (same tile shapes: there K = 128 bf16 elements are 256 bytes, here K = 512
 //                           fp4 elements are): block = 8 waves x 48 queries held as B operands in registers for the whole kernel,
-//                           128-row train tiles double-buffered in LDS (pitch 272 B: conflict-free ds_read_b128), each A read feeds three
-//                           MFMAs, running top-2 per query column in the lanes, insertion code only when some lane has a hit.
+//                           128-row train tiles double-buffered in LDS, filled by LDS-DMA (global_load_lds_dwordx4: no staging registers,
+//                           no ds_write) into an XOR-swizzled image (conflict-free ds_read_b128), each A read feeds three MFMAs, running
+//                           top-2 per query column in the lanes, a block's values ranked while the next block's MFMAs run, insertion
+//                           code only when some lane has a hit.
 #include <atomic>
 
 #include "config.h"
@@ -30,7 +32,6 @@ typedef float hm_f32x4 __attribute__((ext_vector_type(4)));
 static constexpr int HM_TM = 128;             // train rows per tile
 static constexpr int HM_NC = 3;               // 16-query column blocks per wave
 static constexpr int HM_Q = 8 * 16 * HM_NC;   // queries per block (8 waves)
-static constexpr int HM_PITCH = 272;          // bytes per staged train row (256 + 16)
 static constexpr int HM_UNIT_SCALE = 0x7F7F7F7F;   // E8M0 127 = 2^0 in every byte
 static constexpr uint64_t HM_EMPTY = ~0ull;
 // Train popcounts are stored with this bias: the ranking value popcount(t) + 1024 - 2 (t AND q) is then a POSITIVE float (>= 512), and
@@ -62,6 +63,12 @@ __global__ __launch_bounds__(256) void hm_expand_rows_kernel(const uint32_t* __r
     if ((threadIdx.x & 15) == 0) pc[i >> 4] = (float)(v + bias);
 }
 
+// popcounts of the rows past the end of the last tile: +inf
+__global__ void hm_pad_pc_kernel(float* __restrict__ pc, long long n, long long n_pad) {
+    const long long i = n + threadIdx.x;
+    if (i < n_pad) pc[i] = INFINITY;
+}
+
 struct HmTop2 {
     uint32_t d0, d1;   // bit patterns of the (positive) ranking values
     uint32_t i0, i1;
@@ -80,14 +87,17 @@ __device__ __forceinline__ void hm_insert(HmTop2& b, uint32_t d, uint32_t idx) {
     }
 }
 
-// out[split][nq][2]: keys (distance << 32 | row + index_base), EMPTY where the split holds fewer than two rows
+// out[split][nq][2]: keys (distance << 32 | row + index_base), EMPTY where the split holds fewer than two rows.
+// LDS image of a tile (no padding: the tile is filled by LDS-DMA, whose destination is wave-uniform base + 16 * lane): row r at 256 r, and
+// its 16-byte chunk c at position c ^ (r & 15) - the 16 rows a ds_read_b128 group reads chunk c of then sit in 16 different bank groups.
+// The DMA's per-lane SOURCE address applies the same involution, so the image is a plain lane-linear copy for the hardware.
+// tpc is padded to whole tiles with +inf (rows past the end never rank); their operand rows re-read the last row.
 __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
                                                            const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
                                                            int q_tiles, int splits, uint32_t index_base, uint64_t* __restrict__ out) {
     APDS_RAISE_WAVE_PRIORITY();
     extern __shared__ __attribute__((aligned(128))) unsigned char hm_lds[];
-    auto tile_lds = [&](int buf) { return hm_lds + buf * (HM_TM * HM_PITCH); };
-    auto norm_lds = [&](int buf) { return reinterpret_cast<float*>(hm_lds + 2 * HM_TM * HM_PITCH) + buf * HM_TM; };
+    constexpr int TILE_BYTES = HM_TM * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x / q_tiles, qtile = blockIdx.x % q_tiles;   // (consecutive workgroups: the query tiles of one split)
     const int q0 = qtile * HM_Q + wave * 16 * HM_NC;              // this wave's queries
@@ -113,75 +123,86 @@ __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restri
     }
 
     if (tile_begin < tile_end) {
-        // staging: the tile is 128 rows x 256 B = 2048 pieces of 16 B, four per thread; rows past the end re-read the last row and get a
-        // popcount of +inf, so they never rank
-        uint4 pre0, pre1, pre2, pre3;
-        float pre_norm = INFINITY;
-        const int pr = tid >> 4, pg = tid & 15;   // piece p of this thread: row 32 p + pr, 16-byte group pg
-        auto load_tile = [&](int tile) {
-            const int r0 = tile * HM_TM + pr;
-            pre0 = train_fp4[(size_t)min(r0, n_train - 1) * 16 + pg];
-            pre1 = train_fp4[(size_t)min(r0 + 32, n_train - 1) * 16 + pg];
-            pre2 = train_fp4[(size_t)min(r0 + 64, n_train - 1) * 16 + pg];
-            pre3 = train_fp4[(size_t)min(r0 + 96, n_train - 1) * 16 + pg];
-            if (tid < HM_TM) {
-                const int row = tile * HM_TM + tid;
-                pre_norm = row < n_train ? tpc[row] : INFINITY;
+        // staging by LDS-DMA: 32 pieces of 1 KB (4 rows) per tile, four per wave: wave w fills rows [16 w, 16 w + 16); + the popcounts
+        // (two pieces of 64 floats, waves 0 and 1)
+        const int sr = 16 * wave + (lane >> 4);                   // row of piece 0 (pieces i: + 4 i; (row & 15) = 4 i + (lane >> 4))
+        auto stage = [&](int tile, int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int r = sr + 4 * i;
+                const int chunk = (lane & 15) ^ (r & 15);
+                const uint4* src = train_fp4 + (size_t)min(tile * HM_TM + r, n_train - 1) * 16 + chunk;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(hm_lds + buf * TILE_BYTES + (16 * wave + 4 * i) * 256), 16, 0, 0);
+            }
+            if (wave < 2)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tpc + (size_t)tile * HM_TM + 64 * wave + lane),
+                                                 (__attribute__((address_space(3))) void*)(hm_lds + 2 * TILE_BYTES + buf * (HM_TM * 4) + 256 * wave), 4, 0, 0);
+        };
+        // this lane's four A reads of a 16-row block: row (16 rb + col), chunk 4 s + kq at position (4 s + kq) ^ col
+        int aoff[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) aoff[s] = col * 256 + (((4 * s + kq) ^ col) << 4);
+        const int noff = 2 * TILE_BYTES + 16 * kq;                // popcounts of rows 4 kq .. + 3 of a block
+
+        hm_f32x4 acc[HM_NC], prev[HM_NC];   // prev: the block before (+inf in front of the first one: it ranks nothing)
+#pragma unroll
+        for (int c = 0; c < HM_NC; c++) prev[c] = hm_f32x4{INFINITY, INFINITY, INFINITY, INFINITY};
+        uint32_t prev_row0 = 0;
+        auto rank = [&](const hm_f32x4 (&a)[HM_NC], uint32_t row0) {   // the 16 x 48 ranking values of one block against the running top-2
+            bool any_hit = false;
+#pragma unroll
+            for (int c = 0; c < HM_NC; c++) {
+                const uint32_t mn = min(min(__float_as_uint(a[c][0]), __float_as_uint(a[c][1])), min(__float_as_uint(a[c][2]), __float_as_uint(a[c][3])));
+                any_hit |= mn < best[c].d1;
+            }
+            if (__any(any_hit)) {
+#pragma unroll
+                for (int c = 0; c < HM_NC; c++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) hm_insert(best[c], __float_as_uint(a[c][j]), row0 + j);
             }
         };
-        auto commit = [&](int buf) {
-            unsigned char* d = tile_lds(buf) + pr * HM_PITCH + 16 * pg;
-            *reinterpret_cast<uint4*>(d) = pre0;
-            *reinterpret_cast<uint4*>(d + 32 * HM_PITCH) = pre1;
-            *reinterpret_cast<uint4*>(d + 64 * HM_PITCH) = pre2;
-            *reinterpret_cast<uint4*>(d + 96 * HM_PITCH) = pre3;
-            if (tid < HM_TM) norm_lds(buf)[tid] = pre_norm;
-        };
-        load_tile(tile_begin);
-        commit(0);
-        __syncthreads();
 
+        stage(tile_begin, 0);
+        __syncthreads();   // (drains the DMA: vmcnt(0) in front of the barrier)
         for (int tile = tile_begin; tile < tile_end; tile++) {
             const int buf = (tile - tile_begin) & 1;
-            const bool more = tile + 1 < tile_end;
-            if (more) load_tile(tile + 1);
-            const unsigned char* T = tile_lds(buf);
-            const float* Nn = norm_lds(buf);
-#pragma unroll 2
+            if (tile + 1 < tile_end) stage(tile + 1, buf ^ 1);     // lands while this tile is computed; the closing barrier waits for it
+            const unsigned char* T = hm_lds + buf * TILE_BYTES;
+            const unsigned char* Nn = hm_lds + noff + buf * (HM_TM * 4);
+#pragma unroll
             for (int rb = 0; rb < 8; rb++) {                           // 16-row blocks of the tile
-                const hm_f32x4 init = *reinterpret_cast<const hm_f32x4*>(Nn + rb * 16 + 4 * kq);   // popcount of this lane's four rows
-                hm_f32x4 acc[HM_NC];
+                const hm_f32x4 init = *reinterpret_cast<const hm_f32x4*>(Nn + rb * 64);   // biased popcounts of this lane's four rows
+                uint4 a[4];
 #pragma unroll
-                for (int c = 0; c < HM_NC; c++) acc[c] = init;
-                const unsigned char* arow = T + (rb * 16 + col) * HM_PITCH + 16 * kq;
+                for (int s = 0; s < 4; s++) a[s] = *reinterpret_cast<const uint4*>(T + rb * 4096 + aoff[s]);
+                auto steps = [&](int s_lo, int s_hi) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    const uint4 a = *reinterpret_cast<const uint4*>(arow + 64 * s);
-                    const hm_v8i A = {(int)a.x, (int)a.y, (int)a.z, (int)a.w, 0, 0, 0, 0};
+                    for (int s = s_lo; s < s_hi; s++) {
+                        const hm_v8i A = {(int)a[s].x, (int)a[s].y, (int)a[s].z, (int)a[s].w, 0, 0, 0, 0};
 #pragma unroll
-                    for (int c = 0; c < HM_NC; c++) {
-                        const hm_v8i Bv = {(int)B[c][s].x, (int)B[c][s].y, (int)B[c][s].z, (int)B[c][s].w, 0, 0, 0, 0};
-                        acc[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, Bv, acc[c], 4, 4, 0, HM_UNIT_SCALE, 0, HM_UNIT_SCALE);
+                        for (int c = 0; c < HM_NC; c++) {
+                            const hm_v8i Bv = {(int)B[c][s].x, (int)B[c][s].y, (int)B[c][s].z, (int)B[c][s].w, 0, 0, 0, 0};
+                            acc[c] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A, Bv, s == 0 ? init : acc[c], 4, 4, 0, HM_UNIT_SCALE, 0, HM_UNIT_SCALE);
+                        }
                     }
-                }
-                // acc = hamming - popcount(query) for rows 4 kq + j of the block, query column `col` of each of the wave's query blocks
-                bool any_hit = false;
+                };
+                // The PREVIOUS block's values are ranked between this block's two halves of MFMAs: six MFMAs are queued in the matrix pipe
+                // when the vector ALU starts on values that were finished a block ago - no wait states between the two pipes, and the
+                // ranking's issue slots fall into the MFMAs' shadow. (The ranking ends in a branch, so the scheduler cannot move the
+                // second half above it; the barrier keeps it from moving the ranking above the first half.)
+                steps(0, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                rank(prev, prev_row0);
+                steps(2, 4);
 #pragma unroll
-                for (int c = 0; c < HM_NC; c++) {
-                    const uint32_t mn = min(min(__float_as_uint(acc[c][0]), __float_as_uint(acc[c][1])), min(__float_as_uint(acc[c][2]), __float_as_uint(acc[c][3])));
-                    any_hit |= mn < best[c].d1;
-                }
-                if (__any(any_hit)) {
-                    const uint32_t row0 = (uint32_t)(tile * HM_TM + rb * 16 + 4 * kq) + index_base;
-#pragma unroll
-                    for (int c = 0; c < HM_NC; c++)
-#pragma unroll
-                        for (int j = 0; j < 4; j++) hm_insert(best[c], __float_as_uint(acc[c][j]), row0 + j);
-                }
+                for (int c = 0; c < HM_NC; c++) prev[c] = acc[c];
+                prev_row0 = (uint32_t)(tile * HM_TM + rb * 16 + 4 * kq) + index_base;
             }
-            if (more) commit(buf ^ 1);
-            __syncthreads();   // the next tile is staged; everybody is done with this one
+            __syncthreads();   // the next tile has landed; everybody is done with this one
         }
+        rank(prev, prev_row0);
     }
     // a query column lives in four lanes (kq = 0..3, different rows): fold them with shuffles, lanes 0..15 write
 #pragma unroll
@@ -246,12 +267,14 @@ void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4
     if (n <= 0) return;
     hipLaunchKernelGGL(hm_expand_rows_kernel, dim3((unsigned)ceil_div(n * 16, 256)), dim3(256), 0, s, static_cast<const uint32_t*>(rows64), n, query ? 0xCu : 0x2u,
                        query ? 0 : HM_BIAS, static_cast<uint4*>(out_fp4), pc);
+    if (!query && hm_padded_rows(n) > n) hipLaunchKernelGGL(hm_pad_pc_kernel, dim3(1), dim3(HM_TM), 0, s, pc, n, hm_padded_rows(n));
 }
+long long hm_padded_rows(long long n) { return ceil_div(n, (long long)HM_TM) * HM_TM; }
 
 // parts: [p.splits][nq][2] keys
 void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_fp4, const float* tpc, long long nt, const HmPlan& p, uint32_t index_base,
                     uint64_t* parts, hipStream_t s) {
-    const size_t lds = (size_t)2 * HM_TM * HM_PITCH + 2 * HM_TM * sizeof(float);
+    const size_t lds = (size_t)2 * HM_TM * 256 + 2 * HM_TM * sizeof(float);
     static std::atomic<bool> opted{false};   // above the default dynamic-LDS limit: opt in once (idempotent, so a race is harmless)
     if (!opted.load()) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -269,7 +292,7 @@ void* hm_train_create(const void* rows64, long long n, hipStream_t s) {
     t->device = ctx().device;
     t->src = rows64;
     t->n = n;
-    if (hipMalloc(&t->rows, (size_t)n * 256) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&t->pc), (size_t)n * 4) != hipSuccess) {
+    if (hipMalloc(&t->rows, (size_t)n * 256) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&t->pc), (size_t)hm_padded_rows(n) * 4) != hipSuccess) {
         (void)hipGetLastError();
         if (t->rows) (void)hipFree(t->rows);
         delete t;
@@ -300,7 +323,7 @@ void hamming_mfma_topk_device(const void* q, int nq, const void* t, long long nt
     void* q4 = c.alloc((size_t)nq * 256);
     float* qp = c.alloc_n<float>(nq);
     void* t4 = c.alloc((size_t)nt * 256);
-    float* tp = c.alloc_n<float>(nt);
+    float* tp = c.alloc_n<float>(hm_padded_rows(nt));
     {
         KernelTimer timer("hamming_topk_sample", s);   // (the counters' name for what runs in front of the main match kernel)
         hm_expand_device(q, nq, true, q4, qp, s);

@@ -1040,7 +1040,7 @@ static void split_prepass_mfma(TopkSplitState& st, const void* q, int nq, const 
     st.off_top2 = take((size_t)nq * 16);
     if (!shared) {
         st.off_t4 = take((size_t)nt * 256);
-        st.off_tp = take((size_t)nt * 4);
+        st.off_tp = take((size_t)hm_padded_rows(nt) * 4);
     }
     split_reserve(st, need);
     KernelTimer timer("hamming_topk_sample", s);
