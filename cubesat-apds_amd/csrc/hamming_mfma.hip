@@ -17,8 +17,10 @@
 //                           fp4 elements are): block = 8 waves x 48 queries held as B operands in registers for the whole kernel,
 //                           128-row train tiles double-buffered in LDS, filled by LDS-DMA (global_load_lds_dwordx4: no staging registers,
 //                           no ds_write) into an XOR-swizzled image (conflict-free ds_read_b128), each A read feeds three MFMAs, running
-//                           top-2 per query column in the lanes, a block's values ranked while the next block's MFMAs run, insertion
-//                           code only when some lane has a hit.
+//                           top-2 per query column in the lanes, insertion code only when some lane has a hit. (Ranking a block's
+//                           values under the NEXT block's MFMAs was written twice - values carried over, ranking forced between the
+//                           MFMA halves - and both times the compiler put the twelve MFMAs of a block back together and ranked
+//                           behind them; the wait states that costs, s_nop 1 + five ds_reads, are filled by the SIMD's other waves.)
 #include <atomic>
 
 #include "config.h"
@@ -30,7 +32,11 @@ typedef int hm_v8i __attribute__((ext_vector_type(8)));
 typedef float hm_f32x4 __attribute__((ext_vector_type(4)));
 
 static constexpr int HM_TM = 128;             // train rows per tile
-static constexpr int HM_NC = 3;               // 16-query column blocks per wave
+#ifndef APDS_HM_NC
+#define APDS_HM_NC 3
+#endif
+static constexpr int HM_NC = APDS_HM_NC;      // 16-query column blocks per wave (4: 15 registers spill at four waves per SIMD; 7.0 against 5.9 ms on the
+                                              // headline shape, 11.0 against 11.9 on 262143^2: profiles/r04/match_mfma_probe.txt)
 static constexpr int HM_Q = 8 * 16 * HM_NC;   // queries per block (8 waves)
 static constexpr int HM_UNIT_SCALE = 0x7F7F7F7F;   // E8M0 127 = 2^0 in every byte
 static constexpr uint64_t HM_EMPTY = ~0ull;
@@ -92,7 +98,7 @@ __device__ __forceinline__ void hm_insert(HmTop2& b, uint32_t d, uint32_t idx) {
 // its 16-byte chunk c at position c ^ (r & 15) - the 16 rows a ds_read_b128 group reads chunk c of then sit in 16 different bank groups.
 // The DMA's per-lane SOURCE address applies the same involution, so the image is a plain lane-linear copy for the hardware.
 // tpc is padded to whole tiles with +inf (rows past the end never rank); their operand rows re-read the last row.
-__global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
                                                            const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
                                                            int q_tiles, int splits, uint32_t index_base, uint64_t* __restrict__ out) {
     APDS_RAISE_WAVE_PRIORITY();
@@ -145,10 +151,7 @@ __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restri
         for (int s = 0; s < 4; s++) aoff[s] = col * 256 + (((4 * s + kq) ^ col) << 4);
         const int noff = 2 * TILE_BYTES + 16 * kq;                // popcounts of rows 4 kq .. + 3 of a block
 
-        hm_f32x4 acc[HM_NC], prev[HM_NC];   // prev: the block before (+inf in front of the first one: it ranks nothing)
-#pragma unroll
-        for (int c = 0; c < HM_NC; c++) prev[c] = hm_f32x4{INFINITY, INFINITY, INFINITY, INFINITY};
-        uint32_t prev_row0 = 0;
+        hm_f32x4 acc[HM_NC];
         auto rank = [&](const hm_f32x4 (&a)[HM_NC], uint32_t row0) {   // the 16 x 48 ranking values of one block against the running top-2
             bool any_hit = false;
 #pragma unroll
@@ -188,21 +191,11 @@ __global__ __launch_bounds__(512) void hamming_mfma_kernel(const uint4* __restri
                         }
                     }
                 };
-                // The PREVIOUS block's values are ranked between this block's two halves of MFMAs: six MFMAs are queued in the matrix pipe
-                // when the vector ALU starts on values that were finished a block ago - no wait states between the two pipes, and the
-                // ranking's issue slots fall into the MFMAs' shadow. (The ranking ends in a branch, so the scheduler cannot move the
-                // second half above it; the barrier keeps it from moving the ranking above the first half.)
-                steps(0, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                rank(prev, prev_row0);
-                steps(2, 4);
-#pragma unroll
-                for (int c = 0; c < HM_NC; c++) prev[c] = acc[c];
-                prev_row0 = (uint32_t)(tile * HM_TM + rb * 16 + 4 * kq) + index_base;
+                steps(0, 4);
+                rank(acc, (uint32_t)(tile * HM_TM + rb * 16 + 4 * kq) + index_base);
             }
             __syncthreads();   // the next tile has landed; everybody is done with this one
         }
-        rank(prev, prev_row0);
     }
     // a query column lives in four lanes (kq = 0..3, different rows): fold them with shuffles, lanes 0..15 write
 #pragma unroll
