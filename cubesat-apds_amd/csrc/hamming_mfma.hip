@@ -101,7 +101,7 @@ __device__ __forceinline__ void hm_insert(HmTop2& b, uint32_t d, uint32_t idx) {
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
                                                            const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
                                                            int q_tiles, int splits, uint32_t index_base, uint64_t* __restrict__ out) {
-    APDS_RAISE_WAVE_PRIORITY();
+    // (no APDS_RAISE_WAVE_PRIORITY here: this is the kernel the short kernels of the other stages raise their priority against)
     extern __shared__ __attribute__((aligned(128))) unsigned char hm_lds[];
     constexpr int TILE_BYTES = HM_TM * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
