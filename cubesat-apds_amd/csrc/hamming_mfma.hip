@@ -105,7 +105,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     extern __shared__ __attribute__((aligned(128))) unsigned char hm_lds[];
     constexpr int TILE_BYTES = HM_TM * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int split = blockIdx.x / q_tiles, qtile = blockIdx.x % q_tiles;   // (consecutive workgroups: the query tiles of one split)
+    // Workgroup b runs on XCD b % 8 (round-robin dispatch) and every XCD has an L2 of its own. With a multiple of eight splits, split
+    // x + 8 m belongs to XCD x: the workgroups resident on an XCD at any time are consecutive query tiles of one split, start together and
+    // walk the same train tiles at about the same pace - one fetches a tile, the others find it in their L2.
+    int split, qtile;
+    if ((splits & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        split = xcd + 8 * (j / q_tiles);
+        qtile = j % q_tiles;
+    } else {
+        split = blockIdx.x / q_tiles;
+        qtile = blockIdx.x % q_tiles;
+    }
     const int q0 = qtile * HM_Q + wave * 16 * HM_NC;              // this wave's queries
     const int n_tiles = (n_train + HM_TM - 1) / HM_TM;
     const int tile_begin = split * tiles_per_split, tile_end = min(n_tiles, tile_begin + tiles_per_split);
@@ -240,9 +251,10 @@ HmPlan hm_plan(int nq, long long nt) {
     // Splits of the train rows: they fill the slots when the query tiles alone do not, and they set the granularity of the last round of
     // workgroups (92 query tiles x 5 splits = 460 workgroups leave a tenth of the chip idle for the whole launch; x 11 = 1012 fill two
     // rounds to 99 %). The count that minimises rounds x (tiles per split + overhead); the split lists (16 bytes per query and split) stay
-    // below 256 MB. Measured and dropped: splits in multiples of eight pinned to the XCDs (the workgroups of an XCD then share every train
-    // tile through their L2) - no faster on any shape, slower where the fill got worse (profiles/r04/match_mfma_probe.txt): the kernel
-    // does not wait for its tile loads.
+    // below 256 MB. APDS_MATCH_MFMA_XCD=1 (measured, off): splits in multiples of eight pinned to the XCDs - the workgroups of an XCD then
+    // share every train tile through their L2: 1.00 GB fetched per launch instead of 2.65 GB on the headline shape (the expanded DB is
+    // 0.25 GB), and 6.5 ms instead of 6.15: the kernel does not wait for its tile loads, and 16 splits fill the last round worse than 11
+    // (profiles/r04/mfma_xcd_ab.txt).
     const int max_splits = (int)std::max<long long>(1, std::min<long long>(std::min(t_tiles, 128), (16ll << 20) / std::max(nq, 1)));
     long long best_cost = -1;
     p.splits = 1;
@@ -250,6 +262,21 @@ HmPlan hm_plan(int nq, long long nt) {
         const long long rounds = ceil_div((long long)p.q_tiles * sp, (long long)SLOTS);
         const long long cost = rounds * (ceil_div(t_tiles, sp) + OVERHEAD);
         if (best_cost < 0 || cost < best_cost) best_cost = cost, p.splits = sp;
+    }
+    // a multiple of eight splits (pinned to the XCDs, see the kernel) when the model puts it within 5 % of the best count
+    if (config().match_mfma_xcd && t_tiles >= 64) {
+        long long best8 = -1;
+        int sp8 = 0;
+        for (int sp = 8; sp <= std::min(max_splits, 32); sp += 8) {
+            const long long rounds = ceil_div((long long)p.q_tiles * sp, (long long)SLOTS);
+            const long long cost = rounds * (ceil_div(t_tiles, sp) + OVERHEAD);
+            if (best8 < 0 || cost < best8) best8 = cost, sp8 = sp;
+        }
+        if (sp8 && best8 * 100 <= best_cost * 105) {
+            p.splits = sp8;
+            p.tiles_per_split = ceil_div(t_tiles, p.splits);   // (the count stays a multiple of eight: trailing splits may be empty)
+            return p;
+        }
     }
     p.tiles_per_split = ceil_div(t_tiles, p.splits);
     p.splits = ceil_div(t_tiles, p.tiles_per_split);
