@@ -470,8 +470,11 @@ def main():
         match_ops = 32.0 * Q_step * rows_main
         launches_per_step = topk_n / max(args.steps, 1)
         topk_ms_step = topk_ms / max(args.steps, 1)
+        mfma_backend = C.c_int(0)
+        check(L.apds_dev_match_backend(C.byref(mfma_backend)))
         peak = C.c_double(0)
-        check(L.apds_dev_valu_popcount_peak(C.byref(peak)))
+        if not mfma_backend.value:   # the xor + popcount ceiling of the vector-ALU matcher (a register-only microbenchmark: 4 x 32 ms)
+            check(L.apds_dev_valu_popcount_peak(C.byref(peak)))
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -492,8 +495,6 @@ def main():
         achieved_gbps = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if topk_n else 0.0
         achieved_tops = match_ops / max(launches_per_step, 1e-9) / (avg_launch_ms * 1e-3) / 1e12 if topk_n else 0.0
         ms_per_step = elapsed / args.steps * 1e3
-        mfma_backend = C.c_int(0)
-        check(L.apds_dev_match_backend(C.byref(mfma_backend)))
         if mfma_backend.value:
             # The matrix-core matcher (csrc/hamming_mfma.hip): ONE main launch per step over all rows (no threshold pre-pass; "hamming_topk_sample"
             # times the expansion of the frame's queries into FP4 operands - the DB's expanded copy is made once at apds_pipeline_create).
