@@ -69,10 +69,14 @@ __global__ __launch_bounds__(256) void hm_expand_rows_kernel(const uint32_t* __r
     if ((threadIdx.x & 15) == 0) pc[i >> 4] = (float)(v + bias);
 }
 
-// popcounts of the rows past the end of the last tile: +inf
-__global__ void hm_pad_pc_kernel(float* __restrict__ pc, long long n, long long n_pad) {
-    const long long i = n + threadIdx.x;
-    if (i < n_pad) pc[i] = INFINITY;
+// the rows past the end of the last tile: zero operands, popcount +inf (they never rank). One block of 128 threads x 16.
+__global__ void hm_pad_rows_kernel(uint4* __restrict__ rows, float* __restrict__ pc, long long n, long long n_pad) {
+    const long long i = n + (threadIdx.x >> 4);
+    if (i >= n_pad) return;
+    for (long long r = i; r < n_pad; r += 8) {
+        rows[r * 16 + (threadIdx.x & 15)] = make_uint4(0, 0, 0, 0);
+        if ((threadIdx.x & 15) == 0) pc[r] = INFINITY;
+    }
 }
 
 struct HmTop2 {
@@ -97,7 +101,7 @@ __device__ __forceinline__ void hm_insert(HmTop2& b, uint32_t d, uint32_t idx) {
 // LDS image of a tile (no padding: the tile is filled by LDS-DMA, whose destination is wave-uniform base + 16 * lane): row r at 256 r, and
 // its 16-byte chunk c at position c ^ (r & 15) - the 16 rows a ds_read_b128 group reads chunk c of then sit in 16 different bank groups.
 // The DMA's per-lane SOURCE address applies the same involution, so the image is a plain lane-linear copy for the hardware.
-// tpc is padded to whole tiles with +inf (rows past the end never rank); their operand rows re-read the last row.
+// Rows and popcounts are padded to whole tiles (zero operands, +inf: rows past the end never rank).
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
                                                            const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
                                                            int q_tiles, int splits, uint32_t index_base, uint64_t* __restrict__ out) {
@@ -142,16 +146,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (tile_begin < tile_end) {
         // staging by LDS-DMA: 32 pieces of 1 KB (4 rows) per tile, four per wave: wave w fills rows [16 w, 16 w + 16); + the popcounts
         // (two pieces of 64 floats, waves 0 and 1)
-        const int sr = 16 * wave + (lane >> 4);                   // row of piece 0 (pieces i: + 4 i; (row & 15) = 4 i + (lane >> 4))
-        auto stage = [&](int tile, int buf) {
+        // (the expanded rows are padded to whole tiles - zero rows with a popcount of +inf - so a piece's source is a uniform tile base plus a
+        // per-lane constant: scalar address arithmetic only)
+        int soff[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const int r = sr + 4 * i;
-                const int chunk = (lane & 15) ^ (r & 15);
-                const uint4* src = train_fp4 + (size_t)min(tile * HM_TM + r, n_train - 1) * 16 + chunk;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+        for (int i = 0; i < 4; i++) {
+            const int r = 16 * wave + 4 * i + (lane >> 4);
+            soff[i] = r * 256 + (((lane & 15) ^ (r & 15)) << 4);
+        }
+        auto stage = [&](int tile, int buf) {
+            const unsigned char* tbase = reinterpret_cast<const unsigned char*>(train_fp4) + (size_t)tile * TILE_BYTES;   // wave-uniform
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + soff[i]),
                                                  (__attribute__((address_space(3))) void*)(hm_lds + buf * TILE_BYTES + (16 * wave + 4 * i) * 256), 16, 0, 0);
-            }
             if (wave < 2)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tpc + (size_t)tile * HM_TM + 64 * wave + lane),
                                                  (__attribute__((address_space(3))) void*)(hm_lds + 2 * TILE_BYTES + buf * (HM_TM * 4) + 256 * wave), 4, 0, 0);
@@ -163,19 +171,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const int noff = 2 * TILE_BYTES + 16 * kq;                // popcounts of rows 4 kq .. + 3 of a block
 
         hm_f32x4 acc[HM_NC];
-        auto rank = [&](const hm_f32x4 (&a)[HM_NC], uint32_t row0) {   // the 16 x 48 ranking values of one block against the running top-2
-            bool any_hit = false;
+        // Ranking a block: one minimum and one compare per 16 x 16 accumulator in the common case. Only the query blocks in which some lane
+        // has a hit run insertion code (a wave-uniform branch each): the counters put the vector instructions beside the MFMAs at 1.9 per
+        // MFMA when any hit sent all three query blocks through the twelve insertions, and an MFMA leaves the SIMD's issue port free for
+        // only two of them.
+        auto rank = [&](const hm_f32x4 (&a)[HM_NC], uint32_t row0) {
+            bool hit[HM_NC];
 #pragma unroll
             for (int c = 0; c < HM_NC; c++) {
                 const uint32_t mn = min(min(__float_as_uint(a[c][0]), __float_as_uint(a[c][1])), min(__float_as_uint(a[c][2]), __float_as_uint(a[c][3])));
-                any_hit |= mn < best[c].d1;
+                hit[c] = mn < best[c].d1;
             }
-            if (__any(any_hit)) {
 #pragma unroll
-                for (int c = 0; c < HM_NC; c++)
+            for (int c = 0; c < HM_NC; c++)
+                if (__any(hit[c])) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) hm_insert(best[c], __float_as_uint(a[c][j]), row0 + j);
-            }
+                }
         };
 
         stage(tile_begin, 0);
@@ -287,7 +299,8 @@ void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4
     if (n <= 0) return;
     hipLaunchKernelGGL(hm_expand_rows_kernel, dim3((unsigned)ceil_div(n * 16, 256)), dim3(256), 0, s, static_cast<const uint32_t*>(rows64), n, query ? 0xCu : 0x2u,
                        query ? 0 : HM_BIAS, static_cast<uint4*>(out_fp4), pc);
-    if (!query && hm_padded_rows(n) > n) hipLaunchKernelGGL(hm_pad_pc_kernel, dim3(1), dim3(HM_TM), 0, s, pc, n, hm_padded_rows(n));
+    if (!query && hm_padded_rows(n) > n)
+        hipLaunchKernelGGL(hm_pad_rows_kernel, dim3(1), dim3(128), 0, s, static_cast<uint4*>(out_fp4), pc, n, hm_padded_rows(n));
 }
 long long hm_padded_rows(long long n) { return ceil_div(n, (long long)HM_TM) * HM_TM; }
 
@@ -312,7 +325,7 @@ void* hm_train_create(const void* rows64, long long n, hipStream_t s) {
     t->device = ctx().device;
     t->src = rows64;
     t->n = n;
-    if (hipMalloc(&t->rows, (size_t)n * 256) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&t->pc), (size_t)hm_padded_rows(n) * 4) != hipSuccess) {
+    if (hipMalloc(&t->rows, (size_t)hm_padded_rows(n) * 256) != hipSuccess || hipMalloc(reinterpret_cast<void**>(&t->pc), (size_t)hm_padded_rows(n) * 4) != hipSuccess) {
         (void)hipGetLastError();
         if (t->rows) (void)hipFree(t->rows);
         delete t;
@@ -342,7 +355,7 @@ void hamming_mfma_topk_device(const void* q, int nq, const void* t, long long nt
     ThreadCtx& c = ctx();
     void* q4 = c.alloc((size_t)nq * 256);
     float* qp = c.alloc_n<float>(nq);
-    void* t4 = c.alloc((size_t)nt * 256);
+    void* t4 = c.alloc((size_t)hm_padded_rows(nt) * 256);
     float* tp = c.alloc_n<float>(hm_padded_rows(nt));
     {
         KernelTimer timer("hamming_topk_sample", s);   // (the counters' name for what runs in front of the main match kernel)

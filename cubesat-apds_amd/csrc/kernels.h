@@ -22,7 +22,7 @@ struct HmTrain {   // a train set expanded once (256 bytes of fp4 operands per r
     float* pc = nullptr;
 };
 HmPlan hm_plan(int nq, long long nt);
-long long hm_padded_rows(long long n);   // popcount arrays of train rows are padded to whole tiles (+inf): allocate this many floats
+long long hm_padded_rows(long long n);   // expanded train rows and their popcounts are padded to whole tiles: allocate this many rows / floats
 void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4, float* pc, hipStream_t s);
 void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_fp4, const float* tpc, long long nt, const HmPlan& p, uint32_t index_base,
                     uint64_t* parts, hipStream_t s);

@@ -1039,7 +1039,7 @@ static void split_prepass_mfma(TopkSplitState& st, const void* q, int nq, const 
     st.off_parts = take((size_t)st.hp.splits * nq * 16);
     st.off_top2 = take((size_t)nq * 16);
     if (!shared) {
-        st.off_t4 = take((size_t)nt * 256);
+        st.off_t4 = take((size_t)hm_padded_rows(nt) * 256);
         st.off_tp = take((size_t)hm_padded_rows(nt) * 4);
     }
     split_reserve(st, need);
