@@ -413,10 +413,12 @@ def main():
         elapsed, stats, st = timed_stream(frames, args.warmup)
         timers = {"hamming_topk": (st.hamming_topk_ms, st.hamming_topk_launches), "hamming_topk_sample": (st.hamming_topk_sample_ms, st.hamming_topk_sample_launches),
                   "akaze_extract": (st.akaze_extract_ms, st.akaze_extract_calls), "ransac_score": (st.ransac_score_ms, st.ransac_score_launches)}
+        split_scan = bool(st.split_scan)
         pipe.gap_log = [float(st.match_gaps_first_ms[i]) for i in range(min(16, st.match_gaps))]
         pipe.gap_mean = float(st.match_gap_mean_ms) if st.match_gaps else None
         if st.match_lds_cap_set_at_frame >= 0:
             pipe.cap_events = [dict(frame=int(st.match_lds_cap_set_at_frame), gaps_ms=[round(float(g), 2) for g in st.match_lds_cap_gaps_ms])]
+    split_scan = locals().get("split_scan", False)
     elapsed_host = None
     if args.host_frames and not args.serial:
         # the same K steps with every frame coming from pinned host memory: an extraction worker uploads it (hipMemcpyAsync on its own
@@ -558,7 +560,7 @@ def main():
                        "db_composition": ("all rows are AKAZE descriptors of images (shifted frames + %d blended variants), shuffled" % real_variants) if args.db == "real"
                                          else f"{P} AKAZE descriptors of the frames' shifted copies + {NDB - P} i.i.d. random rows", "frames_per_step": world, "parallelism": f"frame-dp{world}+db-shard{world}",
                        "match_backend": "matrix cores (hamming_mfma_kernel)" if mfma_backend.value else "vector ALU (hamming_topk_kernel)",
-                       "stage_overlap": "none (serial)" if args.serial else "extract (2 workers, alternate frames) | match (pre-pass, main scan and merge of consecutive frames on three streams) | homography, software-pipelined over frames by the library's own host threads (apds_pipeline_*: the timed loop is K submits + K polls)",
+                       "stage_overlap": "none (serial)" if args.serial else "extract (2 workers, alternate frames) | match (" + ("pre-pass, main scan and merge of consecutive frames on three streams" if split_scan else "one stream") + ") | homography, software-pipelined over frames by the library's own host threads (apds_pipeline_*: the timed loop is K submits + K polls)",
                        "match_occupancy_cap": ({"lds_bytes": 55000, "set_at": pipe.cap_events[0]} if getattr(pipe, "cap_events", None) else
                                                {"lds_bytes": int(os.environ.get("APDS_MATCH_LDS_CAP", "0") or 0)}),
                        "match_stream_gap_ms": (round(pipe.gap_mean, 3) if getattr(pipe, "gap_mean", None) is not None else None),

@@ -348,19 +348,14 @@ void hm_train_destroy(void* h) {
     if (previous >= 0) (void)hipSetDevice(previous);
 }
 
-// Top-k (k = 1 or 2) of nq queries over nt train rows, both 64-byte rows on the device. out: nq * k keys (distance << 32 | row + index_base).
-void hamming_mfma_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s) {
-    APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "the matrix-core matcher serves k = 1 and k = 2");
-    APDS_REQUIRE(nq > 0 && nt > 0 && nt < (1ll << 31), APDS_ERR_ASSERT, "the matrix-core matcher needs queries and train rows");
+// Top-k (k = 1 or 2) of nq 64-byte query rows against expanded train rows (t4 / tp: hm_expand_device's output, or an HmTrain's).
+static void hm_topk_expanded(const void* q, int nq, const void* t4, const float* tp, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s) {
     ThreadCtx& c = ctx();
     void* q4 = c.alloc((size_t)nq * 256);
     float* qp = c.alloc_n<float>(nq);
-    void* t4 = c.alloc((size_t)hm_padded_rows(nt) * 256);
-    float* tp = c.alloc_n<float>(hm_padded_rows(nt));
     {
         KernelTimer timer("hamming_topk_sample", s);   // (the counters' name for what runs in front of the main match kernel)
         hm_expand_device(q, nq, true, q4, qp, s);
-        hm_expand_device(t, nt, false, t4, tp, s);
     }
     const HmPlan p = hm_plan(nq, nt);
     uint64_t* parts = (p.splits == 1 && k == 2) ? out : c.alloc_n<uint64_t>((size_t)p.splits * nq * 2);
@@ -372,6 +367,27 @@ void hamming_mfma_topk_device(const void* q, int nq, const void* t, long long nt
         if (k == 1) take_first_columns_device(top2, nq, 2, 1, out, s);
     }
     HIP_CHECK(hipGetLastError());
+}
+
+// Top-k (k = 1 or 2) of nq queries over nt train rows, both 64-byte rows on the device. out: nq * k keys (distance << 32 | row + index_base).
+void hamming_mfma_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s) {
+    APDS_REQUIRE(k == 1 || k == 2, APDS_ERR_ASSERT, "the matrix-core matcher serves k = 1 and k = 2");
+    APDS_REQUIRE(nq > 0 && nt > 0 && nt < (1ll << 31), APDS_ERR_ASSERT, "the matrix-core matcher needs queries and train rows");
+    ThreadCtx& c = ctx();
+    void* t4 = c.alloc((size_t)hm_padded_rows(nt) * 256);
+    float* tp = c.alloc_n<float>(hm_padded_rows(nt));
+    {
+        KernelTimer timer("hamming_topk_sample", s);
+        hm_expand_device(t, nt, false, t4, tp, s);
+    }
+    hm_topk_expanded(q, nq, t4, tp, nt, index_base, k, out, s);
+}
+
+// The same against a train set expanded once (hm_train_create).
+void hamming_mfma_topk_train_device(const void* q, int nq, const void* train, uint32_t index_base, int k, uint64_t* out, hipStream_t s) {
+    const HmTrain* t = static_cast<const HmTrain*>(train);
+    APDS_REQUIRE(t && (k == 1 || k == 2) && nq > 0, APDS_ERR_ASSERT, "the matrix-core matcher needs an expanded train set, queries and k = 1 or 2");
+    hm_topk_expanded(q, nq, t->rows, t->pc, t->n, index_base, k, out, s);
 }
 
 }  // namespace apds

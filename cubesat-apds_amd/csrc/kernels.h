@@ -28,6 +28,7 @@ void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_f
                     uint64_t* parts, hipStream_t s);
 void* hm_train_create(const void* rows64, long long n, hipStream_t s);
 void hm_train_destroy(void* train);
+void hamming_mfma_topk_train_device(const void* q, int nq, const void* train, uint32_t index_base, int k, uint64_t* out, hipStream_t s);
 void topk_split_use_train(void* state, const void* hm_train);   // a pre-expanded train set for the state's matrix-core scans (or null)
 // the scan of hamming_topk_device in three separately launched steps on a per-frame state object (k = 1, 2)
 void* topk_split_create();

@@ -291,7 +291,11 @@ struct Pipeline {
             } else {
                 HIP_CHECK(hipStreamWaitEvent(st_match, s->ev_extract, 0));
                 HIP_CHECK(hipEventRecord(s->ev_mstart, st_match));
-                if (K > 0) PIPE_OK(apds_dev_hamming_topk(s->desc, K, db_rows, n_rows, index_base, 2, s->keys, st_match));
+                if (K > 0 && db_expanded) {   // the matrix-core matcher on the DB's expanded copy
+                    PIPE_OK(guarded([&] { hamming_mfma_topk_train_device(s->desc, K, db_expanded, index_base, 2, static_cast<uint64_t*>(s->keys), st_match); }));
+                } else if (K > 0) {
+                    PIPE_OK(apds_dev_hamming_topk(s->desc, K, db_rows, n_rows, index_base, 2, s->keys, st_match));
+                }
                 HIP_CHECK(hipEventRecord(s->ev_match, st_match));
                 HIP_CHECK(hipEventRecord(s->ev_mend, st_match));
             }
@@ -499,7 +503,10 @@ int apds_pipeline_create(void** pipe, const void* db_rows64_dev, int64_t n_rows,
         P->cap = in.max_points > 0 ? std::min(in.max_points, APDS_MAX_POINTS) : APDS_MAX_POINTS;
         P->E = std::max(1, std::min(8, in.extract_workers > 0 ? in.extract_workers : cfg.pipe_extract_workers));
         const int n_slots = std::max(in.n_slots > 0 ? in.n_slots : 6, 2 * P->E);
-        P->split = P->world == 1 && !shard && cfg.pipe_match_split != 0;
+        // three streams for the pre-pass, main scan and merge of consecutive frames: the vector-ALU matcher's pipeline (its pre-pass and record
+        // merge are 0.8 ms of small kernels per frame). The matrix-core matcher has one main launch and two tiny ones: on one stream 131.6
+        // frames/s, split over three 126.8 (profiles/r04/ab_bench_env.txt); APDS_MATCH_SPLIT=2 forces the split for it as well.
+        P->split = P->world == 1 && !shard && (cfg.match_mfma ? cfg.pipe_match_split == 2 : cfg.pipe_match_split != 0);
         // (the starvation watch caps hamming_topk_kernel's occupancy: the matrix-core matcher has no such knob and is not watched)
         P->adaptive_cap = cfg.pipe_adaptive_cap != 0 && P->split && in.match_lds_cap == 0 && !cfg.match_mfma;
         P->extract_delay_s = in.debug_extract_delay_ms > 0 ? in.debug_extract_delay_ms * 1e-3 : 0.0;
@@ -521,7 +528,7 @@ int apds_pipeline_create(void** pipe, const void* db_rows64_dev, int64_t n_rows,
             HIP_CHECK(hipStreamCreateWithPriority(&P->st_gather, hipStreamNonBlocking, hp));
             HIP_CHECK(hipStreamCreateWithPriority(&P->st_counts, hipStreamNonBlocking, hp));
         }
-        if (P->split && cfg.match_mfma) P->db_expanded = hm_train_create(P->db_rows, P->n_rows, P->st_match);
+        if (P->world == 1 && !shard && cfg.match_mfma) P->db_expanded = hm_train_create(P->db_rows, P->n_rows, P->st_match);
         const size_t cap = (size_t)P->cap;
         for (int i = 0; i < n_slots; i++) {
             auto s = std::make_unique<Slot>();
