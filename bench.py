@@ -498,11 +498,13 @@ def main():
         achieved_tops = match_ops / max(launches_per_step, 1e-9) / (avg_launch_ms * 1e-3) / 1e12 if topk_n else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         if mfma_backend.value:
-            # The matrix-core matcher (csrc/hamming_mfma.hip): ONE main launch per step over all rows (no threshold pre-pass; "hamming_topk_sample"
-            # times the expansion of the frame's queries into FP4 operands - the DB's expanded copy is made once at apds_pipeline_create).
+            # The matrix-core matcher (csrc/hamming_mfma.hip): a threshold launch over the leading sixteenth of the rows (at most 65 536; timed as
+            # "hamming_topk_sample" together with the expansion of the frame's queries into FP4 operands - the DB's expanded copy is made once at
+            # apds_pipeline_create) and ONE main launch per step over the rest: the roofline object is for the main launch.
             # Algorithmic work per pair: 512 one-bit products + 512 adds on the padded 64-byte rows (SURVEY 8d counts the same 16 dwords) =
             # 1024 flop; peak = the guide's dense FP4 figure (MI355X_MICROARCH.md: ~10 PF, f8f6f4 with e2m1 operands = 4x the BF16 rate).
-            rows_main = rows_local
+            mfma_sample = min(65536, (rows_local // 16) & ~127) if rows_local >= 262144 else 0   # hamming_mfma.hip: hm_sample_rows (the threshold launch,
+            rows_main = rows_local - mfma_sample                                                  # timed as "hamming_topk_sample" with the query expansion)
             match_ops = 32.0 * Q_step * rows_main
             match_bytes = 64.0 * rows_main + 64.0 * Q_step + 8.0 * Q_step * 2
             bytes_per_launch = match_bytes / max(launches_per_step, 1e-9)

@@ -22,6 +22,7 @@
 //                           MFMA halves - and both times the compiler put the twelve MFMAs of a block back together and ranked
 //                           behind them; the wait states that costs, s_nop 1 + five ds_reads, are filled by the SIMD's other waves.)
 #include <atomic>
+#include <memory>
 
 #include "config.h"
 #include "kernels.h"
@@ -79,6 +80,14 @@ __global__ void hm_pad_rows_kernel(uint4* __restrict__ rows, float* __restrict__
     }
 }
 
+// thr[q]: the kernel's ranking value (hamming - popcount(query) + bias, as float bits) of the second key of a finished top-2 list
+__global__ void hm_thresholds_kernel(const uint64_t* __restrict__ top2, const float* __restrict__ qpc, int nq, uint32_t* __restrict__ thr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const uint64_t k2 = top2[(size_t)i * 2 + 1];
+    thr[i] = k2 == HM_EMPTY ? 0x7F800000u : __float_as_uint((float)((int)(uint32_t)(k2 >> 32) - (int)qpc[i] + HM_BIAS));
+}
+
 struct HmTop2 {
     uint32_t d0, d1;   // bit patterns of the (positive) ranking values
     uint32_t i0, i1;
@@ -104,7 +113,8 @@ __device__ __forceinline__ void hm_insert(HmTop2& b, uint32_t d, uint32_t idx) {
 // Rows and popcounts are padded to whole tiles (zero operands, +inf: rows past the end never rank).
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
                                                            const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
-                                                           int q_tiles, int splits, uint32_t index_base, uint64_t* __restrict__ out) {
+                                                           int q_tiles, int splits, uint32_t index_base, const uint32_t* __restrict__ thr,
+                                                           uint64_t* __restrict__ out) {
     // (no APDS_RAISE_WAVE_PRIORITY here: this is the kernel the short kernels of the other stages raise their priority against)
     extern __shared__ __attribute__((aligned(128))) unsigned char hm_lds[];
     constexpr int TILE_BYTES = HM_TM * 256;
@@ -136,10 +146,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         for (int s = 0; s < 4; s++) B[c][s] = query_fp4[(size_t)qi * 16 + 4 * s + kq];
         qq[c] = qpc[qi];
     }
+    // The running top-2 starts from thr[query] when the caller has one (the second smallest ranking value over a sample of EARLIER rows - lower
+    // indices, so a row of this launch enters the query's final top-2 only with a strictly smaller value): both entries are that value
+    // without a row, real rows push them out, and what is left of them at the end is written as empty. Without it: +inf.
     HmTop2 best[HM_NC];
 #pragma unroll
     for (int c = 0; c < HM_NC; c++) {
-        best[c].d0 = best[c].d1 = 0x7F800000u;   // +inf
+        best[c].d0 = best[c].d1 = thr ? thr[min(q0 + 16 * c + col, nq - 1)] : 0x7F800000u;
         best[c].i0 = best[c].i1 = 0xFFFFFFFFu;
     }
 
@@ -263,10 +276,11 @@ HmPlan hm_plan(int nq, long long nt) {
     // Splits of the train rows: they fill the slots when the query tiles alone do not, and they set the granularity of the last round of
     // workgroups (92 query tiles x 5 splits = 460 workgroups leave a tenth of the chip idle for the whole launch; x 11 = 1012 fill two
     // rounds to 99 %). The count that minimises rounds x (tiles per split + overhead); the split lists (16 bytes per query and split) stay
-    // below 256 MB. APDS_MATCH_MFMA_XCD=1 (measured, off): splits in multiples of eight pinned to the XCDs - the workgroups of an XCD then
-    // share every train tile through their L2: 1.00 GB fetched per launch instead of 2.65 GB on the headline shape (the expanded DB is
-    // 0.25 GB), and 6.5 ms instead of 6.15: the kernel does not wait for its tile loads, and 16 splits fill the last round worse than 11
-    // (profiles/r04/mfma_xcd_ab.txt).
+    // below 256 MB. Then (APDS_MATCH_MFMA_XCD, on): a multiple of eight splits, pinned to the XCDs, when the model puts one within 5 % of
+    // that count - the workgroups of an XCD then share every train tile through their L2. On the headline shape 16 splits instead of 11:
+    // 1.1 GB fetched per match instead of 2.65 GB (the expanded DB is 0.25 GB). Before the threshold launch existed that cost 5 % (every
+    // workgroup pays its start from +inf again: 6.5 against 6.15 ms); with it 1.7 % alone on the GPU, and in the pipeline the step is
+    // 3.4 % SHORTER (138.9 against 134.3 frames/s: the extraction beside it is memory-bound) - profiles/r04/mfma_xcd_ab.txt, ab_bench_env.txt.
     const int max_splits = (int)std::max<long long>(1, std::min<long long>(std::min(t_tiles, 128), (16ll << 20) / std::max(nq, 1)));
     long long best_cost = -1;
     p.splits = 1;
@@ -290,6 +304,7 @@ HmPlan hm_plan(int nq, long long nt) {
             return p;
         }
     }
+    if (config().match_mfma_splits > 0) p.splits = std::min(t_tiles, config().match_mfma_splits);   // (experiments)
     p.tiles_per_split = ceil_div(t_tiles, p.splits);
     p.splits = ceil_div(t_tiles, p.tiles_per_split);
     return p;
@@ -303,19 +318,22 @@ void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4
         hipLaunchKernelGGL(hm_pad_rows_kernel, dim3(1), dim3(128), 0, s, static_cast<uint4*>(out_fp4), pc, n, hm_padded_rows(n));
 }
 long long hm_padded_rows(long long n) { return ceil_div(n, (long long)HM_TM) * HM_TM; }
+// rows of the threshold launch: whole tiles, a sixteenth of the set, at most 65 536; none below 262 144 rows
+long long hm_sample_rows(long long nt) { return nt >= 262144 ? std::min<long long>(65536, (nt / 16) & ~(long long)(HM_TM - 1)) : 0; }
 
 // parts: [p.splits][nq][2] keys
 void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_fp4, const float* tpc, long long nt, const HmPlan& p, uint32_t index_base,
-                    uint64_t* parts, hipStream_t s) {
+                    uint64_t* parts, hipStream_t s, const uint32_t* thr, bool timed) {
     const size_t lds = (size_t)2 * HM_TM * 256 + 2 * HM_TM * sizeof(float);
     static std::atomic<bool> opted{false};   // above the default dynamic-LDS limit: opt in once (idempotent, so a race is harmless)
     if (!opted.load()) {
         HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         opted.store(true);
     }
-    KernelTimer timer("hamming_topk", s);   // (the name the pipeline's counters and bench.py know the main match kernel by)
+    std::unique_ptr<KernelTimer> timer;   // ("hamming_topk": the name the pipeline's counters and bench.py know the main match launch by)
+    if (timed) timer.reset(new KernelTimer("hamming_topk", s));
     hipLaunchKernelGGL(hamming_mfma_kernel, dim3((unsigned)p.q_tiles * p.splits), dim3(512), lds, s, static_cast<const uint4*>(t_fp4), tpc, (int)nt,
-                       static_cast<const uint4*>(q_fp4), qpc, nq, p.tiles_per_split, p.q_tiles, p.splits, index_base, parts);
+                       static_cast<const uint4*>(q_fp4), qpc, nq, p.tiles_per_split, p.q_tiles, p.splits, index_base, thr, parts);
 }
 
 // A train set expanded once (resident databases: the pipeline's, a shard's): rows + popcounts in memory of their own.
@@ -357,15 +375,33 @@ static void hm_topk_expanded(const void* q, int nq, const void* t4, const float*
         KernelTimer timer("hamming_topk_sample", s);   // (the counters' name for what runs in front of the main match kernel)
         hm_expand_device(q, nq, true, q4, qp, s);
     }
-    const HmPlan p = hm_plan(nq, nt);
-    uint64_t* parts = (p.splits == 1 && k == 2) ? out : c.alloc_n<uint64_t>((size_t)p.splits * nq * 2);
-    hm_scan_device(q4, qp, nq, t4, tp, nt, p, index_base, parts, s);
-    if (parts != out) {
-        uint64_t* top2 = k == 2 ? out : c.alloc_n<uint64_t>((size_t)nq * 2);
+    // Long train sets: a first launch over the leading rows (a sixteenth, at most 65 536) gives every query a threshold, and the launch over
+    // the rest starts from it - its workgroups then spend their first tiles like their last ones (a workgroup that starts from +inf runs
+    // insertion code for every block of its first ~1500 rows), which is also what makes many short workgroups affordable.
+    const long long sample = hm_sample_rows(nt);
+    uint64_t* top2 = k == 2 ? out : c.alloc_n<uint64_t>((size_t)nq * 2);
+    if (sample) {
+        const HmPlan pa = hm_plan(nq, sample), pb = hm_plan(nq, nt - sample);
+        uint64_t* parts_a = c.alloc_n<uint64_t>((size_t)pa.splits * nq * 2);
+        uint64_t* parts_b = c.alloc_n<uint64_t>((size_t)(pb.splits + 1) * nq * 2);   // + one list: the sample's top-2
+        uint64_t* top2_a = parts_b + (size_t)pb.splits * nq * 2;
+        uint32_t* thr = c.alloc_n<uint32_t>(nq);
+        {
+            KernelTimer timer("hamming_topk_sample", s);
+            hm_scan_device(q4, qp, nq, t4, tp, sample, pa, index_base, parts_a, s, nullptr, /*timed=*/false);
+            if (pa.splits > 1) merge_topk_device(parts_a, pa.splits, nq, 2, top2_a, s);
+            else HIP_CHECK(hipMemcpyAsync(top2_a, parts_a, (size_t)nq * 16, hipMemcpyDeviceToDevice, s));
+            hipLaunchKernelGGL(hm_thresholds_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, (const uint64_t*)top2_a, (const float*)qp, nq, thr);
+        }
+        hm_scan_device(q4, qp, nq, static_cast<const char*>(t4) + (size_t)sample * 256, tp + sample, nt - sample, pb, index_base + (uint32_t)sample, parts_b, s, thr);
+        merge_topk_device(parts_b, pb.splits + 1, nq, 2, top2, s);
+    } else {
+        const HmPlan p = hm_plan(nq, nt);
+        uint64_t* parts = p.splits == 1 ? top2 : c.alloc_n<uint64_t>((size_t)p.splits * nq * 2);
+        hm_scan_device(q4, qp, nq, t4, tp, nt, p, index_base, parts, s);
         if (p.splits > 1) merge_topk_device(parts, p.splits, nq, 2, top2, s);
-        else top2 = parts;
-        if (k == 1) take_first_columns_device(top2, nq, 2, 1, out, s);
     }
+    if (k == 1) take_first_columns_device(top2, nq, 2, 1, out, s);
     HIP_CHECK(hipGetLastError());
 }
 

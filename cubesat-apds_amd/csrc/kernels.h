@@ -25,7 +25,8 @@ HmPlan hm_plan(int nq, long long nt);
 long long hm_padded_rows(long long n);   // expanded train rows and their popcounts are padded to whole tiles: allocate this many rows / floats
 void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4, float* pc, hipStream_t s);
 void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_fp4, const float* tpc, long long nt, const HmPlan& p, uint32_t index_base,
-                    uint64_t* parts, hipStream_t s);
+                    uint64_t* parts, hipStream_t s, const uint32_t* thr = nullptr, bool timed = true);
+long long hm_sample_rows(long long nt);
 void* hm_train_create(const void* rows64, long long n, hipStream_t s);
 void hm_train_destroy(void* train);
 void hamming_mfma_topk_train_device(const void* q, int nq, const void* train, uint32_t index_base, int k, uint64_t* out, hipStream_t s);

@@ -40,7 +40,8 @@ const Config& config() {
         k.event_scope = env("APDS_EVENT_SCOPE", 2);
         k.flag_fork = env("APDS_FLAG_FORK", 0);
         k.match_mfma = env("APDS_MATCH_MFMA", 1);
-        k.match_mfma_xcd = env("APDS_MATCH_MFMA_XCD", 0);
+        k.match_mfma_xcd = env("APDS_MATCH_MFMA_XCD", 1);
+        k.match_mfma_splits = env("APDS_MATCH_MFMA_SPLITS", 0);
         k.debug_host_time = env("APDS_DEBUG_HOST_TIME", 0);
         k.match_lds_cap = env("APDS_MATCH_LDS_CAP", 0);
         k.match_sample = env("APDS_MATCH_SAMPLE", 16384);
