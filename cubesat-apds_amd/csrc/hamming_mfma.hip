@@ -319,7 +319,10 @@ void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4
 }
 long long hm_padded_rows(long long n) { return ceil_div(n, (long long)HM_TM) * HM_TM; }
 // rows of the threshold launch: whole tiles, a sixteenth of the set, at most 65 536; none below 262 144 rows
-long long hm_sample_rows(long long nt) { return nt >= 262144 ? std::min<long long>(65536, (nt / 16) & ~(long long)(HM_TM - 1)) : 0; }
+long long hm_sample_rows(long long nt) {
+    const long long cap = config().match_mfma_sample;   // APDS_MATCH_MFMA_SAMPLE (0: no threshold launch)
+    return (cap > 0 && nt >= 262144) ? std::min<long long>(cap, (nt / 16) & ~(long long)(HM_TM - 1)) & ~(long long)(HM_TM - 1) : 0;
+}
 
 // parts: [p.splits][nq][2] keys
 void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_fp4, const float* tpc, long long nt, const HmPlan& p, uint32_t index_base,
