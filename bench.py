@@ -498,12 +498,12 @@ def main():
         achieved_tops = match_ops / max(launches_per_step, 1e-9) / (avg_launch_ms * 1e-3) / 1e12 if topk_n else 0.0
         ms_per_step = elapsed / args.steps * 1e3
         if mfma_backend.value:
-            # The matrix-core matcher (csrc/hamming_mfma.hip): a threshold launch over the leading sixteenth of the rows (at most 65 536; timed as
+            # The matrix-core matcher (csrc/hamming_mfma.hip): a threshold launch over the leading rows (a sixteenth, at most 16 384; timed as
             # "hamming_topk_sample" together with the expansion of the frame's queries into FP4 operands - the DB's expanded copy is made once at
             # apds_pipeline_create) and ONE main launch per step over the rest: the roofline object is for the main launch.
             # Algorithmic work per pair: 512 one-bit products + 512 adds on the padded 64-byte rows (SURVEY 8d counts the same 16 dwords) =
             # 1024 flop; peak = the guide's dense FP4 figure (MI355X_MICROARCH.md: ~10 PF, f8f6f4 with e2m1 operands = 4x the BF16 rate).
-            sample_cap = int(os.environ.get("APDS_MATCH_MFMA_SAMPLE", "65536") or 0)
+            sample_cap = int(os.environ.get("APDS_MATCH_MFMA_SAMPLE", "16384") or 0)
             mfma_sample = (min(sample_cap, (rows_local // 16) & ~127) & ~127) if (rows_local >= 262144 and sample_cap > 0) else 0   # hamming_mfma.hip: hm_sample_rows (the threshold launch,
             rows_main = rows_local - mfma_sample                                                  # timed as "hamming_topk_sample" with the query expansion)
             match_ops = 32.0 * Q_step * rows_main

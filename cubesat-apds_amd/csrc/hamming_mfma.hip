@@ -318,7 +318,7 @@ void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4
         hipLaunchKernelGGL(hm_pad_rows_kernel, dim3(1), dim3(128), 0, s, static_cast<uint4*>(out_fp4), pc, n, hm_padded_rows(n));
 }
 long long hm_padded_rows(long long n) { return ceil_div(n, (long long)HM_TM) * HM_TM; }
-// rows of the threshold launch: whole tiles, a sixteenth of the set, at most 65 536; none below 262 144 rows
+// rows of the threshold launch: whole tiles, a sixteenth of the set, at most APDS_MATCH_MFMA_SAMPLE (16 384); none below 262 144 rows
 long long hm_sample_rows(long long nt) {
     const long long cap = config().match_mfma_sample;   // APDS_MATCH_MFMA_SAMPLE (0: no threshold launch)
     return (cap > 0 && nt >= 262144) ? std::min<long long>(cap, (nt / 16) & ~(long long)(HM_TM - 1)) & ~(long long)(HM_TM - 1) : 0;
@@ -378,7 +378,8 @@ static void hm_topk_expanded(const void* q, int nq, const void* t4, const float*
         KernelTimer timer("hamming_topk_sample", s);   // (the counters' name for what runs in front of the main match kernel)
         hm_expand_device(q, nq, true, q4, qp, s);
     }
-    // Long train sets: a first launch over the leading rows (a sixteenth, at most 65 536) gives every query a threshold, and the launch over
+    // Long train sets: a first launch over the leading rows (a sixteenth, at most 16 384: 141.5 frames/s; 32 768: 139.2; 65 536: 138.0; none:
+    // 132.6 - profiles/r04/ab_bench_env.txt) gives every query a threshold, and the launch over
     // the rest starts from it - its workgroups then spend their first tiles like their last ones (a workgroup that starts from +inf runs
     // insertion code for every block of its first ~1500 rows), which is also what makes many short workgroups affordable.
     const long long sample = hm_sample_rows(nt);
