@@ -111,6 +111,7 @@ __device__ __forceinline__ void hm_insert(HmTop2& b, uint32_t d, uint32_t idx) {
 // its 16-byte chunk c at position c ^ (r & 15) - the 16 rows a ds_read_b128 group reads chunk c of then sit in 16 different bank groups.
 // The DMA's per-lane SOURCE address applies the same involution, so the image is a plain lane-linear copy for the hardware.
 // Rows and popcounts are padded to whole tiles (zero operands, +inf: rows past the end never rank).
+template <int PRIO>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
                                                            const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
                                                            int q_tiles, int splits, uint32_t index_base, const uint32_t* __restrict__ thr,
@@ -227,7 +228,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         }
                     }
                 };
+                // a wave about to feed the matrix pipe goes ahead of the SIMD's waves that are ranking: 5.94 -> 5.60 ms alone, 139.4 -> 147.3
+                // frames/s in the pipeline (profiles/r04/mfma_prio_ab.txt, ab_bench_env.txt); levels 1, 2, 3 alike
+                if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
                 steps(0, 4);
+                if (PRIO) __builtin_amdgcn_s_setprio(0);
                 rank(acc, (uint32_t)(tile * HM_TM + rb * 16 + 4 * kq) + index_base);
             }
             __syncthreads();   // the next tile has landed; everybody is done with this one
@@ -330,13 +335,24 @@ void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_f
     const size_t lds = (size_t)2 * HM_TM * 256 + 2 * HM_TM * sizeof(float);
     static std::atomic<bool> opted{false};   // above the default dynamic-LDS limit: opt in once (idempotent, so a race is harmless)
     if (!opted.load()) {
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_mfma_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_mfma_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_mfma_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&hamming_mfma_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         opted.store(true);
     }
     std::unique_ptr<KernelTimer> timer;   // ("hamming_topk": the name the pipeline's counters and bench.py know the main match launch by)
     if (timed) timer.reset(new KernelTimer("hamming_topk", s));
-    hipLaunchKernelGGL(hamming_mfma_kernel, dim3((unsigned)p.q_tiles * p.splits), dim3(512), lds, s, static_cast<const uint4*>(t_fp4), tpc, (int)nt,
-                       static_cast<const uint4*>(q_fp4), qpc, nq, p.tiles_per_split, p.q_tiles, p.splits, index_base, thr, parts);
+    auto go = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)p.q_tiles * p.splits), dim3(512), lds, s, static_cast<const uint4*>(t_fp4), tpc, (int)nt,
+                           static_cast<const uint4*>(q_fp4), qpc, nq, p.tiles_per_split, p.q_tiles, p.splits, index_base, thr, parts);
+    };
+    switch (config().match_mfma_prio) {
+        case 0: go(&hamming_mfma_kernel<0>); break;
+        case 1: go(&hamming_mfma_kernel<1>); break;
+        case 2: go(&hamming_mfma_kernel<2>); break;
+        default: go(&hamming_mfma_kernel<3>); break;
+    }
 }
 
 // A train set expanded once (resident databases: the pipeline's, a shard's): rows + popcounts in memory of their own.
