@@ -504,7 +504,7 @@ def main():
             # Algorithmic work per pair: 512 one-bit products + 512 adds on the padded 64-byte rows (SURVEY 8d counts the same 16 dwords) =
             # 1024 flop; peak = the guide's dense FP4 figure (MI355X_MICROARCH.md: ~10 PF, f8f6f4 with e2m1 operands = 4x the BF16 rate).
             sample_cap = int(os.environ.get("APDS_MATCH_MFMA_SAMPLE", "16384") or 0)
-            mfma_sample = (min(sample_cap, (rows_local // 16) & ~127) & ~127) if (rows_local >= 262144 and sample_cap > 0) else 0   # hamming_mfma.hip: hm_sample_rows (the threshold launch,
+            mfma_sample = (min(sample_cap, (rows_local // 16) & ~127) & ~127) if (rows_local >= 65536 and sample_cap > 0) else 0   # hamming_mfma.hip: hm_sample_rows (the threshold launch,
             rows_main = rows_local - mfma_sample                                                  # timed as "hamming_topk_sample" with the query expansion)
             match_ops = 32.0 * Q_step * rows_main
             match_bytes = 64.0 * rows_main + 64.0 * Q_step + 8.0 * Q_step * 2

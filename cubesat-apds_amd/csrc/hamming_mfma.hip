@@ -323,10 +323,10 @@ void hm_expand_device(const void* rows64, long long n, bool query, void* out_fp4
         hipLaunchKernelGGL(hm_pad_rows_kernel, dim3(1), dim3(128), 0, s, static_cast<uint4*>(out_fp4), pc, n, hm_padded_rows(n));
 }
 long long hm_padded_rows(long long n) { return ceil_div(n, (long long)HM_TM) * HM_TM; }
-// rows of the threshold launch: whole tiles, a sixteenth of the set, at most APDS_MATCH_MFMA_SAMPLE (16 384); none below 262 144 rows
+// rows of the threshold launch: whole tiles, a sixteenth of the set, at most APDS_MATCH_MFMA_SAMPLE (16 384); none below 65 536 rows
 long long hm_sample_rows(long long nt) {
     const long long cap = config().match_mfma_sample;   // APDS_MATCH_MFMA_SAMPLE (0: no threshold launch)
-    return (cap > 0 && nt >= 262144) ? std::min<long long>(cap, (nt / 16) & ~(long long)(HM_TM - 1)) & ~(long long)(HM_TM - 1) : 0;
+    return (cap > 0 && nt >= 65536) ? std::min<long long>(cap, (nt / 16) & ~(long long)(HM_TM - 1)) & ~(long long)(HM_TM - 1) : 0;
 }
 
 // parts: [p.splits][nq][2] keys

@@ -23,7 +23,7 @@ def main():
     g.manual_seed(1)
     mode = os.environ.get("APDS_MATCH_MFMA", "1")
     keep = {}
-    for nq, nt in ((35312, 983616), (5000, 100000), (1000, 3000), (262143, 262143), (20000, 10000000)):
+    for nq, nt in ((35312, 983616), (5000, 100000), (1000, 3000), (262143, 262143), (20000, 10000000), (282496, 125000)):   # the last: one rank's scan of an 8-GPU run
         db = torch.randint(0, 256, (nt, 64), dtype=torch.uint8, device=dev, generator=g)
         q = torch.randint(0, 256, (nq, 64), dtype=torch.uint8, device=dev, generator=g)
         for t in (db, q):
