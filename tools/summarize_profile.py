@@ -21,6 +21,7 @@ for f in find("stats/**/*kernel_stats.csv"):
         print(f"{r['Name'][:70]:70s} {r['Calls']:>7s} {float(r['TotalDurationNs']) / 1e6:10.3f} {float(r['AverageNs']) / 1e3:10.2f} {r['Percentage']:>6s}")
 
 MAIN = {"hamming_mfma_kernel": "matrix cores", "hamming_topk_kernel<4, 2>": "vector ALU"}   # the main match launch of either backend
+# (hamming_mfma_kernel<prio, true> is the main launch behind a threshold launch <prio, false>; both match the pattern, the larger grid is taken)
 res, seen = {}, {}
 for name, counter in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     rows = []
