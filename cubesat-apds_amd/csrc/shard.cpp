@@ -62,10 +62,36 @@ struct HipDevice final : Device {
         HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, st(s)));
         HIP_CHECK(hipStreamSynchronize(st(s)));
     }
+    // the shard's rows as matrix-core operands: made at the first scan and kept (the shard is resident for the handle's life: shard_core.h)
+    std::mutex expanded_m;
+    void* expanded = nullptr;
+    const void* expanded_rows = nullptr;
+    int64_t expanded_n = 0;
+    ~HipDevice() override {
+        if (expanded) hm_train_destroy(expanded);
+    }
     void topk(const void* q, int nq, const void* rows, int64_t n_rows, uint32_t base, int k, void* out, void* s) override {
         // the scan's scratch is the calling thread's workspace, from its start: scans issued by one thread must be ordered on the GPU
         // (one stream, or events), exactly as for apds_dev_hamming_topk
         ctx().ws_reset();
+        if (k <= 2 && config().match_mfma && nq > 0 && n_rows > 0) {
+            void* train = nullptr;
+            {
+                std::lock_guard<std::mutex> g(expanded_m);
+                if (expanded && (expanded_rows != rows || expanded_n != n_rows)) {
+                    hm_train_destroy(expanded);
+                    expanded = nullptr;
+                }
+                if (!expanded) {
+                    expanded = hm_train_create(rows, n_rows, st(s));
+                    expanded_rows = rows;
+                    expanded_n = n_rows;
+                }
+                train = expanded;
+            }
+            hamming_mfma_topk_train_device(q, nq, train, base, k, static_cast<uint64_t*>(out), st(s));
+            return;
+        }
         hamming_topk_device(q, nq, rows, n_rows, base, k, static_cast<uint64_t*>(out), st(s));
     }
     void merge(const void* parts, int nparts, int nq, int k, void* out, void* s) override {
