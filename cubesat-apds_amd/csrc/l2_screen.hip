@@ -103,13 +103,13 @@ __device__ __forceinline__ uint64_t sc_key(float d, uint32_t idx) { return idx =
 //         block, position from an LDS counter: one global counter for all blocks serialised at ~12 ns per append, 0.65 s for the
 //         54 M candidates of config 3); the block's count goes to cand_count[block] (entries past the region are dropped and show
 //         in the count: the host checks it).
-template <int PASS>
+template <int PASS, bool PRIO>
 __global__ __launch_bounds__(512) void l2_screen_kernel(const uint16_t* __restrict__ train_bf, const float* __restrict__ tnorm, int n_train,
                                                         const uint16_t* __restrict__ query_bf, const float* __restrict__ qnorm, int nq, int tiles_per_split,
                                                         uint32_t index_base, uint64_t* __restrict__ out, const float* __restrict__ theta,
                                                         unsigned long long* __restrict__ cand, unsigned long long cand_cap,
                                                         unsigned long long* __restrict__ cand_count) {
-    APDS_RAISE_WAVE_PRIORITY();
+    if (!PRIO) APDS_RAISE_WAVE_PRIORITY();
     // 16-byte aligned: the static LDS word below would otherwise push this array to offset 4 and turn every ds_read_b128 /
     // ds_write_b128 of the tiles into misaligned accesses (measured: 209 -> 1185 ms per pass)
     extern __shared__ __attribute__((aligned(128))) unsigned char sc_lds[];
@@ -187,12 +187,15 @@ __global__ __launch_bounds__(512) void l2_screen_kernel(const uint16_t* __restri
 #pragma unroll
             for (int c = 0; c < SC_NC; c++) acc[c] = init;
             const unsigned char* arow = T + (rb * 16 + col) * SC_PITCH + 16 * kq;
+            // (round 4, from the Hamming matcher: a wave about to feed the matrix pipe goes ahead of the SIMD's waves that are in their epilogue)
+            if (PRIO) __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 const bf16x8 A = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(arow + 64 * s));
 #pragma unroll
                 for (int c = 0; c < SC_NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B[c][s], acc[c], 0, 0, 0);
             }
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
             // epilogue: acc = |t|^2 - 2 q~.t~ for rows 4 kq + j of the block, query column `col` of each of the wave's query blocks
             float mn[SC_NC];
             bool any_hit = false;
@@ -361,11 +364,14 @@ bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt,
     unsigned long long* keys = c.alloc_n<unsigned long long>((size_t)n_blocks * region);
     unsigned long long* counts = c.alloc_n<unsigned long long>(n_blocks);
     const size_t lds = (size_t)2 * SC_TM * SC_PITCH + 2 * SC_TM * sizeof(float);
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&l2_screen_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const bool prio = config().l2_prio != 0;
+    for (const void* kf : {reinterpret_cast<const void*>(&l2_screen_kernel<0, false>), reinterpret_cast<const void*>(&l2_screen_kernel<1, false>),
+                           reinterpret_cast<const void*>(&l2_screen_kernel<0, true>), reinterpret_cast<const void*>(&l2_screen_kernel<1, true>)})
+        HIP_CHECK(hipFuncSetAttribute(kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         KernelTimer timer("l2_screen", s);
-        hipLaunchKernelGGL((l2_screen_kernel<0>), dim3(q_tiles, s_splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)n_sample,
+        auto k0 = prio ? &l2_screen_kernel<0, true> : &l2_screen_kernel<0, false>;
+        hipLaunchKernelGGL(k0, dim3(q_tiles, s_splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)n_sample,
                            (const uint16_t*)qb, (const float*)qn, nq, s_tiles_per_split, index_base, parts, (const float*)nullptr, (unsigned long long*)nullptr, 0ull,
                            (unsigned long long*)nullptr);
     }
@@ -373,7 +379,8 @@ bool l2_topk_screen_device(const float* q, int nq, const float* t, long long nt,
     hipLaunchKernelGGL(screen_theta_kernel, dim3(ceil_div(nq, 256)), dim3(256), 0, s, (const uint64_t*)top2, (const float*)qn, nq, (const unsigned int*)tmax, theta);
     {
         KernelTimer timer("l2_screen", s);
-        hipLaunchKernelGGL((l2_screen_kernel<1>), dim3(q_tiles, splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)nt, (const uint16_t*)qb,
+        auto k1 = prio ? &l2_screen_kernel<1, true> : &l2_screen_kernel<1, false>;
+        hipLaunchKernelGGL(k1, dim3(q_tiles, splits), dim3(512), lds, s, (const uint16_t*)tb, (const float*)tn, (int)nt, (const uint16_t*)qb,
                            (const float*)qn, nq, tiles_per_split, index_base, (uint64_t*)nullptr, (const float*)theta, cand, region, counts);
     }
     std::vector<unsigned long long> hc(n_blocks);
