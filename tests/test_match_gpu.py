@@ -45,6 +45,46 @@ def test_large_db_uses_sample_thresholds(gpu_pkg, oracle_mod):
     assert ((src >= 0) & (src < 16384)).any() and (src >= 16384).any()
 
 
+def test_ties_across_the_threshold_launch(gpu_pkg, oracle_mod):
+    """The matrix-core matcher ranks the leading rows first (a sixteenth of the set, at most 16 384) and starts the launch over the rest from
+    each query's second-best value of that sample: a later row enters only with a strictly smaller value. Planted here, for every query:
+    its best and second best inside the sample, and rows in the rest that tie with the best, tie with the second best (must lose to the
+    lower index), beat both, or are exact copies."""
+    rng = np.random.default_rng(11)
+    nt, nq = 90000, 400                      # sample = 5504 rows
+    db = rng.integers(0, 256, (nt, 61), dtype=np.uint8)
+    db[:, 60] &= 0x3F
+    q = rng.integers(0, 256, (nq, 61), dtype=np.uint8)
+    q[:, 60] &= 0x3F
+
+    def flipped(row, nbits, seed):
+        r = row.copy()
+        for b in np.random.default_rng(seed).choice(480, nbits, replace=False):
+            r[b >> 3] ^= 1 << (b & 7)
+        return r
+    for i in range(nq):
+        db[10 + 13 * i] = flipped(q[i], 5, 3 * i)            # best of the sample: distance 5
+        db[12 + 13 * i] = flipped(q[i], 9, 3 * i + 1)        # second best of the sample: distance 9
+        kind = i % 5
+        r = 6000 + 200 * i                                   # a row of the rest
+        if kind == 0:
+            db[r] = flipped(q[i], 9, 3 * i + 2)              # ties with the sample's second best: the lower index wins
+        elif kind == 1:
+            db[r] = flipped(q[i], 5, 3 * i + 2)              # ties with the best: becomes the second neighbour
+        elif kind == 2:
+            db[r] = flipped(q[i], 2, 3 * i + 2)              # beats both
+        elif kind == 3:
+            db[r] = q[i]                                     # exact copies, twice
+            db[r + 1] = q[i]
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q, db, 2)
+    oracle_mod.set_threads(8)
+    oi, od = oracle_mod.knn_hamming(q, db, 2)
+    assert np.array_equal(dist, od) and np.array_equal(idx, oi)
+    assert (idx[0::5, 1] == 12 + 13 * np.arange(0, nq, 5)).all() and (idx[1::5, 1] == 6000 + 200 * np.arange(1, nq, 5)).all()
+    i1 = gpu_pkg.feature_extraction.knn_match(q, db, 1)[0]
+    assert np.array_equal(i1[:, 0], oi[:, 0])
+
+
 def test_get_knn_matches(gpu_pkg, oracle_mod):
     db = gpu_pkg.synth.make_descriptor_db(10000)
     q, src = gpu_pkg.synth.make_queries(db, 3000)
