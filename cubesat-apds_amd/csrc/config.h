@@ -28,6 +28,7 @@ struct Config {
     int side_probe;       // APDS_SIDE_PROBE   1: pick the side stream by a one-time concurrency probe; 0: the first stream created
     int match_mfma;       // APDS_MATCH_MFMA   1: Hamming top-1 / top-2 on the FP4 matrix pipe (hamming_mfma.hip, default); 0: the vector-ALU kernel
     int l2_prio;           // APDS_L2_PRIO 1: the bf16 screen's waves raise their priority for a block's MFMAs and drop it for the epilogue; 0: priority 3 throughout
+    int match_mfma_lds_pad; // APDS_MATCH_MFMA_LDS_PAD bytes of unused dynamic LDS per matrix-core match workgroup (occupancy experiments)
     int match_mfma_prio;   // APDS_MATCH_MFMA_PRIO wave priority (s_setprio 0..3, default 2) for the twelve MFMAs of a block; back to 0 for the ranking
     int match_mfma_sample; // APDS_MATCH_MFMA_SAMPLE rows of the matrix-core matcher's threshold launch (at most a sixteenth of the set; 0: none)
     int match_mfma_splits; // APDS_MATCH_MFMA_SPLITS n > 0: that many train-row splits instead of the fill model's count (experiments)

@@ -32,13 +32,19 @@ namespace apds {
 typedef int hm_v8i __attribute__((ext_vector_type(8)));
 typedef float hm_f32x4 __attribute__((ext_vector_type(4)));
 
-static constexpr int HM_TM = 128;             // train rows per tile
+#ifndef APDS_HM_WAVES
+#define APDS_HM_WAVES 8
+#endif
+static constexpr int HM_WAVES = APDS_HM_WAVES;   // waves per workgroup; a wave stages 16 rows of a tile. (16: one 1024-thread workgroup per CU, 256-row
+                                                 // tiles, half the barriers: 5.58 against 5.46 ms alone, 148.7 against 147.5 frames/s in the pipeline -
+                                                 // no difference worth a second shape; profiles/r04/match_mfma_probe_w16.txt)
+static constexpr int HM_TM = 16 * HM_WAVES;      // train rows per tile
 #ifndef APDS_HM_NC
 #define APDS_HM_NC 3
 #endif
 static constexpr int HM_NC = APDS_HM_NC;      // 16-query column blocks per wave (4: 15 registers spill at four waves per SIMD; 7.0 against 5.9 ms on the
                                               // headline shape, 11.0 against 11.9 on 262143^2: profiles/r04/match_mfma_probe.txt)
-static constexpr int HM_Q = 8 * 16 * HM_NC;   // queries per block (8 waves)
+static constexpr int HM_Q = HM_WAVES * 16 * HM_NC;   // queries per block
 static constexpr int HM_UNIT_SCALE = 0x7F7F7F7F;   // E8M0 127 = 2^0 in every byte
 static constexpr uint64_t HM_EMPTY = ~0ull;
 // Train popcounts are stored with this bias: the ranking value popcount(t) + 1024 - 2 (t AND q) is then a POSITIVE float (>= 512), and
@@ -114,7 +120,7 @@ __device__ __forceinline__ void hm_insert(HmTop2& b, uint32_t d, uint32_t idx) {
 // THR: the launch starts from thresholds (the main launch behind a threshold launch) - a template parameter so that profilers list the two
 // launches of a match under two names
 template <int PRIO, bool THR>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
+__global__ __launch_bounds__(64 * HM_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
                                                            const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
                                                            int q_tiles, int splits, uint32_t index_base, const uint32_t* __restrict__ thr,
                                                            uint64_t* __restrict__ out) {
@@ -176,7 +182,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int i = 0; i < 4; i++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tbase + soff[i]),
                                                  (__attribute__((address_space(3))) void*)(hm_lds + buf * TILE_BYTES + (16 * wave + 4 * i) * 256), 16, 0, 0);
-            if (wave < 2)
+            if (wave < HM_TM / 64)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tpc + (size_t)tile * HM_TM + 64 * wave + lane),
                                                  (__attribute__((address_space(3))) void*)(hm_lds + 2 * TILE_BYTES + buf * (HM_TM * 4) + 256 * wave), 4, 0, 0);
         };
@@ -214,7 +220,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const unsigned char* T = hm_lds + buf * TILE_BYTES;
             const unsigned char* Nn = hm_lds + noff + buf * (HM_TM * 4);
 #pragma unroll
-            for (int rb = 0; rb < 8; rb++) {                           // 16-row blocks of the tile
+            for (int rb = 0; rb < HM_TM / 16; rb++) {                  // 16-row blocks of the tile
                 const hm_f32x4 init = *reinterpret_cast<const hm_f32x4*>(Nn + rb * 64);   // biased popcounts of this lane's four rows
                 uint4 a[4];
 #pragma unroll
@@ -278,7 +284,7 @@ HmPlan hm_plan(int nq, long long nt) {
     HmPlan p;
     p.q_tiles = ceil_div(nq, HM_Q);
     const int t_tiles = (int)ceil_div(nt, (long long)HM_TM);
-    constexpr int SLOTS = 256 * 2;   // two workgroups fit a CU (LDS, registers)
+    constexpr int SLOTS = 256 * (16 / HM_WAVES);   // two 8-wave workgroups fit a CU (LDS, registers)
     constexpr int OVERHEAD = 4;      // a workgroup's prologue and epilogue (operand loads, pipeline fill, key output) in tile times
     // Splits of the train rows: they fill the slots when the query tiles alone do not, and they set the granularity of the last round of
     // workgroups (92 query tiles x 5 splits = 460 workgroups leave a tenth of the chip idle for the whole launch; x 11 = 1012 fill two
@@ -334,10 +340,11 @@ long long hm_sample_rows(long long nt) {
 // parts: [p.splits][nq][2] keys
 void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_fp4, const float* tpc, long long nt, const HmPlan& p, uint32_t index_base,
                     uint64_t* parts, hipStream_t s, const uint32_t* thr, bool timed) {
-    const size_t lds = (size_t)2 * HM_TM * 256 + 2 * HM_TM * sizeof(float);
+    // (APDS_MATCH_MFMA_LDS_PAD: unused dynamic LDS on top, an experiment knob - e.g. 30000 leaves one workgroup per CU)
+    const size_t lds = (size_t)2 * HM_TM * 256 + 2 * HM_TM * sizeof(float) + (size_t)std::max(0, config().match_mfma_lds_pad);
     static std::atomic<bool> opted{false};   // above the default dynamic-LDS limit: opt in once (idempotent, so a race is harmless)
     if (!opted.load()) {
-        auto opt = [&](auto kernel) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); };
+        auto opt = [&](auto kernel) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); };
         opt(&hamming_mfma_kernel<0, false>), opt(&hamming_mfma_kernel<1, false>), opt(&hamming_mfma_kernel<2, false>), opt(&hamming_mfma_kernel<3, false>);
         opt(&hamming_mfma_kernel<0, true>), opt(&hamming_mfma_kernel<1, true>), opt(&hamming_mfma_kernel<2, true>), opt(&hamming_mfma_kernel<3, true>);
         opted.store(true);
@@ -345,7 +352,7 @@ void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_f
     std::unique_ptr<KernelTimer> timer;   // ("hamming_topk": the name the pipeline's counters and bench.py know the main match launch by)
     if (timed) timer.reset(new KernelTimer("hamming_topk", s));
     auto go = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3((unsigned)p.q_tiles * p.splits), dim3(512), lds, s, static_cast<const uint4*>(t_fp4), tpc, (int)nt,
+        hipLaunchKernelGGL(kernel, dim3((unsigned)p.q_tiles * p.splits), dim3(64 * HM_WAVES), lds, s, static_cast<const uint4*>(t_fp4), tpc, (int)nt,
                            static_cast<const uint4*>(q_fp4), qpc, nq, p.tiles_per_split, p.q_tiles, p.splits, index_base, thr, parts);
     };
     const int prio = std::max(0, std::min(3, config().match_mfma_prio));

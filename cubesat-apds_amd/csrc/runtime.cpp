@@ -45,6 +45,7 @@ const Config& config() {
         k.match_mfma_sample = env("APDS_MATCH_MFMA_SAMPLE", 16384);
         k.match_mfma_prio = env("APDS_MATCH_MFMA_PRIO", 2);
         k.l2_prio = env("APDS_L2_PRIO", 1);
+        k.match_mfma_lds_pad = env("APDS_MATCH_MFMA_LDS_PAD", 0);
         k.debug_host_time = env("APDS_DEBUG_HOST_TIME", 0);
         k.match_lds_cap = env("APDS_MATCH_LDS_CAP", 0);
         k.match_sample = env("APDS_MATCH_SAMPLE", 16384);
