@@ -280,8 +280,10 @@ int apds_db_shard(void* db, int rank, int world, int transport, const apds_comm_
 /* ---- the streamed frame pipeline ------------------------------------------------------------------------------------------------------
  * frame -> apds_dev_akaze_extract -> Hamming top-2 against the resident train rows -> ratio test (lib.rs:107-111) -> matched points
  * (lib.rs:161-180, the intended gather) -> find_homography_mat (mod.rs:231-259), software-pipelined over a stream of frames by host
- * threads INSIDE the library: two extraction workers on alternate frames | the match (threshold pre-pass, main scan and record merge of
- * consecutive frames on three streams; with a shard handle: the query gather of frame i+1 issued before the key exchange of frame i) |
+ * threads INSIDE the library: two extraction workers on alternate frames | the match (matrix-core matcher, the default: one stream, against
+ * a copy of the train rows expanded to FP4 operands once at create - 256 bytes per row on top of the caller's 64; vector-ALU matcher:
+ * threshold pre-pass, main scan and record merge of consecutive frames on three streams; with a shard handle: the query gather of frame
+ * i+1 issued before the key exchange of frame i) |
  * ratio filter + points + homography, each with its own HIP stream and device workspace. This is the composed path the north-star metric
  * (frames/s) is measured on; a host needs four calls. The reference chains the steps only inside unit tests (lib.rs:197-249); its
  * production caller runs extraction from a rayon pool without a lock (preprocessor/src/main.rs:227-245), which is what the workers mirror.
@@ -326,7 +328,8 @@ typedef struct apds_pipeline_counters {
 /* The train set: db_rows64_dev = n_rows x 64-byte rows whose global indices start at index_base (one GPU), or `shard` = an apds_shard_*
  * handle (the rows arguments are then ignored; every rank must submit the same number of frames, and all collective calls of that handle
  * come from the pipeline from then on). db_kps_dev: the keypoints of ALL train rows (n_db_total x 28 bytes, indexed by global row: the
- * matched points' coordinates). Everything is borrowed until apds_pipeline_destroy. The pipeline lives on the calling thread's device. */
+ * matched points' coordinates). Everything is borrowed until apds_pipeline_destroy and must not change meanwhile (the train rows are resident:
+ * the pipeline, like a shard handle, keeps derived copies of them). The pipeline lives on the calling thread's device. */
 int apds_pipeline_create(void** pipe, const void* db_rows64_dev, int64_t n_rows, uint32_t index_base, void* shard, const void* db_kps_dev, int64_t n_db_total,
                          const apds_pipeline_params* params);
 /* Hands one frame over (on_device 0: host memory, uploaded by an extraction worker on its own stream - pinned memory makes the copy
@@ -348,7 +351,9 @@ int apds_pipeline_destroy(void* pipe);
 /* Pack n rows of desc_bytes (<= 64) bytes into 64-byte rows (zero padded). */
 int apds_dev_pack_descriptors(const void* src_rows, int64_t n, int desc_bytes, int64_t src_stride, void* dst_rows64, void* stream);
 
-/* Hamming top-k (k >= 1; k in {1,2} is the tuned path, above 16 one pass per 16 neighbours) of n_query rows against n_train rows, both 64-byte pitch.
+/* Hamming top-k (k >= 1) of n_query rows against n_train rows, both 64-byte pitch. k in {1, 2} - all that lib.rs:94-126 consumes - runs on
+ * the FP4 matrix pipe (bits as e2m1 operands, exact integer distances; the train rows are expanded to 256-byte operand rows in the calling
+ * thread's workspace per call - apds_dev_match_backend); every other k on the vector ALU, above 16 one pass per 16 neighbours.
  * out_keys: n_query*k uint64 = (distance << 32) | (train_index + index_base), ascending; 0xFFFF... when absent.
  * Ordering equals BFMatcher's: by distance, ties to the lower train index. */
 int apds_dev_hamming_topk(const void* query_rows64, int n_query, const void* train_rows64, int64_t n_train,
