@@ -235,7 +235,7 @@ int apds_dev_akaze_extract_batch(const void* imgs, int n_images, size_t image_st
     APDS_RANGE("apds_dev_akaze_extract_batch");
     return guarded([&] {
         APDS_REQUIRE(counts && kps && desc64, APDS_ERR_BAD_ARG, "null output");
-        ctx().ws_reset();
+        ctx().ws_reset(pick_stream(stream));
         akaze_extract_batch_device(imgs, n_images, image_stride, rows, cols, channels, stride, max_points, static_cast<apds_keypoint*>(kps),
                                    static_cast<uint8_t*>(desc64), capacity, counts, pick_stream(stream));
     });
@@ -246,7 +246,7 @@ int apds_dev_akaze_extract(const void* img, int rows, int cols, int channels, si
     APDS_RANGE("apds_dev_akaze_extract");
     return guarded([&] {
         APDS_REQUIRE(n && kps && desc64, APDS_ERR_BAD_ARG, "null output");
-        ctx().ws_reset();
+        ctx().ws_reset(pick_stream(stream));
         *n = akaze_extract_device(img, rows, cols, channels, stride, max_points, static_cast<apds_keypoint*>(kps), static_cast<uint8_t*>(desc64), capacity,
                                   pick_stream(stream));
     });

@@ -104,9 +104,17 @@ struct ThreadCtx {
     void drop_side();
     hipEvent_t fork_event(size_t i);            // i-th reusable event (no timing)
 
+    // A call that hands its result count to the host before its last kernels are done (akaze: the count is final ~0.3 ms before the
+    // descriptors) leaves a TAIL on its stream: the workspace it used is still being read. The next call of this thread re-uses that memory,
+    // so ws_reset() waits for the tail first - unless the next call goes to the same stream, whose order already protects it.
+    hipEvent_t tail_event = nullptr, count_event = nullptr;
+    hipStream_t tail_stream = nullptr;
+    bool tail_pending = false;
+    void mark_tail(hipStream_t s);   // everything queued on s so far is this thread's tail
+
     void ensure();
     void* alloc(size_t bytes);   // valid until the next ws_reset()
-    void ws_reset();             // frees all but one slab sized to the high-water mark
+    void ws_reset(hipStream_t for_stream = nullptr);   // frees all but one slab sized to the high-water mark; for_stream: the stream the coming call uses, if known
     template <class T>
     T* alloc_n(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
 };

@@ -27,6 +27,8 @@ struct Config {
     int akaze_fork;       // APDS_AKAZE_FORK   Hessian kernels on a side stream: 1 when the caller is the only library thread, 0 never, 2 always
     int side_probe;       // APDS_SIDE_PROBE   1: pick the side stream by a one-time concurrency probe; 0: the first stream created
     int match_mfma;       // APDS_MATCH_MFMA   1: Hamming top-1 / top-2 on the FP4 matrix pipe (hamming_mfma.hip, default); 0: the vector-ALU kernel
+    int early_count;       // APDS_EARLY_COUNT 1: an extraction call returns when its keypoint count is known (orientation and descriptors still running on
+                           // the stream; the thread's next call on another stream waits for them); 0: when the stream is idle
     int l2_prio;           // APDS_L2_PRIO 1: the bf16 screen's waves raise their priority for a block's MFMAs and drop it for the epilogue; 0: priority 3 throughout
     int match_mfma_lds_pad; // APDS_MATCH_MFMA_LDS_PAD bytes of unused dynamic LDS per matrix-core match workgroup (occupancy experiments)
     int match_mfma_prio;   // APDS_MATCH_MFMA_PRIO wave priority (s_setprio 0..3, default 2) for the twelve MFMAs of a block; back to 0 for the ranking

@@ -45,6 +45,7 @@ const Config& config() {
         k.match_mfma_sample = env("APDS_MATCH_MFMA_SAMPLE", 16384);
         k.match_mfma_prio = env("APDS_MATCH_MFMA_PRIO", 2);
         k.l2_prio = env("APDS_L2_PRIO", 1);
+        k.early_count = env("APDS_EARLY_COUNT", 1);
         k.match_mfma_lds_pad = env("APDS_MATCH_MFMA_LDS_PAD", 0);
         k.debug_host_time = env("APDS_DEBUG_HOST_TIME", 0);
         k.match_lds_cap = env("APDS_MATCH_LDS_CAP", 0);
@@ -187,6 +188,10 @@ void ThreadCtx::drop_side() {
     if (join_event) (void)hipEventDestroy(join_event);
     join_event = nullptr;
     fork_open = false;
+    if (tail_event) (void)hipEventSynchronize(tail_event), (void)hipEventDestroy(tail_event);
+    if (count_event) (void)hipEventDestroy(count_event);
+    tail_event = count_event = nullptr;
+    tail_pending = false;
     if (fork_flag) (void)hipFree(fork_flag);
     fork_flag = nullptr;
     fork_flag_tried = false;
@@ -283,7 +288,18 @@ void* ThreadCtx::alloc(size_t bytes) {
     return r;
 }
 
-void ThreadCtx::ws_reset() {
+void ThreadCtx::mark_tail(hipStream_t s) {
+    if (!tail_event) HIP_CHECK(hipEventCreateWithFlags(&tail_event, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(tail_event, s));
+    tail_stream = s;
+    tail_pending = true;
+}
+
+void ThreadCtx::ws_reset(hipStream_t for_stream) {
+    if (tail_pending && !(for_stream && for_stream == tail_stream)) {   // (same stream: its order protects the workspace, the tail stays pending for others)
+        HIP_CHECK(hipEventSynchronize(tail_event));
+        tail_pending = false;
+    }
     if (slabs.size() > 1) {
         // one slab for everything the last call asked for (+ 1/16), not the sum of the slabs it happened to open
         const size_t total = call_bytes + call_bytes / 16 + (size_t(1) << 20);

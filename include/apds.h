@@ -346,7 +346,9 @@ int apds_pipeline_destroy(void* pipe);
 
 /* ---- device-resident API ------------------------------------------------------------------- */
 /* All pointers below are HIP device pointers. stream: hipStream_t or NULL (the thread's own stream).
- * Calls are asynchronous on that stream unless they return a count to the host. */
+ * Calls are asynchronous on that stream unless they return a count to the host; apds_dev_akaze_extract(_batch) returns as soon as the
+ * count is known, with the orientation / descriptor kernels still queued on the stream: consumers order themselves on that stream (or an
+ * event recorded on it), as with any asynchronous call. */
 
 /* Pack n rows of desc_bytes (<= 64) bytes into 64-byte rows (zero padded). */
 int apds_dev_pack_descriptors(const void* src_rows, int64_t n, int desc_bytes, int64_t src_stride, void* dst_rows64, void* stream);
