@@ -119,7 +119,10 @@ __device__ __forceinline__ void suppress_round_body(const SuppressArgs& A, int l
         // candidate discards the search; a ready candidate's search window cannot be touched by another candidate of the same round
         // (that is what "ready" means), so reading it early sees the same bytes. (The other order — the search first, the readiness
         // window only for the candidates that have a victim, i.e. half the loads for most candidates — was measured: 65 + 44 us for the
-        // two first rounds against 57 + 41: the round is bound by the dependent round trips, not by the number of loads.)
+        // two first rounds against 57 + 41: the round is bound by the dependent round trips, not by the number of loads. Round 4 measured
+        // the opposite remedy as well — two candidates per trip, their entries, status bytes and windows fetched together: 59 + 40 us,
+        // no change (profiles/r04/timeline_suppress_two_per_trip.txt): 85 000 candidates x ~25 scattered 64-byte lines in 56 us is
+        // 2.4 TB/s of line fetches for a few useful bytes each; the windows' footprint, not their latency, is the round.)
         const int px = A.phase == 0 ? x * diff : x / diff, py = A.phase == 0 ? y * diff : y / diff;
         uint8_t sv[4], mv[4];
 #pragma unroll
