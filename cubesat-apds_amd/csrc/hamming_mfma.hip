@@ -342,7 +342,8 @@ void hm_scan_device(const void* q_fp4, const float* qpc, int nq, const void* t_f
                     uint64_t* parts, hipStream_t s, const uint32_t* thr, bool timed) {
     // (APDS_MATCH_MFMA_LDS_PAD: unused dynamic LDS on top, an experiment knob - e.g. 30000 leaves one workgroup per CU)
     const size_t lds = (size_t)2 * HM_TM * 256 + 2 * HM_TM * sizeof(float) + (size_t)std::max(0, config().match_mfma_lds_pad);
-    static std::atomic<bool> opted{false};   // above the default dynamic-LDS limit: opt in once (idempotent, so a race is harmless)
+    static std::atomic<bool> opted_dev[64];   // above the default dynamic-LDS limit: opt in once per device (idempotent, so a race is harmless)
+    std::atomic<bool>& opted = opted_dev[ctx().device & 63];
     if (!opted.load()) {
         auto opt = [&](auto kernel) { HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); };
         opt(&hamming_mfma_kernel<0, false>), opt(&hamming_mfma_kernel<1, false>), opt(&hamming_mfma_kernel<2, false>), opt(&hamming_mfma_kernel<3, false>);
