@@ -196,7 +196,9 @@ __global__ __launch_bounds__(64 * HM_WAVES) __attribute__((amdgpu_waves_per_eu(4
         // Ranking a block: one minimum and one compare per 16 x 16 accumulator in the common case. Only the query blocks in which some lane
         // has a hit run insertion code (a wave-uniform branch each): the counters put the vector instructions beside the MFMAs at 1.9 per
         // MFMA when any hit sent all three query blocks through the twelve insertions, and an MFMA leaves the SIMD's issue port free for
-        // only two of them.
+        // only two of them. (One threshold per lane - the largest of the three - and one minimum over all twelve values in front of the
+        // per-block tests: 7 instructions and one branch instead of 9 and three in the common case, and 8 % SLOWER on every shape
+        // (profiles/r04/match_mfma_probe_single_threshold.txt): a chain of six dependent minima in front of the branch.)
         auto rank = [&](const hm_f32x4 (&a)[HM_NC], uint32_t row0) {
             bool hit[HM_NC];
 #pragma unroll
