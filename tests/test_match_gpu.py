@@ -21,6 +21,33 @@ def test_knn_match_equals_oracle(gpu_pkg, oracle_mod, nq, nt, k):
     assert np.array_equal(idx, oi)
 
 
+def _numpy_top2(q, db):
+    """Brute force in numpy, independent of oracle/ and of the kernels: popcount by unpackbits, stable argsort = ties to the lower row."""
+    d = _bits(q, db).astype(np.int32)
+    order = np.argsort(d, axis=1, kind="stable")[:, :2]
+    return order.astype(np.int32), np.take_along_axis(d, order, axis=1)
+
+
+def test_knn_match_against_a_numpy_popcount(gpu_pkg):
+    """An anchor that shares no text with the oracle: distances are popcount(xor) by definition and BFMatcher's order is by distance with
+    ties to the lower train index (a stable sort). Both matchers (the default runs here, the other one in
+    test_strip_kernels_gpu.py::test_match_parity_on_the_vector_alu_matcher) must give exactly that, planted duplicates included."""
+    rng = np.random.default_rng(21)
+    db = rng.integers(0, 256, (3000, 61), dtype=np.uint8)
+    db[:, 60] &= 0x3F
+    q = rng.integers(0, 256, (700, 61), dtype=np.uint8)
+    q[:, 60] &= 0x3F
+    q[:200] = db[rng.integers(0, 3000, 200)]                 # exact hits
+    db[1500:1600] = db[100:200]                              # duplicate rows: ties between rows 100.. and 1500..
+    q[200:260] = db[100:160]
+    q[260:300, 7] ^= 0x11                                    # near misses of random rows
+    idx, dist = gpu_pkg.feature_extraction.knn_match(q, db, 2)
+    wi, wd = _numpy_top2(q, db)
+    assert np.array_equal(dist, wd) and np.array_equal(idx, wi)
+    i1, d1 = gpu_pkg.feature_extraction.knn_match(q, db, 1)
+    assert np.array_equal(i1[:, 0], wi[:, 0]) and np.array_equal(d1[:, 0], wd[:, 0])
+
+
 def test_ties_prefer_lower_train_index(gpu_pkg, oracle_mod):
     rng = np.random.default_rng(5)
     # few distinct rows repeated many times: every query has massive ties, across chunk borders too

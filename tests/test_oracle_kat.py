@@ -333,3 +333,20 @@ def test_warp_generic_types_kat(oracle_mod):
     f = rng.normal(0, 10, (9, 12)).astype(np.float32)
     half = oracle_mod.warp_perspective(f, np.array([[1, 0, 0.5], [0, 1, 0.0], [0, 0, 1]]))
     assert np.array_equal(half[:, 1:], (f[:, :-1] * np.float32(0.5) + f[:, 1:] * np.float32(0.5)).astype(np.float32))
+
+
+def test_oracle_hamming_against_a_numpy_popcount(oracle_mod):
+    """The oracle's brute-force matcher against an implementation that shares no text with it: popcount(xor) via numpy.unpackbits and a
+    stable argsort (distance, then lower train index - BFMatcher's order). tests/test_match_gpu.py holds the GPU matchers to the same."""
+    rng = np.random.default_rng(22)
+    db = rng.integers(0, 256, (2500, 61), dtype=np.uint8)
+    db[:, 60] &= 0x3F
+    q = rng.integers(0, 256, (400, 61), dtype=np.uint8)
+    q[:, 60] &= 0x3F
+    q[:150] = db[rng.integers(0, 2500, 150)]
+    db[1200:1300] = db[50:150]
+    q[150:200] = db[50:100]
+    d = np.unpackbits(q[:, None, :] ^ db[None, :, :], axis=2).sum(2).astype(np.int32)
+    order = np.argsort(d, axis=1, kind="stable")[:, :3]
+    oi, od = oracle_mod.knn_hamming(q, db, 3)
+    assert np.array_equal(oi, order.astype(np.int32)) and np.array_equal(od, np.take_along_axis(d, order, axis=1))
