@@ -12,11 +12,14 @@
 
 #include "../../include/apds.h"
 
-// The Hamming match grid keeps every SIMD's VALU issue slots booked for ~30 ms per frame and the hardware arbitrates
-// issue by priority, then age, so co-resident waves of the short, memory-bound kernels of the other stages (running
-// on other streams) would starve. They raise their own wave priority; they need few issue slots, so the match loses
-// almost nothing and the stages overlap.
-#define APDS_RAISE_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(3)
+// The match kernel keeps every SIMD's issue slots booked for milliseconds per frame and the hardware arbitrates issue by priority, then
+// age, so co-resident waves of the short, memory-bound kernels of the other stages (running on other streams) would starve. They raise
+// their own wave priority; they need few issue slots, so the match loses almost nothing and the stages overlap. Level 1 since the matrix-core
+// matcher: above its ranking code (0), below its MFMA bursts (2) - 149.0 frames/s against 147.3 at level 3 or 0 (round 4, three runs each).
+#ifndef APDS_STAGE_WAVE_PRIO
+#define APDS_STAGE_WAVE_PRIO 1
+#endif
+#define APDS_RAISE_WAVE_PRIORITY() __builtin_amdgcn_s_setprio(APDS_STAGE_WAVE_PRIO)
 // First act of a main-chain kernel when a fork is armed (ForkSignal below): its first block reports that the kernel has STARTED, i.e. that
 // everything in front of it on its stream is done and written back. The side stream's hipStreamWaitValue32 waits for that value.
 #define APDS_FORK_SIGNAL(sig)                                                                                              \
