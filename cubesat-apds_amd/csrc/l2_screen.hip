@@ -32,6 +32,9 @@
 // twice the math per issued MFMA, a third more per LDS byte. 144 - 149 VGPRs = three waves per SIMD, so blocks of twelve waves: keys
 // identical, 252 ms per screen instead of 209 (0.43 against 0.51 of the bf16 peak; profiles/r04/l2_screen_mfma32_ab.txt). The
 // sixteen-value minimum tree per accumulator and one wave less per SIMD cost more than the wider instruction returns.)
+// (Round 4, from the Hamming matcher, also measured here: tiles by LDS-DMA into an unpadded XOR-swizzled image instead of register staging -
+// keys identical, 108 instead of 122 VGPRs, 231 ms per step instead of 225.5 (0.506 against 0.519): this kernel's gaps are not where the
+// staging instructions are. The wave-priority change is kept: 0.514 -> 0.519. profiles/r04/l2_prio_ab.txt, l2_glds.txt.)
 #include <cmath>
 
 #include "config.h"
