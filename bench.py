@@ -439,6 +439,7 @@ def main():
     # The main scan alone on an idle GPU (three launches after the timed region): in the streamed run the neighbouring frames' pre-pass and
     # merge, and the extraction, share the GPU with it, so its live launch time reads longer than the kernel needs by itself.
     solo_launch_ms = None
+    other_launch_ms, other_keys_equal = None, None
     if rank == 0 and not args.serial and stats and stats[0]["n_keypoints"] > 0:
         with torch.cuda.stream(setup_stream):
             n_solo = C.c_int(0)
@@ -452,8 +453,21 @@ def main():
                 check(L.apds_dev_hamming_topk(desc.data_ptr(), nq0, db_local.data_ptr(), db_local.shape[0], lo, 2, keys_tmp.data_ptr(), pl.torch_stream()))
             torch.cuda.synchronize()
             ms3, n3 = pkg._lib.kernel_ms("hamming_topk")
-            check(L.apds_dev_timing_enable(0))
             solo_launch_ms = ms3 / max(n3, 1)
+            # the OTHER backend alone on the same buffers (north_star names the integer formulation for the Hamming match: its figures stay
+            # in every line): apds_dev_hamming_topk_backend, 1 = vector ALU, 2 = matrix cores
+            backend_now = C.c_int(0)
+            check(L.apds_dev_match_backend(C.byref(backend_now)))
+            other = 1 if backend_now.value else 2
+            keys_other = torch.empty((nq0, 2), dtype=torch.int64, device=dev)
+            pkg._lib.kernel_ms("hamming_topk")
+            for _ in range(2):
+                check(L.apds_dev_hamming_topk_backend(desc.data_ptr(), nq0, db_local.data_ptr(), db_local.shape[0], lo, 2, keys_other.data_ptr(), other, pl.torch_stream()))
+            torch.cuda.synchronize()
+            ms_o, n_o = pkg._lib.kernel_ms("hamming_topk")
+            other_launch_ms = ms_o / max(n_o, 1)
+            other_keys_equal = bool(torch.equal(keys_tmp, keys_other))
+            check(L.apds_dev_timing_enable(0))
     topk_ms, topk_n = timers.get("hamming_topk", (0.0, 0))
     sample_ms, sample_n = timers.get("hamming_topk_sample", (0.0, 0))
     akaze_ms, akaze_n = timers.get("akaze_extract", (0.0, 0))
@@ -522,6 +536,15 @@ def main():
                                           "launches of the timed region, which share the GPU with the extraction of the following frames"} if solo_launch_ms else None),
                         "algorithmic_flop_per_launch": flop_per_launch, "algorithmic_bytes_per_launch": bytes_per_launch,
                         "tpairs_per_s": Q_step * rows_main / (topk_ms_step * 1e-3) / 1e12 if topk_ms_step else 0.0,
+                        "integer_path": ({"kernel": "hamming_topk_kernel<4,2> (xor + popcount on the vector ALU: APDS_MATCH_MFMA=0, and every k > 2)",
+                                          "avg_launch_ms_solo": other_launch_ms, "bound": "int32-valu",
+                                          "achieved": 32.0 * stats[0]["n_keypoints"] * (rows_local - (min(16384, (rows_local // 16) & ~1023) if rows_local >= 32768 else 0)) / (other_launch_ms * 1e-3) / 1e12,
+                                          "peak": VALU_FP32_LANE_RATE_SPEC / 1e12, "unit": "T lane-op/s",
+                                          "frac": 32.0 * stats[0]["n_keypoints"] * (rows_local - (min(16384, (rows_local // 16) & ~1023) if rows_local >= 32768 else 0)) / (other_launch_ms * 1e-3) / VALU_FP32_LANE_RATE_SPEC,
+                                          "keys_equal_matrix_core_path": other_keys_equal,
+                                          "note": "north_star's formulation of the Hamming match, alone on the GPU on frame 0's queries in this run (its main launch; "
+                                                  "0.97 of the xor + half-rate-popcount ceiling); the matrix-core path returns the same keys"}
+                                         if other_launch_ms else None),
                         "vector_alu_equivalent": {"achieved": lane_equiv, "unit": "T lane-op/s", "vs_valu_peak": lane_equiv / (VALU_FP32_LANE_RATE_SPEC / 1e12),
                                                   "note": "SURVEY 8d's figure for this path (32 xor + popcount lane-operations per pair) divided by the launch time: what the "
                                                           "vector-ALU formulation (APDS_MATCH_MFMA=0, hamming_topk_kernel: 0.63 of the 78.6 T peak, 0.97 of its xor + half-rate-bcnt ceiling) "

@@ -23,7 +23,7 @@ SYMBOLS = [
     "apds_last_error", "apds_free", "apds_device_count", "apds_set_device", "apds_build_info", "apds_thread_release", "apds_live_contexts", "apds_release_cached_memory",
     "apds_akaze_extract", "apds_akaze_extract_batch", "apds_dev_akaze_extract_batch", "apds_tile_extract", "apds_tile_extract_batch", "apds_get_knn_matches", "apds_get_bruteforce_matches", "apds_knn_match",
     "apds_get_points_from_matches", "apds_find_homography", "apds_find_homography_ex", "apds_raster_to_mat",
-    "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_match_lds_cap", "apds_dev_match_last_launch_lds", "apds_dev_match_backend", "apds_dev_ratio_filter",
+    "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_match_lds_cap", "apds_dev_match_last_launch_lds", "apds_dev_match_backend", "apds_dev_hamming_topk_backend", "apds_dev_ratio_filter",
     "apds_dev_cross_check", "apds_dev_akaze_extract", "apds_dev_points_from_matches", "apds_dev_find_homography",
     "apds_dev_valu_popcount_peak", "apds_dev_valu_peak", "apds_dev_valu_peak_modes", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane", "apds_stream_create", "apds_stream_destroy",
     "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective", "apds_warp_perspective_f32", "apds_pnp_solver_ransac", "apds_pnp_hypotheses", "apds_get_world_coordinates", "apds_l2_knn_match", "apds_dev_l2_topk", "apds_dev_l2_topk_ex",
@@ -149,6 +149,7 @@ def lib():
             "apds_dev_match_lds_cap": (i, [i, ip]),
             "apds_dev_match_last_launch_lds": (i, [ip]),
             "apds_dev_match_backend": (i, [ip]),
+            "apds_dev_hamming_topk_backend": (i, [vp, i, vp, i64, u32, i, vp, i, vp]),
             "apds_dev_ratio_filter": (i, [vp, i, i, f, vp, ip, vp]),
             "apds_dev_cross_check": (i, [vp, i64, i, vp, ip, vp]),
             "apds_dev_akaze_extract": (i, [vp, i, i, i, sz, i, vp, vp, i, ip, vp]),

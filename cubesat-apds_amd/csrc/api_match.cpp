@@ -189,6 +189,15 @@ int apds_dev_hamming_topk(const void* q, int nq, const void* t, int64_t nt, uint
     });
 }
 
+int apds_dev_hamming_topk_backend(const void* q, int nq, const void* t, int64_t nt, uint32_t index_base, int k, void* out_keys, int backend, void* stream) {
+    APDS_RANGE("apds_dev_hamming_topk_backend");
+    return guarded([&] {
+        APDS_REQUIRE(nq >= 0 && nt >= 0, APDS_ERR_ASSERT, "negative row count");
+        ctx().ws_reset();
+        hamming_topk_device(q, nq, t, nt, index_base, k, static_cast<uint64_t*>(out_keys), pick_stream(stream), backend);
+    });
+}
+
 int apds_dev_topk_state_create(void** state) {
     return guarded([&] {
         APDS_REQUIRE(state, APDS_ERR_BAD_ARG, "null output");

@@ -6,7 +6,8 @@
 namespace apds {
 
 // match_hamming.hip
-void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s);
+// backend: 0 = the configured one (APDS_MATCH_MFMA), 1 = vector ALU (hamming_topk_kernel), 2 = matrix cores (hamming_mfma_kernel, k <= 2)
+void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out, hipStream_t s, int backend = 0);
 void merge_topk_device(const uint64_t* parts, int nparts, int nq, int k, uint64_t* out, hipStream_t s);
 void take_first_columns_device(const uint64_t* in, int nq, int kin, int kout, uint64_t* out, hipStream_t s);
 // hamming_mfma.hip: the same keys for k = 1, 2 from the FP4 matrix pipe (bit -> e2m1 operand, exact)

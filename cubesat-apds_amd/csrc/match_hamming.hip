@@ -1179,7 +1179,7 @@ void topk_split_merge(void* h, uint32_t index_base, uint64_t* out, hipStream_t s
 // Full top-k of nq queries over nt train rows (device, 64-byte rows). out: nq*k keys. k in {1,2} is the tuned path (the reference only
 // ever consumes the two nearest, lib.rs:107-111); 3 <= k <= 16 run with one query per lane, larger k in pages of 16 (topk_paged_device).
 void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uint32_t index_base, int k, uint64_t* out,
-                         hipStream_t s) {
+                         hipStream_t s, int backend) {
     APDS_REQUIRE(k >= 1, APDS_ERR_ASSERT, "top-k needs k >= 1");
     APDS_REQUIRE(nt < (1ll << 31), APDS_ERR_ASSERT, "train set too large for one call; shard it");
     if (nq <= 0) return;
@@ -1191,7 +1191,8 @@ void hamming_topk_device(const void* q, int nq, const void* t, long long nt, uin
         topk_paged_device(q, nq, t, nt, index_base, k, out, s);
         return;
     }
-    if (k <= 2 && config().match_mfma) {   // the two nearest (all the crate surface consumes) come from the matrix cores
+    APDS_REQUIRE(backend >= 0 && backend <= 2 && !(backend == 2 && k > 2), APDS_ERR_ASSERT, "backend: 0 default, 1 vector ALU, 2 matrix cores (k <= 2)");
+    if (k <= 2 && (backend == 2 || (backend == 0 && config().match_mfma))) {   // the two nearest (all the crate surface consumes) come from the matrix cores
         hamming_mfma_topk_device(q, nq, t, nt, index_base, k, out, s);
         return;
     }

@@ -381,6 +381,10 @@ int apds_dev_match_lds_cap(int bytes, int* previous);
 /* Test hook: the dynamic-LDS request of the most recent scan launch of the process (-1 before the first); equals the cap in force for
  * every kernel variant (all tile widths, all k, persistent grid). */
 int apds_dev_match_last_launch_lds(int* bytes);
+/* apds_dev_hamming_topk on a named backend, whatever APDS_MATCH_MFMA says: 0 = the configured one, 1 = vector ALU (xor + popcount,
+ * any k), 2 = matrix cores (k <= 2). The keys are the same bit for bit; bench.py times both in one run and tests compare them in one process. */
+int apds_dev_hamming_topk_backend(const void* query_rows64, int n_query, const void* train_rows64, int64_t n_train, uint32_t index_base, int k,
+                                  void* out_keys, int backend, void* stream);
 /* Which kernel serves k <= 2 (everything lib.rs:94-126 consumes): *matrix_cores = 1: hamming_mfma_kernel - bits as FP4 (e2m1) operands of
  * v_mfma_scale_f32_16x16x128_f8f6f4, exact integer distances (default); 0: hamming_topk_kernel, xor + popcount on the vector ALU
  * (APDS_MATCH_MFMA=0; also what serves every k > 2). The keys are the same bit for bit. */

@@ -48,6 +48,41 @@ def test_knn_match_against_a_numpy_popcount(gpu_pkg):
     assert np.array_equal(i1[:, 0], wi[:, 0]) and np.array_equal(d1[:, 0], wd[:, 0])
 
 
+@pytest.mark.parametrize("nq,nt,k", [(1, 1, 2), (5, 2, 2), (777, 129, 1), (3000, 70000, 2), (40000, 300000, 2), (260, 65536 + 127, 1)])
+def test_both_backends_give_the_same_keys(gpu_pkg, nq, nt, k):
+    """apds_dev_hamming_topk_backend: the vector-ALU kernel (xor + popcount) and the matrix-core kernel (bits as FP4 operands) in ONE process on
+    the same device buffers: every key (distance << 32 | row) identical, empty slots included (fewer train rows than k), with and without
+    the matrix-core matcher's threshold launch (from 65 536 rows up), duplicate rows planted."""
+    import ctypes as C
+    import torch
+    L, check = gpu_pkg.lib(), gpu_pkg._lib.check
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device=dev)
+    g.manual_seed(nq * 7919 + nt)
+    db = torch.randint(0, 256, (nt, 64), dtype=torch.uint8, device=dev, generator=g)
+    q = torch.randint(0, 256, (nq, 64), dtype=torch.uint8, device=dev, generator=g)
+    for t in (db, q):
+        t[:, 60] &= 0x3F
+        t[:, 61:] = 0
+    m = min(nq, nt, 500)
+    q[:m] = db[torch.randint(0, nt, (m,), device=dev, generator=g)]
+    if nt >= 2000:
+        db[nt // 2: nt // 2 + 300] = db[:300]
+    outs = []
+    for backend in (1, 2):
+        out = torch.full((nq, k), -7, dtype=torch.int64, device=dev)
+        check(L.apds_dev_hamming_topk_backend(q.data_ptr(), nq, db.data_ptr(), nt, 1000, k, out.data_ptr(), backend, None))
+        torch.cuda.synchronize()
+        outs.append(out.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert (outs[0] != -7).all()
+    if nt < k:
+        assert (outs[0][:, nt:] == -1).all()          # EMPTY_KEY = ~0
+    # a named backend refuses what it cannot do
+    big = torch.empty((nq, 3), dtype=torch.int64, device=dev)
+    assert L.apds_dev_hamming_topk_backend(q.data_ptr(), nq, db.data_ptr(), nt, 0, 3, big.data_ptr(), 2, None) == -215
+
+
 def test_ties_prefer_lower_train_index(gpu_pkg, oracle_mod):
     rng = np.random.default_rng(5)
     # few distinct rows repeated many times: every query has massive ties, across chunk borders too
