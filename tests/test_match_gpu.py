@@ -71,6 +71,7 @@ def test_both_backends_give_the_same_keys(gpu_pkg, nq, nt, k):
     outs = []
     for backend in (1, 2):
         out = torch.full((nq, k), -7, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize()   # the library call runs on the library's own stream: torch's writes above must have landed
         check(L.apds_dev_hamming_topk_backend(q.data_ptr(), nq, db.data_ptr(), nt, 1000, k, out.data_ptr(), backend, None))
         torch.cuda.synchronize()
         outs.append(out.cpu().numpy())
