@@ -292,7 +292,10 @@ struct Pipeline {
                 HIP_CHECK(hipStreamWaitEvent(st_match, s->ev_extract, 0));
                 HIP_CHECK(hipEventRecord(s->ev_mstart, st_match));
                 if (K > 0 && db_expanded) {   // the matrix-core matcher on the DB's expanded copy
-                    PIPE_OK(guarded([&] { hamming_mfma_topk_train_device(s->desc, K, db_expanded, index_base, 2, static_cast<uint64_t*>(s->keys), st_match); }));
+                    PIPE_OK(guarded([&] {
+                        ctx().ws_reset();   // (as every entry point does: the scan's scratch is this thread's workspace from its start; one stream orders the frames)
+                        hamming_mfma_topk_train_device(s->desc, K, db_expanded, index_base, 2, static_cast<uint64_t*>(s->keys), st_match);
+                    }));
                 } else if (K > 0) {
                     PIPE_OK(apds_dev_hamming_topk(s->desc, K, db_rows, n_rows, index_base, 2, s->keys, st_match));
                 }
