@@ -151,3 +151,23 @@ def test_reserved_cus_reach_the_match_stream(gpu_pkg):
     finally:
         streamed.close()
     assert streamed._masked_stream_handle is None
+
+
+def test_the_stage_threads_workspaces_do_not_grow_with_the_frame_count(gpu_pkg):
+    """Every stage thread's scratch is its thread workspace, reset at the start of every scan / solve: device memory in use after 60 frames
+    and after 360 more must be the same (round 4: the matrix-core scan of the one-GPU pipeline once skipped that reset and grew by a
+    frame's scratch per frame)."""
+    import torch
+    pl, frames, db, db_xy = _setup(gpu_pkg, T=512, ndb=70000, nframes=2)
+    streamed = pl.StreamedFramePipeline(db, db_xy)
+    try:
+        streamed.run(frames, 60, filter_strength=0.3)
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        for _ in range(3):
+            got, _ = streamed.run(frames, 120, filter_strength=0.3)
+            assert all(r is not None for r in got)
+        torch.cuda.synchronize()
+        assert abs(torch.cuda.mem_get_info()[0] - free0) < 16 << 20
+    finally:
+        streamed.close()
