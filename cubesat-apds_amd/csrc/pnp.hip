@@ -11,6 +11,7 @@
 #include "config.h"
 #include "kernels.h"
 #include "pnp_core.h"
+#include "sqpnp_core.h"
 
 #include <algorithm>
 #include <cstring>
@@ -471,8 +472,12 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     *n_inliers = 0;
     APDS_REQUIRE(obj_xyz && img_xy && K && rvec && tvec && inliers, APDS_ERR_BAD_ARG, "null argument");
     APDS_REQUIRE(n >= 4, APDS_ERR_ASSERT, "solvePnPRansac needs at least 4 correspondences");
-    APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP || method == APDS_SOLVEPNP_P3P || method == APDS_SOLVEPNP_ITERATIVE || method == APDS_SOLVEPNP_AP3P,
-                 APDS_ERR_NOT_IMPLEMENTED, "SOLVEPNP_EPNP (the reference's default), SOLVEPNP_P3P, SOLVEPNP_AP3P and SOLVEPNP_ITERATIVE are implemented");
+    // solvePnPGeneric: SOLVEPNP_DLS and SOLVEPNP_UPNP are "broken implementations" that run EPnP
+    if (method == APDS_SOLVEPNP_DLS || method == APDS_SOLVEPNP_UPNP) method = APDS_SOLVEPNP_EPNP;
+    APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP || method == APDS_SOLVEPNP_P3P || method == APDS_SOLVEPNP_ITERATIVE || method == APDS_SOLVEPNP_AP3P ||
+                     method == APDS_SOLVEPNP_SQPNP,
+                 APDS_ERR_NOT_IMPLEMENTED,
+                 "SOLVEPNP_EPNP (the reference's default), _P3P, _AP3P, _ITERATIVE, _SQPNP and _DLS / _UPNP (= EPnP) are implemented; _IPPE / _IPPE_SQUARE are not");
     // kernel choice of solvePnPRansac: P3P / AP3P on 4 points when asked for, P3P when there are only 4 points; EPnP on 5 otherwise
     const bool ap3p = method == APDS_SOLVEPNP_AP3P;
     const bool p3p = method == APDS_SOLVEPNP_P3P || ap3p || n == 4;
@@ -571,11 +576,25 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
         if (iterative_start_pose(oi.data(), ii.data(), cnt, cam, pose, s)) PoseRefiner{oi.data(), ii.data(), cnt, cam, {}, {}}.run(pose);
         std::memcpy(rvec, pose, 3 * sizeof(double));
         std::memcpy(tvec, pose + 3, 3 * sizeof(double));
+    } else if (method == APDS_SOLVEPNP_SQPNP) {   // the RANSAC kernel stayed EPnP; the last solvePnP over the inliers is SQPnP (sqpnp_core.h)
+        if (!sqpnp::solve(oi.data(), ii.data(), cnt, cam, rvec, tvec)) {   // no pose: solvePnPRansac hands back the RANSAC model and returns false
+            std::memcpy(rvec, best, 3 * sizeof(double));
+            std::memcpy(tvec, best + 3, 3 * sizeof(double));
+            return 0;
+        }
     } else {
         host_epnp<double>(oi.data(), ii.data(), cnt, cam, rvec, tvec);
     }
     *n_inliers = cnt;
     return 1;
+}
+
+// solvePnP(SOLVEPNP_SQPNP) alone, for the parity tests (host arithmetic; no device work)
+int pnp_sqpnp_host(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec) {
+    APDS_REQUIRE(obj_xyz && img_xy && K && rvec && tvec, APDS_ERR_BAD_ARG, "null argument");
+    APDS_REQUIRE(n >= 3, APDS_ERR_ASSERT, "SQPnP needs at least 3 correspondences");
+    const Camera cam{K[0], K[4], K[2], K[5]};
+    return sqpnp::solve(obj_xyz, img_xy, n, cam, rvec, tvec) ? 1 : 0;
 }
 
 // per-stage hooks for the parity tests: the pose of explicit samples (model_points 5: EPnP, 4: P3P; a P3P sample without a pose

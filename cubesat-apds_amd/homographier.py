@@ -127,7 +127,10 @@ class SolvePnPMethod(enum.IntEnum):
     SOLVEPNP_ITERATIVE = 0
     SOLVEPNP_EPNP = 1
     SOLVEPNP_P3P = 2
+    SOLVEPNP_DLS = 3       # OpenCV 4 runs EPnP for DLS and UPNP
+    SOLVEPNP_UPNP = 4
     SOLVEPNP_AP3P = 5
+    SOLVEPNP_SQPNP = 8
 
 
 class ImgObjCorrespondence:
@@ -151,7 +154,8 @@ def pnp_solver_ransac(point_correspondences, camera_intrinsic, iter_count, repro
     """mod.rs:320-369 — solvePnPRansac(useExtrinsicGuess = false). Returns a PNPRANSACSolution, or None when no pose was found
     (Ok(None)); raises MatError("Opencv") for fewer than 4 correspondences (mod.rs:627-638). `dist_coeffs` is accepted and ignored,
     as in the reference, which shadows it with zeros(4,1) before the call (mod.rs:344). Built: SOLVEPNP_EPNP (the default),
-    SOLVEPNP_P3P, SOLVEPNP_AP3P and SOLVEPNP_ITERATIVE (EPnP RANSAC, then solvePnP(ITERATIVE) over the inliers without an extrinsic guess); four correspondences go through P3P
+    SOLVEPNP_P3P, SOLVEPNP_AP3P, SOLVEPNP_ITERATIVE (EPnP RANSAC, then solvePnP(ITERATIVE) over the inliers without an extrinsic guess),
+    SOLVEPNP_SQPNP (EPnP RANSAC, then SQPnP over the inliers) and SOLVEPNP_DLS / SOLVEPNP_UPNP (EPnP, as in OpenCV 4); four correspondences go through P3P
     whatever the method, as in OpenCV."""
     del dist_coeffs
     n = len(point_correspondences)

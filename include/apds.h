@@ -157,13 +157,19 @@ int apds_warp_perspective_f32(const float* src, int rows, int cols, int channels
  * Roumeliotis' algebraic P3P on 4 points) - the final pose over the inliers is EPnP in these cases, as in OpenCV - and APDS_SOLVEPNP_ITERATIVE (EPnP kernel; final pose = solvePnP(ITERATIVE) over
  * the inliers WITHOUT an extrinsic guess, as the reference's use_extrinsic_guess = false makes it: a homography (planar object points) or
  * DLT (>= 6 points) start, then <= 20 Levenberg-Marquardt iterations on the reprojection error; with five non-planar inliers the RANSAC
- * model stays, as in solvePnPRansac). SQPNP / IPPE / ... return APDS_ERR_NOT_IMPLEMENTED.
+ * model stays, as in solvePnPRansac), APDS_SOLVEPNP_SQPNP (EPnP kernel; final pose = Terzakis and Lourakis' SQPnP over the inliers, calib3d/sqpnp.cpp;
+ * no pose in front of the camera -> *found = 0 with the RANSAC model in rvec / tvec, as solvePnPRansac leaves it), APDS_SOLVEPNP_DLS and
+ * APDS_SOLVEPNP_UPNP (OpenCV 4 runs EPnP for both: identical to APDS_SOLVEPNP_EPNP). IPPE / IPPE_SQUARE (planar targets only) return
+ * APDS_ERR_NOT_IMPLEMENTED.
  * n < 4 -> APDS_ERR_ASSERT (mod.rs:627-638).
  * *found = 1: rvec[3], tvec[3], inliers[0..*n_inliers) filled (inliers: caller allocated, n ints); *found = 0: Ok(None). */
 #define APDS_SOLVEPNP_ITERATIVE 0
 #define APDS_SOLVEPNP_EPNP 1
 #define APDS_SOLVEPNP_P3P 2
+#define APDS_SOLVEPNP_DLS 3
+#define APDS_SOLVEPNP_UPNP 4
 #define APDS_SOLVEPNP_AP3P 5
+#define APDS_SOLVEPNP_SQPNP 8
 int apds_pnp_solver_ransac(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, int iter_count, float reproj_thres,
                            double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers, int* found);
 
@@ -445,6 +451,11 @@ int apds_akaze_debug_plane(const uint8_t* img, int rows, int cols, int channels,
  * model_points 5 = EPnP on 5 correspondences, 4 = P3P on 4 (three solve, the fourth ranks; NaNs when there is no pose), 40 = AP3P on 4. */
 int apds_pnp_hypotheses(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, const int32_t* samples, int n_samples,
                         int model_points, double* models);
+
+/* Test hook: cv::solvePnP(..., SOLVEPNP_SQPNP) alone on n >= 3 correspondences - the final pose apds_pnp_solver_ransac computes over
+ * its inliers when the caller names APDS_SOLVEPNP_SQPNP (mod.rs:327,359). Host arithmetic only: one 9 x 9 problem per call whatever n.
+ * *found = 0: no pose (degenerate points, or none in front of the camera). */
+int apds_pnp_sqpnp(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, double* rvec, double* tvec, int* found);
 
 /* Measurement helpers used by bench.py (not part of the reference surface). */
 /* Register-only xor+popcount loop: returns measured lane-ops/s (32-bit xor + bcnt counted as 2 ops). */

@@ -1517,6 +1517,533 @@ bool solve_pnp_ap3p(const T* obj, const T* img, const double* K, double* rvec, d
     return true;
 }
 
+// ---- sqpnp.cpp (Terzakis & Lourakis, "A consistently fast and globally optimal solution to the PnP problem", ECCV 2020) ----
+// solvePnP(SOLVEPNP_SQPNP) over the inliers, as recalled for OpenCV >= 4.7 (the revision with the FOAM nearest rotation and the
+// majority cheirality test): undistortPoints with zero distortion, PoseSolver::solve, the solution with the smallest
+// reprojection error. PARITY UNPINNED (no OpenCV in this image). Chosen where memory does not decide: sums in index order.
+struct SqpnpSolution {
+    double r[9], r_hat[9], t[3], sq_error;
+};
+
+struct SqpnpSolver {
+    static constexpr double RANK_TOLERANCE = 1e-7, SQP_SQUARED_TOLERANCE = 1e-10, SQP_DET_THRESHOLD = 1.001;
+    static constexpr double ORTHOGONALITY_SQUARED_ERROR_THRESHOLD = 1e-8, EQUAL_VECTORS_SQUARED_DIFF = 1e-10;
+    static constexpr double EQUAL_SQUARED_ERRORS_DIFF = 1e-6, POINT_VARIANCE_THRESHOLD = 1e-5;
+    static constexpr int SQP_MAX_ITERATION = 15;
+
+    double omega_[9][9], s_[9], u_[9][9] /* u_[k][i]: component k of eigenvector i */, p_[3][9], point_mean_[3];
+    int num_null_vectors_ = -1, num_solutions_ = 0;
+    SqpnpSolution solutions_[18];
+    const double* obj_ = nullptr;
+    int n_ = 0;
+
+    static double det3x3(const double* e) {
+        return e[0] * e[4] * e[8] + e[1] * e[5] * e[6] + e[2] * e[3] * e[7] - e[6] * e[4] * e[2] - e[7] * e[5] * e[0] - e[8] * e[3] * e[1];
+    }
+
+    static double orthogonalityError(const double* a) {
+        const double sq_norm_a1 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2], sq_norm_a2 = a[3] * a[3] + a[4] * a[4] + a[5] * a[5],
+                     sq_norm_a3 = a[6] * a[6] + a[7] * a[7] + a[8] * a[8];
+        const double dot_a1a2 = a[0] * a[3] + a[1] * a[4] + a[2] * a[5], dot_a1a3 = a[0] * a[6] + a[1] * a[7] + a[2] * a[8],
+                     dot_a2a3 = a[3] * a[6] + a[4] * a[7] + a[5] * a[8];
+        return (sq_norm_a1 - 1) * (sq_norm_a1 - 1) + (sq_norm_a2 - 1) * (sq_norm_a2 - 1) + (sq_norm_a3 - 1) * (sq_norm_a3 - 1) +
+               2 * (dot_a1a2 * dot_a1a2 + dot_a1a3 * dot_a1a3 + dot_a2a3 * dot_a2a3);
+    }
+
+    // analyticalInverse3x3Symm: closed form, cv::invert(DECOMP_SVD) when the determinant is below 1e-8
+    static void analyticalInverse3x3Symm(const double Q[3][3], double Qinv[3][3]) {
+        const double a = Q[0][0], b = Q[1][0], d = Q[1][1], c = Q[2][0], e = Q[2][1], f = Q[2][2];
+        const double t2 = e * e, t4 = a * d, t7 = b * b, t9 = b * c, t12 = c * c;
+        const double det = -t4 * f + a * t2 + t7 * f - 2.0 * t9 * e + t12 * d;
+        if (std::fabs(det) < 1e-8) {
+            svd_invert3(&Q[0][0], &Qinv[0][0]);
+            return;
+        }
+        const double t15 = 1.0 / det, t20 = (-b * f + c * e) * t15, t24 = (b * e - c * d) * t15, t30 = (a * e - t9) * t15;
+        Qinv[0][0] = (-d * f + t2) * t15;
+        Qinv[0][1] = Qinv[1][0] = -t20;
+        Qinv[0][2] = Qinv[2][0] = -t24;
+        Qinv[1][1] = -(a * f - t12) * t15;
+        Qinv[1][2] = Qinv[2][1] = t30;
+        Qinv[2][2] = -(t4 - t7) * t15;
+    }
+
+    // nearestRotationMatrixFOAM: the orthogonal factor of e's polar decomposition from the largest root of FOAM's quartic
+    static void nearestRotationMatrix(const double* e, double* r) {
+        double adj_e[9];
+        adj_e[0] = e[4] * e[8] - e[5] * e[7];
+        adj_e[1] = e[2] * e[7] - e[1] * e[8];
+        adj_e[2] = e[1] * e[5] - e[2] * e[4];
+        adj_e[3] = e[5] * e[6] - e[3] * e[8];
+        adj_e[4] = e[0] * e[8] - e[2] * e[6];
+        adj_e[5] = e[2] * e[3] - e[0] * e[5];
+        adj_e[6] = e[3] * e[7] - e[4] * e[6];
+        adj_e[7] = e[1] * e[6] - e[0] * e[7];
+        adj_e[8] = e[0] * e[4] - e[1] * e[3];
+        const double det_e = e[0] * e[4] * e[8] - e[0] * e[5] * e[7] - e[1] * e[3] * e[8] + e[2] * e[3] * e[7] + e[1] * e[6] * e[5] - e[2] * e[6] * e[4];
+        double e_sq = 0, adj_e_sq = 0;
+        for (int i = 0; i < 9; i++) e_sq += e[i] * e[i];
+        for (int i = 0; i < 9; i++) adj_e_sq += adj_e[i] * adj_e[i];
+        double l = 0.5 * (e_sq + 3.0), lprev = 0.0;
+        if (det_e < 0.0) l = -l;
+        for (int i = 15; std::fabs(l - lprev) > 1E-12 * std::fabs(lprev) && i > 0; --i) {
+            const double tmp = l * l - e_sq;
+            const double p = tmp * tmp - 8.0 * l * det_e - 4.0 * adj_e_sq;
+            const double pp = 8.0 * (0.5 * tmp * l - det_e);
+            lprev = l;
+            l -= p / pp;
+        }
+        const double a = l * l + e_sq;
+        double e_et[9], tmp[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) e_et[3 * i + j] = e[3 * i] * e[3 * j] + e[3 * i + 1] * e[3 * j + 1] + e[3 * i + 2] * e[3 * j + 2];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) tmp[3 * i + j] = e_et[3 * i] * e[j] + e_et[3 * i + 1] * e[3 + j] + e_et[3 * i + 2] * e[6 + j];
+        double denom = l * (l * l - e_sq) - 2.0 * det_e;
+        // DOCUMENTED DEVIATION: denom = (s1 + s2)(s1 + s3)(s2 + s3) of e's singular values. A rank-one e - every null vector of Omega when the
+        // object points are coplanar is one, w n' - makes it vanish and FOAM returns e / l, no rotation at all (the SQP that starts there divides
+        // by zero). Such an e is completed to a rotation the way nearestRotationMatrixSVD (OpenCV <= 4.6) does it: U diag(1, 1, det U det V') V'.
+        if (!(std::fabs(denom) >= 1e-3 * (e_sq * std::sqrt(e_sq)))) {
+            double W[3], Ut[9], Vt[9];
+            svd(e, 3, 3, W, Ut, Vt);
+            const double detuv = det3x3(Ut) * det3x3(Vt);
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) r[3 * i + j] = Ut[i] * Vt[j] + Ut[3 + i] * Vt[3 + j] + (Ut[6 + i] * detuv) * Vt[6 + j];
+            return;
+        }
+        denom = 1.0 / denom;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) r[3 * i + j] = (a * e[3 * i + j] + 2.0 * (l * adj_e[3 * j + i] - tmp[3 * i + j])) * denom;
+    }
+
+    void computeOmega(const double* obj, const double* nimg, int n) {
+        obj_ = obj;
+        n_ = n;
+        std::memset(omega_, 0, sizeof omega_);
+        double qa_sum[3][9];
+        std::memset(qa_sum, 0, sizeof qa_sum);
+        double sum_img_x = 0, sum_img_y = 0, sum_obj[3] = {0, 0, 0}, sum_sq_norm = 0;
+        for (int i = 0; i < n; i++) {
+            const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2], x = nimg[2 * i], y = nimg[2 * i + 1];
+            const double sq_norm = x * x + y * y;
+            sum_sq_norm += sq_norm;
+            sum_img_x += x;
+            sum_img_y += y;
+            sum_obj[0] += X;
+            sum_obj[1] += Y;
+            sum_obj[2] += Z;
+            const double X2 = X * X, XY = X * Y, XZ = X * Z, Y2 = Y * Y, YZ = Y * Z, Z2 = Z * Z;
+            omega_[0][0] += X2; omega_[0][1] += XY; omega_[0][2] += XZ; omega_[1][1] += Y2; omega_[1][2] += YZ; omega_[2][2] += Z2;
+            omega_[0][6] += -x * X2; omega_[0][7] += -x * XY; omega_[0][8] += -x * XZ;
+            omega_[1][7] += -x * Y2; omega_[1][8] += -x * YZ;
+            omega_[2][8] += -x * Z2;
+            omega_[3][6] += -y * X2; omega_[3][7] += -y * XY; omega_[3][8] += -y * XZ;
+            omega_[4][7] += -y * Y2; omega_[4][8] += -y * YZ;
+            omega_[5][8] += -y * Z2;
+            omega_[6][6] += sq_norm * X2; omega_[6][7] += sq_norm * XY; omega_[6][8] += sq_norm * XZ;
+            omega_[7][7] += sq_norm * Y2; omega_[7][8] += sq_norm * YZ;
+            omega_[8][8] += sq_norm * Z2;
+            qa_sum[0][0] += X; qa_sum[0][1] += Y; qa_sum[0][2] += Z;
+            qa_sum[1][3] += X; qa_sum[1][4] += Y; qa_sum[1][5] += Z;
+            qa_sum[0][6] += -x * X; qa_sum[0][7] += -x * Y; qa_sum[0][8] += -x * Z;
+            qa_sum[1][6] += -y * X; qa_sum[1][7] += -y * Y; qa_sum[1][8] += -y * Z;
+            qa_sum[2][0] += -x * X; qa_sum[2][1] += -x * Y; qa_sum[2][2] += -x * Z;
+            qa_sum[2][3] += -y * X; qa_sum[2][4] += -y * Y; qa_sum[2][5] += -y * Z;
+            qa_sum[2][6] += sq_norm * X; qa_sum[2][7] += sq_norm * Y; qa_sum[2][8] += sq_norm * Z;
+        }
+        omega_[1][6] = omega_[0][7]; omega_[2][6] = omega_[0][8]; omega_[2][7] = omega_[1][8];
+        omega_[4][6] = omega_[3][7]; omega_[5][6] = omega_[3][8]; omega_[5][7] = omega_[4][8];
+        omega_[7][6] = omega_[6][7]; omega_[8][6] = omega_[6][8]; omega_[8][7] = omega_[7][8];
+        omega_[3][3] = omega_[0][0]; omega_[3][4] = omega_[0][1]; omega_[3][5] = omega_[0][2];
+        omega_[4][4] = omega_[1][1]; omega_[4][5] = omega_[1][2];
+        omega_[5][5] = omega_[2][2];
+        for (int r = 0; r < 9; r++)
+            for (int c = 0; c < r; c++) omega_[r][c] = omega_[c][r];
+        double q[3][3], q_inv[3][3];
+        q[0][0] = n; q[0][1] = 0; q[0][2] = -sum_img_x;
+        q[1][0] = 0; q[1][1] = n; q[1][2] = -sum_img_y;
+        q[2][0] = -sum_img_x; q[2][1] = -sum_img_y; q[2][2] = sum_sq_norm;
+        analyticalInverse3x3Symm(q, q_inv);
+        for (int i = 0; i < 3; i++)          // p_ = -q_inv * qa_sum
+            for (int j = 0; j < 9; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += -q_inv[i][k] * qa_sum[k][j];
+                p_[i][j] = s;
+            }
+        for (int i = 0; i < 9; i++)          // omega_ += qa_sum.t() * p_
+            for (int j = 0; j < 9; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += qa_sum[k][i] * p_[k][j];
+                omega_[i][j] += s;
+            }
+        // cv::SVD(omega_, FULL_UV): u_ = vt.t()
+        double Ut[81], Vt[81];
+        svd(&omega_[0][0], 9, 9, s_, Ut, Vt);
+        for (int i = 0; i < 9; i++)
+            for (int k = 0; k < 9; k++) u_[k][i] = Vt[i * 9 + k];
+        while (7 - num_null_vectors_ >= 0 && s_[7 - num_null_vectors_] < RANK_TOLERANCE) num_null_vectors_++;
+        ++num_null_vectors_;
+        const double inv_n = 1.0 / n;
+        for (int k = 0; k < 3; k++) point_mean_[k] = sum_obj[k] * inv_n;
+    }
+
+    // an orthonormal basis H of the row space of the constraints' Jacobian at r, K = J H (lower triangular), N = a basis of its null space
+    static void computeRowAndNullspace(const double* r, double H[9][6], double N[9][3], double K[6][6]) {
+        const double norm_threshold = 0.1;
+        std::memset(H, 0, sizeof(double) * 54);
+        std::memset(K, 0, sizeof(double) * 36);
+        // 1. q1
+        const double norm_r1 = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+        const double inv_norm_r1 = norm_r1 > 1e-5 ? 1.0 / norm_r1 : 0.0;
+        H[0][0] = r[0] * inv_norm_r1; H[1][0] = r[1] * inv_norm_r1; H[2][0] = r[2] * inv_norm_r1;
+        K[0][0] = 2 * norm_r1;
+        // 2. q2
+        const double norm_r2 = std::sqrt(r[3] * r[3] + r[4] * r[4] + r[5] * r[5]);
+        const double inv_norm_r2 = 1.0 / norm_r2;
+        H[3][1] = r[3] * inv_norm_r2; H[4][1] = r[4] * inv_norm_r2; H[5][1] = r[5] * inv_norm_r2;
+        K[1][0] = 0; K[1][1] = 2 * norm_r2;
+        // 3. q3
+        const double norm_r3 = std::sqrt(r[6] * r[6] + r[7] * r[7] + r[8] * r[8]);
+        const double inv_norm_r3 = 1.0 / norm_r3;
+        H[6][2] = r[6] * inv_norm_r3; H[7][2] = r[7] * inv_norm_r3; H[8][2] = r[8] * inv_norm_r3;
+        K[2][0] = K[2][1] = 0; K[2][2] = 2 * norm_r3;
+        // 4. q4
+        const double dot_j4q1 = r[3] * H[0][0] + r[4] * H[1][0] + r[5] * H[2][0], dot_j4q2 = r[0] * H[3][1] + r[1] * H[4][1] + r[2] * H[5][1];
+        H[0][3] = r[3] - dot_j4q1 * H[0][0]; H[1][3] = r[4] - dot_j4q1 * H[1][0]; H[2][3] = r[5] - dot_j4q1 * H[2][0];
+        H[3][3] = r[0] - dot_j4q2 * H[3][1]; H[4][3] = r[1] - dot_j4q2 * H[4][1]; H[5][3] = r[2] - dot_j4q2 * H[5][1];
+        const double inv_norm_j4 = 1.0 / std::sqrt(H[0][3] * H[0][3] + H[1][3] * H[1][3] + H[2][3] * H[2][3] + H[3][3] * H[3][3] + H[4][3] * H[4][3] + H[5][3] * H[5][3]);
+        for (int i = 0; i < 6; i++) H[i][3] *= inv_norm_j4;
+        K[3][0] = r[3] * H[0][0] + r[4] * H[1][0] + r[5] * H[2][0];
+        K[3][1] = r[0] * H[3][1] + r[1] * H[4][1] + r[2] * H[5][1];
+        K[3][2] = 0;
+        K[3][3] = r[3] * H[0][3] + r[4] * H[1][3] + r[5] * H[2][3] + r[0] * H[3][3] + r[1] * H[4][3] + r[2] * H[5][3];
+        // 5. q5
+        const double dot_j5q2 = r[6] * H[3][1] + r[7] * H[4][1] + r[8] * H[5][1];
+        const double dot_j5q3 = r[3] * H[6][2] + r[4] * H[7][2] + r[5] * H[8][2];
+        const double dot_j5q4 = r[6] * H[3][3] + r[7] * H[4][3] + r[8] * H[5][3];
+        H[0][4] = -dot_j5q4 * H[0][3]; H[1][4] = -dot_j5q4 * H[1][3]; H[2][4] = -dot_j5q4 * H[2][3];
+        H[3][4] = r[6] - dot_j5q2 * H[3][1] - dot_j5q4 * H[3][3];
+        H[4][4] = r[7] - dot_j5q2 * H[4][1] - dot_j5q4 * H[4][3];
+        H[5][4] = r[8] - dot_j5q2 * H[5][1] - dot_j5q4 * H[5][3];
+        H[6][4] = r[3] - dot_j5q3 * H[6][2]; H[7][4] = r[4] - dot_j5q3 * H[7][2]; H[8][4] = r[5] - dot_j5q3 * H[8][2];
+        {
+            double sq = 0;
+            for (int i = 0; i < 9; i++) sq += H[i][4] * H[i][4];
+            const double inv = 1.0 / std::sqrt(sq);
+            for (int i = 0; i < 9; i++) H[i][4] *= inv;
+        }
+        K[4][0] = 0;
+        K[4][1] = r[6] * H[3][1] + r[7] * H[4][1] + r[8] * H[5][1];
+        K[4][2] = r[3] * H[6][2] + r[4] * H[7][2] + r[5] * H[8][2];
+        K[4][3] = r[6] * H[3][3] + r[7] * H[4][3] + r[8] * H[5][3];
+        K[4][4] = r[6] * H[3][4] + r[7] * H[4][4] + r[8] * H[5][4] + r[3] * H[6][4] + r[4] * H[7][4] + r[5] * H[8][4];
+        // 6. q6
+        const double dot_j6q1 = r[6] * H[0][0] + r[7] * H[1][0] + r[8] * H[2][0];
+        const double dot_j6q3 = r[0] * H[6][2] + r[1] * H[7][2] + r[2] * H[8][2];
+        const double dot_j6q4 = r[6] * H[0][3] + r[7] * H[1][3] + r[8] * H[2][3];
+        const double dot_j6q5 = r[0] * H[6][4] + r[1] * H[7][4] + r[2] * H[8][4] + r[6] * H[0][4] + r[7] * H[1][4] + r[8] * H[2][4];
+        H[0][5] = r[6] - dot_j6q1 * H[0][0] - dot_j6q4 * H[0][3] - dot_j6q5 * H[0][4];
+        H[1][5] = r[7] - dot_j6q1 * H[1][0] - dot_j6q4 * H[1][3] - dot_j6q5 * H[1][4];
+        H[2][5] = r[8] - dot_j6q1 * H[2][0] - dot_j6q4 * H[2][3] - dot_j6q5 * H[2][4];
+        H[3][5] = -dot_j6q5 * H[3][4] - dot_j6q4 * H[3][3];
+        H[4][5] = -dot_j6q5 * H[4][4] - dot_j6q4 * H[4][3];
+        H[5][5] = -dot_j6q5 * H[5][4] - dot_j6q4 * H[5][3];
+        H[6][5] = r[0] - dot_j6q3 * H[6][2] - dot_j6q5 * H[6][4];
+        H[7][5] = r[1] - dot_j6q3 * H[7][2] - dot_j6q5 * H[7][4];
+        H[8][5] = r[2] - dot_j6q3 * H[8][2] - dot_j6q5 * H[8][4];
+        {
+            double sq = 0;
+            for (int i = 0; i < 9; i++) sq += H[i][5] * H[i][5];
+            const double inv = 1.0 / std::sqrt(sq);
+            for (int i = 0; i < 9; i++) H[i][5] *= inv;
+        }
+        K[5][0] = r[6] * H[0][0] + r[7] * H[1][0] + r[8] * H[2][0];
+        K[5][1] = 0;
+        K[5][2] = r[0] * H[6][2] + r[1] * H[7][2] + r[2] * H[8][2];
+        K[5][3] = r[6] * H[0][3] + r[7] * H[1][3] + r[8] * H[2][3];
+        K[5][4] = r[6] * H[0][4] + r[7] * H[1][4] + r[8] * H[2][4] + r[0] * H[6][4] + r[1] * H[7][4] + r[2] * H[8][4];
+        K[5][5] = r[6] * H[0][5] + r[7] * H[1][5] + r[8] * H[2][5] + r[0] * H[6][5] + r[1] * H[7][5] + r[2] * H[8][5];
+        // the projector onto the null space of H, and three of its columns: the longest, the one most orthogonal to it, then to both
+        double Pn[9][9];
+        for (int i = 0; i < 9; i++)
+            for (int j = 0; j < 9; j++) {
+                double s = 0;
+                for (int k = 0; k < 6; k++) s += H[i][k] * H[j][k];
+                Pn[i][j] = (i == j ? 1.0 : 0.0) - s;
+            }
+        auto col_dot = [&](int a, int b) {
+            double s = 0;
+            for (int k = 0; k < 9; k++) s += Pn[k][a] * Pn[k][b];
+            return s;
+        };
+        int index1 = 0, index2 = 0, index3 = 0;
+        double max_norm1 = DBL_MIN, min_dot12 = DBL_MAX, min_dot1323 = DBL_MAX, col_norms[9];
+        for (int i = 0; i < 9; i++) {
+            col_norms[i] = std::sqrt(col_dot(i, i));
+            if (col_norms[i] >= norm_threshold && max_norm1 < col_norms[i]) {
+                max_norm1 = col_norms[i];
+                index1 = i;
+            }
+        }
+        for (int k = 0; k < 9; k++) N[k][0] = Pn[k][index1] * (1.0 / max_norm1);
+        for (int i = 0; i < 9; i++) {
+            if (i == index1) continue;
+            if (col_norms[i] >= norm_threshold) {
+                const double cos_v1_x_col = std::fabs(col_dot(i, index1) / col_norms[i]);
+                if (cos_v1_x_col <= min_dot12) {
+                    index2 = i;
+                    min_dot12 = cos_v1_x_col;
+                }
+            }
+        }
+        {
+            double d = 0;
+            for (int k = 0; k < 9; k++) d += Pn[k][index2] * N[k][0];
+            for (int k = 0; k < 9; k++) N[k][1] = Pn[k][index2] - d * N[k][0];
+            double sq = 0;
+            for (int k = 0; k < 9; k++) sq += N[k][1] * N[k][1];
+            const double inv = 1.0 / std::sqrt(sq);
+            for (int k = 0; k < 9; k++) N[k][1] *= inv;
+        }
+        for (int i = 0; i < 9; i++) {
+            if (i == index2 || i == index1) continue;
+            if (col_norms[i] >= norm_threshold) {
+                const double cos_v1_x_col = std::fabs(col_dot(i, index1) / col_norms[i]);
+                const double cos_v2_x_col = std::fabs(col_dot(i, index2) / col_norms[i]);
+                if (cos_v1_x_col + cos_v2_x_col <= min_dot1323) {
+                    index3 = i;
+                    min_dot1323 = cos_v2_x_col + cos_v2_x_col;   // (sic: sqpnp.cpp stores twice the second cosine)
+                }
+            }
+        }
+        {
+            double d1 = 0, d0 = 0;
+            for (int k = 0; k < 9; k++) d1 += Pn[k][index3] * N[k][1];
+            for (int k = 0; k < 9; k++) d0 += Pn[k][index3] * N[k][0];
+            for (int k = 0; k < 9; k++) N[k][2] = Pn[k][index3] - d1 * N[k][1] - d0 * N[k][0];
+            double sq = 0;
+            for (int k = 0; k < 9; k++) sq += N[k][2] * N[k][2];
+            const double inv = 1.0 / std::sqrt(sq);
+            for (int k = 0; k < 9; k++) N[k][2] *= inv;
+        }
+    }
+
+    void solveSQPSystem(const double* r, double* delta) const {
+        const double sqnorm_r1 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2], sqnorm_r2 = r[3] * r[3] + r[4] * r[4] + r[5] * r[5],
+                     sqnorm_r3 = r[6] * r[6] + r[7] * r[7] + r[8] * r[8];
+        const double dot_r1r2 = r[0] * r[3] + r[1] * r[4] + r[2] * r[5], dot_r1r3 = r[0] * r[6] + r[1] * r[7] + r[2] * r[8],
+                     dot_r2r3 = r[3] * r[6] + r[4] * r[7] + r[5] * r[8];
+        double N[9][3], H[9][6], JH[6][6];
+        computeRowAndNullspace(r, H, N, JH);
+        const double g[6] = {1 - sqnorm_r1, 1 - sqnorm_r2, 1 - sqnorm_r3, -dot_r1r2, -dot_r2r3, -dot_r1r3};
+        double x[6];
+        x[0] = g[0] / JH[0][0];
+        x[1] = g[1] / JH[1][1];
+        x[2] = g[2] / JH[2][2];
+        x[3] = (g[3] - JH[3][0] * x[0] - JH[3][1] * x[1]) / JH[3][3];
+        x[4] = (g[4] - JH[4][1] * x[1] - JH[4][2] * x[2] - JH[4][3] * x[3]) / JH[4][4];
+        x[5] = (g[5] - JH[5][0] * x[0] - JH[5][2] * x[2] - JH[5][3] * x[3] - JH[5][4] * x[4]) / JH[5][5];
+        for (int i = 0; i < 9; i++) {   // delta = H x
+            double s = 0;
+            for (int k = 0; k < 6; k++) s += H[i][k] * x[k];
+            delta[i] = s;
+        }
+        double NtOmega[3][9], W[3][3], Winv[3][3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 9; j++) {
+                double s = 0;
+                for (int k = 0; k < 9; k++) s += N[k][i] * omega_[k][j];
+                NtOmega[i][j] = s;
+            }
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 9; k++) s += NtOmega[i][k] * N[k][j];
+                W[i][j] = s;
+            }
+        analyticalInverse3x3Symm(W, Winv);
+        // y = -Winv * NtOmega * (delta + r), evaluated left to right: (-Winv * NtOmega) first
+        double WN[3][9], y[3];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 9; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += -Winv[i][k] * NtOmega[k][j];
+                WN[i][j] = s;
+            }
+        for (int i = 0; i < 3; i++) {
+            double s = 0;
+            for (int k = 0; k < 9; k++) s += WN[i][k] * (delta[k] + r[k]);
+            y[i] = s;
+        }
+        for (int i = 0; i < 9; i++) {   // delta += N y
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += N[i][k] * y[k];
+            delta[i] += s;
+        }
+    }
+
+    SqpnpSolution runSQP(const double* r0) const {
+        double r[9], delta[9];
+        std::memcpy(r, r0, sizeof r);
+        double delta_squared_norm = DBL_MAX;
+        int step = 0;
+        while (delta_squared_norm > SQP_SQUARED_TOLERANCE && step++ < SQP_MAX_ITERATION) {
+            solveSQPSystem(r, delta);
+            for (int i = 0; i < 9; i++) r[i] += delta[i];
+            delta_squared_norm = 0;
+            for (int i = 0; i < 9; i++) delta_squared_norm += delta[i] * delta[i];
+        }
+        SqpnpSolution solution{};
+        double det_r = det3x3(r);
+        if (det_r < 0) {
+            for (int i = 0; i < 9; i++) r[i] = -r[i];
+            det_r = -det_r;
+        }
+        std::memcpy(solution.r, r, sizeof r);
+        if (det_r > SQP_DET_THRESHOLD)
+            nearestRotationMatrix(r, solution.r_hat);
+        else
+            std::memcpy(solution.r_hat, r, sizeof r);
+        return solution;
+    }
+
+    void translationOf(SqpnpSolution& s) const {   // t = p_ * r_hat
+        for (int i = 0; i < 3; i++) {
+            double a = 0;
+            for (int k = 0; k < 9; k++) a += p_[i][k] * s.r_hat[k];
+            s.t[i] = a;
+        }
+    }
+
+    bool positiveDepth(const SqpnpSolution& s) const {
+        const double* r = s.r_hat;
+        return r[6] * point_mean_[0] + r[7] * point_mean_[1] + r[8] * point_mean_[2] + s.t[2] > 0;
+    }
+
+    bool positiveMajorityDepths(const SqpnpSolution& s) const {
+        const double* r = s.r_hat;
+        int npos = 0, nneg = 0;
+        for (int i = 0; i < n_; i++) {
+            if (r[6] * obj_[3 * i] + r[7] * obj_[3 * i + 1] + r[8] * obj_[3 * i + 2] + s.t[2] > 0)
+                ++npos;
+            else
+                ++nneg;
+        }
+        return npos >= nneg;
+    }
+
+    void checkSolution(SqpnpSolution& solution, double& min_error) {
+        // DOCUMENTED DEVIATION (a guard sqpnp.cpp does not have): runSQP hands back r unprojected when det r <= 1.001, so a start inside Omega's
+        // null space (coplanar object points: the rank-one matrices w n') can come back as a near-zero, non-orthogonal "solution" of cost 0
+        // whose depth test passes or fails by rounding; accepted, it ends the search. Candidates that are not rotations are dropped here.
+        if (!(orthogonalityError(solution.r_hat) <= 0.1)) return;
+        if (!(positiveDepth(solution) || positiveMajorityDepths(solution))) return;
+        double e = 0;   // (omega_ * r_hat) . r_hat
+        for (int i = 0; i < 9; i++) {
+            double s = 0;
+            for (int k = 0; k < 9; k++) s += omega_[i][k] * solution.r_hat[k];
+            e += s * solution.r_hat[i];
+        }
+        solution.sq_error = e;
+        if (std::fabs(min_error - solution.sq_error) > EQUAL_SQUARED_ERRORS_DIFF) {
+            if (min_error > solution.sq_error) {
+                min_error = solution.sq_error;
+                solutions_[0] = solution;
+                num_solutions_ = 1;
+            }
+        } else {
+            bool found = false;
+            for (int i = 0; i < num_solutions_; i++) {
+                double d = 0;
+                for (int k = 0; k < 9; k++) d += (solutions_[i].r_hat[k] - solution.r_hat[k]) * (solutions_[i].r_hat[k] - solution.r_hat[k]);
+                if (d < EQUAL_VECTORS_SQUARED_DIFF) {
+                    if (solutions_[i].sq_error > solution.sq_error) solutions_[i] = solution;
+                    found = true;
+                    break;
+                }
+            }
+            if (!found) solutions_[num_solutions_++] = solution;
+            if (min_error > solution.sq_error) min_error = solution.sq_error;
+        }
+    }
+
+    void tryBothSigns(const double* e, double& min_sq_err) {
+        double neg[9], start[9];
+        for (int k = 0; k < 9; k++) neg[k] = -e[k];
+        nearestRotationMatrix(e, start);
+        SqpnpSolution a = runSQP(start);
+        translationOf(a);
+        checkSolution(a, min_sq_err);
+        nearestRotationMatrix(neg, start);
+        SqpnpSolution b = runSQP(start);
+        translationOf(b);
+        checkSolution(b, min_sq_err);
+    }
+
+    void solveInternal() {
+        double min_sq_err = DBL_MAX;
+        const int num_eigen_points = num_null_vectors_ > 0 ? num_null_vectors_ : 1;
+        const double SQRT3 = std::sqrt(3.0);
+        for (int i = 9 - num_eigen_points; i < 9; i++) {
+            double e[9];
+            for (int k = 0; k < 9; k++) e[k] = SQRT3 * u_[k][i];
+            if (orthogonalityError(e) < ORTHOGONALITY_SQUARED_ERROR_THRESHOLD) {   // e is a rotation up to its sign: no SQP needed
+                SqpnpSolution s{};
+                const double d = det3x3(e);
+                for (int k = 0; k < 9; k++) s.r_hat[k] = d * e[k];
+                translationOf(s);
+                checkSolution(s, min_sq_err);
+            } else {
+                tryBothSigns(e, min_sq_err);
+            }
+        }
+        int index, c = 1;
+        while ((index = 9 - num_eigen_points - c) > 0 && min_sq_err > 3 * s_[index]) {
+            double e[9];
+            for (int k = 0; k < 9; k++) e[k] = u_[k][index];
+            tryBothSigns(e, min_sq_err);
+            c++;
+        }
+    }
+};
+
+// solvePnP(flags = SOLVEPNP_SQPNP) on double points: returns false where OpenCV's asserts would throw (degenerate point sets)
+bool solve_pnp_sqpnp(const double* obj, const double* img, int n, const double* K, double* rvec, double* tvec) {
+    if (n < 3) return false;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5], ifx = 1. / fx, ify = 1. / fy;
+    std::vector<double> nimg(2 * (size_t)n);
+    for (int i = 0; i < n; i++) {   // undistortPoints with zero distortion
+        nimg[2 * i] = (img[2 * i] - cx) * ifx;
+        nimg[2 * i + 1] = (img[2 * i + 1] - cy) * ify;
+    }
+    SqpnpSolver solver;
+    solver.computeOmega(obj, nimg.data(), n);
+    if (!(solver.s_[0] >= 1e-7) || solver.num_null_vectors_ > 6) return false;
+    solver.solveInternal();
+    if (solver.num_solutions_ <= 0) return false;
+    // solvePnPGeneric orders the solutions by their reprojection error; solvePnP takes the first
+    int best = 0;
+    double best_err = DBL_MAX;
+    for (int si = 0; si < solver.num_solutions_; si++) {
+        const SqpnpSolution& s = solver.solutions_[si];
+        double err = 0;
+        for (int i = 0; i < n; i++) {
+            const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+            const double xc = s.r_hat[0] * X + s.r_hat[1] * Y + s.r_hat[2] * Z + s.t[0], yc = s.r_hat[3] * X + s.r_hat[4] * Y + s.r_hat[5] * Z + s.t[1],
+                         zc = s.r_hat[6] * X + s.r_hat[7] * Y + s.r_hat[8] * Z + s.t[2];
+            const double iz = 1. / zc, du = xc * iz * fx + cx - img[2 * i], dv = yc * iz * fy + cy - img[2 * i + 1];
+            err += du * du + dv * dv;
+        }
+        if (err < best_err) {
+            best_err = err;
+            best = si;
+        }
+    }
+    rodrigues_to_vector(solver.solutions_[best].r_hat, rvec);
+    for (int k = 0; k < 3; k++) tvec[k] = solver.solutions_[best].t[k];
+    return true;
+}
+
 int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     p = std::max(p, 0.);
     p = std::min(p, 1.);
@@ -1611,8 +2138,10 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
                             double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers) {
     *n_inliers = 0;
     if (n < 4 || !obj_xyz || !img_xy || !K) return -215;          // CV_Assert(npoints >= 4 && ...)
-    if (method != 0 /* SOLVEPNP_ITERATIVE */ && method != 1 /* SOLVEPNP_EPNP */ && method != 2 /* SOLVEPNP_P3P */ && method != 5 /* SOLVEPNP_AP3P */)
-        return -213;   // SQPNP, IPPE, ...: not restated
+    if (method == 3 /* SOLVEPNP_DLS */ || method == 4 /* SOLVEPNP_UPNP */) method = 1;   // solvePnPGeneric: "broken implementation", both run EPnP
+    if (method != 0 /* SOLVEPNP_ITERATIVE */ && method != 1 /* SOLVEPNP_EPNP */ && method != 2 /* SOLVEPNP_P3P */ && method != 5 /* SOLVEPNP_AP3P */ &&
+        method != 8 /* SOLVEPNP_SQPNP */)
+        return -213;   // IPPE, IPPE_SQUARE (planar targets only): not restated
     // kernel choice of solvePnPRansac: P3P / AP3P on 4 points when asked for, P3P when there are only 4 points; EPnP on 5 otherwise
     const bool ap3p = method == 5;
     const bool p3p = method == 2 || method == 5 || n == 4;
@@ -1685,11 +2214,23 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
         if (initial_pose_no_guess(oi.data(), ii.data(), cnt, camK, param)) refine_pose_lm(oi.data(), ii.data(), cnt, camK, param);
         std::memcpy(rvec, param, 3 * sizeof(double));
         std::memcpy(tvec, param + 3, 3 * sizeof(double));
+    } else if (method == 8) {
+        // SOLVEPNP_SQPNP: EPnP stays the RANSAC kernel (solvepnp.cpp: only P3P / AP3P replace it), the final solvePnP over the inliers is SQPnP.
+        // No solution: solvePnPRansac hands back the RANSAC model and returns false.
+        if (!solve_pnp_sqpnp(oi.data(), ii.data(), cnt, K, rvec, tvec)) {
+            std::memcpy(rvec, best_r, sizeof best_r);
+            std::memcpy(tvec, best_t, sizeof best_t);
+            return 0;
+        }
     } else {
         solve_pnp_epnp<double>(oi.data(), ii.data(), cnt, K, rvec, tvec);
     }
     *n_inliers = cnt;
     return 1;
+}
+
+int oracle_solve_pnp_sqpnp(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec) {
+    return solve_pnp_sqpnp(obj_xyz, img_xy, n, K, rvec, tvec) ? 1 : 0;
 }
 
 }  // extern "C"

@@ -324,3 +324,150 @@ def test_gpu_iterative_pnp_against_external_anchors(gpu_pkg):
             return False, None, None, None
         return True, sol.rvec.mat.ravel(), sol.tvec.mat.ravel(), sol.inliers.mat.ravel()
     check_iterative_pnp_solver(solve, gpu_pkg.synth)
+
+
+# ---------------------------------------------------------------------------------------------------------------- SQPnP (round 4)
+def sqpnp_cost(R, t, obj, img, K):
+    """SQPnP's own objective, written from the paper's definition and not from either implementation: the squared distance between each
+    camera-frame point and its image ray scaled to the point's depth, sum_i |(Xc - x Zc, Yc - y Zc)|^2 with (x, y) the normalised pixel."""
+    xn = (img - np.array([K[0, 2], K[1, 2]])) / np.array([K[0, 0], K[1, 1]])
+    cam = obj @ R.T + t
+    return float(np.sum((cam[:, 0] - xn[:, 0] * cam[:, 2]) ** 2 + (cam[:, 1] - xn[:, 1] * cam[:, 2]) ** 2))
+
+
+def small_rotation(w):
+    return rodrigues(np.asarray(w, np.float64))
+
+
+def check_sqpnp_pose(r, t, obj, img, K, others=()):
+    """A pose SQPnP reports must be (a) a proper rotation, (b) a stationary point of sqpnp_cost over SO(3) x R^3 (central differences along
+    the six generators, written here), and (c) the GLOBAL minimiser: no worse than any other pose offered (EPnP's, the planted one) or 300
+    random rotations about it with their own best translation."""
+    R = rodrigues(r)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-9) and abs(np.linalg.det(R) - 1) < 1e-9
+    f = sqpnp_cost(R, t, obj, img, K)
+    spread = float(np.sum((obj - obj.mean(0)) ** 2)) + 1e-12
+    h = 1e-6
+    for k in range(6):
+        d = np.zeros(6)
+        d[k] = h
+        fp = sqpnp_cost(small_rotation(d[:3]) @ R, t + d[3:], obj, img, K)
+        fm = sqpnp_cost(small_rotation(-d[:3]) @ R, t - d[3:], obj, img, K)
+        assert abs(fp - fm) / (2 * h) <= 1e-5 * spread, (k, (fp - fm) / (2 * h))                 # (b)
+    for Ro, to in others:
+        assert f <= sqpnp_cost(Ro, to, obj, img, K) * (1 + 1e-9) + 1e-12                       # (c) against the poses of other solvers
+    xn = (img - np.array([K[0, 2], K[1, 2]])) / np.array([K[0, 0], K[1, 1]])
+    rng = np.random.default_rng(5)
+    for _ in range(300):                                                                      # (c) against rotations around it
+        Rp = small_rotation(rng.normal(0, rng.choice([1e-3, 0.05, 1.0]), 3)) @ R
+        # the translation that is optimal for Rp: linear least squares on the two residual rows per point
+        A = np.zeros((2 * len(obj), 3))
+        A[0::2, 0] = 1
+        A[0::2, 2] = -xn[:, 0]
+        A[1::2, 1] = 1
+        A[1::2, 2] = -xn[:, 1]
+        rot = obj @ Rp.T
+        b = np.empty(2 * len(obj))
+        b[0::2] = -(rot[:, 0] - xn[:, 0] * rot[:, 2])
+        b[1::2] = -(rot[:, 1] - xn[:, 1] * rot[:, 2])
+        tp = np.linalg.lstsq(A, b, rcond=None)[0]
+        if np.mean((rot + tp)[:, 2] > 0) < 0.5:
+            continue                                                                          # behind the camera: not a candidate
+        assert f <= sqpnp_cost(Rp, tp, obj, img, K) * (1 + 1e-9) + 1e-12
+
+
+def check_sqpnp_direct(direct, synth):
+    """solvePnP(SOLVEPNP_SQPNP) alone: the construction of the data comes back on noise-free points (general position, a plane, a
+    nearly flat cloud, from three points up to thousands), and with pixel noise the pose is the global minimum of SQPnP's objective."""
+    rng = np.random.default_rng(91)
+    K = np.array([[900.0, 0, 640], [0, 880, 360], [0, 0, 1]])
+    for case, n in enumerate([4, 5, 6, 12, 100, 5000, 40, 40]):
+        rvec = rng.normal(0, [0.2, 0.8, 1.5, 2.5][case % 4], 3)
+        tvec = np.array([0.3, -0.2, 7.0]) + rng.normal(0, 0.4, 3)
+        obj = rng.uniform(-1, 1, (n, 3))
+        if case == 6:
+            obj[:, 2] = 0.25                      # a plane that does not pass through the origin
+        if case == 7:
+            obj[:, 2] *= 1e-3                     # nearly flat
+        img = project(obj, rodrigues(rvec), tvec, K)
+        ok, r, t = direct(obj, img, K)
+        assert ok and np.allclose(rodrigues(r), rodrigues(rvec), atol=1e-7) and np.allclose(t, tvec, atol=1e-6), (case, n)
+        noisy = img + rng.normal(0, 0.7, img.shape)
+        ok, r, t = direct(obj, noisy, K)
+        assert ok
+        check_sqpnp_pose(r, t, obj, noisy, K, others=[(rodrigues(rvec), tvec)])
+        if n >= 12:
+            assert np.allclose(rodrigues(r), rodrigues(rvec), atol=0.05) and np.allclose(t, tvec, atol=0.3)
+    # points behind the camera only (the data of a camera looking away): no pose
+    obj = rng.uniform(-1, 1, (30, 3))
+    img = project(obj, np.eye(3), np.array([0, 0, 5.0]), K)
+    ok, r, t = direct(obj, img, K)
+    assert ok and t[2] > 0      # SQPnP keeps the solution in front of the camera (the mirrored one is rejected)
+
+
+def check_sqpnp_ransac(solve, synth):
+    """pnp_solver_ransac with SOLVEPNP_SQPNP: EPnP stays the RANSAC kernel (same inliers as the default method), the final pose is
+    SQPnP's global minimum over those inliers; DLS and UPNP are EPnP."""
+    obj, img, K, rvec, tvec, flag = synth.make_pnp_set(3000, seed=61, inlier_frac=0.65, noise=0.4)
+    ok, r, t, idx = solve(obj, img, K, 500, 3.0, 0.99, 8)            # 8 = SOLVEPNP_SQPNP
+    ok_e, re, te, idx_e = solve(obj, img, K, 500, 3.0, 0.99, 1)      # 1 = SOLVEPNP_EPNP
+    assert ok and ok_e and np.array_equal(idx, idx_e)
+    o, i = obj[idx].astype(np.float32).astype(np.float64), img[idx].astype(np.float32).astype(np.float64)   # the solver sees float copies
+    check_sqpnp_pose(r, t, o, i, K, others=[(rodrigues(re), te), (rodrigues(rvec), tvec)])
+    assert np.allclose(rodrigues(r), rodrigues(rvec), atol=2e-3) and np.allclose(t, tvec, rtol=3e-3, atol=1.0)
+    assert not np.array_equal(r, re)                                  # a different final solver ran
+    for alias in (3, 4):                                              # SOLVEPNP_DLS, SOLVEPNP_UPNP
+        ok_a, ra, ta, idx_a = solve(obj, img, K, 500, 3.0, 0.99, alias)
+        assert ok_a and np.array_equal(ra, re) and np.array_equal(ta, te) and np.array_equal(idx_a, idx_e)
+    # noise-free, planar terrain, six points
+    obj, img, K, rvec, tvec, _ = synth.make_pnp_set(400, seed=63, inlier_frac=1.1, noise=0.0)
+    ok, r, t, idx = solve(obj, img, K, 100, 2.0, 0.99, 8)
+    assert ok and len(idx) == 400 and np.abs(project(obj, rodrigues(r), t, K) - img).max() < 1e-3
+    obj = obj.copy()
+    obj[:, 2] = 0.0
+    img = project(obj, rodrigues(rvec), tvec, K)
+    ok, r, t, idx = solve(obj, img, K, 100, 2.0, 0.99, 8)
+    assert ok and len(idx) == 400 and np.abs(project(obj, rodrigues(r), t, K) - img).max() < 1e-3
+    obj, img, K, rvec, tvec, _ = synth.make_pnp_set(6, seed=65, inlier_frac=1.1, noise=0.0)
+    ok, r, t, idx = solve(obj, img, K, 100, 2.0, 0.99, 8)
+    # (solvePnPRansac hands the solver float copies of the points: pixel coordinates near 2800 carry 2.4e-4 of rounding each)
+    assert ok and len(idx) == 6 and np.abs(project(obj, rodrigues(r), t, K) - img).max() < 5e-3
+
+
+def test_oracle_sqpnp_against_external_anchors(pkg, oracle_mod):
+    def direct(obj, img, K):
+        rc, r, t = oracle_mod.solve_pnp_sqpnp(obj, img, K)
+        return rc == 1, r, t
+
+    def solve(obj, img, K, iters, thr, conf, method):
+        rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, iters, thr, conf, method=method)
+        return rc == 1, r, t, idx
+    check_sqpnp_direct(direct, pkg.synth)
+    check_sqpnp_ransac(solve, pkg.synth)
+
+
+def product_sqpnp(pkg, obj, img, K):
+    """apds_pnp_sqpnp through the C ABI: the product's own text (csrc/sqpnp_core.h), host arithmetic, no device needed."""
+    import ctypes as C
+    obj, img, K = (np.ascontiguousarray(a, np.float64) for a in (obj, img, K))
+    r, t, found = np.zeros(3), np.zeros(3), C.c_int(0)
+    rc = pkg.lib().apds_pnp_sqpnp(pkg._lib.ptr(obj), pkg._lib.ptr(img), len(obj), pkg._lib.ptr(K), pkg._lib.ptr(r), pkg._lib.ptr(t), C.byref(found))
+    assert rc == 0, pkg.lib().apds_last_error()
+    return found.value == 1, r, t
+
+
+def test_product_sqpnp_against_external_anchors(pkg):
+    check_sqpnp_direct(lambda obj, img, K: product_sqpnp(pkg, obj, img, K), pkg.synth)
+
+
+@pytest.mark.gpu
+def test_gpu_sqpnp_against_external_anchors(gpu_pkg):
+    hg = gpu_pkg.homographier
+
+    def solve(obj, img, K, iters, thr, conf, method):
+        corr = [hg.ImgObjCorrespondence(o, i) for o, i in zip(obj, img)]
+        sol = hg.pnp_solver_ransac(corr, hg.Cmat(np.ascontiguousarray(K, np.float64), np.float64), iters, thr, conf, None, hg.SolvePnPMethod(method))
+        if sol is None:
+            return False, None, None, None
+        return True, sol.rvec.mat.ravel(), sol.tvec.mat.ravel(), sol.inliers.mat.ravel()
+    check_sqpnp_ransac(solve, gpu_pkg.synth)

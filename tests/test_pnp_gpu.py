@@ -118,7 +118,7 @@ def test_ap3p_ransac_matches_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, 
 def test_four_points_and_unbuilt_methods(gpu_pkg, oracle_mod):
     hg = gpu_pkg.homographier
     obj, img, K, _, _, inl = gpu_pkg.synth.make_pnp_set(400, inlier_frac=0.5, noise=0.5)
-    for method in (8, 6):        # SOLVEPNP_SQPNP, SOLVEPNP_IPPE: handed through like every Option<SolvePnPMethod> (mod.rs:359), not built
+    for method in (6, 7):        # SOLVEPNP_IPPE, SOLVEPNP_IPPE_SQUARE (planar targets only): handed through like every Option<SolvePnPMethod> (mod.rs:359), not built
         with pytest.raises(hg.MatError) as e:
             _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, method)
         assert e.value.inner.code == -213
@@ -154,3 +154,41 @@ def test_iterative_method_equals_oracle(gpu_pkg, oracle_mod, n, frac, noise, ite
     sol_e = _solve(gpu_pkg, obj, img, K, iters, thr, 0.99, None)
     if noise > 0:
         assert not np.array_equal(sol_e.rvec.mat.ravel(), r)
+
+
+@pytest.mark.parametrize("n,frac,noise,iters,thr", [(600, 0.7, 0.5, 300, 3.0), (5000, 0.4, 0.8, 1000, 4.0), (40, 1.1, 0.3, 100, 3.0), (6, 1.1, 0.0, 50, 2.0),
+                                                   (5, 1.1, 0.0, 50, 2.0)])
+def test_sqpnp_method_equals_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, thr):
+    # SolvePnPMethod::SOLVEPNP_SQPNP (mod.rs:327,359-360): the RANSAC stage is EPnP's, the final pose is SQPnP over the inliers
+    # (csrc/sqpnp_core.h against the oracle's separate restatement) - inliers and pose bit-identical
+    hg = gpu_pkg.homographier
+    obj, img, K, _, _, _ = gpu_pkg.synth.make_pnp_set(n, seed=0x5190 + n, inlier_frac=frac, noise=noise)
+    sol = _solve(gpu_pkg, obj, img, K, iters, thr, 0.99, hg.SolvePnPMethod.SOLVEPNP_SQPNP)
+    rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, iters, thr, 0.99, method=8)
+    assert rc == 1 and sol is not None
+    assert np.array_equal(sol.inliers.mat.ravel(), idx)
+    assert np.array_equal(sol.rvec.mat.ravel(), r) and np.array_equal(sol.tvec.mat.ravel(), t)
+    sol_e = _solve(gpu_pkg, obj, img, K, iters, thr, 0.99, None)
+    assert np.array_equal(sol_e.inliers.mat.ravel(), idx)          # same RANSAC kernel, same consensus set
+    if noise > 0 and n > 5:
+        assert not np.array_equal(sol_e.rvec.mat.ravel(), r)       # another final solver ran
+    # planar terrain (every null vector of SQPnP's 9 x 9 matrix is rank one there)
+    flat = obj.copy()
+    flat[:, 2] = 12.5
+    sol = _solve(gpu_pkg, flat, img, K, iters, thr, 0.99, hg.SolvePnPMethod.SOLVEPNP_SQPNP)
+    rc, r, t, idx = oracle_mod.solve_pnp_ransac(flat, img, K, iters, thr, 0.99, method=8)
+    assert (sol is not None) == (rc == 1)
+    if sol is not None:
+        assert np.array_equal(sol.inliers.mat.ravel(), idx) and np.array_equal(sol.rvec.mat.ravel(), r) and np.array_equal(sol.tvec.mat.ravel(), t)
+
+
+def test_dls_and_upnp_run_epnp(gpu_pkg, oracle_mod):
+    # OpenCV 4's solvePnPGeneric sends SOLVEPNP_DLS and SOLVEPNP_UPNP to EPnP ("broken implementation"): identical answers
+    hg = gpu_pkg.homographier
+    obj, img, K, _, _, _ = gpu_pkg.synth.make_pnp_set(1500, seed=77, inlier_frac=0.6, noise=0.5)
+    want = _solve(gpu_pkg, obj, img, K, 400, 3.0, 0.99, None)
+    for method in (hg.SolvePnPMethod.SOLVEPNP_DLS, hg.SolvePnPMethod.SOLVEPNP_UPNP):
+        got = _solve(gpu_pkg, obj, img, K, 400, 3.0, 0.99, method)
+        rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, 400, 3.0, 0.99, method=int(method))
+        assert rc == 1 and np.array_equal(got.inliers.mat.ravel(), idx) and np.array_equal(got.rvec.mat.ravel(), r) and np.array_equal(got.tvec.mat.ravel(), t)
+        assert np.array_equal(got.rvec.mat.ravel(), want.rvec.mat.ravel()) and np.array_equal(got.tvec.mat.ravel(), want.tvec.mat.ravel())
