@@ -8,6 +8,7 @@ hamming_1k_4k.npz  : 1000 queries x 4000 train rows (seeded) -> top-2 indices an
 homography_200.npz : 200 point pairs (40 % inliers) -> H (RANSAC, thr 3) and inlier mask
 ingest.npz         : band_merger / warp_perspective expected bytes for seeded inputs
 pnp_400.npz        : 400 3D-2D correspondences (60 % inliers) -> solvePnPRansac pose + inlier indices, EPnP and P3P
+pnp_sqpnp_400.npz  : the same correspondences -> solvePnPRansac with SOLVEPNP_SQPNP (EPnP's consensus set, SQPnP's pose over it)
 world_coordinates.npz : 500 mosaic pixels -> ECEF through two geotransforms and a seeded elevation raster
 """
 import os
@@ -75,6 +76,8 @@ def main_extra():
         rc, r, t, idx = oracle.solve_pnp_ransac(obj, img, K, 500, 3.0, 0.99, method)
         out.update({name + "_rc": rc, name + "_rvec": r, name + "_tvec": t, name + "_inliers": idx})
     np.savez_compressed(os.path.join(HERE, "pnp_400.npz"), **out)
+    rc, r, t, idx = oracle.solve_pnp_ransac(obj, img, K, 500, 3.0, 0.99, 8)
+    np.savez_compressed(os.path.join(HERE, "pnp_sqpnp_400.npz"), sqpnp_rc=rc, sqpnp_rvec=r, sqpnp_tvec=t, sqpnp_inliers=idx)
     xy, dgt, egt, elevation = world_inputs()
     rc, xyz = oracle.world_coordinates(xy, dgt, egt, elevation)
     np.savez_compressed(os.path.join(HERE, "world_coordinates.npz"), rc=rc, xyz=xyz)
