@@ -475,9 +475,9 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     // solvePnPGeneric: SOLVEPNP_DLS and SOLVEPNP_UPNP are "broken implementations" that run EPnP
     if (method == APDS_SOLVEPNP_DLS || method == APDS_SOLVEPNP_UPNP) method = APDS_SOLVEPNP_EPNP;
     APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP || method == APDS_SOLVEPNP_P3P || method == APDS_SOLVEPNP_ITERATIVE || method == APDS_SOLVEPNP_AP3P ||
-                     method == APDS_SOLVEPNP_SQPNP,
+                     method == APDS_SOLVEPNP_SQPNP || method == APDS_SOLVEPNP_IPPE_SQUARE,
                  APDS_ERR_NOT_IMPLEMENTED,
-                 "SOLVEPNP_EPNP (the reference's default), _P3P, _AP3P, _ITERATIVE, _SQPNP and _DLS / _UPNP (= EPnP) are implemented; _IPPE / _IPPE_SQUARE are not");
+                 "SOLVEPNP_EPNP (the reference's default), _P3P, _AP3P, _ITERATIVE, _SQPNP, _DLS / _UPNP (= EPnP) and _IPPE_SQUARE are implemented; _IPPE is not");
     // kernel choice of solvePnPRansac: P3P / AP3P on 4 points when asked for, P3P when there are only 4 points; EPnP on 5 otherwise
     const bool ap3p = method == APDS_SOLVEPNP_AP3P;
     const bool p3p = method == APDS_SOLVEPNP_P3P || ap3p || n == 4;
@@ -570,6 +570,9 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
             inliers[cnt++] = i;
         }
     APDS_REQUIRE(cnt == maxGood, APDS_ERR_INTERNAL, "inlier mask disagrees with the scored count");
+    // SOLVEPNP_IPPE_SQUARE: the RANSAC kernel was EPnP on 5 points (or the direct P3P solve above for n == 4), and the final solvePnP over
+    // the >= 5 inliers starts with CV_Assert(npoints == 4): solvePnPRansac rethrows it, the reference returns Err(MatError::Opencv)
+    APDS_REQUIRE(method != APDS_SOLVEPNP_IPPE_SQUARE, APDS_ERR_ASSERT, "SOLVEPNP_IPPE_SQUARE: solvePnP asserts npoints == 4 on the inlier set");
     if (method == APDS_SOLVEPNP_ITERATIVE) {   // no extrinsic guess (mod.rs:354): homography / DLT start, then Levenberg-Marquardt
         double pose[6];
         std::memcpy(pose, best, sizeof(pose));   // (what stays when five non-planar inliers cannot start the DLT)

@@ -159,8 +159,10 @@ int apds_warp_perspective_f32(const float* src, int rows, int cols, int channels
  * DLT (>= 6 points) start, then <= 20 Levenberg-Marquardt iterations on the reprojection error; with five non-planar inliers the RANSAC
  * model stays, as in solvePnPRansac), APDS_SOLVEPNP_SQPNP (EPnP kernel; final pose = Terzakis and Lourakis' SQPnP over the inliers, calib3d/sqpnp.cpp;
  * no pose in front of the camera -> *found = 0 with the RANSAC model in rvec / tvec, as solvePnPRansac leaves it), APDS_SOLVEPNP_DLS and
- * APDS_SOLVEPNP_UPNP (OpenCV 4 runs EPnP for both: identical to APDS_SOLVEPNP_EPNP). IPPE / IPPE_SQUARE (planar targets only) return
- * APDS_ERR_NOT_IMPLEMENTED.
+ * APDS_SOLVEPNP_UPNP (OpenCV 4 runs EPnP for both: identical to APDS_SOLVEPNP_EPNP), APDS_SOLVEPNP_IPPE_SQUARE (what solvePnPRansac makes of it:
+ * four correspondences are solved by P3P directly like under every other flag; with more, the final solvePnP over the >= 5 inliers of the
+ * EPnP RANSAC asserts npoints == 4 -> APDS_ERR_ASSERT, the reference's Err(MatError::Opencv); no consensus -> *found = 0). IPPE (planar
+ * targets only) returns APDS_ERR_NOT_IMPLEMENTED.
  * n < 4 -> APDS_ERR_ASSERT (mod.rs:627-638).
  * *found = 1: rvec[3], tvec[3], inliers[0..*n_inliers) filled (inliers: caller allocated, n ints); *found = 0: Ok(None). */
 #define APDS_SOLVEPNP_ITERATIVE 0
@@ -169,6 +171,7 @@ int apds_warp_perspective_f32(const float* src, int rows, int cols, int channels
 #define APDS_SOLVEPNP_DLS 3
 #define APDS_SOLVEPNP_UPNP 4
 #define APDS_SOLVEPNP_AP3P 5
+#define APDS_SOLVEPNP_IPPE_SQUARE 7
 #define APDS_SOLVEPNP_SQPNP 8
 int apds_pnp_solver_ransac(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, int iter_count, float reproj_thres,
                            double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers, int* found);

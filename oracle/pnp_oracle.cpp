@@ -2140,8 +2140,8 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
     if (n < 4 || !obj_xyz || !img_xy || !K) return -215;          // CV_Assert(npoints >= 4 && ...)
     if (method == 3 /* SOLVEPNP_DLS */ || method == 4 /* SOLVEPNP_UPNP */) method = 1;   // solvePnPGeneric: "broken implementation", both run EPnP
     if (method != 0 /* SOLVEPNP_ITERATIVE */ && method != 1 /* SOLVEPNP_EPNP */ && method != 2 /* SOLVEPNP_P3P */ && method != 5 /* SOLVEPNP_AP3P */ &&
-        method != 8 /* SOLVEPNP_SQPNP */)
-        return -213;   // IPPE, IPPE_SQUARE (planar targets only): not restated
+        method != 8 /* SOLVEPNP_SQPNP */ && method != 7 /* SOLVEPNP_IPPE_SQUARE */)
+        return -213;   // IPPE (planar targets only): not restated
     // kernel choice of solvePnPRansac: P3P / AP3P on 4 points when asked for, P3P when there are only 4 points; EPnP on 5 otherwise
     const bool ap3p = method == 5;
     const bool p3p = method == 2 || method == 5 || n == 4;
@@ -2206,6 +2206,7 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
             for (int c = 0; c < 2; c++) ii.push_back((double)ip[2 * (size_t)i + c]);
             inliers[cnt++] = i;
         }
+    if (method == 7) return -215;   // SOLVEPNP_IPPE_SQUARE: solvePnP's CV_Assert(npoints == 4) on >= 5 inliers, rethrown by solvePnPRansac
     if (method == 0) {
         // SOLVEPNP_ITERATIVE: solvePnP over the inliers WITHOUT an extrinsic guess (mod.rs:354): homography / DLT start, then the
         // Levenberg-Marquardt refinement. Five non-planar inliers cannot start the DLT: solvePnPRansac keeps the RANSAC model then.

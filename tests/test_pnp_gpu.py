@@ -118,15 +118,19 @@ def test_ap3p_ransac_matches_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, 
 def test_four_points_and_unbuilt_methods(gpu_pkg, oracle_mod):
     hg = gpu_pkg.homographier
     obj, img, K, _, _, inl = gpu_pkg.synth.make_pnp_set(400, inlier_frac=0.5, noise=0.5)
-    for method in (6, 7):        # SOLVEPNP_IPPE, SOLVEPNP_IPPE_SQUARE (planar targets only): handed through like every Option<SolvePnPMethod> (mod.rs:359), not built
-        with pytest.raises(hg.MatError) as e:
-            _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, method)
-        assert e.value.inner.code == -213
+    with pytest.raises(hg.MatError) as e:   # SOLVEPNP_IPPE (planar targets only): handed through like every Option<SolvePnPMethod> (mod.rs:359), not built
+        _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, 6)
+    assert e.value.inner.code == -213
+    # SOLVEPNP_IPPE_SQUARE: the final solvePnP over the >= 5 inliers asserts npoints == 4; solvePnPRansac rethrows -> Err(MatError::Opencv)
+    with pytest.raises(hg.MatError) as e:
+        _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, hg.SolvePnPMethod.SOLVEPNP_IPPE_SQUARE)
+    assert e.value.kind == "Opencv" and e.value.inner.code == -215
+    assert oracle_mod.solve_pnp_ransac(obj, img, K, 100, 3.0, 0.99, method=7)[0] == -215
     # exactly four correspondences: one direct P3P solve, whatever the method (OpenCV switches kernels)
     o4, i4 = obj[inl][:4], img[inl][:4]
-    for method in (None, hg.SolvePnPMethod.SOLVEPNP_P3P):
+    for method in (None, hg.SolvePnPMethod.SOLVEPNP_P3P, hg.SolvePnPMethod.SOLVEPNP_IPPE_SQUARE, hg.SolvePnPMethod.SOLVEPNP_SQPNP):
         sol = _solve(gpu_pkg, o4, i4, K, 100, 3.0, 0.99, method)
-        rc, r, t, idx = oracle_mod.solve_pnp_ransac(o4, i4, K, 100, 3.0, 0.99, method=2 if method else 1)
+        rc, r, t, idx = oracle_mod.solve_pnp_ransac(o4, i4, K, 100, 3.0, 0.99, method=int(method) if method else 1)
         assert (sol is not None) == (rc == 1)
         if sol is not None:
             assert list(sol.inliers.mat.ravel()) == [0, 1, 2, 3] and np.array_equal(sol.rvec.mat.ravel(), r) and np.array_equal(sol.tvec.mat.ravel(), t)
