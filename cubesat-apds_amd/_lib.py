@@ -26,7 +26,7 @@ SYMBOLS = [
     "apds_dev_pack_descriptors", "apds_dev_hamming_topk", "apds_dev_merge_topk", "apds_dev_match_lds_cap", "apds_dev_match_last_launch_lds", "apds_dev_match_backend", "apds_dev_hamming_topk_backend", "apds_dev_ratio_filter",
     "apds_dev_cross_check", "apds_dev_akaze_extract", "apds_dev_points_from_matches", "apds_dev_find_homography",
     "apds_dev_valu_popcount_peak", "apds_dev_valu_peak", "apds_dev_valu_peak_modes", "apds_dev_last_kernel_ms", "apds_dev_timing_enable", "apds_akaze_debug_plane", "apds_stream_create", "apds_stream_destroy",
-    "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective", "apds_warp_perspective_f32", "apds_pnp_solver_ransac", "apds_pnp_hypotheses", "apds_pnp_sqpnp", "apds_get_world_coordinates", "apds_l2_knn_match", "apds_dev_l2_topk", "apds_dev_l2_topk_ex",
+    "apds_band_merger", "apds_dev_band_merger", "apds_warp_perspective", "apds_warp_perspective_f32", "apds_pnp_solver_ransac", "apds_pnp_hypotheses", "apds_pnp_sqpnp", "apds_pnp_ippe", "apds_get_world_coordinates", "apds_l2_knn_match", "apds_dev_l2_topk", "apds_dev_l2_topk_ex",
     "apds_db_create", "apds_db_destroy", "apds_db_rows", "apds_db_insert_image", "apds_db_select", "apds_db_view", "apds_db_view_download", "apds_db_knn_match",
     "apds_comm_id_create", "apds_shard_create", "apds_shard_destroy", "apds_shard_info", "apds_shard_counts", "apds_shard_knn", "apds_shard_knn_replicated", "apds_shard_slot_create",
     "apds_shard_slot_destroy", "apds_shard_gather", "apds_shard_scan", "apds_shard_exchange_merge", "apds_db_shard",
@@ -170,6 +170,7 @@ def lib():
             "apds_pnp_solver_ransac": (i, [vp, vp, i, vp, i, f, d, i, vp, vp, vp, ip, ip]),
             "apds_pnp_hypotheses": (i, [vp, vp, i, vp, vp, i, i, vp]),
             "apds_pnp_sqpnp": (i, [vp, vp, i, vp, vp, vp, vp]),
+            "apds_pnp_ippe": (i, [vp, vp, i, vp, vp, vp, vp]),
             "apds_get_world_coordinates": (i, [vp, i, vp, vp, vp, i, i, vp]),
             "apds_l2_knn_match": (i, [vp, i, vp, i, i, i, vp, vp]),
             "apds_dev_l2_topk": (i, [vp, i, vp, i64, i, u32, i, vp, vp]),

@@ -34,6 +34,14 @@ int apds_pnp_sqpnp(const double* obj_xyz, const double* img_xy, int n, const dou
     });
 }
 
+int apds_pnp_ippe(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, double* rvec, double* tvec, int* found) {
+    return guarded([&] {
+        APDS_REQUIRE(found, APDS_ERR_BAD_ARG, "null argument");
+        *found = 0;
+        *found = pnp_ippe_host(obj_xyz, img_xy, n, camera_intrinsic, rvec, tvec);
+    });
+}
+
 int apds_get_world_coordinates(const double* xy, int n, const double* dataset_gt, const double* elevation_gt, const double* elevation, int ew, int eh,
                                double* xyz) {
     return guarded([&] {

@@ -88,6 +88,7 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
                       double* rvec, double* tvec, int32_t* inliers, int* n_inliers, hipStream_t s);
 void pnp_hypotheses_device(const double* obj_xyz, const double* img_xy, int n, const double* K, const int32_t* idx5, int B, int model_points,
                            double* models_host, hipStream_t s);
+int pnp_ippe_host(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec);
 int pnp_sqpnp_host(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec);
 
 }  // namespace apds

@@ -12,6 +12,7 @@
 #include "kernels.h"
 #include "pnp_core.h"
 #include "sqpnp_core.h"
+#include "ippe_core.h"
 
 #include <algorithm>
 #include <cstring>
@@ -475,9 +476,8 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     // solvePnPGeneric: SOLVEPNP_DLS and SOLVEPNP_UPNP are "broken implementations" that run EPnP
     if (method == APDS_SOLVEPNP_DLS || method == APDS_SOLVEPNP_UPNP) method = APDS_SOLVEPNP_EPNP;
     APDS_REQUIRE(method == APDS_SOLVEPNP_EPNP || method == APDS_SOLVEPNP_P3P || method == APDS_SOLVEPNP_ITERATIVE || method == APDS_SOLVEPNP_AP3P ||
-                     method == APDS_SOLVEPNP_SQPNP || method == APDS_SOLVEPNP_IPPE_SQUARE,
-                 APDS_ERR_NOT_IMPLEMENTED,
-                 "SOLVEPNP_EPNP (the reference's default), _P3P, _AP3P, _ITERATIVE, _SQPNP, _DLS / _UPNP (= EPnP) and _IPPE_SQUARE are implemented; _IPPE is not");
+                     method == APDS_SOLVEPNP_SQPNP || method == APDS_SOLVEPNP_IPPE_SQUARE || method == APDS_SOLVEPNP_IPPE,
+                 APDS_ERR_NOT_IMPLEMENTED, "unknown cv::SolvePnPMethod (MAX_COUNT and beyond)");
     // kernel choice of solvePnPRansac: P3P / AP3P on 4 points when asked for, P3P when there are only 4 points; EPnP on 5 otherwise
     const bool ap3p = method == APDS_SOLVEPNP_AP3P;
     const bool p3p = method == APDS_SOLVEPNP_P3P || ap3p || n == 4;
@@ -579,8 +579,11 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
         if (iterative_start_pose(oi.data(), ii.data(), cnt, cam, pose, s)) PoseRefiner{oi.data(), ii.data(), cnt, cam, {}, {}}.run(pose);
         std::memcpy(rvec, pose, 3 * sizeof(double));
         std::memcpy(tvec, pose + 3, 3 * sizeof(double));
-    } else if (method == APDS_SOLVEPNP_SQPNP) {   // the RANSAC kernel stayed EPnP; the last solvePnP over the inliers is SQPnP (sqpnp_core.h)
-        if (!sqpnp::solve(oi.data(), ii.data(), cnt, cam, rvec, tvec)) {   // no pose: solvePnPRansac hands back the RANSAC model and returns false
+    } else if (method == APDS_SOLVEPNP_SQPNP || method == APDS_SOLVEPNP_IPPE) {
+        // the RANSAC kernel stayed EPnP; the last solvePnP over the inliers is SQPnP (sqpnp_core.h) or IPPE (ippe_core.h: planar targets;
+        // inliers that are not coplanar have no IPPE pose)
+        const bool posed = method == APDS_SOLVEPNP_IPPE ? ippe::solve(oi.data(), ii.data(), cnt, cam, rvec, tvec) : sqpnp::solve(oi.data(), ii.data(), cnt, cam, rvec, tvec);
+        if (!posed) {   // no pose: solvePnPRansac hands back the RANSAC model and returns false
             std::memcpy(rvec, best, 3 * sizeof(double));
             std::memcpy(tvec, best + 3, 3 * sizeof(double));
             return 0;
@@ -590,6 +593,14 @@ int pnp_ransac_device(const double* obj_xyz, const double* img_xy, int n, const 
     }
     *n_inliers = cnt;
     return 1;
+}
+
+// solvePnP(SOLVEPNP_IPPE) alone, for the parity tests (host arithmetic; no device work)
+int pnp_ippe_host(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec) {
+    APDS_REQUIRE(obj_xyz && img_xy && K && rvec && tvec, APDS_ERR_BAD_ARG, "null argument");
+    APDS_REQUIRE(n >= 4, APDS_ERR_ASSERT, "IPPE needs at least 4 correspondences");
+    const Camera cam{K[0], K[4], K[2], K[5]};
+    return ippe::solve(obj_xyz, img_xy, n, cam, rvec, tvec) ? 1 : 0;
 }
 
 // solvePnP(SOLVEPNP_SQPNP) alone, for the parity tests (host arithmetic; no device work)

@@ -130,6 +130,7 @@ class SolvePnPMethod(enum.IntEnum):
     SOLVEPNP_DLS = 3       # OpenCV 4 runs EPnP for DLS and UPNP
     SOLVEPNP_UPNP = 4
     SOLVEPNP_AP3P = 5
+    SOLVEPNP_IPPE = 6          # planar targets: inliers that are not coplanar give no pose (None)
     SOLVEPNP_IPPE_SQUARE = 7   # solvePnPRansac: P3P for four points, otherwise the final solve's npoints == 4 assertion (an error)
     SOLVEPNP_SQPNP = 8
 

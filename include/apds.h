@@ -161,8 +161,11 @@ int apds_warp_perspective_f32(const float* src, int rows, int cols, int channels
  * no pose in front of the camera -> *found = 0 with the RANSAC model in rvec / tvec, as solvePnPRansac leaves it), APDS_SOLVEPNP_DLS and
  * APDS_SOLVEPNP_UPNP (OpenCV 4 runs EPnP for both: identical to APDS_SOLVEPNP_EPNP), APDS_SOLVEPNP_IPPE_SQUARE (what solvePnPRansac makes of it:
  * four correspondences are solved by P3P directly like under every other flag; with more, the final solvePnP over the >= 5 inliers of the
- * EPnP RANSAC asserts npoints == 4 -> APDS_ERR_ASSERT, the reference's Err(MatError::Opencv); no consensus -> *found = 0). IPPE (planar
- * targets only) returns APDS_ERR_NOT_IMPLEMENTED.
+ * EPnP RANSAC asserts npoints == 4 -> APDS_ERR_ASSERT, the reference's Err(MatError::Opencv); no consensus -> *found = 0), APDS_SOLVEPNP_IPPE
+ * (EPnP kernel; final pose = Collins and Bartoli's plane-based solver, calib3d/ippe.cpp, over the inliers: object points moved to the plane
+ * z = 0 about their centroid, Harker-O'Leary homography, the better of the two poses; inliers that are not coplanar within 1e-3 of their own
+ * unit have no IPPE pose -> *found = 0 with the RANSAC model in rvec / tvec, as solvePnPRansac leaves it). Values past cv::SolvePnPMethod's
+ * last member return APDS_ERR_NOT_IMPLEMENTED.
  * n < 4 -> APDS_ERR_ASSERT (mod.rs:627-638).
  * *found = 1: rvec[3], tvec[3], inliers[0..*n_inliers) filled (inliers: caller allocated, n ints); *found = 0: Ok(None). */
 #define APDS_SOLVEPNP_ITERATIVE 0
@@ -171,6 +174,7 @@ int apds_warp_perspective_f32(const float* src, int rows, int cols, int channels
 #define APDS_SOLVEPNP_DLS 3
 #define APDS_SOLVEPNP_UPNP 4
 #define APDS_SOLVEPNP_AP3P 5
+#define APDS_SOLVEPNP_IPPE 6
 #define APDS_SOLVEPNP_IPPE_SQUARE 7
 #define APDS_SOLVEPNP_SQPNP 8
 int apds_pnp_solver_ransac(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, int iter_count, float reproj_thres,
@@ -459,6 +463,8 @@ int apds_pnp_hypotheses(const double* obj_xyz, const double* img_xy, int n, cons
  * its inliers when the caller names APDS_SOLVEPNP_SQPNP (mod.rs:327,359). Host arithmetic only: one 9 x 9 problem per call whatever n.
  * *found = 0: no pose (degenerate points, or none in front of the camera). */
 int apds_pnp_sqpnp(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, double* rvec, double* tvec, int* found);
+/* Test hook: cv::solvePnP(..., SOLVEPNP_IPPE) alone on n >= 4 correspondences (host arithmetic); *found = 0: the object points are not coplanar. */
+int apds_pnp_ippe(const double* obj_xyz, const double* img_xy, int n, const double* camera_intrinsic, double* rvec, double* tvec, int* found);
 
 /* Measurement helpers used by bench.py (not part of the reference surface). */
 /* Register-only xor+popcount loop: returns measured lane-ops/s (32-bit xor + bcnt counted as 2 ops). */

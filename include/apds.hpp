@@ -208,7 +208,7 @@ inline Result<Cmat<T>, MatError> warp_image_perspective(const Cmat<T>& src, cons
 }
 
 /// opencv::calib3d::SolvePnPMethod values the reference can pass (mod.rs:4,327)
-enum class SolvePnPMethod { SOLVEPNP_ITERATIVE = 0, SOLVEPNP_EPNP = 1, SOLVEPNP_P3P = 2, SOLVEPNP_DLS = 3, SOLVEPNP_UPNP = 4, SOLVEPNP_AP3P = 5, SOLVEPNP_IPPE_SQUARE = 7, SOLVEPNP_SQPNP = 8 };
+enum class SolvePnPMethod { SOLVEPNP_ITERATIVE = 0, SOLVEPNP_EPNP = 1, SOLVEPNP_P3P = 2, SOLVEPNP_DLS = 3, SOLVEPNP_UPNP = 4, SOLVEPNP_AP3P = 5, SOLVEPNP_IPPE = 6, SOLVEPNP_IPPE_SQUARE = 7, SOLVEPNP_SQPNP = 8 };
 
 /// mod.rs:52-65
 struct ImgObjCorrespondence {

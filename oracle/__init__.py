@@ -92,6 +92,8 @@ def lib():
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_solve_pnp_epnp.restype = C.c_int
         L.oracle_solve_pnp_epnp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_solve_pnp_ippe.restype = C.c_int
+        L.oracle_solve_pnp_ippe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_solve_pnp_sqpnp.restype = C.c_int
         L.oracle_solve_pnp_sqpnp.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_pnp_ransac_samples.restype = C.c_int
@@ -401,6 +403,16 @@ def solve_pnp_epnp(obj, img, K):
     K = np.ascontiguousarray(K, np.float64).reshape(9)
     rvec, tvec = np.zeros(3), np.zeros(3)
     rc = lib().oracle_solve_pnp_epnp(_ptr(obj), _ptr(img), len(obj), _ptr(K), _ptr(rvec), _ptr(tvec))
+    return rc, rvec, tvec
+
+
+def solve_pnp_ippe(obj, img, K):
+    """cv::solvePnP(..., SOLVEPNP_IPPE) on double points: (1 = a pose, rvec, tvec); 0 for object points that are not coplanar."""
+    obj = np.ascontiguousarray(obj, np.float64).reshape(-1, 3)
+    img = np.ascontiguousarray(img, np.float64).reshape(-1, 2)
+    K = np.ascontiguousarray(K, np.float64).reshape(9)
+    rvec, tvec = np.zeros(3), np.zeros(3)
+    rc = lib().oracle_solve_pnp_ippe(_ptr(obj), _ptr(img), len(obj), _ptr(K), _ptr(rvec), _ptr(tvec))
     return rc, rvec, tvec
 
 

@@ -111,6 +111,7 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
                             double confidence, int method, double* rvec, double* tvec, int32_t* inliers, int* n_inliers);
 /* helpers exposed for GPU per-stage parity */
 int  oracle_solve_pnp_epnp(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec);
+int  oracle_solve_pnp_ippe(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec);    /* solvePnP(SOLVEPNP_IPPE), 1 = a pose */
 int  oracle_solve_pnp_sqpnp(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec);   /* solvePnP(SOLVEPNP_SQPNP), 1 = a pose */
 int  oracle_pnp_ransac_samples(int n, int iters, int32_t* idx5 /* iters*5 */);
 int  oracle_pnp_hypothesis(const double* obj_xyz, const double* img_xy, const int32_t* idx5, const double* K, double* rvec, double* tvec);

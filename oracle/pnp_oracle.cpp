@@ -2044,6 +2044,349 @@ bool solve_pnp_sqpnp(const double* obj, const double* img, int n, const double* 
     return true;
 }
 
+// ---- ippe.cpp (Collins & Bartoli, "Infinitesimal plane-based pose estimation", IJCV 2014) -----------------------------------------
+// solvePnP(flags = SOLVEPNP_IPPE) over the inliers, as recalled for OpenCV 4.8: undistortPoints with zero distortion,
+// IPPE::PoseSolver::solveGeneric (object points moved to the plane z = 0 about their centroid, homography by Harker & O'Leary's
+// method, the two rotations from the homography's Jacobian at the origin, a translation for each by linear least squares), the pose
+// that reprojects better first. Object points that are not coplanar within IPPE_SMALL = 1e-3 make OpenCV's solver throw inside
+// solvePnPGeneric's try block: no solution. PARITY UNPINNED. DOCUMENTED DEVIATIONS: the eigenvector of the smallest eigenvalue of the
+// 3 x 3 matrix D'D is taken from this file's one-sided Jacobi SVD, not cv::eigen (the same vector to rounding; H is divided by H(2,2), so
+// its sign is immaterial); the square roots in computeRotations are taken of max(0, .) (rounding can push their arguments below zero);
+// rotateVec2ZAxis turns -z onto +z by half a turn about x (see there).
+struct Ippe {
+    static constexpr double IPPE_SMALL = 1e-3;
+
+    static void rotateVec2ZAxis(const double a[3], double Ra[9]) {
+        double ax = a[0], ay = a[1], az = a[2];
+        const double nrm = std::sqrt(ax * ax + ay * ay + az * az);
+        ax = ax / nrm;
+        ay = ay / nrm;
+        az = az / nrm;
+        const double c = az;
+        if (std::fabs(1.0 + c) < (double)FLT_EPSILON) {
+            // a = -z: half a turn about x. (Memory of ippe.cpp says diag(1, 1, -1) here, which is a reflection: the pose built on it has
+            // det -1 and Rodrigues makes nonsense of it - tests/test_external_anchors.py, a plane z = const seen from its back. GUESSED.)
+            for (int i = 0; i < 9; i++) Ra[i] = 0;
+            Ra[0] = 1.0;
+            Ra[4] = -1.0;
+            Ra[8] = -1.0;
+        } else {
+            const double d = 1.0 / (1.0 + c), ax2 = ax * ax, ay2 = ay * ay, axay = ax * ay;
+            Ra[0] = -ax2 * d + 1.0;
+            Ra[1] = -axay * d;
+            Ra[2] = -ax;
+            Ra[3] = -axay * d;
+            Ra[4] = -ay2 * d + 1.0;
+            Ra[5] = -ay;
+            Ra[6] = ax;
+            Ra[7] = ay;
+            Ra[8] = 1.0 - (ax2 + ay2) * d;
+        }
+    }
+
+    // zero-centred object points on the plane z = 0 (canon: n x 2) and the 4 x 4 transform that takes model points there; false = not coplanar
+    static bool makeCanonicalObjectPoints(const double* obj, int n, std::vector<double>& canon, double M2C[16]) {
+        std::vector<double> UZero(3 * (size_t)n);
+        double xBar = 0, yBar = 0, zBar = 0;
+        bool isOnZPlane = true;
+        for (int i = 0; i < n; i++) {
+            const double x = obj[3 * i], y = obj[3 * i + 1], z = obj[3 * i + 2];
+            xBar += x;
+            yBar += y;
+            zBar += z;
+            if (std::fabs(z) > IPPE_SMALL) isOnZPlane = false;
+        }
+        xBar = xBar / n;
+        yBar = yBar / n;
+        zBar = zBar / n;
+        for (int i = 0; i < n; i++) {
+            UZero[3 * i] = obj[3 * i] - xBar;
+            UZero[3 * i + 1] = obj[3 * i + 1] - yBar;
+            UZero[3 * i + 2] = obj[3 * i + 2] - zBar;
+        }
+        canon.resize(2 * (size_t)n);
+        for (int i = 0; i < 16; i++) M2C[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        if (isOnZPlane) {
+            M2C[3] = -xBar;
+            M2C[7] = -yBar;
+            M2C[11] = -zBar;
+            for (int i = 0; i < n; i++) {
+                canon[2 * i] = UZero[3 * i];
+                canon[2 * i + 1] = UZero[3 * i + 1];
+            }
+            return true;
+        }
+        double R[9];
+        // computeObjextSpaceR3Pts: the plane's normal from the first three points
+        const double *p1 = obj, *p2 = obj + 3, *p3 = obj + 6;
+        double nx = (p1[1] - p2[1]) * (p1[2] - p3[2]) - (p1[1] - p3[1]) * (p1[2] - p2[2]);
+        double ny = (p1[0] - p3[0]) * (p1[2] - p2[2]) - (p1[0] - p2[0]) * (p1[2] - p3[2]);
+        double nz = (p1[0] - p2[0]) * (p1[1] - p3[1]) - (p1[0] - p3[0]) * (p1[1] - p2[1]);
+        const double nrm = std::sqrt(nx * nx + ny * ny + nz * nz);
+        if (nrm > IPPE_SMALL) {
+            const double v[3] = {nx / nrm, ny / nrm, nz / nrm};
+            rotateVec2ZAxis(v, R);
+        } else {
+            // computeObjextSpaceRSvD: R = U' of the SVD of UZero UZero'
+            double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, W[3], Ut[9], Vt[9];
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) {
+                    double s = 0;
+                    for (int i = 0; i < n; i++) s += UZero[3 * i + a] * UZero[3 * i + b];
+                    S[3 * a + b] = s;
+                }
+            svd(S, 3, 3, W, Ut, Vt);
+            if (!(W[2] / W[1] < IPPE_SMALL)) return false;   // CV_Assert(s3 / s2 < IPPE_SMALL)
+            std::memcpy(R, Ut, sizeof R);
+            const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+            if (det < 0) {
+                R[6] = -R[6];
+                R[7] = -R[7];
+                R[8] = -R[8];
+            }
+        }
+        for (int i = 0; i < n; i++) {
+            const double* u = &UZero[3 * i];
+            const double ax = R[0] * u[0] + R[1] * u[1] + R[2] * u[2], ay = R[3] * u[0] + R[4] * u[1] + R[5] * u[2], az = R[6] * u[0] + R[7] * u[1] + R[8] * u[2];
+            canon[2 * i] = ax;
+            canon[2 * i + 1] = ay;
+            if (std::fabs(az) > IPPE_SMALL) return false;   // "Cannot transform object points to the plane z=0!"
+        }
+        // MRot * MCenter
+        const double c[3] = {-xBar, -yBar, -zBar};
+        for (int r = 0; r < 3; r++) {
+            for (int k = 0; k < 3; k++) M2C[4 * r + k] = R[3 * r + k];
+            M2C[4 * r + 3] = R[3 * r] * c[0] + R[3 * r + 1] * c[1] + R[3 * r + 2] * c[2];
+        }
+        return true;
+    }
+
+    // zero mean, mean squared distance 2: DataN (2 x n as two rows), T (back) and Ti (forth)
+    static void normalizeDataIsotropic(const double* pts, int n, std::vector<double>& DataN, double T[9], double Ti[9]) {
+        double xm = 0, ym = 0;
+        for (int i = 0; i < n; i++) {
+            xm += pts[2 * i];
+            ym += pts[2 * i + 1];
+        }
+        xm = xm / (double)n;
+        ym = ym / (double)n;
+        double kappa = 0;
+        DataN.resize(2 * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            const double xh = pts[2 * i] - xm, yh = pts[2 * i + 1] - ym;
+            DataN[i] = xh;
+            DataN[n + i] = yh;
+            kappa = kappa + xh * xh + yh * yh;
+        }
+        const double beta = std::sqrt(2 * n / kappa);
+        for (size_t i = 0; i < DataN.size(); i++) DataN[i] = DataN[i] * beta;
+        for (int i = 0; i < 9; i++) T[i] = Ti[i] = 0;
+        T[0] = 1.0 / beta;
+        T[4] = 1.0 / beta;
+        T[2] = xm;
+        T[5] = ym;
+        T[8] = 1;
+        Ti[0] = beta;
+        Ti[4] = beta;
+        Ti[2] = -beta * xm;
+        Ti[5] = -beta * ym;
+        Ti[8] = 1;
+    }
+
+    static void mul33(const double* A, const double* B, double* C) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += A[3 * i + k] * B[3 * k + j];
+                C[3 * i + j] = s;
+            }
+    }
+
+    // HomographyHO::homographyHO: src (n x 2, canonical object points) -> targ (n x 2, normalised image points)
+    static void homographyHO(const double* src, const double* targ, int n, double H[9]) {
+        std::vector<double> A, B;
+        double TA[9], TAi[9], TB[9], TBi[9];
+        normalizeDataIsotropic(src, n, A, TA, TAi);
+        normalizeDataIsotropic(targ, n, B, TB, TBi);
+        const double *Ax = &A[0], *Ay = &A[n], *Bx_ = &B[0], *By_ = &B[n];
+        std::vector<double> C1(n), C2(n), C3(n), C4(n), Mx(3 * (size_t)n), My(3 * (size_t)n);
+        double mC1 = 0, mC2 = 0, mC3 = 0, mC4 = 0;
+        for (int i = 0; i < n; i++) {
+            C1[i] = -Bx_[i] * Ax[i];
+            C2[i] = -Bx_[i] * Ay[i];
+            C3[i] = -By_[i] * Ax[i];
+            C4[i] = -By_[i] * Ay[i];
+            mC1 += C1[i];
+            mC2 += C2[i];
+            mC3 += C3[i];
+            mC4 += C4[i];
+        }
+        mC1 /= n;
+        mC2 /= n;
+        mC3 /= n;
+        mC4 /= n;
+        for (int i = 0; i < n; i++) {
+            Mx[3 * i] = C1[i] - mC1;
+            Mx[3 * i + 1] = C2[i] - mC2;
+            Mx[3 * i + 2] = -Bx_[i];
+            My[3 * i] = C3[i] - mC3;
+            My[3 * i + 1] = C4[i] - mC4;
+            My[3 * i + 2] = -By_[i];
+        }
+        double g00 = 0, g01 = 0, g11 = 0;   // DataA * DataA'
+        for (int i = 0; i < n; i++) {
+            g00 += Ax[i] * Ax[i];
+            g01 += Ax[i] * Ay[i];
+            g11 += Ay[i] * Ay[i];
+        }
+        const double dt = g00 * g11 - g01 * g01;
+        const double gi00 = g11 / dt, gi01 = -g01 / dt, gi10 = -g01 / dt, gi11 = g00 / dt;
+        std::vector<double> Pp(2 * (size_t)n);   // DataADataATi * DataA
+        for (int i = 0; i < n; i++) {
+            Pp[i] = gi00 * Ax[i] + gi01 * Ay[i];
+            Pp[n + i] = gi10 * Ax[i] + gi11 * Ay[i];
+        }
+        double Bx[6], By[6];   // 2 x 3: Pp * Mx, Pp * My
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 3; c++) {
+                double sx = 0, sy = 0;
+                for (int i = 0; i < n; i++) {
+                    sx += Pp[r * n + i] * Mx[3 * i + c];
+                    sy += Pp[r * n + i] * My[3 * i + c];
+                }
+                Bx[3 * r + c] = sx;
+                By[3 * r + c] = sy;
+            }
+        double DDT[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        std::vector<double> D(6 * (size_t)n);   // rows 0..n-1: Mx - DataA' Bx, rows n..2n-1: My - DataA' By
+        for (int i = 0; i < n; i++)
+            for (int c = 0; c < 3; c++) {
+                D[3 * i + c] = Mx[3 * i + c] - (Ax[i] * Bx[c] + Ay[i] * Bx[3 + c]);
+                D[3 * (n + i) + c] = My[3 * i + c] - (Ax[i] * By[c] + Ay[i] * By[3 + c]);
+            }
+        for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+                double s = 0;
+                for (int i = 0; i < 2 * n; i++) s += D[3 * i + a] * D[3 * i + b];
+                DDT[3 * a + b] = s;
+            }
+        double W[3], Ut[9], Vt[9];
+        svd(DDT, 3, 3, W, Ut, Vt);
+        const double h789[3] = {Vt[6], Vt[7], Vt[8]};
+        double Hn[9];
+        for (int r = 0; r < 2; r++) {
+            Hn[r] = -(Bx[3 * r] * h789[0] + Bx[3 * r + 1] * h789[1] + Bx[3 * r + 2] * h789[2]);
+            Hn[3 + r] = -(By[3 * r] * h789[0] + By[3 * r + 1] * h789[1] + By[3 * r + 2] * h789[2]);
+        }
+        Hn[2] = -(mC1 * h789[0] + mC2 * h789[1]);
+        Hn[5] = -(mC3 * h789[0] + mC4 * h789[1]);
+        Hn[6] = h789[0];
+        Hn[7] = h789[1];
+        Hn[8] = h789[2];
+        double tmp[9];
+        mul33(TB, Hn, tmp);
+        mul33(tmp, TAi, H);
+        const double h22_inv = 1 / H[8];
+        for (int i = 0; i < 9; i++) H[i] = H[i] * h22_inv;
+    }
+
+    static void computeRotations(double j00, double j01, double j10, double j11, double p, double q, double R1[9], double R2[9]) {
+        double Rv[9], RvT[9];
+        const double v[3] = {p, q, 1};
+        rotateVec2ZAxis(v, RvT);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) Rv[3 * i + j] = RvT[3 * j + i];
+        const double rv00 = Rv[0], rv01 = Rv[1], rv02 = Rv[2], rv10 = Rv[3], rv11 = Rv[4], rv12 = Rv[5], rv20 = Rv[6], rv21 = Rv[7], rv22 = Rv[8];
+        const double b00 = rv00 - p * rv20, b01 = rv01 - p * rv21, b10 = rv10 - q * rv20, b11 = rv11 - q * rv21;
+        const double dtinv = 1.0 / ((b00 * b11 - b01 * b10));
+        const double binv00 = dtinv * b11, binv01 = -dtinv * b01, binv10 = -dtinv * b10, binv11 = dtinv * b00;
+        const double a00 = binv00 * j00 + binv01 * j10, a01 = binv00 * j01 + binv01 * j11, a10 = binv10 * j00 + binv11 * j10, a11 = binv10 * j01 + binv11 * j11;
+        const double ata00 = a00 * a00 + a01 * a01, ata01 = a00 * a10 + a01 * a11, ata11 = a10 * a10 + a11 * a11;
+        const double gamma2 = 0.5 * (ata00 + ata11 + std::sqrt((ata00 - ata11) * (ata00 - ata11) + 4.0 * ata01 * ata01));
+        const double gamma = std::sqrt(gamma2);
+        const double rtilde00 = a00 / gamma, rtilde01 = a01 / gamma, rtilde10 = a10 / gamma, rtilde11 = a11 / gamma;
+        const double rtilde00_2 = rtilde00 * rtilde00, rtilde01_2 = rtilde01 * rtilde01, rtilde10_2 = rtilde10 * rtilde10, rtilde11_2 = rtilde11 * rtilde11;
+        double b0 = std::sqrt(std::max(0.0, -rtilde00_2 - rtilde10_2 + 1));
+        double b1 = std::sqrt(std::max(0.0, -rtilde01_2 - rtilde11_2 + 1));
+        const double sp = (-rtilde00 * rtilde01 - rtilde10 * rtilde11);
+        if (sp < 0) b1 = -b1;
+        const double c0 = b1 * rtilde10 - b0 * rtilde11, c1 = b0 * rtilde01 - b1 * rtilde00, c2 = rtilde00 * rtilde11 - rtilde01 * rtilde10;
+        const double rvr[3][3] = {{rv00, rv01, rv02}, {rv10, rv11, rv12}, {rv20, rv21, rv22}};
+        for (int r = 0; r < 3; r++) {
+            R1[3 * r] = (rtilde00)*rvr[r][0] + (rtilde10)*rvr[r][1] + (b0)*rvr[r][2];
+            R1[3 * r + 1] = (rtilde01)*rvr[r][0] + (rtilde11)*rvr[r][1] + (b1)*rvr[r][2];
+            R1[3 * r + 2] = c0 * rvr[r][0] + c1 * rvr[r][1] + c2 * rvr[r][2];
+            R2[3 * r] = (rtilde00)*rvr[r][0] + (rtilde10)*rvr[r][1] + (-b0) * rvr[r][2];
+            R2[3 * r + 1] = (rtilde01)*rvr[r][0] + (rtilde11)*rvr[r][1] + (-b1) * rvr[r][2];
+            R2[3 * r + 2] = (-c0) * rvr[r][0] + (-c1) * rvr[r][1] + c2 * rvr[r][2];
+        }
+    }
+
+    // the translation that goes with R: normal equations of the 2n x 3 system
+    static void computeTranslation(const double* canon, const double* nimg, int n, const double R[9], double t[3]) {
+        const double ATA00 = (double)n, ATA11 = (double)n;
+        double ATA02 = 0, ATA12 = 0, ATA22 = 0, ATb0 = 0, ATb1 = 0, ATb2 = 0;
+        for (int i = 0; i < n; i++) {
+            const double X = canon[2 * i], Y = canon[2 * i + 1];
+            const double rx = R[0] * X + R[1] * Y, ry = R[3] * X + R[4] * Y, rz = R[6] * X + R[7] * Y;
+            const double a2 = -nimg[2 * i], b2 = -nimg[2 * i + 1];
+            ATA02 = ATA02 + a2;
+            ATA12 = ATA12 + b2;
+            ATA22 = ATA22 + (a2 * a2) + (b2 * b2);
+            const double bx = -a2 * rz - rx, by = -b2 * rz - ry;
+            ATb0 = ATb0 + bx;
+            ATb1 = ATb1 + by;
+            ATb2 = ATb2 + a2 * bx + b2 * by;
+        }
+        const double detAInv = 1.0 / (ATA00 * ATA11 * ATA22 - ATA00 * ATA12 * ATA12 - ATA02 * ATA02 * ATA11);
+        const double S00 = ATA11 * ATA22 - ATA12 * ATA12, S01 = ATA02 * ATA12, S02 = -ATA02 * ATA11, S11 = ATA00 * ATA22 - ATA02 * ATA02, S12 = -ATA00 * ATA12,
+                     S22 = ATA00 * ATA11;
+        t[0] = detAInv * (S00 * ATb0 + S01 * ATb1 + S02 * ATb2);
+        t[1] = detAInv * (S01 * ATb0 + S11 * ATb1 + S12 * ATb2);
+        t[2] = detAInv * (S02 * ATb0 + S12 * ATb1 + S22 * ATb2);
+    }
+};
+
+bool solve_pnp_ippe(const double* obj, const double* img, int n, const double* K, double* rvec, double* tvec) {
+    if (n < 4) return false;
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5], ifx = 1. / fx, ify = 1. / fy;
+    std::vector<double> nimg(2 * (size_t)n), canon;
+    for (int i = 0; i < n; i++) {
+        nimg[2 * i] = (img[2 * i] - cx) * ifx;
+        nimg[2 * i + 1] = (img[2 * i + 1] - cy) * ify;
+    }
+    double M2C[16], H[9];
+    if (!Ippe::makeCanonicalObjectPoints(obj, n, canon, M2C)) return false;
+    Ippe::homographyHO(canon.data(), nimg.data(), n, H);
+    const double j00 = H[0] - H[6] * H[2], j01 = H[1] - H[7] * H[2], j10 = H[3] - H[6] * H[5], j11 = H[4] - H[7] * H[5];
+    double Rc[2][9], tc[2][3];
+    Ippe::computeRotations(j00, j01, j10, j11, H[2], H[5], Rc[0], Rc[1]);
+    double pose_R[2][9], pose_t[2][3], perr[2];
+    for (int s = 0; s < 2; s++) {
+        Ippe::computeTranslation(canon.data(), nimg.data(), n, Rc[s], tc[s]);
+        // M = [Rc tc] * MmodelPoints2Canonical
+        for (int r = 0; r < 3; r++) {
+            for (int c = 0; c < 3; c++) pose_R[s][3 * r + c] = Rc[s][3 * r] * M2C[c] + Rc[s][3 * r + 1] * M2C[4 + c] + Rc[s][3 * r + 2] * M2C[8 + c];
+            pose_t[s][r] = Rc[s][3 * r] * M2C[3] + Rc[s][3 * r + 1] * M2C[7] + Rc[s][3 * r + 2] * M2C[11] + tc[s][r];
+        }
+        double err = 0;   // the order solvePnPGeneric gives its solutions: reprojection error in pixels
+        for (int i = 0; i < n; i++) {
+            const double X = obj[3 * i], Y = obj[3 * i + 1], Z = obj[3 * i + 2];
+            const double* R = pose_R[s];
+            const double xc = R[0] * X + R[1] * Y + R[2] * Z + pose_t[s][0], yc = R[3] * X + R[4] * Y + R[5] * Z + pose_t[s][1],
+                         zc = R[6] * X + R[7] * Y + R[8] * Z + pose_t[s][2];
+            const double iz = 1. / zc, du = xc * iz * fx + cx - img[2 * i], dv = yc * iz * fy + cy - img[2 * i + 1];
+            err += du * du + dv * dv;
+        }
+        perr[s] = err;
+    }
+    const int best = perr[1] < perr[0] ? 1 : 0;
+    if (!(perr[best] == perr[best])) return false;   // NaN: a degenerate homography
+    rodrigues_to_vector(pose_R[best], rvec);
+    for (int k = 0; k < 3; k++) tvec[k] = pose_t[best][k];
+    return true;
+}
+
 int update_num_iters(double p, double ep, int modelPoints, int maxIters) {
     p = std::max(p, 0.);
     p = std::min(p, 1.);
@@ -2140,8 +2483,8 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
     if (n < 4 || !obj_xyz || !img_xy || !K) return -215;          // CV_Assert(npoints >= 4 && ...)
     if (method == 3 /* SOLVEPNP_DLS */ || method == 4 /* SOLVEPNP_UPNP */) method = 1;   // solvePnPGeneric: "broken implementation", both run EPnP
     if (method != 0 /* SOLVEPNP_ITERATIVE */ && method != 1 /* SOLVEPNP_EPNP */ && method != 2 /* SOLVEPNP_P3P */ && method != 5 /* SOLVEPNP_AP3P */ &&
-        method != 8 /* SOLVEPNP_SQPNP */ && method != 7 /* SOLVEPNP_IPPE_SQUARE */)
-        return -213;   // IPPE (planar targets only): not restated
+        method != 8 /* SOLVEPNP_SQPNP */ && method != 7 /* SOLVEPNP_IPPE_SQUARE */ && method != 6 /* SOLVEPNP_IPPE */)
+        return -213;   // past the last member of cv::SolvePnPMethod
     // kernel choice of solvePnPRansac: P3P / AP3P on 4 points when asked for, P3P when there are only 4 points; EPnP on 5 otherwise
     const bool ap3p = method == 5;
     const bool p3p = method == 2 || method == 5 || n == 4;
@@ -2215,6 +2558,14 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
         if (initial_pose_no_guess(oi.data(), ii.data(), cnt, camK, param)) refine_pose_lm(oi.data(), ii.data(), cnt, camK, param);
         std::memcpy(rvec, param, 3 * sizeof(double));
         std::memcpy(tvec, param + 3, 3 * sizeof(double));
+    } else if (method == 6) {
+        // SOLVEPNP_IPPE: EPnP stays the RANSAC kernel; the final solvePnP over the inliers is IPPE. Inliers that are not coplanar: its solver
+        // throws inside solvePnPGeneric's try block, solvePnP finds nothing, solvePnPRansac hands back the RANSAC model and returns false.
+        if (!solve_pnp_ippe(oi.data(), ii.data(), cnt, K, rvec, tvec)) {
+            std::memcpy(rvec, best_r, sizeof best_r);
+            std::memcpy(tvec, best_t, sizeof best_t);
+            return 0;
+        }
     } else if (method == 8) {
         // SOLVEPNP_SQPNP: EPnP stays the RANSAC kernel (solvepnp.cpp: only P3P / AP3P replace it), the final solvePnP over the inliers is SQPnP.
         // No solution: solvePnPRansac hands back the RANSAC model and returns false.
@@ -2228,6 +2579,10 @@ int oracle_solve_pnp_ransac(const double* obj_xyz, const double* img_xy, int n, 
     }
     *n_inliers = cnt;
     return 1;
+}
+
+int oracle_solve_pnp_ippe(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec) {
+    return solve_pnp_ippe(obj_xyz, img_xy, n, K, rvec, tvec) ? 1 : 0;
 }
 
 int oracle_solve_pnp_sqpnp(const double* obj_xyz, const double* img_xy, int n, const double* K, double* rvec, double* tvec) {

@@ -471,3 +471,57 @@ def test_gpu_sqpnp_against_external_anchors(gpu_pkg):
             return False, None, None, None
         return True, sol.rvec.mat.ravel(), sol.tvec.mat.ravel(), sol.inliers.mat.ravel()
     check_sqpnp_ransac(solve, gpu_pkg.synth)
+
+
+# ---------------------------------------------------------------------------------------------------------------- IPPE (round 4)
+def check_ippe_direct(direct):
+    """solvePnP(SOLVEPNP_IPPE) alone. IPPE is a closed-form method (a homography, its Jacobian at the centroid, two candidate rotations), not
+    a minimiser, so the anchors are the construction of the data: noise-free points of ANY plane (through the origin, off it, tilted, with the
+    first three points collinear) give back the pose they were projected with; with pixel noise the pose is a proper rotation within the
+    noise's reach of the planted one and reprojects to the noise level; a cloud with relief has no IPPE pose."""
+    rng = np.random.default_rng(17)
+    K = np.array([[900.0, 0, 640], [0, 880, 360], [0, 0, 1]])
+    for case, n in enumerate([4, 5, 12, 100, 3000, 60, 60]):
+        rvec = rng.normal(0, [0.2, 0.6, 1.0][case % 3], 3)
+        tvec = np.array([0.3, -0.2, 7.0]) + rng.normal(0, 0.4, 3)
+        obj = rng.uniform(-1, 1, (n, 3))
+        obj[:, 2] = 0.0
+        if case in (1, 3):
+            obj[:, 2] = -0.4
+        if case in (2, 4, 6):
+            obj = obj @ rodrigues(rng.normal(0, 1.0, 3)).T + rng.normal(0, 1.0, 3)
+        if case == 5:
+            obj[1] = 0.5 * (obj[0] + obj[2])
+            obj = obj @ rodrigues(np.array([0.4, -0.3, 0.2])).T + 0.1
+        img = project(obj, rodrigues(rvec), tvec, K)
+        ok, r, t = direct(obj, img, K)
+        assert ok and np.allclose(rodrigues(r), rodrigues(rvec), atol=1e-8) and np.allclose(t, tvec, atol=1e-7), (case, n)
+        if n >= 12:
+            noisy = img + rng.normal(0, 0.5, img.shape)
+            ok, r, t = direct(obj, noisy, K)
+            R = rodrigues(r)
+            assert ok and np.allclose(R @ R.T, np.eye(3), atol=1e-9) and abs(np.linalg.det(R) - 1) < 1e-9
+            assert np.allclose(R, rodrigues(rvec), atol=0.05) and np.allclose(t, tvec, atol=0.3), (case, n)
+            assert np.sqrt(np.mean((project(obj, R, t, K) - noisy) ** 2)) < 1.0      # 0.5 px of noise per coordinate
+    obj = rng.uniform(-1, 1, (50, 3))                                                # relief of +-1 against IPPE's 1e-3
+    ok, r, t = direct(obj, project(obj, np.eye(3), np.array([0, 0, 6.0]), K), K)
+    assert not ok
+
+
+def test_oracle_ippe_against_external_anchors(oracle_mod):
+    def direct(obj, img, K):
+        rc, r, t = oracle_mod.solve_pnp_ippe(obj, img, K)
+        return rc == 1, r, t
+    check_ippe_direct(direct)
+
+
+def test_product_ippe_against_external_anchors(pkg):
+    import ctypes as C
+
+    def direct(obj, img, K):
+        obj, img, K = (np.ascontiguousarray(a, np.float64) for a in (obj, img, K))
+        r, t, found = np.zeros(3), np.zeros(3), C.c_int(0)
+        rc = pkg.lib().apds_pnp_ippe(pkg._lib.ptr(obj), pkg._lib.ptr(img), len(obj), pkg._lib.ptr(K), pkg._lib.ptr(r), pkg._lib.ptr(t), C.byref(found))
+        assert rc == 0, pkg.lib().apds_last_error()
+        return found.value == 1, r, t
+    check_ippe_direct(direct)

@@ -261,7 +261,8 @@ def test_pnp_ransac_recovers_planted_pose(oracle_mod, pkg):
     rc8, r8, t8, idx8 = oracle_mod.solve_pnp_ransac(obj, img, K, 1000, 3.0, 0.99, method=8)
     assert rc8 == 1 and np.array_equal(idx8, idx) and not np.array_equal(r8, r)
     assert np.allclose(r8, rvec, atol=2e-3) and np.allclose(t8, tvec, rtol=2e-3, atol=0.5)
-    assert oracle_mod.solve_pnp_ransac(obj, img, K, method=6)[0] == -213   # IPPE (planar targets only) is not restated
+    assert oracle_mod.solve_pnp_ransac(obj, img, K, method=9)[0] == -213   # past the last cv::SolvePnPMethod
+    assert oracle_mod.solve_pnp_ransac(obj, img, K, 1000, 3.0, 0.99, method=6)[0] == 0   # IPPE: these object points are not coplanar - no pose
     assert oracle_mod.solve_pnp_ransac(obj, img, K, method=7)[0] == -215   # IPPE_SQUARE: the final solvePnP's CV_Assert(npoints == 4)
     # SOLVEPNP_ITERATIVE: EPnP's RANSAC (hence the same inliers as the default method), then the Levenberg-Marquardt refinement
     rc0, r0, t0, idx0 = oracle_mod.solve_pnp_ransac(obj, img, K, 1000, 3.0, 0.99, method=0)

@@ -118,9 +118,12 @@ def test_ap3p_ransac_matches_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, 
 def test_four_points_and_unbuilt_methods(gpu_pkg, oracle_mod):
     hg = gpu_pkg.homographier
     obj, img, K, _, _, inl = gpu_pkg.synth.make_pnp_set(400, inlier_frac=0.5, noise=0.5)
-    with pytest.raises(hg.MatError) as e:   # SOLVEPNP_IPPE (planar targets only): handed through like every Option<SolvePnPMethod> (mod.rs:359), not built
-        _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, 6)
+    with pytest.raises(hg.MatError) as e:   # a value past cv::SolvePnPMethod's last member
+        _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, 9)
     assert e.value.inner.code == -213
+    # SOLVEPNP_IPPE on object points that are not coplanar: OpenCV's plane solver refuses, solvePnPRansac returns false -> Ok(None)
+    assert _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, hg.SolvePnPMethod.SOLVEPNP_IPPE) is None
+    assert oracle_mod.solve_pnp_ransac(obj, img, K, 100, 3.0, 0.99, method=6)[0] == 0
     # SOLVEPNP_IPPE_SQUARE: the final solvePnP over the >= 5 inliers asserts npoints == 4; solvePnPRansac rethrows -> Err(MatError::Opencv)
     with pytest.raises(hg.MatError) as e:
         _solve(gpu_pkg, obj, img, K, 100, 3.0, 0.99, hg.SolvePnPMethod.SOLVEPNP_IPPE_SQUARE)
@@ -196,3 +199,41 @@ def test_dls_and_upnp_run_epnp(gpu_pkg, oracle_mod):
         rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, 400, 3.0, 0.99, method=int(method))
         assert rc == 1 and np.array_equal(got.inliers.mat.ravel(), idx) and np.array_equal(got.rvec.mat.ravel(), r) and np.array_equal(got.tvec.mat.ravel(), t)
         assert np.array_equal(got.rvec.mat.ravel(), want.rvec.mat.ravel()) and np.array_equal(got.tvec.mat.ravel(), want.tvec.mat.ravel())
+
+
+def _planar_set(synth, n, seed, frac, noise, tilt):
+    """make_pnp_set's correspondences with the object points pressed onto a plane (optionally tilted and off the origin) and the inliers'
+    pixels re-projected from the planted pose."""
+    obj, img, K, rvec, tvec, flag = synth.make_pnp_set(n, seed=seed, inlier_frac=frac, noise=noise)
+    rng = np.random.default_rng(seed)
+    obj = obj.copy()
+    obj[:, 2] = 0.0
+    if tilt:
+        a = rng.normal(size=3)
+        th = np.linalg.norm(a)
+        k = a / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        obj = obj @ (np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)).T + np.array([3.0, -2.0, 5.0])
+    th = np.linalg.norm(rvec)
+    k = rvec / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+    cam = obj[flag] @ R.T + tvec
+    img = img.copy()
+    img[flag] = cam[:, :2] / cam[:, 2:3] * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]]) + rng.normal(0, noise, (int(flag.sum()), 2))
+    return obj, img, K, rvec, tvec, flag
+
+
+@pytest.mark.parametrize("n,frac,noise,iters,thr,tilt", [(600, 0.7, 0.5, 300, 3.0, False), (5000, 0.4, 0.8, 1000, 4.0, True), (40, 1.1, 0.3, 100, 3.0, True),
+                                                        (6, 1.1, 0.0, 50, 2.0, False)])
+def test_ippe_method_equals_oracle(gpu_pkg, oracle_mod, n, frac, noise, iters, thr, tilt):
+    # SolvePnPMethod::SOLVEPNP_IPPE (mod.rs:327,359-360) on a planar target: EPnP's RANSAC, IPPE over the inliers (csrc/ippe_core.h against
+    # the oracle's separate restatement) - inliers and pose bit-identical
+    hg = gpu_pkg.homographier
+    obj, img, K, rvec, tvec, _ = _planar_set(gpu_pkg.synth, n, 0x1BBE + n, frac, noise, tilt)
+    sol = _solve(gpu_pkg, obj, img, K, iters, thr, 0.99, hg.SolvePnPMethod.SOLVEPNP_IPPE)
+    rc, r, t, idx = oracle_mod.solve_pnp_ransac(obj, img, K, iters, thr, 0.99, method=6)
+    assert (sol is not None) == (rc == 1)
+    if sol is not None:
+        assert np.array_equal(sol.inliers.mat.ravel(), idx)
+        assert np.array_equal(sol.rvec.mat.ravel(), r) and np.array_equal(sol.tvec.mat.ravel(), t)

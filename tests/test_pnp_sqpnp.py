@@ -53,6 +53,46 @@ def test_product_sqpnp_equals_the_oracle_bit_for_bit(pkg, oracle_mod):
     assert poses >= 450
 
 
+def test_product_ippe_equals_the_oracle_bit_for_bit(pkg, oracle_mod):
+    """The same for SOLVEPNP_IPPE (csrc/ippe_core.h through apds_pnp_ippe against the oracle's restatement): planes through and off the
+    origin, tilted planes, planes whose first three points are collinear (the SVD branch), clouds that are not planar and lines (no pose:
+    both sides must say so)."""
+    rng = np.random.default_rng(2027)
+    K = np.array([[800.0, 0, 320], [0, 820, 240], [0, 0, 1]])
+    poses = 0
+    for trial in range(600):
+        n = int(rng.choice([4, 5, 6, 8, 20, 100, 1000]))
+        rv = rng.normal(size=3) * rng.choice([0.01, 0.5, 1.2])
+        t = np.array([0.2, -0.1, 6.0]) + rng.normal(size=3) * 0.5
+        obj = rng.uniform(-1, 1, size=(n, 3))
+        obj[:, 2] = 0
+        shape = trial % 6
+        if shape == 1:
+            obj[:, 2] = 0.3
+        elif shape == 2:
+            obj = obj @ _rot(rng.normal(size=3)).T + rng.normal(size=3)
+        elif shape == 3:
+            obj[:, 2] = rng.normal(size=n) * 0.02
+        elif shape == 4:
+            obj[1] = obj[0] + (obj[2] - obj[0]) * 0.5
+            obj = obj @ _rot(rng.normal(size=3)).T + 0.2
+        elif shape == 5:
+            obj[:, 1] = obj[:, 0] * 0.5
+        cam = obj @ _rot(rv).T + t
+        img = np.stack([cam[:, 0] / cam[:, 2] * K[0, 0] + K[0, 2], cam[:, 1] / cam[:, 2] * K[1, 1] + K[1, 2]], 1)
+        img = img + rng.normal(size=img.shape) * rng.choice([0, 0.1, 2.0, 30.0])
+        obj, img = np.ascontiguousarray(obj), np.ascontiguousarray(img)
+        r, tt, found = np.zeros(3), np.zeros(3), C.c_int(-1)
+        rc = pkg.lib().apds_pnp_ippe(pkg._lib.ptr(obj), pkg._lib.ptr(img), n, pkg._lib.ptr(K), pkg._lib.ptr(r), pkg._lib.ptr(tt), C.byref(found))
+        assert rc == 0, pkg.lib().apds_last_error()
+        orc, ro, to = oracle_mod.solve_pnp_ippe(obj, img, K)
+        assert found.value == orc, (trial, n, shape)
+        if orc:
+            poses += 1
+            assert np.array_equal(r, ro, equal_nan=True) and np.array_equal(tt, to, equal_nan=True), (trial, n, shape, r - ro, tt - to)
+    assert poses >= 350
+
+
 def test_sqpnp_argument_checks(pkg):
     K = np.eye(3)
     obj, img = np.zeros((2, 3)), np.zeros((2, 2))
