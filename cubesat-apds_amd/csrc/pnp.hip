@@ -7,7 +7,9 @@
 // samples is solved one thread per sample (12x12 system in LDS), every hypothesis of the batch is scored against all
 // points in one launch, and the host replays the sequential accept/shorten logic over the batch's counts; the result is
 // the model and inlier set the sequential loop would have produced. The final EPnP over the inliers runs on the host in
-// the same code (pnp_core.h), as OpenCV does it once, in index order.
+// the same code (pnp_core.h), as OpenCV does it once, in index order. Every member of cv::SolvePnPMethod is served: P3P / AP3P swap
+// the RANSAC kernel (4-point samples); ITERATIVE, SQPNP (sqpnp_core.h) and IPPE (ippe_core.h) swap the final solve; DLS / UPNP are
+// EPnP in OpenCV 4; IPPE_SQUARE ends in solvePnP's npoints == 4 assertion unless there are exactly four correspondences (P3P).
 #include "config.h"
 #include "kernels.h"
 #include "pnp_core.h"
