@@ -9,6 +9,7 @@ homography_200.npz : 200 point pairs (40 % inliers) -> H (RANSAC, thr 3) and inl
 ingest.npz         : band_merger / warp_perspective expected bytes for seeded inputs
 pnp_400.npz        : 400 3D-2D correspondences (60 % inliers) -> solvePnPRansac pose + inlier indices, EPnP and P3P
 pnp_sqpnp_400.npz  : the same correspondences -> solvePnPRansac with SOLVEPNP_SQPNP (EPnP's consensus set, SQPnP's pose over it)
+pnp_ippe_400.npz   : 400 correspondences of a tilted PLANAR target (60 % inliers) -> solvePnPRansac with SOLVEPNP_IPPE
 world_coordinates.npz : 500 mosaic pixels -> ECEF through two geotransforms and a seeded elevation raster
 """
 import os
@@ -59,6 +60,25 @@ def pnp_inputs():
     return obj, img, K
 
 
+def pnp_planar_inputs():
+    """pnp_inputs() pressed onto a tilted plane off the origin; the inliers' pixels re-projected from the planted pose (+ 0.5 px noise)."""
+    obj, img, K, rvec, tvec, flag = synth.make_pnp_set(400, seed=0x504E5000 + 401, inlier_frac=0.6, noise=0.5)
+    rng = np.random.default_rng(0x1BBE)
+
+    def rot(v):
+        th = np.linalg.norm(v)
+        k = v / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+    obj = obj.copy()
+    obj[:, 2] = 0.0
+    obj = obj @ rot(np.array([0.3, -0.2, 0.5])).T + np.array([3.0, -2.0, 5.0])
+    cam = obj[flag] @ rot(rvec).T + tvec
+    img = img.copy()
+    img[flag] = cam[:, :2] / cam[:, 2:3] * np.array([K[0, 0], K[1, 1]]) + np.array([K[0, 2], K[1, 2]]) + rng.normal(0, 0.5, (int(flag.sum()), 2))
+    return np.ascontiguousarray(obj), np.ascontiguousarray(img), K
+
+
 def world_inputs():
     rng = np.random.default_rng(20261004)
     dgt = [9.0, 1e-4, 0.0, 57.0, 0.0, -1e-4]
@@ -78,6 +98,9 @@ def main_extra():
     np.savez_compressed(os.path.join(HERE, "pnp_400.npz"), **out)
     rc, r, t, idx = oracle.solve_pnp_ransac(obj, img, K, 500, 3.0, 0.99, 8)
     np.savez_compressed(os.path.join(HERE, "pnp_sqpnp_400.npz"), sqpnp_rc=rc, sqpnp_rvec=r, sqpnp_tvec=t, sqpnp_inliers=idx)
+    obj, img, K = pnp_planar_inputs()
+    rc, r, t, idx = oracle.solve_pnp_ransac(obj, img, K, 500, 3.0, 0.99, 6)
+    np.savez_compressed(os.path.join(HERE, "pnp_ippe_400.npz"), ippe_rc=rc, ippe_rvec=r, ippe_tvec=t, ippe_inliers=idx)
     xy, dgt, egt, elevation = world_inputs()
     rc, xyz = oracle.world_coordinates(xy, dgt, egt, elevation)
     np.savez_compressed(os.path.join(HERE, "world_coordinates.npz"), rc=rc, xyz=xyz)
