@@ -39,6 +39,11 @@ static constexpr int HM_WAVES = APDS_HM_WAVES;   // waves per workgroup; a wave 
                                                  // tiles, half the barriers: 5.58 against 5.46 ms alone, 148.7 against 147.5 frames/s in the pipeline -
                                                  // no difference worth a second shape; profiles/r04/match_mfma_probe_w16.txt)
 static constexpr int HM_TM = 16 * HM_WAVES;      // train rows per tile
+#ifndef APDS_HM_WPE
+#define APDS_HM_WPE 4
+#endif
+// waves per SIMD the kernel is compiled for (4: two 8-wave workgroups per CU. The 12-wave shape - APDS_HM_WAVES=12 APDS_HM_WPE=3, one
+// workgroup per CU with a quarter of the registers left to the other stages' kernels - is a build-time experiment)
 #ifndef APDS_HM_NC
 #define APDS_HM_NC 3
 #endif
@@ -120,7 +125,7 @@ __device__ __forceinline__ void hm_insert(HmTop2& b, uint32_t d, uint32_t idx) {
 // THR: the launch starts from thresholds (the main launch behind a threshold launch) - a template parameter so that profilers list the two
 // launches of a match under two names
 template <int PRIO, bool THR>
-__global__ __launch_bounds__(64 * HM_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
+__global__ __launch_bounds__(64 * HM_WAVES) __attribute__((amdgpu_waves_per_eu(APDS_HM_WPE, APDS_HM_WPE))) void hamming_mfma_kernel(const uint4* __restrict__ train_fp4, const float* __restrict__ tpc, int n_train,
                                                            const uint4* __restrict__ query_fp4, const float* __restrict__ qpc, int nq, int tiles_per_split,
                                                            int q_tiles, int splits, uint32_t index_base, const uint32_t* __restrict__ thr,
                                                            uint64_t* __restrict__ out) {
@@ -338,7 +343,7 @@ long long hm_padded_rows(long long n) { return ceil_div(n, (long long)HM_TM) * H
 // rows of the threshold launch: whole tiles, a sixteenth of the set, at most APDS_MATCH_MFMA_SAMPLE (16 384); none below 65 536 rows
 long long hm_sample_rows(long long nt) {
     const long long cap = config().match_mfma_sample;   // APDS_MATCH_MFMA_SAMPLE (0: no threshold launch)
-    return (cap > 0 && nt >= 65536) ? std::min<long long>(cap, (nt / 16) & ~(long long)(HM_TM - 1)) & ~(long long)(HM_TM - 1) : 0;
+    return (cap > 0 && nt >= 65536) ? std::min<long long>(cap, nt / 16 / HM_TM * HM_TM) / HM_TM * HM_TM : 0;   // whole tiles (HM_TM need not be a power of two)
 }
 
 // parts: [p.splits][nq][2] keys
